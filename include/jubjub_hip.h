@@ -1,0 +1,137 @@
+/*
+ * jubjub_hip.h — C ABI of libjubjub_hip.so, the MI355X-native batched Jubjub engine.
+ *
+ * This is the drop-in boundary for the scalar-multiplication hot path of the zkcrypto/jubjub crate
+ * (reference: /root/reference, crate jubjub 0.10.0).  The reference has no FFI; its boundary is its public
+ * Rust API.  Rust struct layouts are unspecified, so the only stable representations — and the wire formats
+ * here — are the ones the reference itself exposes publicly:
+ *
+ *   scalar            32 bytes, little-endian integer      Fr::to_bytes / from_bytes      src/fr.rs:268-308
+ *                     (ladder entry points take the raw 32-byte bit pattern, top 4 bits ignored:
+ *                      ExtendedPoint::multiply / multiply_bits  src/lib.rs:272-301, 357-385, 831-833)
+ *   base field elem   32 bytes, canonical little-endian     Fq::to_bytes / from_bytes      src/lib.rs:456-457, 500
+ *   affine point      64 bytes = u || v, each canonical LE  AffinePoint::get_u/get_v       src/lib.rs:630-637,
+ *                                                           from_raw_unchecked             src/lib.rs:662-664
+ *   compressed point  32 bytes, v with sign(u) in bit 255   AffinePoint::to_bytes          src/lib.rs:455-464
+ *   validity          one uint8_t per element (1 = Some, 0 = None); output zeroed when 0   (CtOption / Choice)
+ *
+ * Pointers may be host or device pointers (detected per pointer with hipPointerGetAttributes); host data is
+ * staged through the context's buffers.  With device pointers the call is asynchronous on the context's
+ * stream; with any host pointer it returns after the results are in host memory.  A context belongs to one
+ * device (one process per GPU is the intended deployment); calls on one context must not overlap.
+ *
+ * Every function returns 0 on success or a negative jj_status.
+ */
+#ifndef JUBJUB_HIP_H
+#define JUBJUB_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct jj_ctx jj_ctx;
+typedef struct jj_table jj_table;
+
+typedef enum {
+  JJ_OK = 0,
+  JJ_ERR_INVALID = -1,   /* bad argument (null pointer, unknown op, length mismatch: cf. the assert at src/lib.rs:841) */
+  JJ_ERR_HIP = -2,       /* a HIP runtime call failed; see jj_last_error() */
+  JJ_ERR_NOMEM = -3,
+  JJ_ERR_NODEVICE = -4   /* no gfx950 device visible — there is no CPU fallback */
+} jj_status;
+
+/* ---- context ------------------------------------------------------------------------------------------- */
+int jj_ctx_create(int device, jj_ctx** out);
+int jj_ctx_destroy(jj_ctx* ctx);
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the context's own stream. */
+int jj_ctx_set_stream(jj_ctx* ctx, void* hip_stream);
+int jj_ctx_sync(jj_ctx* ctx);
+const char* jj_last_error(jj_ctx* ctx);
+int jj_version(void);
+/* Device properties used for roofline accounting: out[0]=CU count, out[1]=clock kHz, out[2]=wavefront size. */
+int jj_device_info(jj_ctx* ctx, int64_t out[4]);
+
+/* ---- fields: Fq (base, = bls12_381::Scalar, src/lib.rs:62) and Fr (scalar, src/fr.rs) ------------------------ */
+/* Elements are 32-byte little-endian integers; inputs are reduced mod p like from_raw (src/fr.rs:347-349),
+ * outputs are canonical.  reference: add 638-647, sub 620-634, mul 592-616, neg 651-665, square 353-381,
+ * double 261-263, invert 438-540 (ok=0 & out=0 for zero), sqrt 384-399 (Fr) / Tonelli-Shanks (Fq, bls12_381). */
+int jj_fq_add(jj_ctx*, size_t n, const void* a, const void* b, void* out);
+int jj_fq_sub(jj_ctx*, size_t n, const void* a, const void* b, void* out);
+int jj_fq_mul(jj_ctx*, size_t n, const void* a, const void* b, void* out);
+int jj_fq_neg(jj_ctx*, size_t n, const void* a, void* out);
+int jj_fq_square(jj_ctx*, size_t n, const void* a, void* out);
+int jj_fq_double(jj_ctx*, size_t n, const void* a, void* out);
+int jj_fq_invert(jj_ctx*, size_t n, const void* a, void* out, uint8_t* ok);
+int jj_fq_sqrt(jj_ctx*, size_t n, const void* a, void* out, uint8_t* ok);
+int jj_fr_add(jj_ctx*, size_t n, const void* a, const void* b, void* out);
+int jj_fr_sub(jj_ctx*, size_t n, const void* a, const void* b, void* out);
+int jj_fr_mul(jj_ctx*, size_t n, const void* a, const void* b, void* out);
+int jj_fr_neg(jj_ctx*, size_t n, const void* a, void* out);
+int jj_fr_square(jj_ctx*, size_t n, const void* a, void* out);
+int jj_fr_double(jj_ctx*, size_t n, const void* a, void* out);
+int jj_fr_invert(jj_ctx*, size_t n, const void* a, void* out, uint8_t* ok);
+int jj_fr_sqrt(jj_ctx*, size_t n, const void* a, void* out, uint8_t* ok);
+/* from_bytes: ok=0 (and out=0) when the integer is >= p (src/fr.rs:268-292).  from_bytes_wide: 64-byte input
+ * reduced mod p (src/fr.rs:312-343). */
+int jj_fq_from_bytes(jj_ctx*, size_t n, const void* in32, void* out, uint8_t* ok);
+int jj_fr_from_bytes(jj_ctx*, size_t n, const void* in32, void* out, uint8_t* ok);
+int jj_fq_from_bytes_wide(jj_ctx*, size_t n, const void* in64, void* out);
+int jj_fr_from_bytes_wide(jj_ctx*, size_t n, const void* in64, void* out);
+
+/* ---- elementwise point operations (affine in, affine out; extended coordinates inside) ----------------- */
+/* double src/lib.rs:739-828; add/sub = Ext +/- Affine src/lib.rs:1012-1028; neg 92-104; mul_by_cofactor 722-724 */
+int jj_point_double(jj_ctx*, size_t n, const void* p, void* out);
+int jj_point_add(jj_ctx*, size_t n, const void* p, const void* q, void* out);
+int jj_point_sub(jj_ctx*, size_t n, const void* p, const void* q, void* out);
+int jj_point_neg(jj_ctx*, size_t n, const void* p, void* out);
+int jj_point_mul_by_cofactor(jj_ctx*, size_t n, const void* p, void* out);
+/* AffinePoint::to_niels src/lib.rs:652-658: out = 96 bytes (v+u, v-u, 2d*u*v), each canonical LE */
+int jj_point_to_niels(jj_ctx*, size_t n, const void* p, void* out96);
+/* predicates -> uint8_t; src/lib.rs:691-719 and (is_on_curve) 670-675 */
+int jj_is_identity(jj_ctx*, size_t n, const void* p, uint8_t* out);
+int jj_is_small_order(jj_ctx*, size_t n, const void* p, uint8_t* out);
+int jj_is_torsion_free(jj_ctx*, size_t n, const void* p, uint8_t* out);
+int jj_is_prime_order(jj_ctx*, size_t n, const void* p, uint8_t* out);
+int jj_is_on_curve(jj_ctx*, size_t n, const void* p, uint8_t* out);
+/* Sum for ExtendedPoint (src/lib.rs:183-193): out = one affine point = sum of n affine points (identity if n=0) */
+int jj_point_sum(jj_ctx*, size_t n, const void* p, void* out64);
+
+/* ---- scalar multiplication ----------------------------------------------------------------------------- */
+/* out[i] = to_affine(points[i] * scalars[i])   (`ExtendedPoint * Fr`, src/lib.rs:873-879 -> 831-833 -> 357-379).
+ * scalars are raw 32-byte patterns; only the low 252 bits are used, as in the reference ladder.
+ * Windowed signed-digit ladder with a per-lane table; results are specified for on-curve points. */
+int jj_varbase_mul(jj_ctx*, size_t n, const void* scalars32, const void* points64, void* out64);
+/* Same group element, but computed with the reference's exact 252-step double-and-add-always ladder and
+ * returned in projective form: out = 160 bytes (U,V,Z,T1,T2 canonical LE) matching the Rust ExtendedPoint
+ * fields bit for bit.  For parity testing, not for throughput. */
+int jj_varbase_mul_exact(jj_ctx*, size_t n, const void* scalars32, const void* points64, void* out160);
+
+/* Fixed-base: `AffineNielsPoint * Fr` / multiply_bits (src/lib.rs:272-310) for one base point.
+ * The table holds signed-window multiples of the base as affine-Niels triples; it is staged in LDS by the kernel. */
+int jj_fixedbase_table_create(jj_ctx*, const void* base64, int window_bits /* 0 = default */, jj_table** out);
+int jj_fixedbase_table_destroy(jj_ctx*, jj_table* t);
+int jj_fixedbase_mul(jj_ctx*, const jj_table* t, size_t n, const void* scalars32, void* out64);
+
+/* Multi-scalar multiplication: out = to_affine(sum_i points[i] * scalars[i])  (semantics: iterator Sum of
+ * `p * k`, src/lib.rs:183-193 + 873-879; the reference has no MSM algorithm).  n = 0 gives the identity. */
+int jj_msm(jj_ctx*, size_t n, const void* scalars32, const void* points64, void* out64);
+
+/* ---- encodings ----------------------------------------------------------------------------------------- */
+#define JJ_DECOMPRESS_ZIP216          1u  /* reject the two non-canonical encodings (src/lib.rs:469-471, 522-531) */
+#define JJ_DECOMPRESS_TORSION_FREE    2u  /* additionally require [r]P = O  (SubgroupPoint::from_bytes, lib.rs:1427-1429) */
+#define JJ_DECOMPRESS_NOT_SMALL_ORDER 4u  /* additionally reject small-order points (lib.rs:699-705) */
+#define JJ_DECOMPRESS_CLEAR_COFACTOR  8u  /* return [8]P (lib.rs:722-724, 1343-1345) */
+/* AffinePoint::from_bytes / from_bytes_pre_zip216_compatibility / batch_from_bytes (src/lib.rs:469-627) */
+int jj_decompress(jj_ctx*, size_t n, const void* in32, unsigned flags, void* out64, uint8_t* ok);
+/* AffinePoint::to_bytes src/lib.rs:455-464 */
+int jj_compress(jj_ctx*, size_t n, const void* points64, void* out32);
+/* batch_normalize src/lib.rs:1084-1107: n x 160 bytes (U,V,Z,T1,T2 canonical LE) -> n x 64 bytes affine */
+int jj_batch_normalize(jj_ctx*, size_t n, const void* ext160, void* out64);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JUBJUB_HIP_H */

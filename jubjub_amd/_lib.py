@@ -1,0 +1,74 @@
+"""ctypes binding of libjubjub_hip.so (C ABI in include/jubjub_hip.h).  Fails loudly if the library is missing:
+there is no CPU fallback in the product path."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libjubjub_hip.so")
+
+JJ_OK, JJ_ERR_INVALID, JJ_ERR_HIP, JJ_ERR_NOMEM, JJ_ERR_NODEVICE = 0, -1, -2, -3, -4
+
+_vp, _sz, _u8p = C.c_void_p, C.c_size_t, C.c_void_p
+
+# name -> argtypes after the context pointer
+_SIGS = {}
+for _f in ("fq", "fr"):
+    for _op in ("add", "sub", "mul"):
+        _SIGS["jj_%s_%s" % (_f, _op)] = [_sz, _vp, _vp, _vp]
+    for _op in ("neg", "square", "double", "from_bytes_wide"):
+        _SIGS["jj_%s_%s" % (_f, _op)] = [_sz, _vp, _vp]
+    for _op in ("invert", "sqrt", "from_bytes"):
+        _SIGS["jj_%s_%s" % (_f, _op)] = [_sz, _vp, _vp, _u8p]
+for _op in ("double", "neg", "mul_by_cofactor", "to_niels"):
+    _SIGS["jj_point_" + _op] = [_sz, _vp, _vp]
+for _op in ("add", "sub"):
+    _SIGS["jj_point_" + _op] = [_sz, _vp, _vp, _vp]
+for _op in ("is_identity", "is_small_order", "is_torsion_free", "is_prime_order", "is_on_curve"):
+    _SIGS["jj_" + _op] = [_sz, _vp, _u8p]
+_SIGS.update({
+    "jj_point_sum": [_sz, _vp, _vp],
+    "jj_varbase_mul": [_sz, _vp, _vp, _vp],
+    "jj_varbase_mul_exact": [_sz, _vp, _vp, _vp],
+    "jj_fixedbase_table_destroy": [_vp],
+    "jj_fixedbase_mul": [_vp, _sz, _vp, _vp],
+    "jj_msm": [_sz, _vp, _vp, _vp],
+    "jj_decompress": [_sz, _vp, C.c_uint, _vp, _u8p],
+    "jj_compress": [_sz, _vp, _vp],
+    "jj_batch_normalize": [_sz, _vp, _vp],
+    "jj_ctx_set_stream": [_vp],
+    "jj_ctx_sync": [],
+})
+
+EXPORTS = sorted(list(_SIGS) + ["jj_ctx_create", "jj_ctx_destroy", "jj_last_error", "jj_version", "jj_device_info",
+                                "jj_fixedbase_table_create"])
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libjubjub_hip.so is not built (%s). Run `python -m jubjub_amd.build` or __graft_entry__.build(); "
+            "there is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, args in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype = C.c_int
+        fn.argtypes = [_vp] + args
+    lib.jj_ctx_create.restype = C.c_int
+    lib.jj_ctx_create.argtypes = [C.c_int, C.POINTER(_vp)]
+    lib.jj_ctx_destroy.restype = C.c_int
+    lib.jj_ctx_destroy.argtypes = [_vp]
+    lib.jj_last_error.restype = C.c_char_p
+    lib.jj_last_error.argtypes = [_vp]
+    lib.jj_version.restype = C.c_int
+    lib.jj_version.argtypes = []
+    lib.jj_device_info.restype = C.c_int
+    lib.jj_device_info.argtypes = [_vp, C.POINTER(C.c_int64)]
+    lib.jj_fixedbase_table_create.restype = C.c_int
+    lib.jj_fixedbase_table_create.argtypes = [_vp, _vp, C.c_int, C.POINTER(_vp)]
+    _lib = lib
+    return lib

@@ -1,0 +1,143 @@
+// Jubjub twisted-Edwards group law on CDNA4 — device code, one point per lane, all coordinates in registers.
+//
+// Formulas are the reference's (same completed-point structure, so projective coordinates agree with the
+// Rust code up to the field representation):
+//   double        : reference ExtendedPoint::double           src/lib.rs:739-828  (4S + 3M)
+//   add ExtNiels  : reference Add<&ExtendedNielsPoint>        src/lib.rs:883-920  (8M)
+//   add AffNiels  : reference Add<&AffineNielsPoint>          src/lib.rs:944-968  (7M)
+//   into_extended : reference CompletedPoint::into_extended   src/lib.rs:1052-1060
+// Lazy-reduction bounds of every intermediate are verified by tools/bounds_check.py.
+#pragma once
+#include "jj_field.h"
+
+namespace jj {
+
+struct Affine { Fe u, v; };                 // reference AffinePoint          src/lib.rs:80-84
+struct Ext { Fe u, v, z, t1, t2; };         // reference ExtendedPoint        src/lib.rs:138-145
+struct ANiels { Fe vpu, vmu, t2d; };        // reference AffineNielsPoint     src/lib.rs:254-259
+struct ENiels { Fe vpu, vmu, z, t2d; };     // reference ExtendedNielsPoint   src/lib.rs:326-332
+
+struct Curve {
+  typedef Fq F;
+
+  static JJ_DEV Ext identity() { Ext p; p.u = F::zero(); p.v = F::one(); p.z = F::one(); p.t1 = F::zero(); p.t2 = F::zero(); return p; }  // lib.rs:680-688
+  static JJ_DEV ANiels aniels_identity() { ANiels n; n.vpu = F::one(); n.vmu = F::one(); n.t2d = F::zero(); return n; }                      // lib.rs:263-269
+  static JJ_DEV ENiels eniels_identity() { ENiels n; n.vpu = F::one(); n.vmu = F::one(); n.z = F::one(); n.t2d = F::zero(); return n; }       // lib.rs:347-354
+  static JJ_DEV Ext from_affine(const Affine& a) { Ext p; p.u = a.u; p.v = a.v; p.z = F::one(); p.t1 = a.u; p.t2 = a.v; return p; }           // lib.rs:640-648
+
+  // completed point (u:z, v:t) -> extended; lib.rs:1052-1060.  cu,ct,cz N-like; cv L.
+  static JJ_DEV Ext into_extended(const Fe& cu, const Fe& cv, const Fe& cz, const Fe& ct) {
+    Ext p;
+    p.u = F::mul(cu, ct);
+    p.v = F::mul(cv, cz);
+    p.z = F::mul(cz, ct);
+    p.t1 = cu;
+    p.t2 = cv;
+    return p;
+  }
+
+  // lib.rs:739-828
+  static JJ_DEV Ext dbl(const Ext& p) {
+    const Fe uu = F::sqr(p.u);
+    const Fe vv = F::sqr(p.v);
+    const Fe zz = F::sqr(p.z);
+    const Fe uv2 = F::sqr(F::add(p.u, p.v));
+    const Fe vpu = F::add(vv, uu);            // VV + UU   (L)
+    const Fe vmu = F::sub(vv, uu);            // VV - UU   (N, +3p)
+    const Fe zz2 = F::add(zz, zz);            // 2 Z^2     (L)
+    const Fe cu = F::sub(uv2, vpu);           // (U+V)^2 - (VV+UU)
+    const Fe ct = F::sub_wide(zz2, vmu);      // 2Z^2 - (VV-UU)
+    return into_extended(cu, vpu, vmu, ct);
+  }
+
+  // lib.rs:883-920
+  static JJ_DEV Ext add(const Ext& p, const ENiels& n) {
+    const Fe a = F::mul(F::sub(p.v, p.u), n.vmu);
+    const Fe b = F::mul(F::add(p.v, p.u), n.vpu);
+    const Fe c = F::mul(F::mul(p.t1, p.t2), n.t2d);
+    const Fe zz = F::mul(p.z, n.z);
+    const Fe d = F::add(zz, zz);
+    return into_extended(F::sub(b, a), F::add(b, a), F::carry(F::add(d, c)), F::sub(d, c));
+  }
+  // lib.rs:922-940
+  static JJ_DEV Ext sub(const Ext& p, const ENiels& n) {
+    const Fe a = F::mul(F::sub(p.v, p.u), n.vpu);
+    const Fe b = F::mul(F::add(p.v, p.u), n.vmu);
+    const Fe c = F::mul(F::mul(p.t1, p.t2), n.t2d);
+    const Fe zz = F::mul(p.z, n.z);
+    const Fe d = F::add(zz, zz);
+    return into_extended(F::sub(b, a), F::add(b, a), F::sub(d, c), F::carry(F::add(d, c)));
+  }
+  // lib.rs:944-968
+  static JJ_DEV Ext add(const Ext& p, const ANiels& n) {
+    const Fe a = F::mul(F::sub(p.v, p.u), n.vmu);
+    const Fe b = F::mul(F::add(p.v, p.u), n.vpu);
+    const Fe c = F::mul(F::mul(p.t1, p.t2), n.t2d);
+    const Fe d = F::add(p.z, p.z);
+    return into_extended(F::sub(b, a), F::add(b, a), F::carry(F::add(d, c)), F::sub(d, c));
+  }
+  // lib.rs:970-988
+  static JJ_DEV Ext sub(const Ext& p, const ANiels& n) {
+    const Fe a = F::mul(F::sub(p.v, p.u), n.vpu);
+    const Fe b = F::mul(F::add(p.v, p.u), n.vmu);
+    const Fe c = F::mul(F::mul(p.t1, p.t2), n.t2d);
+    const Fe d = F::add(p.z, p.z);
+    return into_extended(F::sub(b, a), F::add(b, a), F::sub(d, c), F::carry(F::add(d, c)));
+  }
+
+  // lib.rs:652-658 : (v+u, v-u, u*v*2d), all N
+  static JJ_DEV ANiels to_niels(const Affine& a) {
+    ANiels n;
+    n.vpu = F::carry(F::add(a.v, a.u));
+    n.vmu = F::sub(a.v, a.u);
+    n.t2d = F::mul(F::mul(a.u, a.v), F::konst(FqP::D2));
+    return n;
+  }
+  // lib.rs:728-735
+  static JJ_DEV ENiels to_niels(const Ext& p) {
+    ENiels n;
+    n.vpu = F::carry(F::add(p.v, p.u));
+    n.vmu = F::sub(p.v, p.u);
+    n.z = p.z;
+    n.t2d = F::mul(F::mul(p.t1, p.t2), F::konst(FqP::D2));
+    return n;
+  }
+  // -(vpu, vmu, t2d) = (vmu, vpu, -t2d)   (negation of the underlying point, lib.rs:92-104)
+  static JJ_DEV ENiels neg(const ENiels& n) { ENiels r; r.vpu = n.vmu; r.vmu = n.vpu; r.z = n.z; r.t2d = F::neg(n.t2d); return r; }
+  static JJ_DEV ANiels neg(const ANiels& n) { ANiels r; r.vpu = n.vmu; r.vmu = n.vpu; r.t2d = F::neg(n.t2d); return r; }
+  // lib.rs:195-211
+  static JJ_DEV Ext neg(const Ext& p) { Ext r; r.u = F::neg(p.u); r.v = p.v; r.z = p.z; r.t1 = F::neg(p.t1); r.t2 = p.t2; return r; }
+
+  // masked select: mask all-ones -> b
+  static JJ_DEV ENiels select(const ENiels& a, const ENiels& b, u32 mask) {
+    ENiels r; r.vpu = F::select(a.vpu, b.vpu, mask); r.vmu = F::select(a.vmu, b.vmu, mask); r.z = F::select(a.z, b.z, mask); r.t2d = F::select(a.t2d, b.t2d, mask); return r;
+  }
+  static JJ_DEV ANiels select(const ANiels& a, const ANiels& b, u32 mask) {
+    ANiels r; r.vpu = F::select(a.vpu, b.vpu, mask); r.vmu = F::select(a.vmu, b.vmu, mask); r.t2d = F::select(a.t2d, b.t2d, mask); return r;
+  }
+
+  static JJ_DEV Ext mul_by_cofactor(const Ext& p) { return dbl(dbl(dbl(p))); }                       // lib.rs:722-724
+  static JJ_DEV bool is_identity(const Ext& p) { return F::is_zero(p.u) && F::eq(p.v, p.z); }        // lib.rs:691-696
+  static JJ_DEV bool is_small_order(const Ext& p) { return F::is_zero(dbl(dbl(p)).u); }              // lib.rs:699-705
+  // v^2 - u^2 == 1 + d u^2 v^2   (lib.rs:670-675)
+  static JJ_DEV bool is_on_curve(const Affine& a) {
+    const Fe u2 = F::sqr(a.u), v2 = F::sqr(a.v);
+    const Fe lhs = F::sub(v2, u2);
+    const Fe rhs = F::add(F::one(), F::mul(F::konst(FqP::D), F::mul(u2, v2)));
+    return F::eq(lhs, rhs);
+  }
+
+  // exact reference ladder: 252 iterations of double + add-select, bits 251..0 (lib.rs:357-379)
+  static JJ_DEV Ext ladder_exact(const ENiels& n, const u32 (&k)[8]) {
+    const ENiels zero = eniels_identity();
+    Ext acc = identity();
+    for (int i = 251; i >= 0; i--) {
+      acc = dbl(acc);
+      const u32 bit = (k[i >> 5] >> (i & 31)) & 1u;
+      acc = add(acc, select(zero, n, 0u - bit));
+    }
+    return acc;
+  }
+};
+
+}  // namespace jj

@@ -1,0 +1,504 @@
+// libjubjub_hip.so — host side of the C ABI declared in include/jubjub_hip.h.
+// Owns the device context (stream, staging + workspace buffers) and launches the kernels in jj_kernels.h.
+// There is no CPU fallback: without a gfx950 device jj_ctx_create fails with JJ_ERR_NODEVICE.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <algorithm>
+
+#include "../../include/jubjub_hip.h"
+#include "jj_kernels.h"
+
+using namespace jj;
+
+#define JJ_VERSION 100  /* 0.1.0 */
+#define JJ_API extern "C" __attribute__((visibility("default")))
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct jj_table {
+  u32* dev = nullptr;      // FB_ENTRIES x ANIELS_WORDS
+  int window_bits = FB_W;
+};
+
+struct jj_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  int cus = 0, clock_khz = 0, wave = 64;
+  std::string err;
+  // staging for host-pointer arguments (inputs 0..3, outputs 0..1) and kernel workspaces
+  DevBuf in[4], out[2], okb, ws_ext, ws_scratch, ws_tables, ws_tmp[4];
+};
+
+#define HIPCHK(ctx, call)                                                                   \
+  do {                                                                                      \
+    hipError_t e_ = (call);                                                                 \
+    if (e_ != hipSuccess) {                                                                 \
+      char b_[256];                                                                         \
+      snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      (ctx)->err = b_;                                                                      \
+      return JJ_ERR_HIP;                                                                    \
+    }                                                                                       \
+  } while (0)
+
+static int ensure(jj_ctx* c, DevBuf& b, size_t bytes) {
+  if (bytes <= b.cap) return JJ_OK;
+  if (b.p) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+  size_t want = std::max(bytes, (size_t)4096);
+  hipError_t e = hipMalloc(&b.p, want);
+  if (e != hipSuccess) { c->err = std::string("hipMalloc failed: ") + hipGetErrorString(e); b.p = nullptr; return JJ_ERR_NOMEM; }
+  b.cap = want;
+  return JJ_OK;
+}
+
+static bool is_device_ptr(const void* p) {
+  if (!p) return false;
+  hipPointerAttribute_t a;
+  hipError_t e = hipPointerGetAttributes(&a, p);
+  if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+  return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+// Resolves an input pointer: device pointers pass through (must be 16-byte aligned), host data is copied into a
+// staging buffer.
+static int stage_in(jj_ctx* c, int slot, const void* p, size_t bytes, const void** dev) {
+  if (bytes == 0) { *dev = nullptr; return JJ_OK; }
+  if (!p) { c->err = "null input pointer"; return JJ_ERR_INVALID; }
+  if (is_device_ptr(p)) {
+    if (((uintptr_t)p & 15u) != 0) { c->err = "device pointers must be 16-byte aligned"; return JJ_ERR_INVALID; }
+    *dev = p; return JJ_OK;
+  }
+  int rc = ensure(c, c->in[slot], bytes); if (rc) return rc;
+  if (bytes) HIPCHK(c, hipMemcpyAsync(c->in[slot].p, p, bytes, hipMemcpyHostToDevice, c->stream));
+  *dev = c->in[slot].p; return JJ_OK;
+}
+struct OutRef { void* user; void* dev; size_t bytes; bool host; };
+static int stage_out(jj_ctx* c, DevBuf& buf, void* p, size_t bytes, OutRef* o) {
+  o->user = p; o->bytes = bytes;
+  if (bytes == 0) { o->dev = nullptr; o->host = false; return JJ_OK; }
+  if (!p) { c->err = "null output pointer"; return JJ_ERR_INVALID; }
+  if (is_device_ptr(p)) {
+    if (((uintptr_t)p & 15u) != 0) { c->err = "device pointers must be 16-byte aligned"; return JJ_ERR_INVALID; }
+    o->dev = p; o->host = false; return JJ_OK;
+  }
+  int rc = ensure(c, buf, bytes); if (rc) return rc;
+  o->dev = buf.p; o->host = true; return JJ_OK;
+}
+static int finish_out(jj_ctx* c, const OutRef& o, bool* need_sync) {
+  if (o.host) {
+    if (o.bytes) HIPCHK(c, hipMemcpyAsync(o.user, o.dev, o.bytes, hipMemcpyDeviceToHost, c->stream));
+    *need_sync = true;
+  }
+  return JJ_OK;
+}
+static int finish(jj_ctx* c, bool need_sync) {
+  HIPCHK(c, hipGetLastError());
+  if (need_sync) HIPCHK(c, hipStreamSynchronize(c->stream));
+  return JJ_OK;
+}
+static inline unsigned blocks_for(size_t n, unsigned bs = 256) { return (unsigned)((n + bs - 1) / bs); }
+
+// ---------------------------------------------------------------------------------------------------- context
+JJ_API int jj_version(void) { return JJ_VERSION; }
+
+JJ_API int jj_ctx_create(int device, jj_ctx** out) {
+  if (!out) return JJ_ERR_INVALID;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) { (void)hipGetLastError(); return JJ_ERR_NODEVICE; }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return JJ_ERR_NODEVICE;
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return JJ_ERR_NODEVICE;   // this library ships gfx950 code only
+  if (hipSetDevice(device) != hipSuccess) return JJ_ERR_HIP;
+  jj_ctx* c = new jj_ctx();
+  c->device = device;
+  c->cus = prop.multiProcessorCount;
+  c->clock_khz = prop.clockRate;
+  c->wave = prop.warpSize;
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return JJ_ERR_HIP; }
+  c->stream = c->own_stream;
+  // the fixed-base kernel needs the full 160 KiB LDS carve-out
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fixedbase), hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS_BYTES);
+  *out = c;
+  return JJ_OK;
+}
+JJ_API int jj_ctx_destroy(jj_ctx* c) {
+  if (!c) return JJ_ERR_INVALID;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  DevBuf* all[] = {&c->in[0], &c->in[1], &c->in[2], &c->in[3], &c->out[0], &c->out[1], &c->okb, &c->ws_ext, &c->ws_scratch, &c->ws_tables,
+                   &c->ws_tmp[0], &c->ws_tmp[1], &c->ws_tmp[2], &c->ws_tmp[3]};
+  for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+  return JJ_OK;
+}
+JJ_API int jj_ctx_set_stream(jj_ctx* c, void* s) {
+  if (!c) return JJ_ERR_INVALID;
+  c->stream = s ? (hipStream_t)s : c->own_stream;
+  return JJ_OK;
+}
+JJ_API int jj_ctx_sync(jj_ctx* c) {
+  if (!c) return JJ_ERR_INVALID;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return JJ_OK;
+}
+JJ_API const char* jj_last_error(jj_ctx* c) { return c ? c->err.c_str() : "null context"; }
+JJ_API int jj_device_info(jj_ctx* c, int64_t out[4]) {
+  if (!c || !out) return JJ_ERR_INVALID;
+  out[0] = c->cus; out[1] = c->clock_khz; out[2] = c->wave; out[3] = 0;
+  return JJ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------- fields
+template <class P, int OP>
+static int field_op(jj_ctx* c, size_t n, const void* a, const void* b, void* out, uint8_t* ok, bool want_ok) {
+  if (!c) return JJ_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t in_bytes = (OP == OP_FROM_WIDE ? 64 : 32) * n;
+  const void *da = nullptr, *db = nullptr;
+  int rc;
+  if ((rc = stage_in(c, 0, a, in_bytes, &da))) return rc;
+  const bool binary = (OP == OP_ADD || OP == OP_SUB || OP == OP_MUL);
+  if (binary && (rc = stage_in(c, 1, b, 32 * n, &db))) return rc;
+  OutRef o, ok_o; ok_o.host = false; ok_o.dev = nullptr;
+  if ((rc = stage_out(c, c->out[0], out, 32 * n, &o))) return rc;
+  if (want_ok && (rc = stage_out(c, c->okb, ok, n, &ok_o))) return rc;
+  if (n) hipLaunchKernelGGL((k_field_op<P, OP>), dim3(blocks_for(n)), dim3(256), 0, c->stream, n, da, db, o.dev, (uint8_t*)ok_o.dev);
+  bool sync = false;
+  if ((rc = finish_out(c, o, &sync))) return rc;
+  if (want_ok && (rc = finish_out(c, ok_o, &sync))) return rc;
+  return finish(c, sync);
+}
+#define FIELD_BIN(name, P, OP) JJ_API int name(jj_ctx* c, size_t n, const void* a, const void* b, void* out) { return field_op<P, OP>(c, n, a, b, out, nullptr, false); }
+#define FIELD_UN(name, P, OP) JJ_API int name(jj_ctx* c, size_t n, const void* a, void* out) { return field_op<P, OP>(c, n, a, nullptr, out, nullptr, false); }
+#define FIELD_UN_OK(name, P, OP) JJ_API int name(jj_ctx* c, size_t n, const void* a, void* out, uint8_t* ok) { if (!ok) return JJ_ERR_INVALID; return field_op<P, OP>(c, n, a, nullptr, out, ok, true); }
+FIELD_BIN(jj_fq_add, FqP, OP_ADD) FIELD_BIN(jj_fq_sub, FqP, OP_SUB) FIELD_BIN(jj_fq_mul, FqP, OP_MUL)
+FIELD_UN(jj_fq_neg, FqP, OP_NEG) FIELD_UN(jj_fq_square, FqP, OP_SQUARE) FIELD_UN(jj_fq_double, FqP, OP_DOUBLE)
+FIELD_UN_OK(jj_fq_invert, FqP, OP_INVERT) FIELD_UN_OK(jj_fq_sqrt, FqP, OP_SQRT) FIELD_UN_OK(jj_fq_from_bytes, FqP, OP_FROM_BYTES)
+FIELD_UN(jj_fq_from_bytes_wide, FqP, OP_FROM_WIDE)
+FIELD_BIN(jj_fr_add, FrP, OP_ADD) FIELD_BIN(jj_fr_sub, FrP, OP_SUB) FIELD_BIN(jj_fr_mul, FrP, OP_MUL)
+FIELD_UN(jj_fr_neg, FrP, OP_NEG) FIELD_UN(jj_fr_square, FrP, OP_SQUARE) FIELD_UN(jj_fr_double, FrP, OP_DOUBLE)
+FIELD_UN_OK(jj_fr_invert, FrP, OP_INVERT) FIELD_UN_OK(jj_fr_sqrt, FrP, OP_SQRT) FIELD_UN_OK(jj_fr_from_bytes, FrP, OP_FROM_BYTES)
+FIELD_UN(jj_fr_from_bytes_wide, FrP, OP_FROM_WIDE)
+
+// ---------------------------------------------------------------------------------------------------- normalisation
+static SoA soa_of(DevBuf& b, size_t n) { SoA s; s.base = (u32*)b.p; s.n = n; return s; }
+static int ensure_ext(jj_ctx* c, size_t n, int coords) { return ensure(c, c->ws_ext, (size_t)coords * NL * 4 * std::max(n, (size_t)1)); }
+
+// ext SoA (coords 0..2) -> affine 64 B (mode 0) or compressed 32 B (mode 1) at device pointer dout
+static int normalize_launch(jj_ctx* c, size_t n, SoA ext, void* dout, int mode) {
+  if (!n) return JJ_OK;
+  int rc = ensure(c, c->ws_scratch, (size_t)NL * 4 * n); if (rc) return rc;
+  SoA scratch = soa_of(c->ws_scratch, n);
+  // chunk length: amortise the ~330-multiplication inversion, but keep >= ~8 waves per CU in flight
+  const size_t lanes_wanted = (size_t)c->cus * 64 * 8;
+  if (n >= lanes_wanted * 32) { size_t T = (n + 31) / 32; hipLaunchKernelGGL((k_normalize<32>), dim3(blocks_for(T)), dim3(256), 0, c->stream, n, T, ext, scratch, dout, mode); }
+  else if (n >= lanes_wanted * 4) { size_t T = (n + 15) / 16; hipLaunchKernelGGL((k_normalize<16>), dim3(blocks_for(T)), dim3(256), 0, c->stream, n, T, ext, scratch, dout, mode); }
+  else { size_t T = (n + 3) / 4; hipLaunchKernelGGL((k_normalize<4>), dim3(blocks_for(T)), dim3(256), 0, c->stream, n, T, ext, scratch, dout, mode); }
+  return JJ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------- point ops
+template <int OP>
+static int point_op(jj_ctx* c, size_t n, const void* p, const void* q, void* out, size_t out_elem) {
+  if (!c) return JJ_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  const void *dp = nullptr, *dq = nullptr;
+  int rc;
+  if ((rc = stage_in(c, 0, p, 64 * n, &dp))) return rc;
+  if ((OP == PT_ADD || OP == PT_SUB) && (rc = stage_in(c, 1, q, 64 * n, &dq))) return rc;
+  OutRef o;
+  if ((rc = stage_out(c, c->out[0], out, out_elem * n, &o))) return rc;
+  if ((rc = ensure_ext(c, n, 3))) return rc;
+  SoA ext = soa_of(c->ws_ext, n);
+  if (n) {
+    hipLaunchKernelGGL((k_point_op<OP>), dim3(blocks_for(n)), dim3(256), 0, c->stream, n, dp, dq, ext, o.dev);
+    if (OP <= PT_COFACTOR && (rc = normalize_launch(c, n, ext, o.dev, 0))) return rc;
+  }
+  bool sync = false;
+  if ((rc = finish_out(c, o, &sync))) return rc;
+  return finish(c, sync);
+}
+JJ_API int jj_point_double(jj_ctx* c, size_t n, const void* p, void* out) { return point_op<PT_DOUBLE>(c, n, p, nullptr, out, 64); }
+JJ_API int jj_point_add(jj_ctx* c, size_t n, const void* p, const void* q, void* out) { return point_op<PT_ADD>(c, n, p, q, out, 64); }
+JJ_API int jj_point_sub(jj_ctx* c, size_t n, const void* p, const void* q, void* out) { return point_op<PT_SUB>(c, n, p, q, out, 64); }
+JJ_API int jj_point_neg(jj_ctx* c, size_t n, const void* p, void* out) { return point_op<PT_NEG>(c, n, p, nullptr, out, 64); }
+JJ_API int jj_point_mul_by_cofactor(jj_ctx* c, size_t n, const void* p, void* out) { return point_op<PT_COFACTOR>(c, n, p, nullptr, out, 64); }
+JJ_API int jj_point_to_niels(jj_ctx* c, size_t n, const void* p, void* out96) { return point_op<PT_TO_NIELS>(c, n, p, nullptr, out96, 96); }
+JJ_API int jj_is_identity(jj_ctx* c, size_t n, const void* p, uint8_t* out) { return point_op<PT_IS_IDENTITY>(c, n, p, nullptr, out, 1); }
+JJ_API int jj_is_small_order(jj_ctx* c, size_t n, const void* p, uint8_t* out) { return point_op<PT_IS_SMALL_ORDER>(c, n, p, nullptr, out, 1); }
+JJ_API int jj_is_on_curve(jj_ctx* c, size_t n, const void* p, uint8_t* out) { return point_op<PT_IS_ON_CURVE>(c, n, p, nullptr, out, 1); }
+
+// ---------------------------------------------------------------------------------------------------- var-base
+// launch geometry of the windowed ladder: persistent grid, one 1152-byte table slot per lane
+static void varbase_geometry(jj_ctx* c, size_t n, unsigned* blocks, size_t* threads) {
+  const size_t max_threads = (size_t)c->cus * 256 * 2;         // 2 blocks of 256 per CU = 2 waves / SIMD
+  size_t t = std::min(max_threads, ((n + 255) / 256) * 256);
+  if (t == 0) t = 256;
+  *blocks = (unsigned)(t / 256); *threads = t;
+}
+static int varbase_to_ext(jj_ctx* c, size_t n, const void* ds, const void* dp, SoA ext, bool five) {
+  unsigned blocks; size_t threads;
+  varbase_geometry(c, n, &blocks, &threads);
+  int rc = ensure(c, c->ws_tables, threads * (size_t)(VB_TABLE * ENIELS_WORDS) * 4); if (rc) return rc;
+  if (five) hipLaunchKernelGGL(k_varbase5, dim3(blocks), dim3(256), 0, c->stream, n, ds, dp, (u32*)c->ws_tables.p, ext);
+  else hipLaunchKernelGGL(k_varbase, dim3(blocks), dim3(256), 0, c->stream, n, ds, dp, (u32*)c->ws_tables.p, ext);
+  return JJ_OK;
+}
+JJ_API int jj_varbase_mul(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out) {
+  if (!c) return JJ_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  const void *ds, *dp; int rc; OutRef o;
+  if ((rc = stage_in(c, 0, scalars, 32 * n, &ds))) return rc;
+  if ((rc = stage_in(c, 1, points, 64 * n, &dp))) return rc;
+  if ((rc = stage_out(c, c->out[0], out, 64 * n, &o))) return rc;
+  if ((rc = ensure_ext(c, n, 3))) return rc;
+  SoA ext = soa_of(c->ws_ext, n);
+  if (n) {
+    if ((rc = varbase_to_ext(c, n, ds, dp, ext, false))) return rc;
+    if ((rc = normalize_launch(c, n, ext, o.dev, 0))) return rc;
+  }
+  bool sync = false;
+  if ((rc = finish_out(c, o, &sync))) return rc;
+  return finish(c, sync);
+}
+JJ_API int jj_varbase_mul_exact(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out160) {
+  if (!c) return JJ_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  const void *ds, *dp; int rc; OutRef o;
+  if ((rc = stage_in(c, 0, scalars, 32 * n, &ds))) return rc;
+  if ((rc = stage_in(c, 1, points, 64 * n, &dp))) return rc;
+  if ((rc = stage_out(c, c->out[0], out160, 160 * n, &o))) return rc;
+  if (n) hipLaunchKernelGGL(k_varbase_exact, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, ds, dp, o.dev);
+  bool sync = false;
+  if ((rc = finish_out(c, o, &sync))) return rc;
+  return finish(c, sync);
+}
+
+// [r]P == O for affine device points -> ok bytes (combine: 0 set, 1 and)
+static int torsion_free_dev(jj_ctx* c, size_t n, const void* dpts, uint8_t* dok, int combine) {
+  int rc;
+  if ((rc = ensure(c, c->ws_tmp[0], 32 * std::max(n, (size_t)1)))) return rc;
+  if ((rc = ensure(c, c->ws_tmp[1], 32))) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->ws_tmp[1].p, FR_MODULUS_BYTES, 32, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_fill_scalar, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, c->ws_tmp[0].p, (const uint8_t*)c->ws_tmp[1].p);
+  if ((rc = ensure_ext(c, n, 3))) return rc;
+  SoA ext = soa_of(c->ws_ext, n);
+  if ((rc = varbase_to_ext(c, n, c->ws_tmp[0].p, dpts, ext, false))) return rc;
+  hipLaunchKernelGGL(k_is_identity_ext, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, ext, dok, combine);
+  return JJ_OK;
+}
+static int torsion_pred(jj_ctx* c, size_t n, const void* p, uint8_t* out, bool prime_order) {
+  if (!c) return JJ_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  const void* dp; int rc; OutRef o;
+  if ((rc = stage_in(c, 0, p, 64 * n, &dp))) return rc;
+  if ((rc = stage_out(c, c->okb, out, n, &o))) return rc;
+  if (n) {
+    if ((rc = torsion_free_dev(c, n, dp, (uint8_t*)o.dev, 0))) return rc;
+    if (prime_order) {   // & !is_identity  (reference src/lib.rs:717-719)
+      if ((rc = ensure(c, c->ws_tmp[2], n))) return rc;
+      if ((rc = ensure_ext(c, n, 3))) return rc;
+      hipLaunchKernelGGL((k_point_op<PT_IS_IDENTITY>), dim3(blocks_for(n)), dim3(256), 0, c->stream, n, dp, (const void*)nullptr, soa_of(c->ws_ext, n), c->ws_tmp[2].p);
+      hipLaunchKernelGGL(k_and_bytes, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, (uint8_t*)o.dev, (const uint8_t*)c->ws_tmp[2].p, 1);
+    }
+  }
+  bool sync = false;
+  if ((rc = finish_out(c, o, &sync))) return rc;
+  return finish(c, sync);
+}
+JJ_API int jj_is_torsion_free(jj_ctx* c, size_t n, const void* p, uint8_t* out) { return torsion_pred(c, n, p, out, false); }
+JJ_API int jj_is_prime_order(jj_ctx* c, size_t n, const void* p, uint8_t* out) { return torsion_pred(c, n, p, out, true); }
+
+// ---------------------------------------------------------------------------------------------------- fixed-base
+JJ_API int jj_fixedbase_table_create(jj_ctx* c, const void* base64, int window_bits, jj_table** out) {
+  if (!c || !out || !base64) return JJ_ERR_INVALID;
+  if (window_bits != 0 && window_bits != FB_W) { c->err = "only window_bits = 6 (or 0 = default) is built"; return JJ_ERR_INVALID; }
+  HIPCHK(c, hipSetDevice(c->device));
+  uint8_t base[64];
+  if (is_device_ptr(base64)) { HIPCHK(c, hipMemcpy(base, base64, 64, hipMemcpyDeviceToHost)); } else memcpy(base, base64, 64);
+  // entry (i, j) = (j+1) * 64^i * B ; entry FB_NWIN*FB_ENT = 64^42 * B.  Build the scalars on the host, multiply on the GPU.
+  const size_t ne = FB_ENTRIES;
+  std::vector<uint8_t> scal(ne * 32, 0), pts(ne * 64);
+  for (size_t e = 0; e < ne; e++) {
+    const int i = (int)(e / FB_ENT), j = (int)(e % FB_ENT);
+    const unsigned mult = (e == (size_t)FB_NWIN * FB_ENT) ? 1u : (unsigned)(j + 1);
+    const int bit = 6 * i;                                   // mult << bit, mult <= 32 (6 bits)
+    uint8_t* s = &scal[e * 32];
+    unsigned long long v = (unsigned long long)mult << (bit & 7);
+    for (int b = 0; b < 3 && (bit >> 3) + b < 32; b++) s[(bit >> 3) + b] = (uint8_t)(v >> (8 * b));
+    memcpy(&pts[e * 64], base, 64);
+  }
+  // NB: 64^42 = 2^252 has bit 252 set, which the ladder ignores (top four bits); build it as 2 * (2^251 * B) instead.
+  {
+    uint8_t* s = &scal[(size_t)FB_NWIN * FB_ENT * 32];
+    memset(s, 0, 32); s[31] = 0x08;                          // 2^251
+  }
+  std::vector<uint8_t> aff(ne * 64);
+  int rc = jj_varbase_mul(c, ne, scal.data(), pts.data(), aff.data()); if (rc) return rc;
+  // double the last entry: 2^252 B
+  rc = jj_point_double(c, 1, &aff[(size_t)FB_NWIN * FB_ENT * 64], &aff[(size_t)FB_NWIN * FB_ENT * 64]); if (rc) return rc;
+  jj_table* t = new jj_table();
+  if (hipMalloc((void**)&t->dev, (size_t)FB_LDS_BYTES) != hipSuccess) { delete t; c->err = "hipMalloc(table) failed"; return JJ_ERR_NOMEM; }
+  const void* dpts;
+  if ((rc = stage_in(c, 0, aff.data(), ne * 64, &dpts))) { (void)hipFree(t->dev); delete t; return rc; }
+  hipLaunchKernelGGL(k_affine_to_table, dim3(blocks_for(ne)), dim3(256), 0, c->stream, ne, dpts, t->dev);
+  rc = finish(c, true);
+  if (rc) { (void)hipFree(t->dev); delete t; return rc; }
+  *out = t;
+  return JJ_OK;
+}
+JJ_API int jj_fixedbase_table_destroy(jj_ctx* c, jj_table* t) {
+  if (!c || !t) return JJ_ERR_INVALID;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  if (t->dev) (void)hipFree(t->dev);
+  delete t;
+  return JJ_OK;
+}
+JJ_API int jj_fixedbase_mul(jj_ctx* c, const jj_table* t, size_t n, const void* scalars, void* out) {
+  if (!c || !t) return JJ_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  const void* ds; int rc; OutRef o;
+  if ((rc = stage_in(c, 0, scalars, 32 * n, &ds))) return rc;
+  if ((rc = stage_out(c, c->out[0], out, 64 * n, &o))) return rc;
+  if ((rc = ensure_ext(c, n, 3))) return rc;
+  SoA ext = soa_of(c->ws_ext, n);
+  if (n) {
+    const unsigned blocks = (unsigned)std::min((size_t)c->cus, (n + 511) / 512);   // one 512-thread workgroup per CU (LDS-bound)
+    hipLaunchKernelGGL(k_fixedbase, dim3(blocks), dim3(512), FB_LDS_BYTES, c->stream, n, ds, (const u32*)t->dev, ext);
+    if ((rc = normalize_launch(c, n, ext, o.dev, 0))) return rc;
+  }
+  bool sync = false;
+  if ((rc = finish_out(c, o, &sync))) return rc;
+  return finish(c, sync);
+}
+
+// ---------------------------------------------------------------------------------------------------- sums / MSM
+// folds a 5-coordinate SoA of n extended points down to one, result left in (U,V,Z) coords of the returned SoA
+static int sum_reduce(jj_ctx* c, size_t n, DevBuf* a, DevBuf* b, SoA* result) {
+  constexpr int FOLD = 32;
+  DevBuf* cur = a; DevBuf* nxt = b;
+  size_t m = n;
+  while (m > 1) {
+    const size_t T = (m + FOLD - 1) / FOLD;
+    int rc = ensure(c, *nxt, (size_t)5 * NL * 4 * T); if (rc) return rc;
+    hipLaunchKernelGGL((k_sum_pass<FOLD>), dim3(blocks_for(T)), dim3(256), 0, c->stream, m, T, soa_of(*cur, m), soa_of(*nxt, T));
+    std::swap(cur, nxt);
+    m = T;
+  }
+  *result = soa_of(*cur, 1);
+  return JJ_OK;
+}
+static const uint8_t AFFINE_IDENTITY_BYTES[64] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1};
+static int write_identity(jj_ctx* c, const OutRef& o) {
+  HIPCHK(c, hipMemcpyAsync(o.dev, AFFINE_IDENTITY_BYTES, 64, hipMemcpyHostToDevice, c->stream));
+  return JJ_OK;
+}
+JJ_API int jj_point_sum(jj_ctx* c, size_t n, const void* p, void* out64) {
+  if (!c) return JJ_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc; OutRef o;
+  if ((rc = stage_out(c, c->out[0], out64, 64, &o))) return rc;
+  if (n == 0) { if ((rc = write_identity(c, o))) return rc; }
+  else {
+    const void* dp;
+    if ((rc = stage_in(c, 0, p, 64 * n, &dp))) return rc;
+    if ((rc = ensure(c, c->ws_tmp[2], (size_t)5 * NL * 4 * n))) return rc;
+    hipLaunchKernelGGL(k_affine_to_soa5, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, dp, soa_of(c->ws_tmp[2], n));
+    SoA res;
+    if ((rc = sum_reduce(c, n, &c->ws_tmp[2], &c->ws_tmp[3], &res))) return rc;
+    if ((rc = normalize_launch(c, 1, res, o.dev, 0))) return rc;
+  }
+  bool sync = false;
+  if ((rc = finish_out(c, o, &sync))) return rc;
+  return finish(c, sync);
+}
+JJ_API int jj_msm(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out64) {
+  if (!c) return JJ_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc; OutRef o;
+  if ((rc = stage_out(c, c->out[0], out64, 64, &o))) return rc;
+  if (n == 0) { if ((rc = write_identity(c, o))) return rc; }
+  else {
+    const void *ds, *dp;
+    if ((rc = stage_in(c, 0, scalars, 32 * n, &ds))) return rc;
+    if ((rc = stage_in(c, 1, points, 64 * n, &dp))) return rc;
+    if ((rc = ensure(c, c->ws_tmp[2], (size_t)5 * NL * 4 * n))) return rc;
+    if ((rc = varbase_to_ext(c, n, ds, dp, soa_of(c->ws_tmp[2], n), true))) return rc;
+    SoA res;
+    if ((rc = sum_reduce(c, n, &c->ws_tmp[2], &c->ws_tmp[3], &res))) return rc;
+    if ((rc = normalize_launch(c, 1, res, o.dev, 0))) return rc;
+  }
+  bool sync = false;
+  if ((rc = finish_out(c, o, &sync))) return rc;
+  return finish(c, sync);
+}
+
+// ---------------------------------------------------------------------------------------------------- encodings
+JJ_API int jj_compress(jj_ctx* c, size_t n, const void* points, void* out32) {
+  if (!c) return JJ_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  const void* dp; int rc; OutRef o;
+  if ((rc = stage_in(c, 0, points, 64 * n, &dp))) return rc;
+  if ((rc = stage_out(c, c->out[0], out32, 32 * n, &o))) return rc;
+  if (n) hipLaunchKernelGGL(k_compress, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, dp, o.dev);
+  bool sync = false;
+  if ((rc = finish_out(c, o, &sync))) return rc;
+  return finish(c, sync);
+}
+JJ_API int jj_decompress(jj_ctx* c, size_t n, const void* in32, unsigned flags, void* out64, uint8_t* ok) {
+  if (!c || !ok) return JJ_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  const void* di; int rc; OutRef o, ko;
+  if ((rc = stage_in(c, 0, in32, 32 * n, &di))) return rc;
+  if ((rc = stage_out(c, c->out[0], out64, 64 * n, &o))) return rc;
+  if ((rc = stage_out(c, c->okb, ok, n, &ko))) return rc;
+  if (n) {
+    hipLaunchKernelGGL(k_decompress, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, di, flags, o.dev, (uint8_t*)ko.dev);
+    // Invalid encodings were written as (0,0); the subgroup kernels below may compute garbage for them, the ok byte masks it.
+    if (flags & JJ_DECOMPRESS_TORSION_FREE) { if ((rc = torsion_free_dev(c, n, o.dev, (uint8_t*)ko.dev, 1))) return rc; }
+    if (flags & JJ_DECOMPRESS_NOT_SMALL_ORDER) {
+      if ((rc = ensure(c, c->ws_tmp[2], n))) return rc;
+      if ((rc = ensure_ext(c, n, 3))) return rc;
+      hipLaunchKernelGGL((k_point_op<PT_IS_SMALL_ORDER>), dim3(blocks_for(n)), dim3(256), 0, c->stream, n, (const void*)o.dev, (const void*)nullptr, soa_of(c->ws_ext, n), c->ws_tmp[2].p);
+      hipLaunchKernelGGL(k_and_bytes, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, (uint8_t*)ko.dev, (const uint8_t*)c->ws_tmp[2].p, 1);
+    }
+    if (flags & JJ_DECOMPRESS_CLEAR_COFACTOR) {
+      if ((rc = ensure_ext(c, n, 3))) return rc;
+      SoA ext = soa_of(c->ws_ext, n);
+      hipLaunchKernelGGL((k_point_op<PT_COFACTOR>), dim3(blocks_for(n)), dim3(256), 0, c->stream, n, (const void*)o.dev, (const void*)nullptr, ext, o.dev);
+      if ((rc = normalize_launch(c, n, ext, o.dev, 0))) return rc;
+    }
+    if (flags & (JJ_DECOMPRESS_TORSION_FREE | JJ_DECOMPRESS_NOT_SMALL_ORDER | JJ_DECOMPRESS_CLEAR_COFACTOR))
+      hipLaunchKernelGGL(k_mask_outputs, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, o.dev, (const uint8_t*)ko.dev);
+  }
+  bool sync = false;
+  if ((rc = finish_out(c, o, &sync))) return rc;
+  if ((rc = finish_out(c, ko, &sync))) return rc;
+  return finish(c, sync);
+}
+JJ_API int jj_batch_normalize(jj_ctx* c, size_t n, const void* ext160, void* out64) {
+  if (!c) return JJ_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  const void* de; int rc; OutRef o;
+  if ((rc = stage_in(c, 0, ext160, 160 * n, &de))) return rc;
+  if ((rc = stage_out(c, c->out[0], out64, 64 * n, &o))) return rc;
+  if ((rc = ensure_ext(c, n, 3))) return rc;
+  SoA ext = soa_of(c->ws_ext, n);
+  if (n) {
+    hipLaunchKernelGGL(k_ext160_to_soa, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, de, ext);
+    if ((rc = normalize_launch(c, n, ext, o.dev, 0))) return rc;
+  }
+  bool sync = false;
+  if ((rc = finish_out(c, o, &sync))) return rc;
+  return finish(c, sync);
+}

@@ -1,0 +1,235 @@
+// Jubjub prime-field arithmetic for CDNA4 (gfx950) — device code.
+//
+// Representation (MI355X-first, NOT the reference's 4x64 layout): one field element per lane, held in
+// registers as 9 limbs x 29 bits ("reduced radix"), Montgomery form with R = 2^261.
+//
+// Why: measured on MI355X (experiments/ubench, profiles/ubench_r1.txt) v_mad_u64_u32 issues at the same
+// 4-cycle/wave64 rate as every other VOP3 instruction, but any multi-word carry chain goes through an SGPR
+// carry (v_add_co/v_addc_co), which on gfx940/950 costs an extra 2 wait states per link ("VALU writes SGPR ->
+// VALU reads it").  With 29-bit limbs a 9x9 schoolbook column sum (<= 18 products of < 2^61) never overflows a
+// 64-bit VGPR pair, so a Montgomery product is 153 back-to-back v_mad_u64_u32 (81 a*b + 72 m*p) plus ~75 plain
+// shift/mask/add instructions and NO carry flags at all.  Additions are 9 independent v_add_u32 (lazy, no
+// carry); subtraction adds a limb-lifted multiple of p (value K*p) so no limb underflows.
+//
+// What it restates: results are the same canonical residues as the reference's Fq/Fr (reference
+// src/fr.rs:246-665 is the template for both fields; Fq = bls12_381::Scalar).  Only canonical little-endian
+// 32-byte encodings cross the kernel boundary (reference Fr::to_bytes src/fr.rs:296-308, from_bytes 268-292).
+//
+// Bounds contract (checked by tools/bounds_check.py and by tests at extreme values):
+//   "N"   : limbs < 2^29 (top limb small), value < 2p            -- output of mul/sqr/sub/norm
+//   "L"   : limbs < 2^30 + 2^8,            value < 4p            -- output of add(N, N)
+//   mul/sqr inputs: per-limb bound product A*B < 2^60.6, value product alpha*beta <= 64 (in units of p)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "jj_constants.h"
+
+namespace jj {
+
+#define JJ_DEV __device__ __forceinline__
+
+struct Fe {
+  u32 l[NL];
+};
+
+template <class P>
+struct Field {
+  // ---------------------------------------------------------------- constants
+  static JJ_DEV Fe one() { Fe r; _Pragma("unroll") for (int i = 0; i < NL; i++) r.l[i] = P::ONE[i]; return r; }
+  static JJ_DEV Fe zero() { Fe r; _Pragma("unroll") for (int i = 0; i < NL; i++) r.l[i] = 0; return r; }
+  template <int N>
+  static JJ_DEV Fe konst(const u32 (&c)[N]) { Fe r; _Pragma("unroll") for (int i = 0; i < NL; i++) r.l[i] = c[i]; return r; }
+
+  // ---------------------------------------------------------------- Montgomery reduction of 17 columns
+  // c[0..16] hold the column sums of a 9x9 limb product (each < ~2^63); on return r = (sum c[k] 2^(29k)) / 2^261 mod p
+  // with limbs < 2^29.  Mirrors the role of reference montgomery_reduce (src/fr.rs:544-588) with 29-bit digits.
+  static JJ_DEV Fe reduce(u64 (&c)[2 * NL]) {
+    _Pragma("unroll") for (int k = 0; k < NL; k++) {
+      u32 m;
+      if constexpr (P::NINV == LMASK) m = (0u - (u32)c[k]) & LMASK;   // p = 1 mod 2^29  (Fq): m = -c
+      else m = ((u32)c[k] * P::NINV) & LMASK;                          // generic (Fr)
+      if constexpr (P::P[0] == 1u) c[k] += m;
+      else c[k] += (u64)m * P::P[0];
+      c[k + 1] += c[k] >> LB;                                           // low 29 bits of c[k] are now zero
+      _Pragma("unroll") for (int j = 1; j < NL; j++) c[k + j] += (u64)m * P::P[j];
+    }
+    Fe r;
+    _Pragma("unroll") for (int k = NL; k < 2 * NL - 1; k++) {
+      r.l[k - NL] = (u32)c[k] & LMASK;
+      c[k + 1] += c[k] >> LB;
+    }
+    r.l[NL - 1] = (u32)c[2 * NL - 1];
+    return r;
+  }
+
+  // r = a*b/R mod p.  reference Fr::mul src/fr.rs:592-616.
+  static JJ_DEV Fe mul(const Fe& a, const Fe& b) {
+    u64 c[2 * NL];
+    _Pragma("unroll") for (int k = 0; k < 2 * NL - 1; k++) {
+      u64 s = 0;
+      _Pragma("unroll") for (int i = 0; i < NL; i++) {
+        const int j = k - i;
+        if (j >= 0 && j < NL) s += (u64)a.l[i] * b.l[j];
+      }
+      c[k] = s;
+    }
+    c[2 * NL - 1] = 0;
+    return reduce(c);
+  }
+
+  // r = a*a/R mod p.  reference Fr::square src/fr.rs:353-381 (same cross-term doubling idea).
+  static JJ_DEV Fe sqr(const Fe& a) {
+    u32 a2[NL];
+    _Pragma("unroll") for (int i = 0; i < NL; i++) a2[i] = a.l[i] << 1;
+    u64 c[2 * NL];
+    _Pragma("unroll") for (int k = 0; k < 2 * NL - 1; k++) {
+      u64 s = 0;
+      _Pragma("unroll") for (int i = 0; i < NL; i++) {
+        const int j = k - i;
+        if (j > i && j < NL) s += (u64)a.l[i] * a2[j];
+      }
+      if ((k & 1) == 0) s += (u64)a.l[k / 2] * a.l[k / 2];
+      c[k] = s;
+    }
+    c[2 * NL - 1] = 0;
+    return reduce(c);
+  }
+
+  // ---------------------------------------------------------------- additive ops (lazy, carry-free)
+  // r = a + b, no carry.  reference Fr::add src/fr.rs:638-647 (which reduces; we defer).
+  static JJ_DEV Fe add(const Fe& a, const Fe& b) {
+    Fe r; _Pragma("unroll") for (int i = 0; i < NL; i++) r.l[i] = a.l[i] + b.l[i]; return r;
+  }
+  // one parallel carry step: limbs < 2^32 in, limbs <= 2^29 + 7 out, value unchanged.
+  static JJ_DEV Fe carry(const Fe& a) {
+    Fe r;
+    r.l[0] = a.l[0] & LMASK;
+    _Pragma("unroll") for (int i = 1; i < NL - 1; i++) r.l[i] = (a.l[i] & LMASK) + (a.l[i - 1] >> LB);
+    r.l[NL - 1] = a.l[NL - 1] + (a.l[NL - 2] >> LB);
+    return r;
+  }
+  // r = a - b (+ 3p), b with limbs <= 2^30, value(b) < 3p.  Output carried ("N"-like limbs <= 2^29+7).
+  // reference Fr::sub src/fr.rs:620-634.
+  static JJ_DEV Fe sub(const Fe& a, const Fe& b) {
+    Fe t; _Pragma("unroll") for (int i = 0; i < NL; i++) t.l[i] = a.l[i] + P::BIAS_N[i] - b.l[i];
+    return carry(t);
+  }
+  // r = a - b (+ 5p), b with limbs <= 2^31, value(b) < 5p.
+  static JJ_DEV Fe sub_wide(const Fe& a, const Fe& b) {
+    Fe t; _Pragma("unroll") for (int i = 0; i < NL; i++) t.l[i] = a.l[i] + P::BIAS_L[i] - b.l[i];
+    return carry(t);
+  }
+  // r = -a (+3p).  reference Fr::neg src/fr.rs:651-665.
+  static JJ_DEV Fe neg(const Fe& a) {
+    Fe t; _Pragma("unroll") for (int i = 0; i < NL; i++) t.l[i] = P::BIAS_N[i] - a.l[i];
+    return carry(t);
+  }
+  static JJ_DEV Fe dbl(const Fe& a) { return add(a, a); }  // reference Fr::double src/fr.rs:261-263
+
+  // ---------------------------------------------------------------- canonical form
+  // exact sequential carry: limbs < 2^32 in, limbs < 2^29 out (top limb takes the rest)
+  static JJ_DEV Fe carry_full(const Fe& a) {
+    Fe r; u32 c = 0;
+    _Pragma("unroll") for (int i = 0; i < NL - 1; i++) { u32 t = a.l[i] + c; r.l[i] = t & LMASK; c = t >> LB; }
+    r.l[NL - 1] = a.l[NL - 1] + c;
+    return r;
+  }
+  // a normalized (limbs < 2^29), value < 2p  ->  value mod p in [0, p)
+  static JJ_DEV Fe cond_sub_p(const Fe& a) {
+    Fe d; int32_t borrow = 0;
+    _Pragma("unroll") for (int i = 0; i < NL; i++) {
+      int32_t t = (int32_t)a.l[i] - (int32_t)P::P[i] + borrow;
+      d.l[i] = (u32)t & LMASK;
+      borrow = t >> LB;  // arithmetic: 0 or -1
+    }
+    // borrow == -1  <=> a < p : keep a
+    const u32 keep = (u32)borrow;  // all-ones or zero
+    Fe r; _Pragma("unroll") for (int i = 0; i < NL; i++) r.l[i] = (a.l[i] & keep) | (d.l[i] & ~keep);
+    return r;
+  }
+  // Any in-contract element (value < 64p/.., limbs <= 2^31) -> the unique Montgomery representative in [0,p), limbs < 2^29.
+  static JJ_DEV Fe canon(const Fe& a) { return cond_sub_p(mul(a, one())); }
+  static JJ_DEV bool is_zero_canon(const Fe& a) {
+    u32 o = 0; _Pragma("unroll") for (int i = 0; i < NL; i++) o |= a.l[i]; return o == 0;
+  }
+  static JJ_DEV bool eq_canon(const Fe& a, const Fe& b) {
+    u32 o = 0; _Pragma("unroll") for (int i = 0; i < NL; i++) o |= a.l[i] ^ b.l[i]; return o == 0;
+  }
+  static JJ_DEV bool is_zero(const Fe& a) { return is_zero_canon(canon(a)); }          // reference ct_eq(&zero)
+  static JJ_DEV bool eq(const Fe& a, const Fe& b) { return eq_canon(canon(a), canon(b)); }  // reference Fr::ct_eq src/fr.rs:48-55
+  // select: mask all-ones -> b, zero -> a (reference conditional_select src/fr.rs:64-73); bit-masking, not v_cndmask
+  static JJ_DEV Fe select(const Fe& a, const Fe& b, u32 mask) {
+    Fe r; _Pragma("unroll") for (int i = 0; i < NL; i++) r.l[i] = a.l[i] ^ ((a.l[i] ^ b.l[i]) & mask); return r;
+  }
+
+  // ---------------------------------------------------------------- wire format: 8 x u32 little-endian canonical words
+  // plain 256-bit integer -> 9x29 limbs (no reduction)
+  static JJ_DEV Fe unpack(const u32 (&w)[8]) {
+    Fe r;
+    _Pragma("unroll") for (int i = 0; i < NL; i++) {
+      const int bit = LB * i, wi = bit >> 5, sh = bit & 31;
+      u32 v = w[wi] >> sh;
+      if (sh > 32 - LB && wi + 1 < 8) v |= w[wi + 1] << (32 - sh);
+      r.l[i] = v & LMASK;
+    }
+    return r;
+  }
+  // limbs < 2^29 (value < 2^256) -> 8 words
+  static JJ_DEV void pack(u32 (&w)[8], const Fe& a) {
+    _Pragma("unroll") for (int wi = 0; wi < 8; wi++) {
+      const int bit = 32 * wi, li = bit / LB, sh = bit % LB;   // word starts inside limb li at offset sh
+      u32 v = a.l[li] >> sh;
+      const int got = LB - sh;
+      if (got < 32 && li + 1 < NL) v |= a.l[li + 1] << got;
+      if (got + LB < 32 && li + 2 < NL) v |= a.l[li + 2] << (got + LB);
+      w[wi] = v;
+    }
+  }
+  // reference Fr::from_raw src/fr.rs:347-349 : any 256-bit integer -> element (reduced mod p), Montgomery form
+  static JJ_DEV Fe from_words(const u32 (&w)[8]) { return mul(unpack(w), konst(P::R2)); }
+  // reference Fr::from_bytes src/fr.rs:268-292 : ok iff integer < p
+  static JJ_DEV Fe from_words_checked(const u32 (&w)[8], bool& ok) {
+    Fe x = unpack(w);
+    int32_t borrow = 0;
+    _Pragma("unroll") for (int i = 0; i < NL; i++) { int32_t t = (int32_t)x.l[i] - (int32_t)P::P[i] + borrow; borrow = t >> LB; }
+    ok = (borrow != 0);
+    return mul(x, konst(P::R2));
+  }
+  // reference Fr::to_bytes src/fr.rs:296-308 : Montgomery -> canonical integer words
+  static JJ_DEV void to_words(u32 (&w)[8], const Fe& a) {
+    Fe plain; _Pragma("unroll") for (int i = 0; i < NL; i++) plain.l[i] = (i == 0);
+    pack(w, cond_sub_p(mul(a, plain)));
+  }
+  // reference Fr::from_bytes_wide / from_u512 src/fr.rs:312-343 : 512-bit integer mod p
+  static JJ_DEV Fe from_words_wide(const u32 (&lo)[8], const u32 (&hi)[8]) {
+    return add(mul(unpack(lo), konst(P::R2)), mul(unpack(hi), konst(P::R2_256)));
+  }
+
+  // ---------------------------------------------------------------- exponentiation
+  // a^e for a public fixed exponent given as 8 x 32-bit words (4-bit fixed windows).
+  // reference Fr::pow_vartime src/fr.rs:422-434 (same value; exponent is public so no select needed).
+  template <int NW>
+  static JJ_DEV Fe pow_words(const Fe& a, const u32 (&e)[NW]) {
+    Fe tab[16];
+    tab[0] = one(); tab[1] = a;
+    for (int i = 2; i < 16; i++) tab[i] = mul(tab[i - 1], a);
+    Fe r = one();
+    bool started = false;
+    for (int wi = NW - 1; wi >= 0; wi--) {
+      const u32 word = e[wi];
+      for (int n = 7; n >= 0; n--) {
+        const u32 d = (word >> (4 * n)) & 15u;   // wave-uniform (public exponent)
+        if (started) { r = sqr(r); r = sqr(r); r = sqr(r); r = sqr(r); }
+        if (d) { r = started ? mul(r, tab[d]) : tab[d]; started = true; }
+      }
+    }
+    return r;
+  }
+  // reference Fr::invert src/fr.rs:438-540 : a^(p-2); ok = (a != 0); returns 0 when a == 0
+  static JJ_DEV Fe invert(const Fe& a) { return pow_words(a, P::PM2); }
+};
+
+typedef Field<FqP> Fq;
+typedef Field<FrP> Fr;
+
+}  // namespace jj

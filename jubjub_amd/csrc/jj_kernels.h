@@ -1,0 +1,512 @@
+// HIP kernels of the Jubjub engine (gfx950).  One field element / one curve point per lane, limbs in VGPRs.
+// Included by jj_engine.hip only.
+#pragma once
+#include "jj_curve.h"
+
+namespace jj {
+
+// ------------------------------------------------------------------------------------------------ I/O helpers
+// 32-byte wire elements are read/written as two 16-byte vectors per lane: 64 lanes x 32 B = 2 KiB contiguous per
+// wave instruction pair (coalesced AoS).  Pointers must be 16-byte aligned.
+static JJ_DEV void load8(u32 (&w)[8], const void* base, size_t idx) {
+  const uint4* p = reinterpret_cast<const uint4*>(static_cast<const uint8_t*>(base) + idx * 32);
+  const uint4 a = p[0], b = p[1];
+  w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+}
+static JJ_DEV void store8(void* base, size_t idx, const u32 (&w)[8]) {
+  uint4* p = reinterpret_cast<uint4*>(static_cast<uint8_t*>(base) + idx * 32);
+  p[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  p[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+static JJ_DEV void zero8(u32 (&w)[8]) { _Pragma("unroll") for (int i = 0; i < 8; i++) w[i] = 0; }
+
+// Internal device format for points between kernels: structure-of-arrays, limb-major: X[limb][i] (u32), so every
+// limb load/store of a wave is one contiguous 256-byte segment.
+struct SoA {
+  u32* base;      // [ncoord][NL][n]
+  size_t n;
+  JJ_DEV void put(int coord, size_t i, const Fe& a) const {
+    _Pragma("unroll") for (int l = 0; l < NL; l++) base[((size_t)coord * NL + l) * n + i] = a.l[l];
+  }
+  JJ_DEV Fe get(int coord, size_t i) const {
+    Fe a; _Pragma("unroll") for (int l = 0; l < NL; l++) a.l[l] = base[((size_t)coord * NL + l) * n + i]; return a;
+  }
+};
+
+static JJ_DEV Affine load_affine(const void* pts, size_t i) {
+  u32 wu[8], wv[8];
+  load8(wu, pts, 2 * i); load8(wv, pts, 2 * i + 1);
+  Affine a; a.u = Fq::from_words(wu); a.v = Fq::from_words(wv);   // from_raw semantics (reduces mod q)
+  return a;
+}
+static JJ_DEV void store_affine(void* out, size_t i, const Fe& u, const Fe& v) {
+  u32 w[8];
+  Fq::to_words(w, u); store8(out, 2 * i, w);
+  Fq::to_words(w, v); store8(out, 2 * i + 1, w);
+}
+
+// ------------------------------------------------------------------------------------------------ K1: field ops
+enum FieldOp { OP_ADD = 0, OP_SUB, OP_MUL, OP_NEG, OP_SQUARE, OP_DOUBLE, OP_INVERT, OP_SQRT, OP_FROM_BYTES, OP_FROM_WIDE };
+
+// Fr::sqrt: a^((r+1)/4), Some iff it squares back (reference src/fr.rs:384-399)
+static JJ_DEV Fe fr_sqrt(const Fe& a, bool& ok) {
+  const Fe s = Fr::pow_words(a, FrP::SQRT_EXP);
+  ok = Fr::eq(Fr::sqr(s), a);
+  return s;
+}
+// Fq::sqrt: Tonelli-Shanks with S = 32 and ROOT_OF_UNITY = 7^t, same value as ff::helpers::sqrt_tonelli_shanks
+// (bls12_381 0.8.0 Scalar::sqrt; call sites reference src/lib.rs:515,610,1253).  x = a^((t+1)/2) * g^s.
+static JJ_DEV Fe fq_sqrt(const Fe& a, bool& ok) {
+  const Fe w = Fq::pow_words(a, FqP::TM1D2);
+  Fe x = Fq::mul(a, w);
+  Fe b = Fq::canon(Fq::mul(x, w));
+  Fe z = Fq::konst(FqP::ROOT_OF_UNITY);
+  const Fe one = Fq::canon(Fq::one());
+  int v = 32;
+  #pragma unroll 1
+  for (int max_v = 32; max_v >= 1; max_v--) {
+    int k = 1;
+    Fe tmp = Fq::canon(Fq::sqr(b));
+    u32 j_less_than_v = ~0u;
+    #pragma unroll 1
+    for (int j = 2; j < max_v; j++) {
+      const u32 tmp_is_one = Fq::eq_canon(tmp, one) ? ~0u : 0u;
+      const Fe squared = Fq::canon(Fq::sqr(Fq::select(tmp, z, tmp_is_one)));
+      tmp = Fq::select(squared, tmp, tmp_is_one);
+      const Fe new_z = Fq::select(z, squared, tmp_is_one);
+      j_less_than_v &= (j != v) ? ~0u : 0u;
+      k = tmp_is_one ? k : j;
+      z = Fq::select(z, new_z, j_less_than_v);
+    }
+    const Fe result = Fq::mul(x, z);
+    x = Fq::select(result, x, Fq::eq_canon(b, one) ? ~0u : 0u);
+    z = Fq::sqr(z);
+    b = Fq::canon(Fq::mul(b, z));
+    v = k;
+  }
+  ok = Fq::eq(Fq::sqr(x), a);
+  return x;
+}
+
+template <class P, int OP>
+__global__ void __launch_bounds__(256) k_field_op(size_t n, const void* a, const void* b, void* out, uint8_t* okp) {
+  typedef Field<P> F;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 wa[8], wb[8], wo[8];
+  bool ok = true;
+  Fe r;
+  if constexpr (OP == OP_FROM_WIDE) {
+    load8(wa, a, 2 * i); load8(wb, a, 2 * i + 1);
+    r = F::from_words_wide(wa, wb);
+  } else if constexpr (OP == OP_FROM_BYTES) {
+    load8(wa, a, i);
+    r = F::from_words_checked(wa, ok);
+  } else {
+    load8(wa, a, i);
+    const Fe x = F::from_words(wa);
+    if constexpr (OP == OP_ADD || OP == OP_SUB || OP == OP_MUL) {
+      load8(wb, b, i);
+      const Fe y = F::from_words(wb);
+      if constexpr (OP == OP_ADD) r = F::add(x, y);
+      if constexpr (OP == OP_SUB) r = F::sub(x, y);
+      if constexpr (OP == OP_MUL) r = F::mul(x, y);
+    }
+    if constexpr (OP == OP_NEG) r = F::neg(x);
+    if constexpr (OP == OP_SQUARE) r = F::sqr(x);
+    if constexpr (OP == OP_DOUBLE) r = F::dbl(x);
+    if constexpr (OP == OP_INVERT) { ok = !F::is_zero(x); r = F::invert(x); }
+    if constexpr (OP == OP_SQRT) {
+      if constexpr (P::PBITS == 255) r = fq_sqrt(x, ok); else r = fr_sqrt(x, ok);
+    }
+  }
+  F::to_words(wo, r);
+  if (!ok) zero8(wo);
+  store8(out, i, wo);
+  if (okp) okp[i] = ok ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------ K2: point ops
+enum PointOp { PT_DOUBLE = 0, PT_ADD, PT_SUB, PT_NEG, PT_COFACTOR, PT_TO_NIELS,
+               PT_IS_IDENTITY, PT_IS_SMALL_ORDER, PT_IS_ON_CURVE };
+
+// Elementwise point ops.  Results leave as extended (U,V,Z) in the SoA buffer `ext` and are normalised by
+// k_normalize (one shared inversion per chunk), except the byte-valued predicates / to_niels.
+template <int OP>
+__global__ void __launch_bounds__(256) k_point_op(size_t n, const void* p, const void* q, SoA ext, void* out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Affine a = load_affine(p, i);
+  Ext e = Curve::from_affine(a), r;
+  if constexpr (OP == PT_DOUBLE) r = Curve::dbl(e);
+  if constexpr (OP == PT_ADD) r = Curve::add(e, Curve::to_niels(load_affine(q, i)));
+  if constexpr (OP == PT_SUB) r = Curve::sub(e, Curve::to_niels(load_affine(q, i)));
+  if constexpr (OP == PT_NEG) r = Curve::neg(e);
+  if constexpr (OP == PT_COFACTOR) r = Curve::mul_by_cofactor(e);
+  if constexpr (OP <= PT_COFACTOR) { ext.put(0, i, r.u); ext.put(1, i, r.v); ext.put(2, i, r.z); }
+  if constexpr (OP == PT_TO_NIELS) {
+    const ANiels t = Curve::to_niels(a);
+    u32 w[8];
+    Fq::to_words(w, t.vpu); store8(out, 3 * i, w);
+    Fq::to_words(w, t.vmu); store8(out, 3 * i + 1, w);
+    Fq::to_words(w, t.t2d); store8(out, 3 * i + 2, w);
+  }
+  if constexpr (OP == PT_IS_IDENTITY) static_cast<uint8_t*>(out)[i] = Curve::is_identity(e);
+  if constexpr (OP == PT_IS_SMALL_ORDER) static_cast<uint8_t*>(out)[i] = Curve::is_small_order(e);
+  if constexpr (OP == PT_IS_ON_CURVE) static_cast<uint8_t*>(out)[i] = Curve::is_on_curve(a);
+}
+
+// ------------------------------------------------------------------------------------------------ K5: normalise
+// batch_normalize (reference src/lib.rs:1084-1107, ff::BatchInverter): each lane owns CHUNK elements
+// (element j of lane t is index t + j*T, so every access is coalesced), multiplies their Z's through, inverts
+// once, and walks back.  Zero Z's are skipped like ff's BatchInverter (cannot occur for valid points).
+// mode 0: write affine 64 B; mode 1: write compressed 32 B (AffinePoint::to_bytes, src/lib.rs:455-464);
+// mode 2: write `ok`-style byte is_identity (U == 0 && V == Z) without inversion.
+template <int CHUNK>
+__global__ void __launch_bounds__(256) k_normalize(size_t n, size_t T, SoA ext, SoA scratch, void* out, int mode) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  Fe acc = Fq::one();
+  #pragma unroll 1
+  for (int j = 0; j < CHUNK; j++) {
+    const size_t i = t + (size_t)j * T;
+    if (i >= n) break;
+    scratch.put(0, i, acc);
+    const Fe z = ext.get(2, i);
+    const u32 zz = Fq::is_zero(z) ? ~0u : 0u;
+    acc = Fq::select(Fq::mul(acc, z), acc, zz);
+  }
+  Fe inv = Fq::invert(acc);
+  #pragma unroll 1
+  for (int j = CHUNK - 1; j >= 0; j--) {
+    const size_t i = t + (size_t)j * T;
+    if (i >= n) continue;
+    const Fe z = ext.get(2, i);
+    const u32 zz = Fq::is_zero(z) ? ~0u : 0u;
+    const Fe zinv = Fq::select(Fq::mul(inv, scratch.get(0, i)), Fq::zero(), zz);
+    inv = Fq::select(Fq::mul(inv, z), inv, zz);
+    const Fe u = Fq::mul(ext.get(0, i), zinv), v = Fq::mul(ext.get(1, i), zinv);
+    if (mode == 0) {
+      store_affine(out, i, u, v);
+    } else {
+      u32 wu[8], wv[8];
+      Fq::to_words(wu, u); Fq::to_words(wv, v);
+      wv[7] |= (wu[0] & 1u) << 31;
+      store8(out, i, wv);
+    }
+  }
+}
+
+// extended SoA -> is_identity byte (reference src/lib.rs:691-696), optionally AND/ANDN into an existing ok byte
+__global__ void __launch_bounds__(256) k_is_identity_ext(size_t n, SoA ext, uint8_t* out, int combine /*0 set,1 and,2 and-not*/) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool id = Fq::is_zero(ext.get(0, i)) && Fq::eq(ext.get(1, i), ext.get(2, i));
+  if (combine == 0) out[i] = id;
+  else if (combine == 1) out[i] = out[i] & (id ? 1 : 0);
+  else out[i] = out[i] & (id ? 0 : 1);
+}
+
+// user-facing batch_normalize input: 160-byte canonical (U,V,Z,T1,T2) -> SoA
+__global__ void __launch_bounds__(256) k_ext160_to_soa(size_t n, const void* ext160, SoA ext) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 w[8];
+  _Pragma("unroll") for (int c = 0; c < 3; c++) { load8(w, ext160, 5 * i + c); ext.put(c, i, Fq::from_words(w)); }
+}
+
+// ------------------------------------------------------------------------------------------------ K3: variable-base
+// Signed 4-bit fixed-window ladder, one scalar-mul per lane.  k (low 252 bits) is recoded as
+// k = sum_{i<63} d_i 16^i + d_63 16^63, d_i in [-8,7], d_63 in {0,1}, via k' = k + 0x888..8 (digit = nibble(k') - 8).
+// The lane's table {1..8}P (ExtendedNiels, 144 B each) lives in a per-lane slot of a global workspace (L2/MALL
+// resident); the entry for the next window is fetched before the four doublings that precede its use.
+// Group element equals the reference ladder's (src/lib.rs:357-379, 831-833); negation is exact on the whole curve.
+constexpr int VB_TABLE = 8;
+constexpr int ENIELS_WORDS = 4 * NL;   // 36 words = 144 B
+
+static JJ_DEV void store_eniels(u32* slot, const ENiels& n) {
+  uint4* p = reinterpret_cast<uint4*>(slot);
+  const Fe* c[4] = {&n.vpu, &n.vmu, &n.z, &n.t2d};
+  u32 w[ENIELS_WORDS];
+  _Pragma("unroll") for (int k = 0; k < 4; k++) _Pragma("unroll") for (int l = 0; l < NL; l++) w[k * NL + l] = c[k]->l[l];
+  _Pragma("unroll") for (int v = 0; v < ENIELS_WORDS / 4; v++) p[v] = make_uint4(w[4 * v], w[4 * v + 1], w[4 * v + 2], w[4 * v + 3]);
+}
+static JJ_DEV ENiels load_eniels(const u32* slot) {
+  const uint4* p = reinterpret_cast<const uint4*>(slot);
+  u32 w[ENIELS_WORDS];
+  _Pragma("unroll") for (int v = 0; v < ENIELS_WORDS / 4; v++) { const uint4 x = p[v]; w[4 * v] = x.x; w[4 * v + 1] = x.y; w[4 * v + 2] = x.z; w[4 * v + 3] = x.w; }
+  ENiels n;
+  _Pragma("unroll") for (int l = 0; l < NL; l++) { n.vpu.l[l] = w[l]; n.vmu.l[l] = w[NL + l]; n.z.l[l] = w[2 * NL + l]; n.t2d.l[l] = w[3 * NL + l]; }
+  return n;
+}
+// recode: k' = (k & (2^252-1)) + 0x0888...8 (63 nibbles of 8)
+static JJ_DEV void recode_signed4(u32 (&k)[8]) {
+  k[7] &= 0x0fffffffu;
+  u64 c = 0;
+  _Pragma("unroll") for (int i = 0; i < 8; i++) {
+    const u64 t = (u64)k[i] + RECODE4[i] + c;
+    k[i] = (u32)t; c = t >> 32;
+  }
+}
+// apply sign / zero to a table entry: digit d in [-8,7] given as nibble nb = d + 8
+static JJ_DEV ENiels signed_entry(const ENiels& e, u32 nb) {
+  const u32 is_neg = (nb < 8u) ? ~0u : 0u;
+  const u32 is_zero = (nb == 8u) ? ~0u : 0u;
+  ENiels r = Curve::select(e, Curve::neg(e), is_neg);
+  return Curve::select(r, Curve::eniels_identity(), is_zero);
+}
+static JJ_DEV u32 table_index(u32 nb) {   // |d| - 1, clamped to 0 for d == 0
+  const int d = (int)nb - 8;
+  const int a = d < 0 ? -d : d;
+  return (u32)(a > 0 ? a - 1 : 0);
+}
+
+static JJ_DEV Ext varbase_windowed(const Affine& P, u32 (&k)[8], u32* slot) {
+  // table: slot[j] = (j+1) P
+  const ANiels pn = Curve::to_niels(P);
+  Ext cur = Curve::from_affine(P);
+  store_eniels(slot, Curve::to_niels(cur));
+  #pragma unroll 1
+  for (int j = 1; j < VB_TABLE; j++) {
+    cur = Curve::add(cur, pn);
+    store_eniels(slot + j * ENIELS_WORDS, Curve::to_niels(cur));
+  }
+  recode_signed4(k);
+  // top digit d_63 in {0,1}
+  const u32 top = (k[7] >> 28) & 1u;
+  const Ext Pe = Curve::from_affine(P), id = Curve::identity();
+  Ext acc;
+  acc.u = Fq::select(id.u, Pe.u, 0u - top); acc.v = Fq::select(id.v, Pe.v, 0u - top); acc.z = Pe.z;
+  acc.t1 = Fq::select(id.t1, Pe.t1, 0u - top); acc.t2 = Fq::select(id.t2, Pe.t2, 0u - top);
+  #pragma unroll 1
+  for (int i = 62; i >= 0; i--) {
+    u32 word = k[0];
+    _Pragma("unroll") for (int w = 1; w < 8; w++) word = ((i >> 3) == w) ? k[w] : word;
+    const u32 nb = (word >> ((i & 7) * 4)) & 15u;
+    const ENiels e = load_eniels(slot + table_index(nb) * ENIELS_WORDS);
+    #pragma unroll 1
+    for (int d = 0; d < 4; d++) acc = Curve::dbl(acc);
+    acc = Curve::add(acc, signed_entry(e, nb));
+  }
+  return acc;
+}
+
+// grid-stride over scalars; each thread owns one table slot
+__global__ void __launch_bounds__(256) k_varbase(size_t n, const void* scalars, const void* points, u32* tables, SoA ext) {
+  const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t T = (size_t)gridDim.x * blockDim.x;
+  u32* slot = tables + gtid * (size_t)(VB_TABLE * ENIELS_WORDS);
+  #pragma unroll 1
+  for (size_t i = gtid; i < n; i += T) {
+    u32 k[8];
+    load8(k, scalars, i);
+    const Affine P = load_affine(points, i);
+    const Ext r = varbase_windowed(P, k, slot);
+    ext.put(0, i, r.u); ext.put(1, i, r.v); ext.put(2, i, r.z);
+  }
+}
+// the reference's exact ladder; writes all five projective coordinates canonically (160 B)
+__global__ void __launch_bounds__(256) k_varbase_exact(size_t n, const void* scalars, const void* points, void* out160) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 k[8];
+  load8(k, scalars, i);
+  const Affine P = load_affine(points, i);
+  const ENiels pn = Curve::to_niels(Curve::from_affine(P));
+  const ENiels zero = Curve::eniels_identity();
+  Ext acc = Curve::identity();
+  #pragma unroll 1
+  for (int i2 = 251; i2 >= 0; i2--) {
+    u32 word = k[0];
+    _Pragma("unroll") for (int w = 1; w < 8; w++) word = ((i2 >> 5) == w) ? k[w] : word;
+    const u32 bit = (word >> (i2 & 31)) & 1u;
+    acc = Curve::dbl(acc);
+    acc = Curve::add(acc, Curve::select(zero, pn, 0u - bit));
+  }
+  u32 w[8];
+  Fq::to_words(w, acc.u); store8(out160, 5 * i, w);
+  Fq::to_words(w, acc.v); store8(out160, 5 * i + 1, w);
+  Fq::to_words(w, acc.z); store8(out160, 5 * i + 2, w);
+  Fq::to_words(w, acc.t1); store8(out160, 5 * i + 3, w);
+  Fq::to_words(w, acc.t2); store8(out160, 5 * i + 4, w);
+}
+
+// ------------------------------------------------------------------------------------------------ K4: fixed-base
+// Signed 6-bit windows: k = sum_{i<42} d_i 64^i + d_42 64^42, d_i in [-32,31], d_42 in {0,1} (k' = k + 0x820820..).
+// Table[i][j] = (j+1) * 64^i * B as AffineNiels (27 limbs + 1 pad = 112 B), i < 42, j < 32, plus one entry for the
+// top carry window.  The whole table (1345 entries, 147 KiB) is staged into LDS once per workgroup; every
+// scalar-mul is then 43 mixed additions and no doubling.
+constexpr int FB_W = 6;
+constexpr int FB_NWIN = 42;
+constexpr int FB_ENT = 32;
+constexpr int FB_ENTRIES = FB_NWIN * FB_ENT + 1;
+constexpr int ANIELS_WORDS = 28;   // 27 + 1 pad, 16-byte multiple
+constexpr int FB_LDS_BYTES = FB_ENTRIES * ANIELS_WORDS * 4;
+
+static JJ_DEV ANiels lds_aniels(const u32* e) {
+  const uint4* p = reinterpret_cast<const uint4*>(e);
+  u32 w[ANIELS_WORDS];
+  _Pragma("unroll") for (int v = 0; v < ANIELS_WORDS / 4; v++) { const uint4 x = p[v]; w[4 * v] = x.x; w[4 * v + 1] = x.y; w[4 * v + 2] = x.z; w[4 * v + 3] = x.w; }
+  ANiels n;
+  _Pragma("unroll") for (int l = 0; l < NL; l++) { n.vpu.l[l] = w[l]; n.vmu.l[l] = w[NL + l]; n.t2d.l[l] = w[2 * NL + l]; }
+  return n;
+}
+// bits [6i, 6i+6) of the 256-bit little-endian integer k
+static JJ_DEV u32 window6(const u32 (&k)[8], int i) {
+  const int bit = 6 * i, wi = bit >> 5, sh = bit & 31;
+  u32 lo = k[0], hi = k[1];
+  _Pragma("unroll") for (int w = 1; w < 8; w++) { lo = (wi == w) ? k[w] : lo; hi = (wi == w) ? (w < 7 ? k[w + 1] : 0u) : hi; }
+  const u64 both = ((u64)hi << 32) | lo;
+  return (u32)(both >> sh) & 63u;
+}
+
+__global__ void __launch_bounds__(512) k_fixedbase(size_t n, const void* scalars, const u32* table, SoA ext) {
+  extern __shared__ __attribute__((aligned(16))) u32 lds[];
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(table);
+    uint4* dst = reinterpret_cast<uint4*>(lds);
+    for (int v = threadIdx.x; v < FB_LDS_BYTES / 16; v += blockDim.x) dst[v] = src[v];
+  }
+  __syncthreads();
+  const size_t T = (size_t)gridDim.x * blockDim.x;
+  #pragma unroll 1
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += T) {
+    u32 k[8];
+    load8(k, scalars, idx);
+    // recode: k' = (k mod 2^252) + sum_{i<42} 32 * 64^i
+    k[7] &= 0x0fffffffu;
+    {
+      u64 c = 0;
+      _Pragma("unroll") for (int i = 0; i < 8; i++) { const u64 t = (u64)k[i] + RECODE6[i] + c; k[i] = (u32)t; c = t >> 32; }
+    }
+    const u32 top = (k[7] >> 28) & 1u;                      // d_42
+    const ANiels idn = Curve::aniels_identity();
+    Ext acc = Curve::identity();
+    acc = Curve::add(acc, Curve::select(idn, lds_aniels(lds + (size_t)(FB_NWIN * FB_ENT) * ANIELS_WORDS), 0u - top));
+    #pragma unroll 1
+    for (int i = FB_NWIN - 1; i >= 0; i--) {
+      const u32 nb = window6(k, i);                          // d + 32
+      const int d = (int)nb - 32;
+      const u32 a = (u32)(d < 0 ? -d : d);
+      const u32 j = a ? a - 1 : 0;
+      const ANiels e = lds_aniels(lds + ((size_t)i * FB_ENT + j) * ANIELS_WORDS);
+      ANiels s = Curve::select(e, Curve::neg(e), d < 0 ? ~0u : 0u);
+      s = Curve::select(s, idn, a == 0 ? ~0u : 0u);
+      acc = Curve::add(acc, s);
+    }
+    ext.put(0, idx, acc.u); ext.put(1, idx, acc.v); ext.put(2, idx, acc.z);
+  }
+}
+// affine points (64 B canonical) -> table entries (AffineNiels limbs, 112 B)
+__global__ void __launch_bounds__(256) k_affine_to_table(size_t n, const void* pts, u32* table) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const ANiels t = Curve::to_niels(load_affine(pts, i));
+  u32* e = table + i * ANIELS_WORDS;
+  // canonical Montgomery limbs so the table is a deterministic function of the base point
+  const Fe a = Fq::canon(t.vpu), b = Fq::canon(t.vmu), c = Fq::canon(t.t2d);
+  _Pragma("unroll") for (int l = 0; l < NL; l++) { e[l] = a.l[l]; e[NL + l] = b.l[l]; e[2 * NL + l] = c.l[l]; }
+  e[27] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------ sums (MSM tail, point_sum)
+// Each lane folds FOLD strided extended points (Ext + Ext = to_niels + add, reference src/lib.rs:992-999).
+template <int FOLD>
+__global__ void __launch_bounds__(256) k_sum_pass(size_t n, size_t T, SoA in, SoA out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  Ext acc = Curve::identity();
+  #pragma unroll 1
+  for (int j = 0; j < FOLD; j++) {
+    const size_t i = t + (size_t)j * T;
+    if (i >= n) break;
+    Ext e; e.u = in.get(0, i); e.v = in.get(1, i); e.z = in.get(2, i); e.t1 = in.get(3, i); e.t2 = in.get(4, i);
+    acc = Curve::add(acc, Curve::to_niels(e));
+  }
+  out.put(0, t, acc.u); out.put(1, t, acc.v); out.put(2, t, acc.z); out.put(3, t, Fq::carry(acc.t1)); out.put(4, t, Fq::carry(acc.t2));
+}
+__global__ void __launch_bounds__(256) k_affine_to_soa5(size_t n, const void* pts, SoA ext) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Affine a = load_affine(pts, i);
+  ext.put(0, i, a.u); ext.put(1, i, a.v); ext.put(2, i, Fq::one()); ext.put(3, i, a.u); ext.put(4, i, a.v);
+}
+// varbase writing all five coordinates (MSM terms)
+__global__ void __launch_bounds__(256) k_varbase5(size_t n, const void* scalars, const void* points, u32* tables, SoA ext) {
+  const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t T = (size_t)gridDim.x * blockDim.x;
+  u32* slot = tables + gtid * (size_t)(VB_TABLE * ENIELS_WORDS);
+  #pragma unroll 1
+  for (size_t i = gtid; i < n; i += T) {
+    u32 k[8];
+    load8(k, scalars, i);
+    const Affine P = load_affine(points, i);
+    const Ext r = varbase_windowed(P, k, slot);
+    ext.put(0, i, r.u); ext.put(1, i, r.v); ext.put(2, i, r.z); ext.put(3, i, Fq::carry(r.t1)); ext.put(4, i, Fq::carry(r.t2));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ K6: decompress
+// AffinePoint::from_bytes_inner (reference src/lib.rs:492-534).  Writes the affine point in device SoA form
+// (coords 0,1 = u,v ; Z = 1) plus ok; follow-up kernels apply the subgroup options.
+__global__ void __launch_bounds__(256) k_decompress(size_t n, const void* in32, unsigned flags, void* out64, uint8_t* okp) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 w[8];
+  load8(w, in32, i);
+  const u32 sign = w[7] >> 31;
+  w[7] &= 0x7fffffffu;
+  bool ok;
+  const Fe v = Fq::from_words_checked(w, ok);
+  const Fe v2 = Fq::sqr(v);
+  const Fe num = Fq::sub(v2, Fq::one());
+  const Fe den = Fq::add(Fq::one(), Fq::mul(Fq::konst(FqP::D), v2));
+  const Fe u2 = Fq::mul(num, Fq::invert(den));
+  bool sq_ok;
+  const Fe u = fq_sqrt(u2, sq_ok);
+  ok = ok && sq_ok;
+  u32 wu[8];
+  Fq::to_words(wu, u);
+  const u32 flip = (wu[0] ^ sign) & 1u;
+  u32 nz = 0; _Pragma("unroll") for (int j = 0; j < 8; j++) nz |= wu[j];
+  const bool u_is_zero = (nz == 0);
+  if ((flags & 1u) && u_is_zero && flip) ok = false;
+  u32 wn[8];
+  Fq::to_words(wn, Fq::neg(u));
+  u32 wv[8];
+  Fq::to_words(wv, v);
+  _Pragma("unroll") for (int j = 0; j < 8; j++) { wu[j] = flip ? wn[j] : wu[j]; if (!ok) { wu[j] = 0; wv[j] = 0; } }
+  store8(out64, 2 * i, wu);
+  store8(out64, 2 * i + 1, wv);
+  okp[i] = ok ? 1 : 0;
+}
+// AffinePoint::to_bytes (reference src/lib.rs:455-464) for affine input
+__global__ void __launch_bounds__(256) k_compress(size_t n, const void* pts, void* out32) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 wu[8], wv[8], t[8];
+  load8(t, pts, 2 * i); Fq::to_words(wu, Fq::from_words(t));
+  load8(t, pts, 2 * i + 1); Fq::to_words(wv, Fq::from_words(t));
+  wv[7] |= (wu[0] & 1u) << 31;
+  store8(out32, i, wv);
+}
+// zero the 64-byte outputs whose ok byte is 0
+__global__ void __launch_bounds__(256) k_mask_outputs(size_t n, void* out64, const uint8_t* ok) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (!ok[i]) { u32 z[8]; zero8(z); store8(out64, 2 * i, z); store8(out64, 2 * i + 1, z); }
+}
+__global__ void __launch_bounds__(256) k_fill_scalar(size_t n, void* scalars, const uint8_t* pattern32) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 w[8];
+  load8(w, pattern32, 0);
+  store8(scalars, i, w);
+}
+__global__ void __launch_bounds__(256) k_and_bytes(size_t n, uint8_t* a, const uint8_t* b, int negate_b) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  a[i] = a[i] & (negate_b ? (b[i] ^ 1) : b[i]);
+}
+
+}  // namespace jj

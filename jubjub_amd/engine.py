@@ -1,0 +1,226 @@
+"""
+Batched Jubjub engine: thin, typed Python front-end over the C ABI (include/jubjub_hip.h).
+
+Arguments are arrays of wire-format bytes — numpy uint8 arrays (host; staged by the library) or torch uint8 CUDA
+tensors (device; zero-copy, asynchronous on torch's current stream).  Results come back as the same kind.
+Shapes: scalars / field elements (n, 32); affine points (n, 64); compressed points (n, 32).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+FLAG_ZIP216 = 1
+FLAG_TORSION_FREE = 2
+FLAG_NOT_SMALL_ORDER = 4
+FLAG_CLEAR_COFACTOR = 8
+
+
+class JubjubError(RuntimeError):
+    pass
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+class _Arg:
+    """Normalises one array argument to (pointer, keepalive)."""
+
+    def __init__(self, x, width):
+        if _is_torch(x):
+            import torch
+
+            if x.dtype != torch.uint8:
+                raise TypeError("torch arguments must be uint8")
+            x = x.contiguous()
+            if width is not None and x.numel() % width:
+                raise ValueError("byte length %d is not a multiple of %d" % (x.numel(), width))
+            self.n = x.numel() // width if width else x.numel()
+            self.ptr = x.data_ptr()
+            self.keep = x
+            self.torch = True
+            self.device = x.device
+        else:
+            a = np.ascontiguousarray(x, dtype=np.uint8)
+            if width is not None and a.size % width:
+                raise ValueError("byte length %d is not a multiple of %d" % (a.size, width))
+            self.n = a.size // width if width else a.size
+            self.ptr = a.ctypes.data if a.size else None
+            self.keep = a
+            self.torch = False
+            self.device = None
+
+
+class FixedBaseTable:
+    def __init__(self, engine, handle):
+        self._engine = engine
+        self._h = handle
+
+    def close(self):
+        if self._h is not None and self._engine._ctx is not None:
+            self._engine._lib.jj_fixedbase_table_destroy(self._engine._ctx, self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Engine:
+    def __init__(self, device=0):
+        self._lib = _lib.load()
+        ctx = C.c_void_p()
+        rc = self._lib.jj_ctx_create(int(device), C.byref(ctx))
+        if rc != 0:
+            self._ctx = None
+            raise JubjubError("jj_ctx_create(device=%d) failed with %d (%s)" % (
+                device, rc, "no gfx950 GPU visible; there is no CPU fallback" if rc == _lib.JJ_ERR_NODEVICE else "HIP error"))
+        self._ctx = ctx
+        self.device = int(device)
+
+    # -------------------------------------------------------------- plumbing
+    def close(self):
+        if self._ctx is not None:
+            self._lib.jj_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise JubjubError("libjubjub_hip error %d: %s" % (rc, self._lib.jj_last_error(self._ctx).decode()))
+
+    def sync(self):
+        self._check(self._lib.jj_ctx_sync(self._ctx))
+
+    def device_info(self):
+        out = (C.c_int64 * 4)()
+        self._check(self._lib.jj_device_info(self._ctx, out))
+        return {"cus": out[0], "clock_khz": out[1], "wavefront": out[2]}
+
+    def _bind_stream(self, args):
+        """When any argument is a torch CUDA tensor, run on torch's current stream."""
+        if any(a.torch for a in args):
+            import torch
+
+            s = torch.cuda.current_stream(args[[a.torch for a in args].index(True)].device).cuda_stream
+            self._lib.jj_ctx_set_stream(self._ctx, C.c_void_p(s))
+        else:
+            self._lib.jj_ctx_set_stream(self._ctx, None)
+
+    def _alloc(self, like, n, width):
+        if like.torch:
+            import torch
+
+            t = torch.empty((n, width) if width > 1 else (n,), dtype=torch.uint8, device=like.device)
+            return t, t.data_ptr()
+        a = np.empty((n, width) if width > 1 else (n,), dtype=np.uint8)
+        return a, (a.ctypes.data if a.size else None)
+
+    def _call(self, name, ins, in_widths, out_widths, extra_before=(), extra_mid=(), n_override=None):
+        args = [_Arg(x, w) for x, w in zip(ins, in_widths)]
+        n = args[0].n if n_override is None else n_override
+        for a in args[1:]:
+            if a.n != n and n_override is None:
+                raise ValueError("length mismatch: %d vs %d" % (a.n, n))  # cf. the assert at reference src/lib.rs:841
+        self._bind_stream(args)
+        outs, optrs = [], []
+        for w in out_widths:
+            o, p = self._alloc(args[0], n if n_override is None else 1, w)
+            outs.append(o)
+            optrs.append(p)
+        fn = getattr(self._lib, name)
+        rc = fn(self._ctx, *extra_before, C.c_size_t(n), *[a.ptr for a in args], *extra_mid, *optrs)
+        self._check(rc)
+        return outs[0] if len(outs) == 1 else tuple(outs)
+
+    # -------------------------------------------------------------- fields (reference src/fr.rs; Fq = bls12_381::Scalar)
+    def field_binary(self, field, op, a, b):
+        return self._call("jj_%s_%s" % (field, op), [a, b], [32, 32], [32])
+
+    def field_unary(self, field, op, a):
+        return self._call("jj_%s_%s" % (field, op), [a], [32], [32])
+
+    def field_unary_ok(self, field, op, a):
+        return self._call("jj_%s_%s" % (field, op), [a], [32], [32, 1])
+
+    def from_bytes_wide(self, field, a):
+        return self._call("jj_%s_from_bytes_wide" % field, [a], [64], [32])
+
+    # -------------------------------------------------------------- points
+    def point_double(self, p):
+        return self._call("jj_point_double", [p], [64], [64])
+
+    def point_add(self, p, q):
+        return self._call("jj_point_add", [p, q], [64, 64], [64])
+
+    def point_sub(self, p, q):
+        return self._call("jj_point_sub", [p, q], [64, 64], [64])
+
+    def point_neg(self, p):
+        return self._call("jj_point_neg", [p], [64], [64])
+
+    def mul_by_cofactor(self, p):
+        return self._call("jj_point_mul_by_cofactor", [p], [64], [64])
+
+    def to_niels(self, p):
+        return self._call("jj_point_to_niels", [p], [64], [96])
+
+    def predicate(self, name, p):
+        return self._call("jj_" + name, [p], [64], [1])
+
+    def point_sum(self, p):
+        return self._sum_like("jj_point_sum", [p], [64])
+
+    def _sum_like(self, name, ins, widths):
+        args = [_Arg(x, w) for x, w in zip(ins, widths)]
+        n = args[0].n
+        for a in args[1:]:
+            if a.n != n:
+                raise ValueError("length mismatch")
+        self._bind_stream(args)
+        out, optr = self._alloc(args[0], 1, 64)
+        # zero-length numpy arrays have no data pointer; the library ignores inputs when n == 0
+        rc = getattr(self._lib, name)(self._ctx, C.c_size_t(n), *[a.ptr for a in args], optr)
+        self._check(rc)
+        return out.reshape(64)
+
+    # -------------------------------------------------------------- scalar multiplication
+    def varbase_mul(self, scalars, points):
+        return self._call("jj_varbase_mul", [scalars, points], [32, 64], [64])
+
+    def varbase_mul_exact(self, scalars, points):
+        return self._call("jj_varbase_mul_exact", [scalars, points], [32, 64], [160])
+
+    def fixedbase_table(self, base, window_bits=0):
+        a = _Arg(base, 64)
+        if a.n != 1:
+            raise ValueError("base must be one affine point (64 bytes)")
+        self._bind_stream([a])
+        h = C.c_void_p()
+        self._check(self._lib.jj_fixedbase_table_create(self._ctx, a.ptr, int(window_bits), C.byref(h)))
+        return FixedBaseTable(self, h)
+
+    def fixedbase_mul(self, table, scalars):
+        return self._call("jj_fixedbase_mul", [scalars], [32], [64], extra_before=(table._h,))
+
+    def msm(self, scalars, points):
+        return self._sum_like("jj_msm", [scalars, points], [32, 64])
+
+    # -------------------------------------------------------------- encodings
+    def decompress(self, enc, flags=FLAG_ZIP216):
+        return self._call("jj_decompress", [enc], [32], [64, 1], extra_mid=(C.c_uint(flags),))
+
+    def compress(self, points):
+        return self._call("jj_compress", [points], [64], [32])
+
+    def batch_normalize(self, ext160):
+        return self._call("jj_batch_normalize", [ext160], [160], [64])

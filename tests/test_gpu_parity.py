@@ -1,0 +1,207 @@
+"""
+GPU parity tests: every entry point of the C ABI (through jubjub_amd.Engine) against the pinned oracle on the
+same seeded inputs, bit-exact, plus the reference's own known-answer vectors (tests/golden/reference_vectors.json).
+Run with:  python -m pytest tests -m gpu
+"""
+import numpy as np
+import pytest
+
+from oracle import c_oracle as O
+from oracle import jubjub_ref as J
+from util import (EDGE_SCALARS, Q, R, arr32, arr64, b32, pt64, rand_points, rand_scalars, to_int, to_pt, torsion_points)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from jubjub_amd import Engine
+
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def field_inputs(p, seed, n=1000):
+    rng = np.random.default_rng(seed)
+    edge = [0, 1, 2, p - 1, p - 2, p, p + 1, (p - 1) // 2, (1 << 255) - 1, (1 << 256) - 1, 1 << 255, 3 * p]
+    edge = [e for e in edge if e < (1 << 256)]
+    a = np.concatenate([arr32(edge), rng.integers(0, 256, size=(n, 32), dtype=np.uint8)])
+    b = np.concatenate([arr32(list(reversed(edge))), rng.integers(0, 256, size=(n, 32), dtype=np.uint8)])
+    return a, b
+
+
+@pytest.mark.parametrize("fname,which,p", [("fq", O.FQ, Q), ("fr", O.FR, R)])
+def test_field_ops(eng, fname, which, p):
+    a, b = field_inputs(p, 11 + which)
+    for op in ("add", "sub", "mul"):
+        assert (eng.field_binary(fname, op, a, b) == O.field_op(which, op, a, b)[0]).all(), op
+    for op in ("neg", "square", "double"):
+        assert (eng.field_unary(fname, op, a) == O.field_op(which, op, a)[0]).all(), op
+    out, ok = eng.field_unary_ok(fname, "invert", a)
+    eo, ek = O.field_op(which, "invert", a)
+    assert (ok == ek).all() and (out == eo).all()
+    out, ok = eng.field_unary_ok(fname, "from_bytes", a)
+    eo, ek = O.from_bytes(which, a)
+    assert (ok == ek).all() and (out == eo).all()
+    wide = np.concatenate([a, b], axis=1)
+    assert (eng.from_bytes_wide(fname, wide) == O.from_bytes_wide(which, wide)).all()
+    # empty batch
+    assert eng.field_binary(fname, "mul", a[:0], b[:0]).shape == (0, 32)
+
+
+@pytest.mark.parametrize("fname,which,p", [("fq", O.FQ, Q), ("fr", O.FR, R)])
+def test_field_sqrt(eng, fname, which, p):
+    a, _ = field_inputs(p, 23 + which, n=300)
+    sq = O.field_op(which, "square", a)[0]
+    x = np.concatenate([a, sq])
+    out, ok = eng.field_unary_ok(fname, "sqrt", x)
+    eo, ek = O.field_op(which, "sqrt", x)
+    assert (ok == ek).all()
+    assert (out == eo).all()
+    assert ok[len(a):].all()
+
+
+def test_fr_golden_vectors(eng, golden):
+    # reference src/fr.rs:856-961 and src/lib.rs:1758-1776 through the GPU path
+    tb = golden["fr"]["to_bytes"]
+    neg1 = eng.field_unary("fr", "neg", arr32([1]))
+    assert bytes(neg1[0]) == bytes(tb["neg_one"])
+    bad = np.array(golden["fr"]["from_bytes_invalid"]["cases"], np.uint8)
+    assert not eng.field_unary_ok("fr", "from_bytes", bad)[1].any()
+    assert eng.field_unary_ok("fr", "from_bytes", np.array([tb["neg_one"]], np.uint8))[1].all()
+    t = golden["fr_mul_consistency_mont"]
+    a, b, c = (J.FR.from_mont_limbs([int(x, 16) for x in t[k]]) for k in "abc")
+    assert to_int(eng.field_binary("fr", "mul", arr32([a]), arr32([b]))[0]) == c
+    mx = eng.from_bytes_wide("fr", np.full((1, 64), 0xFF, np.uint8))
+    assert J.FR.to_mont_limbs(to_int(mx[0])) == [int(x, 16) for x in golden["fr"]["from_bytes_wide"]["max_output_mont"]]
+
+
+def test_point_ops(eng, golden):
+    P = rand_points(1, 300)
+    Qp = rand_points(2, 300)
+    tors = torsion_points(golden)
+    ident = arr64([J.AFFINE_IDENTITY])
+    P = np.concatenate([P, tors, ident, P[:4], P[:4]])
+    Qp = np.concatenate([Qp, tors[::-1], ident, P[:4], O.point_op("neg", P[:4])])
+    for op in ("double", "neg", "mul_by_cofactor"):
+        got = getattr(eng, "point_" + op if op != "mul_by_cofactor" else op)(P)
+        assert (got == O.point_op(op, P)).all(), op
+    assert (eng.point_add(P, Qp) == O.point_op("add", P, Qp)).all()
+    assert (eng.point_sub(P, Qp) == O.point_op("sub", P, Qp)).all()
+    assert (eng.to_niels(P) == O.to_niels(P)).all()
+    for pred in ("is_identity", "is_small_order", "is_on_curve", "is_torsion_free", "is_prime_order"):
+        assert (eng.predicate(pred, P) == O.predicate(pred, P)).all(), pred
+    off = P.copy()
+    off[:, 0] ^= 1
+    assert (eng.predicate("is_on_curve", off) == O.predicate("is_on_curve", off)).all()
+    assert (eng.point_sum(P) == O.point_sum(P)).all()
+    assert to_pt(eng.point_sum(P[:0])) == J.AFFINE_IDENTITY
+
+
+def test_varbase_edges(eng, golden):
+    pts = np.concatenate([rand_points(3, 8), torsion_points(golden), arr64([J.GENERATOR, J.AFFINE_IDENTITY])])
+    S, Pn = [], []
+    for k in EDGE_SCALARS:
+        for p in pts:
+            S.append(b32(k))
+            Pn.append(p)
+    S, Pn = np.stack(S), np.stack(Pn)
+    assert (eng.varbase_mul(S, Pn) == O.varbase_mul(S, Pn)).all()
+
+
+def test_varbase_random(eng):
+    n = 3000   # not a multiple of the block size; exercises the grid-stride tail
+    S = rand_scalars(5, n, full_width=True)
+    P = rand_points(6, n)
+    got = eng.varbase_mul(S, P)
+    assert (got == O.varbase_mul(S, P)).all()
+    assert eng.varbase_mul(S[:0], P[:0]).shape == (0, 64)
+    assert (eng.varbase_mul(S[:1], P[:1]) == got[:1]).all()
+
+
+def test_varbase_exact_projective(eng):
+    n = 200
+    S = np.concatenate([arr32(EDGE_SCALARS), rand_scalars(7, n)])
+    P = rand_points(8, len(S))
+    got = eng.varbase_mul_exact(S, P)
+    assert (got == O.varbase_mul_ext(S, P)).all()      # all five projective coordinates, bit for bit
+
+
+def test_eight_torsion_through_gpu(eng, golden):
+    # reference find_eight_torsion (src/lib.rs:1679-1696)
+    g = eng.varbase_mul(np.array([golden["FR_MODULUS_BYTES"]["bytes"]], np.uint8), arr64([J.GENERATOR]))
+    tors = torsion_points(golden)
+    cur = g.copy()
+    for t in tors:
+        assert (cur[0] == t).all()
+        cur = eng.point_add(cur, g)
+
+
+def test_fixedbase(eng):
+    for base in (J.GENERATOR, to_pt(O.point_op("mul_by_cofactor", arr64([J.GENERATOR]))[0]), to_pt(rand_points(9, 1)[0])):
+        tab = eng.fixedbase_table(pt64(base))
+        S = np.concatenate([arr32(EDGE_SCALARS), rand_scalars(10, 2500, full_width=True)])
+        got = eng.fixedbase_mul(tab, S)
+        assert (got == O.fixedbase_mul(S, pt64(base))).all()
+        assert eng.fixedbase_mul(tab, S[:0]).shape == (0, 64)
+        tab.close()
+
+
+def test_msm(eng):
+    for n in (0, 1, 2, 33, 1000):
+        S = rand_scalars(12 + n, n, full_width=True)
+        P = rand_points(13 + n, n, subgroup=(n % 2 == 0))
+        assert (eng.msm(S, P) == O.msm(S, P)).all(), n
+
+
+def test_serialization_golden(eng, golden):
+    encs = np.array(golden["serialization_16"]["encodings"], np.uint8)
+    gen8 = eng.mul_by_cofactor(arr64([J.GENERATOR]))
+    pts = eng.varbase_mul(arr32(list(range(1, 17))), np.repeat(gen8, 16, axis=0))
+    assert (eng.compress(pts) == encs).all()                          # reference src/lib.rs:1811-1887
+    out, ok = eng.decompress(encs)
+    assert ok.all() and (out == pts).all()
+    z = np.array(golden["zip216_noncanonical"]["encodings"], np.uint8)  # reference src/lib.rs:1893-1935
+    assert not eng.decompress(z)[1].any()
+    o2, k2 = eng.decompress(z, flags=0)
+    assert k2.all()
+    re = eng.compress(o2)
+    re[:, 31] |= 0x80
+    assert (re == z).all()
+
+
+def test_decompress_flags(eng, golden):
+    rng = np.random.default_rng(77)
+    valid = O.compress(np.concatenate([rand_points(14, 200), rand_points(15, 100, subgroup=True), torsion_points(golden)]))
+    junk = rng.integers(0, 256, size=(300, 32), dtype=np.uint8)
+    special = np.stack([b32(Q), b32(Q - 1), b32(Q + 1), b32((1 << 255) | 1), b32(0), b32((1 << 256) - 1)])
+    E = np.concatenate([valid, junk, special, np.array(golden["zip216_noncanonical"]["encodings"], np.uint8)])
+    for flags in (0, 1, 1 | 2, 1 | 4, 1 | 8, 1 | 2 | 4 | 8, 2 | 8):
+        out, ok = eng.decompress(E, flags)
+        eo, ek = O.decompress(E, flags)
+        assert (ok == ek).all(), flags
+        assert (out == eo).all(), flags
+    assert (eng.compress(O.decompress(valid, 0)[0]) == valid).all()
+
+
+def test_batch_normalize(eng):
+    S = rand_scalars(16, 700)
+    P = rand_points(17, 700)
+    ext = O.varbase_mul_ext(S, P)
+    assert (eng.batch_normalize(ext) == O.batch_normalize(ext)).all()
+    assert (eng.batch_normalize(ext[:5]) == O.batch_normalize(ext[:5])).all()
+
+
+def test_torch_device_tensors(eng):
+    torch = pytest.importorskip("torch")
+    S = rand_scalars(18, 4096)
+    P = rand_points(19, 4096)
+    dS, dP = torch.from_numpy(S).cuda(), torch.from_numpy(P).cuda()
+    out = eng.varbase_mul(dS, dP)
+    assert out.is_cuda and out.shape == (4096, 64)
+    assert (out.cpu().numpy() == O.varbase_mul(S, P)).all()
+    a = eng.field_binary("fq", "mul", dS, dS)
+    assert (a.cpu().numpy() == O.field_op(O.FQ, "mul", S, S)[0]).all()
+    with pytest.raises(Exception):
+        eng.varbase_mul(dS.flatten()[1:1 + 32 * 8].reshape(8, 32), dP[:8])   # misaligned device pointer is rejected
