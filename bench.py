@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""
+bench.py — headline benchmark of the MI355X Jubjub engine (BASELINE.json metric: Jubjub scalar-muls/sec).
+
+  python bench.py --gpus N --steps K --warmup W [--workload varbase|fixedbase|msm|decompress] [--log2n L]
+
+One "step" = one pass of the hot path over one batch of synthetic inputs already resident in HBM.
+N = 1 default workload: BASELINE.json configs[1] — 2^20 variable-base scalar-muls (random 252-bit scalars x random
+curve points).  N > 1: one process per GPU (launched by torch.distributed.run), every rank runs the same batch
+size on its own shard (weak scaling, no data-path collective for the independent-batch workloads; the MSM
+workload all-gathers one 64-byte partial point per rank over RCCL).  Rank 0 prints ONE JSON line.
+
+The JSON carries:
+  roofline     integer-VALU roofline of the dominant kernel (this path is carry-free integer multiply-add work,
+               not HBM- or MFMA-bound): achieved = algorithmic IMAD32/s with the SURVEY §8(d) convention
+               (field mul = 128, square = 100 IMAD32) for the algorithm the kernel actually runs, divided by the
+               kernel's HIP-event duration; peak = v_mad_u64_u32 rate measured live on this device
+               (jj_peak_imad32).  `hbm` gives the algorithmic HBM bytes/s beside the 8 TB/s peak to show the
+               kernel is not memory-limited.
+  cpu_baseline the oracle's C port of the reference algorithm (exact 252-step ladder, 4x64 Montgomery limbs)
+               timed with OpenMP on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+# Field-operation counts of the algorithms the kernels actually run, per unit.
+# IMAD32 convention: M = 128, S = 100.
+WORK = {
+    # table build 67M; 63 windows x (4 dbl (4S+3M) + 8M add) ; load 2M ; normalise 7M + (255S+78M)/32 inversion share
+    "varbase": {"S": 63 * 16 + 8, "M": 67 + 63 * 20 + 2 + 7 + 3, "bytes": 32 + 64 + 64},
+    # 43 mixed adds x 7M ; normalise as above
+    "fixedbase": {"S": 8, "M": 43 * 7 + 7 + 3, "bytes": 32 + 64},
+    # msm v1 = var-base terms + 10M per fold add
+    "msm": {"S": 63 * 16 + 8, "M": 67 + 63 * 20 + 2 + 10, "bytes": 32 + 64},
+    # decompress: from_bytes 1M, 1S, 2M, inversion 255S+78M, sqrt ~ (222S+56M) + (528S + 64M) ; to_bytes
+    "decompress": {"S": 1 + 255 + 222 + 528, "M": 1 + 2 + 78 + 56 + 64 + 4, "bytes": 32 + 65},
+}
+# the reference's own algorithm for comparison in the JSON
+REFERENCE_WORK = {"varbase": {"S": 1008, "M": 2774}, "fixedbase": {"S": 1008, "M": 2520}}
+
+
+def imad32(w):
+    return 100 * w["S"] + 128 * w["M"]
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="varbase", choices=sorted(WORK))
+    ap.add_argument("--log2n", type=int, default=None, help="log2 of the per-GPU batch (default: 20 varbase/msm, 24 fixedbase, 22 decompress)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target wall time of the CPU baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(workload, target_s):
+    """Times the oracle's C port of the reference algorithm on the host cores (reported baseline, not a target)."""
+    import numpy as np
+
+    from oracle import c_oracle as O
+    from oracle import jubjub_ref as J
+
+    cores = os.cpu_count() or 1
+    try:
+        import ctypes
+
+        omp = ctypes.CDLL("libgomp.so.1")
+        cores = int(omp.omp_get_max_threads())
+    except Exception:
+        pass
+    base = np.frombuffer(J.GENERATOR[0].to_bytes(32, "little") + J.GENERATOR[1].to_bytes(32, "little"), dtype=np.uint8)
+    rng = np.random.default_rng(2024)
+
+    def run(n):
+        s = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+        s[:, 31] &= 0x0F
+        if workload == "fixedbase":
+            t0 = time.perf_counter(); O.fixedbase_mul(s, base); return time.perf_counter() - t0
+        pts = O.fixedbase_mul(s[::-1].copy(), base)
+        if workload == "decompress":
+            enc = O.compress(pts)
+            t0 = time.perf_counter(); O.decompress(enc, 1); return time.perf_counter() - t0
+        if workload == "msm":
+            t0 = time.perf_counter(); O.msm(s, pts); return time.perf_counter() - t0
+        t0 = time.perf_counter(); O.varbase_mul(s, pts); return time.perf_counter() - t0
+
+    probe = max(64, 16 * cores)
+    t = run(probe)
+    n = int(max(probe, min(1 << 18, probe * target_s / max(t, 1e-6))))
+    t = run(n)
+    unit = {"varbase": "scalar-muls/s", "fixedbase": "scalar-muls/s", "msm": "terms/s", "decompress": "points/s"}[workload]
+    return {"value": n / t, "unit": unit, "cores": cores, "kind": "port",
+            "sample": "%d units of the same synthetic workload, reference algorithm (exact 252-step ladder / per-point decode), "
+                      "oracle/jubjub_oracle.c -O3 + OpenMP, %.1f s wall" % (n, t)}
+
+
+def main():
+    a = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from jubjub_amd import Engine
+    from oracle import jubjub_ref as J
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    n_gpus = world if distributed else 1
+    if a.gpus != n_gpus and rank == 0:
+        print("note: --gpus %d but WORLD_SIZE=%d; using %d" % (a.gpus, world, n_gpus), file=sys.stderr)
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    eng = Engine(local_rank)
+
+    wl = a.workload
+    log2n = a.log2n if a.log2n is not None else {"varbase": 20, "fixedbase": 24, "msm": 20, "decompress": 22}[wl]
+    n = 1 << log2n
+
+    # ---- synthetic inputs, generated on the device, resident in HBM before the timed region
+    g = torch.Generator(device=dev)
+    g.manual_seed(0x4A55424A5542 + rank)
+    scalars = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
+    scalars[:, 31] &= 0x0F                                          # uniform below 2^252 (reference ladder width)
+    base = torch.from_numpy(np.frombuffer(J.GENERATOR[0].to_bytes(32, "little") + J.GENERATOR[1].to_bytes(32, "little"), dtype=np.uint8).copy()).to(dev)
+    table = eng.fixedbase_table(base)
+    points = None
+    if wl in ("varbase", "msm", "decompress"):
+        ks = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
+        points = eng.fixedbase_mul(table, ks)                       # random points of the full group (order 8r), on-curve by construction
+        assert bool(eng.predicate("is_on_curve", points[:4096]).all())
+    enc = eng.compress(points) if wl == "decompress" else None
+
+    def step():
+        if wl == "varbase":
+            return eng.varbase_mul(scalars, points)
+        if wl == "fixedbase":
+            return eng.fixedbase_mul(table, scalars)
+        if wl == "decompress":
+            return eng.decompress(enc, 1)
+        part = eng.msm(scalars, points)                             # one partial point per rank
+        if distributed:
+            parts = [torch.empty_like(part) for _ in range(world)]
+            dist.all_gather(parts, part)                            # 64 B per rank over RCCL/xGMI; EC add is not a reduce op
+            part = eng.point_sum(torch.stack(parts))
+        return part
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    eng.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    main_ms, tail_ms = eng.profile_read()
+    eng.profile(False)
+    if distributed:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    units_per_step = n * n_gpus
+    value = units_per_step * a.steps / dt
+    res = {
+        "metric": "Jubjub scalar-muls/sec (%s)" % wl if wl in ("varbase", "fixedbase") else "Jubjub %s units/sec" % wl,
+        "value": value,
+        "unit": {"varbase": "scalar-muls/s", "fixedbase": "scalar-muls/s", "msm": "terms/s", "decompress": "points/s"}[wl],
+        "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": dt / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u32x9 (29-bit limbs, v_mad_u64_u32 integer multiply-add)",
+        "data": "synthetic",
+        "config": {"workload": "%s, 2^%d units per GPU per step (BASELINE.json configs[%d])" % (
+            wl, log2n, {"varbase": 1, "fixedbase": 2, "msm": 3, "decompress": 4}[wl]),
+            "scalars": "uniform 252-bit", "points": "random points of the full group (order 8r), affine 64 B",
+            "parallelism": "independent shards, one process per GPU" + ("; all_gather of 64 B partial points" if wl == "msm" else "")},
+    }
+    if rank == 0:
+        w = WORK[wl]
+        if main_ms:
+            kern_ms = sum(main_ms) / len(main_ms)
+            tail = sum(tail_ms) / len(tail_ms)
+        else:                                                       # workloads without the event hooks: whole step
+            kern_ms, tail = dt / a.steps * 1e3, 0.0
+        peak = eng.peak_imad32()
+        achieved = n * imad32(w) / (kern_ms * 1e-3)
+        res["roofline"] = {
+            "bound": "valu_int32", "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TIMAD32/s",
+            "frac": achieved / peak, "traffic": None,
+            "kernel": {"varbase": "k_varbase", "fixedbase": "k_fixedbase", "msm": "k_varbase5", "decompress": "k_decompress"}[wl],
+            "kernel_ms": kern_ms, "tail_ms": tail,
+            "work_per_unit": {"field_squares": w["S"], "field_muls": w["M"], "imad32": imad32(w), "convention": "M=128,S=100 (SURVEY 8d)"},
+            "reference_algorithm_imad32": imad32(REFERENCE_WORK[wl]) if wl in REFERENCE_WORK else None,
+            "hbm": {"achieved": n * w["bytes"] / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": n * w["bytes"] / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "bytes_per_unit": w["bytes"]},
+        }
+        if not a.no_cpu_baseline and n_gpus == 1:
+            res["cpu_baseline"] = cpu_baseline(wl, a.cpu_seconds)
+        print(json.dumps(res))
+    table.close()
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

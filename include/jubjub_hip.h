@@ -54,6 +54,14 @@ int jj_version(void);
 /* Device properties used for roofline accounting: out[0]=CU count, out[1]=clock kHz, out[2]=wavefront size. */
 int jj_device_info(jj_ctx* ctx, int64_t out[4]);
 
+/* Per-call kernel timing with HIP events on the launch stream (for roofline accounting).  While enabled, each
+ * jj_varbase_mul / jj_fixedbase_mul call records (main kernel ms, normalise-tail ms); read drains the log. */
+int jj_ctx_profile(jj_ctx* ctx, int enable);
+int jj_ctx_profile_read(jj_ctx* ctx, int max, float* main_ms, float* tail_ms, int* count);
+/* Integer-VALU roofline denominator, measured on this device: sustained v_mad_u64_u32 (32x32+64 -> 64 multiply-
+ * accumulate) lane-operations per second. */
+int jj_peak_imad32(jj_ctx* ctx, double* out_per_sec);
+
 /* ---- fields: Fq (base, = bls12_381::Scalar, src/lib.rs:62) and Fr (scalar, src/fr.rs) ------------------------ */
 /* Elements are 32-byte little-endian integers; inputs are reduced mod p like from_raw (src/fr.rs:347-349),
  * outputs are canonical.  reference: add 638-647, sub 620-634, mul 592-616, neg 651-665, square 353-381,

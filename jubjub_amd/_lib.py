@@ -37,12 +37,38 @@ _SIGS.update({
     "jj_batch_normalize": [_sz, _vp, _vp],
     "jj_ctx_set_stream": [_vp],
     "jj_ctx_sync": [],
+    "jj_ctx_profile": [C.c_int],
+    "jj_ctx_profile_read": [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)],
+    "jj_peak_imad32": [C.POINTER(C.c_double)],
 })
 
 EXPORTS = sorted(list(_SIGS) + ["jj_ctx_create", "jj_ctx_destroy", "jj_last_error", "jj_version", "jj_device_info",
                                 "jj_fixedbase_table_create"])
 
 _lib = None
+
+
+def _preload_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64 (same soname as /opt/rocm's).  Two HIP runtimes in one
+    process see no devices, so when torch is installed we make its copy the process-wide runtime *before* our
+    library resolves libamdhip64.so.7; a later `import torch` then reuses it.  JJ_HIP_RUNTIME=system opts out."""
+    import importlib.util
+    import sys
+
+    if os.environ.get("JJ_HIP_RUNTIME", "") == "system" or "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
 
 
 def load():
@@ -53,6 +79,7 @@ def load():
         raise RuntimeError(
             "libjubjub_hip.so is not built (%s). Run `python -m jubjub_amd.build` or __graft_entry__.build(); "
             "there is no CPU fallback." % LIB_PATH)
+    _preload_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, args in _SIGS.items():
         fn = getattr(lib, name)

@@ -35,7 +35,27 @@ struct jj_ctx {
   std::string err;
   // staging for host-pointer arguments (inputs 0..3, outputs 0..1) and kernel workspaces
   DevBuf in[4], out[2], okb, ws_ext, ws_scratch, ws_tables, ws_tmp[4];
+  // optional per-call kernel timing (HIP events on the launch stream): e0 | main kernel | e1 | normalise tail | e2
+  bool profile = false;
+  struct Rec { hipEvent_t e0, e1, e2; };
+  std::vector<Rec> recs;
+  size_t rec_used = 0;
 };
+
+static void prof_mark(jj_ctx* c, int which) {
+  if (!c->profile) return;
+  if (which == 0) {
+    if (c->rec_used == c->recs.size()) {
+      jj_ctx::Rec r;
+      if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess || hipEventCreate(&r.e2) != hipSuccess) return;
+      c->recs.push_back(r);
+    }
+    (void)hipEventRecord(c->recs[c->rec_used].e0, c->stream);
+  } else if (c->rec_used < c->recs.size()) {
+    if (which == 1) (void)hipEventRecord(c->recs[c->rec_used].e1, c->stream);
+    else { (void)hipEventRecord(c->recs[c->rec_used].e2, c->stream); c->rec_used++; }
+  }
+}
 
 #define HIPCHK(ctx, call)                                                                   \
   do {                                                                                      \
@@ -136,6 +156,7 @@ JJ_API int jj_ctx_destroy(jj_ctx* c) {
   DevBuf* all[] = {&c->in[0], &c->in[1], &c->in[2], &c->in[3], &c->out[0], &c->out[1], &c->okb, &c->ws_ext, &c->ws_scratch, &c->ws_tables,
                    &c->ws_tmp[0], &c->ws_tmp[1], &c->ws_tmp[2], &c->ws_tmp[3]};
   for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
+  for (auto& r : c->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); (void)hipEventDestroy(r.e2); }
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
   return JJ_OK;
@@ -154,6 +175,53 @@ JJ_API const char* jj_last_error(jj_ctx* c) { return c ? c->err.c_str() : "null 
 JJ_API int jj_device_info(jj_ctx* c, int64_t out[4]) {
   if (!c || !out) return JJ_ERR_INVALID;
   out[0] = c->cus; out[1] = c->clock_khz; out[2] = c->wave; out[3] = 0;
+  return JJ_OK;
+}
+
+JJ_API int jj_ctx_profile(jj_ctx* c, int enable) {
+  if (!c) return JJ_ERR_INVALID;
+  c->profile = enable != 0;
+  c->rec_used = 0;
+  return JJ_OK;
+}
+// Returns up to `max` (main_ms, tail_ms) pairs recorded since jj_ctx_profile(ctx, 1) and resets the log.
+JJ_API int jj_ctx_profile_read(jj_ctx* c, int max, float* main_ms, float* tail_ms, int* count) {
+  if (!c || !count) return JJ_ERR_INVALID;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int k = 0;
+  for (size_t i = 0; i < c->rec_used && k < max; i++, k++) {
+    float a = 0, b = 0;
+    HIPCHK(c, hipEventElapsedTime(&a, c->recs[i].e0, c->recs[i].e1));
+    HIPCHK(c, hipEventElapsedTime(&b, c->recs[i].e1, c->recs[i].e2));
+    if (main_ms) main_ms[k] = a;
+    if (tail_ms) tail_ms[k] = b;
+  }
+  *count = k;
+  c->rec_used = 0;
+  return JJ_OK;
+}
+// Measured integer-VALU roofline denominator: sustained v_mad_u64_u32 lane-operations per second on this device.
+JJ_API int jj_peak_imad32(jj_ctx* c, double* out_per_sec) {
+  if (!c || !out_per_sec) return JJ_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = ensure(c, c->ws_tmp[0], (size_t)c->cus * 8 * 256 * 4); if (rc) return rc;
+  const int iters = 4000, blocks = c->cus * 8;
+  hipEvent_t e0, e1;
+  HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+  double best = 0;
+  for (int rep = 0; rep < 3; rep++) {
+    hipLaunchKernelGGL(k_peak_mad, dim3(blocks), dim3(256), 0, c->stream, (u32*)c->ws_tmp[0].p, rep == 0 ? 50 : iters, 12345u);
+    if (rep == 0) continue;
+    HIPCHK(c, hipEventRecord(e0, c->stream));
+    hipLaunchKernelGGL(k_peak_mad, dim3(blocks), dim3(256), 0, c->stream, (u32*)c->ws_tmp[0].p, iters, 12345u);
+    HIPCHK(c, hipEventRecord(e1, c->stream));
+    HIPCHK(c, hipEventSynchronize(e1));
+    float ms = 0; HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+    const double ops = (double)iters * 64.0 /* mads per iteration */ * 256.0 * blocks;
+    best = std::max(best, ops / (ms * 1e-3));
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  *out_per_sec = best;
   return JJ_OK;
 }
 
@@ -263,8 +331,11 @@ JJ_API int jj_varbase_mul(jj_ctx* c, size_t n, const void* scalars, const void* 
   if ((rc = ensure_ext(c, n, 3))) return rc;
   SoA ext = soa_of(c->ws_ext, n);
   if (n) {
+    prof_mark(c, 0);
     if ((rc = varbase_to_ext(c, n, ds, dp, ext, false))) return rc;
+    prof_mark(c, 1);
     if ((rc = normalize_launch(c, n, ext, o.dev, 0))) return rc;
+    prof_mark(c, 2);
   }
   bool sync = false;
   if ((rc = finish_out(c, o, &sync))) return rc;
@@ -374,8 +445,11 @@ JJ_API int jj_fixedbase_mul(jj_ctx* c, const jj_table* t, size_t n, const void* 
   SoA ext = soa_of(c->ws_ext, n);
   if (n) {
     const unsigned blocks = (unsigned)std::min((size_t)c->cus, (n + 511) / 512);   // one 512-thread workgroup per CU (LDS-bound)
+    prof_mark(c, 0);
     hipLaunchKernelGGL(k_fixedbase, dim3(blocks), dim3(512), FB_LDS_BYTES, c->stream, n, ds, (const u32*)t->dev, ext);
+    prof_mark(c, 1);
     if ((rc = normalize_launch(c, n, ext, o.dev, 0))) return rc;
+    prof_mark(c, 2);
   }
   bool sync = false;
   if ((rc = finish_out(c, o, &sync))) return rc;

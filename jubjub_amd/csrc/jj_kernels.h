@@ -509,4 +509,20 @@ __global__ void __launch_bounds__(256) k_and_bytes(size_t n, uint8_t* a, const u
   a[i] = a[i] & (negate_b ? (b[i] ^ 1) : b[i]);
 }
 
+// ------------------------------------------------------------------------------------------------ roofline probe
+// 8 independent v_mad_u64_u32 chains per lane, 64 mads per loop iteration: the measured peak IMAD32 rate.
+__global__ void __launch_bounds__(256) k_peak_mad(u32* out, int iters, u32 seed) {
+  u64 acc[8];
+  const u32 a = seed * 2654435761u + threadIdx.x, b = (seed ^ (blockIdx.x * 40503u)) | 1u;
+  _Pragma("unroll") for (int k = 0; k < 8; k++) acc[k] = (((u64)a << 32) | b) + k * 77u;
+  for (int it = 0; it < iters; it++) {
+    _Pragma("unroll") for (int r = 0; r < 8; r++) {
+      _Pragma("unroll") for (int k = 0; k < 8; k++) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[k]) : "v"(a), "v"(b) : "vcc");
+    }
+  }
+  u64 s = 0;
+  _Pragma("unroll") for (int k = 0; k < 8; k++) s ^= acc[k];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (u32)s ^ (u32)(s >> 32);
+}
+
 }  // namespace jj

@@ -106,6 +106,21 @@ class Engine:
         self._check(self._lib.jj_device_info(self._ctx, out))
         return {"cus": out[0], "clock_khz": out[1], "wavefront": out[2]}
 
+    def profile(self, enable=True):
+        self._check(self._lib.jj_ctx_profile(self._ctx, 1 if enable else 0))
+
+    def profile_read(self, max_records=4096):
+        a = (C.c_float * max_records)()
+        b = (C.c_float * max_records)()
+        k = C.c_int(0)
+        self._check(self._lib.jj_ctx_profile_read(self._ctx, max_records, a, b, C.byref(k)))
+        return [a[i] for i in range(k.value)], [b[i] for i in range(k.value)]
+
+    def peak_imad32(self):
+        out = C.c_double(0)
+        self._check(self._lib.jj_peak_imad32(self._ctx, C.byref(out)))
+        return out.value
+
     def _bind_stream(self, args):
         """When any argument is a torch CUDA tensor, run on torch's current stream."""
         if any(a.torch for a in args):
