@@ -46,8 +46,10 @@ typedef enum {
 /* ---- context ------------------------------------------------------------------------------------------- */
 int jj_ctx_create(int device, jj_ctx** out);
 int jj_ctx_destroy(jj_ctx* ctx);
-/* Run on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the context's own stream. */
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream; NULL = HIP's default stream).  A new context
+ * starts on its own non-blocking stream; jj_ctx_use_own_stream() returns to it. */
 int jj_ctx_set_stream(jj_ctx* ctx, void* hip_stream);
+int jj_ctx_use_own_stream(jj_ctx* ctx);
 int jj_ctx_sync(jj_ctx* ctx);
 const char* jj_last_error(jj_ctx* ctx);
 int jj_version(void);

@@ -37,6 +37,7 @@ _SIGS.update({
     "jj_batch_normalize": [_sz, _vp, _vp],
     "jj_ctx_set_stream": [_vp],
     "jj_ctx_sync": [],
+    "jj_ctx_use_own_stream": [],
     "jj_ctx_profile": [C.c_int],
     "jj_ctx_profile_read": [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)],
     "jj_peak_imad32": [C.POINTER(C.c_double)],

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -36,6 +37,7 @@ struct jj_ctx {
   // staging for host-pointer arguments (inputs 0..3, outputs 0..1) and kernel workspaces
   DevBuf in[4], out[2], okb, ws_ext, ws_scratch, ws_tables, ws_tmp[4];
   // optional per-call kernel timing (HIP events on the launch stream): e0 | main kernel | e1 | normalise tail | e2
+  int vb_blocks_per_cu = 3;      // var-base ladder: 163 VGPRs -> 3 waves/SIMD resident (JJ_VB_BLOCKS_PER_CU overrides)
   bool profile = false;
   struct Rec { hipEvent_t e0, e1, e2; };
   std::vector<Rec> recs;
@@ -144,6 +146,7 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
   c->wave = prop.warpSize;
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return JJ_ERR_HIP; }
   c->stream = c->own_stream;
+  if (const char* e = getenv("JJ_VB_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) c->vb_blocks_per_cu = v; }
   // the fixed-base kernel needs the full 160 KiB LDS carve-out
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fixedbase), hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS_BYTES);
   *out = c;
@@ -163,7 +166,12 @@ JJ_API int jj_ctx_destroy(jj_ctx* c) {
 }
 JJ_API int jj_ctx_set_stream(jj_ctx* c, void* s) {
   if (!c) return JJ_ERR_INVALID;
-  c->stream = s ? (hipStream_t)s : c->own_stream;
+  c->stream = (hipStream_t)s;            // NULL is HIP's default (null) stream — e.g. torch's default stream
+  return JJ_OK;
+}
+JJ_API int jj_ctx_use_own_stream(jj_ctx* c) {
+  if (!c) return JJ_ERR_INVALID;
+  c->stream = c->own_stream;
   return JJ_OK;
 }
 JJ_API int jj_ctx_sync(jj_ctx* c) {
@@ -308,7 +316,7 @@ JJ_API int jj_is_on_curve(jj_ctx* c, size_t n, const void* p, uint8_t* out) { re
 // ---------------------------------------------------------------------------------------------------- var-base
 // launch geometry of the windowed ladder: persistent grid, one 1152-byte table slot per lane
 static void varbase_geometry(jj_ctx* c, size_t n, unsigned* blocks, size_t* threads) {
-  const size_t max_threads = (size_t)c->cus * 256 * 2;         // 2 blocks of 256 per CU = 2 waves / SIMD
+  const size_t max_threads = (size_t)c->cus * 256 * c->vb_blocks_per_cu;   // k blocks of 256 per CU = k waves / SIMD
   size_t t = std::min(max_threads, ((n + 255) / 256) * 256);
   if (t == 0) t = 256;
   *blocks = (unsigned)(t / 256); *threads = t;

@@ -32,6 +32,22 @@ struct Fe {
   u32 l[NL];
 };
 
+// d = a*b + c as ONE v_mad_u64_u32 with a fixed association: c is the accumulator coming in, so a carry from the
+// previous column rides in as the addend of the next column's first multiply-add (hipcc would otherwise
+// re-associate every column into an independent chain and spend an extra v_lshl_add_u64 per column to merge).
+// Not volatile: the scheduler may still interleave independent field operations.
+static JJ_DEV u64 mad_vv(u32 a, u32 b, u64 c) {
+  u64 d;
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c) : "vcc");
+  return d;
+}
+// same with a wave-uniform (compile-time constant) multiplier held in an SGPR
+static JJ_DEV u64 mad_vs(u32 a, u32 k, u64 c) {
+  u64 d;
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "s"(k), "v"(c) : "vcc");
+  return d;
+}
+
 template <class P>
 struct Field {
   // ---------------------------------------------------------------- constants
@@ -62,7 +78,52 @@ struct Field {
     return r;
   }
 
-  // r = a*b/R mod p.  reference Fr::mul src/fr.rs:592-616.
+#ifndef JJ_MUL_VARIANT
+#define JJ_MUL_VARIANT 1
+#endif
+#if JJ_MUL_VARIANT == 2
+  // Variant 2: finely-integrated product scanning with pinned association (mad_vv / mad_vs).
+  template <bool SQUARE>
+  static JJ_DEV Fe mul_fips(const Fe& a, const Fe& b) {
+    u32 m[NL];
+    u32 b2[NL];
+    if constexpr (SQUARE) { _Pragma("unroll") for (int i = 0; i < NL; i++) b2[i] = a.l[i] << 1; }
+    Fe r;
+    u64 acc = 0;
+    _Pragma("unroll") for (int k = 0; k < 2 * NL - 1; k++) {
+      _Pragma("unroll") for (int i = 0; i < NL; i++) {
+        const int j = k - i;
+        if (j < 0 || j >= NL) continue;
+        if constexpr (SQUARE) {
+          if (j > i) acc = mad_vv(a.l[i], b2[j], acc);
+          else if (j == i) acc = mad_vv(a.l[i], a.l[i], acc);
+        } else {
+          acc = mad_vv(a.l[i], b.l[j], acc);
+        }
+      }
+      _Pragma("unroll") for (int i = 0; i < NL; i++) {
+        const int j = k - i;
+        if (i >= k || j < 1 || j >= NL) continue;
+        acc = mad_vs(m[i], P::P[j], acc);
+      }
+      if (k < NL) {
+        u32 mk;
+        if constexpr (P::NINV == LMASK) mk = (0u - (u32)acc) & LMASK;
+        else mk = ((u32)acc * P::NINV) & LMASK;
+        m[k] = mk;
+        if constexpr (P::P[0] == 1u) acc += mk; else acc = mad_vs(mk, P::P[0], acc);
+      } else {
+        r.l[k - NL] = (u32)acc & LMASK;
+      }
+      acc >>= LB;
+    }
+    r.l[NL - 1] = (u32)acc;
+    return r;
+  }
+  static JJ_DEV Fe mul(const Fe& a, const Fe& b) { return mul_fips<false>(a, b); }
+  static JJ_DEV Fe sqr(const Fe& a) { return mul_fips<true>(a, a); }
+#elif JJ_MUL_VARIANT == 0
+  // Variant 0: all product columns first, then a separate reduction sweep (reduce()).
   static JJ_DEV Fe mul(const Fe& a, const Fe& b) {
     u64 c[2 * NL];
     _Pragma("unroll") for (int k = 0; k < 2 * NL - 1; k++) {
@@ -76,8 +137,6 @@ struct Field {
     c[2 * NL - 1] = 0;
     return reduce(c);
   }
-
-  // r = a*a/R mod p.  reference Fr::square src/fr.rs:353-381 (same cross-term doubling idea).
   static JJ_DEV Fe sqr(const Fe& a) {
     u32 a2[NL];
     _Pragma("unroll") for (int i = 0; i < NL; i++) a2[i] = a.l[i] << 1;
@@ -94,6 +153,57 @@ struct Field {
     c[2 * NL - 1] = 0;
     return reduce(c);
   }
+#else
+  // Variant 1 (default): finely-integrated product scanning.  One running 64-bit accumulator walks the 18
+  // columns; the carry out of column k is simply the addend of the first v_mad_u64_u32 of column k+1, so carry
+  // propagation costs no instruction.  Per column: the a*b terms, the m_i*p_j terms, then (k < 9) the Montgomery
+  // digit m_k = -acc mod 2^29 and acc = (acc + m_k) >> 29, or (k >= 9) emit a limb and shift.
+  // r = a*b/R mod p.  reference Fr::mul src/fr.rs:592-616 + montgomery_reduce 544-588.
+  template <bool SQUARE>
+  static JJ_DEV Fe mul_fips(const Fe& a, const Fe& b) {
+    u32 m[NL];
+    u32 b2[NL];
+    if constexpr (SQUARE) { _Pragma("unroll") for (int i = 0; i < NL; i++) b2[i] = a.l[i] << 1; }
+    Fe r;
+    u64 acc = 0;
+    u32 p0 = P::P[0];
+    asm("" : "+s"(p0));   // opaque to the optimiser
+    _Pragma("unroll") for (int k = 0; k < 2 * NL - 1; k++) {
+      _Pragma("unroll") for (int i = 0; i < NL; i++) {
+        const int j = k - i;
+        if (j < 0 || j >= NL) continue;
+        if constexpr (SQUARE) {
+          if (j > i) acc += (u64)a.l[i] * b2[j];
+          else if (j == i) acc += (u64)a.l[i] * a.l[i];
+        } else {
+          acc += (u64)a.l[i] * b.l[j];
+        }
+      }
+      _Pragma("unroll") for (int i = 0; i < NL; i++) {
+        const int j = k - i;
+        if (i >= k || i >= NL || j < 1 || j >= NL) continue;   // m_i exists for i < min(k, 9); p_0 handled below
+        acc += (u64)m[i] * P::P[j];
+      }
+      if (k < NL) {
+        u32 mk;
+        if constexpr (P::NINV == LMASK) mk = (0u - (u32)acc) & LMASK;
+        else mk = ((u32)acc * P::NINV) & LMASK;
+        m[k] = mk;
+        // acc += mk * p_0.  For Fq p_0 = 1: multiplying by an opaque 1 keeps this a single v_mad_u64_u32 instead
+        // of zero-extending mk into a register pair (v_mov) and a 64-bit add.
+        acc += (u64)mk * p0;
+      } else {
+        r.l[k - NL] = (u32)acc & LMASK;
+      }
+      acc >>= LB;
+    }
+    r.l[NL - 1] = (u32)acc;
+    return r;
+  }
+  static JJ_DEV Fe mul(const Fe& a, const Fe& b) { return mul_fips<false>(a, b); }
+  // r = a*a/R mod p.  reference Fr::square src/fr.rs:353-381 (same cross-term doubling idea).
+  static JJ_DEV Fe sqr(const Fe& a) { return mul_fips<true>(a, a); }
+#endif
 
   // ---------------------------------------------------------------- additive ops (lazy, carry-free)
   // r = a + b, no carry.  reference Fr::add src/fr.rs:638-647 (which reduces; we defer).

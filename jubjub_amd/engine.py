@@ -127,9 +127,9 @@ class Engine:
             import torch
 
             s = torch.cuda.current_stream(args[[a.torch for a in args].index(True)].device).cuda_stream
-            self._lib.jj_ctx_set_stream(self._ctx, C.c_void_p(s))
+            self._lib.jj_ctx_set_stream(self._ctx, C.c_void_p(s))   # s == 0 is torch's default (null) stream
         else:
-            self._lib.jj_ctx_set_stream(self._ctx, None)
+            self._lib.jj_ctx_use_own_stream(self._ctx)
 
     def _alloc(self, like, n, width):
         if like.torch:
