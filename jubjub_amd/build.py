@@ -30,7 +30,7 @@ def build(force=False, verbose=False):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden",
-           "-Wall", "-Wno-unused-function", "-o", OUT, SRC]
+           "-Wall", "-Wno-unused-function", "-o", OUT, SRC] + os.environ.get("JJ_CXXFLAGS", "").split()
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -37,7 +37,7 @@ struct jj_ctx {
   // staging for host-pointer arguments (inputs 0..3, outputs 0..1) and kernel workspaces
   DevBuf in[4], out[2], okb, ws_ext, ws_scratch, ws_tables, ws_tmp[4];
   // optional per-call kernel timing (HIP events on the launch stream): e0 | main kernel | e1 | normalise tail | e2
-  int vb_blocks_per_cu = 3;      // var-base ladder: 163 VGPRs -> 3 waves/SIMD resident (JJ_VB_BLOCKS_PER_CU overrides)
+  int vb_blocks_per_cu = 2;      // var-base ladder: 2 waves/SIMD (3 blocks/CU distribute unevenly over the 4 SIMDs: measured slower)
   bool profile = false;
   struct Rec { hipEvent_t e0, e1, e2; };
   std::vector<Rec> recs;

@@ -268,8 +268,12 @@ struct Field {
   static JJ_DEV bool is_zero(const Fe& a) { return is_zero_canon(canon(a)); }          // reference ct_eq(&zero)
   static JJ_DEV bool eq(const Fe& a, const Fe& b) { return eq_canon(canon(a), canon(b)); }  // reference Fr::ct_eq src/fr.rs:48-55
   // select: mask all-ones -> b, zero -> a (reference conditional_select src/fr.rs:64-73); bit-masking, not v_cndmask
+  // The mask is made opaque so hipcc emits one v_bfi_b32 per limb: it would otherwise rebuild a v_cmp +
+  // v_cndmask_b32_e32 (VCC) sequence, and on gfx950 a VOP2 v_cndmask that re-reads a VCC written several
+  // instructions earlier issues at ~22 cycles instead of 4 (measured: experiments/ubench/ubench2.hip).
   static JJ_DEV Fe select(const Fe& a, const Fe& b, u32 mask) {
-    Fe r; _Pragma("unroll") for (int i = 0; i < NL; i++) r.l[i] = a.l[i] ^ ((a.l[i] ^ b.l[i]) & mask); return r;
+    asm("" : "+v"(mask));
+    Fe r; _Pragma("unroll") for (int i = 0; i < NL; i++) r.l[i] = (b.l[i] & mask) | (a.l[i] & ~mask); return r;
   }
 
   // ---------------------------------------------------------------- wire format: 8 x u32 little-endian canonical words

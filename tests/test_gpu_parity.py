@@ -205,3 +205,26 @@ def test_torch_device_tensors(eng):
     assert (a.cpu().numpy() == O.field_op(O.FQ, "mul", S, S)[0]).all()
     with pytest.raises(Exception):
         eng.varbase_mul(dS.flatten()[1:1 + 32 * 8].reshape(8, 32), dP[:8])   # misaligned device pointer is rejected
+
+
+def test_committed_oracle_vectors_gpu(eng):
+    """GPU path against the committed fixtures tests/golden/oracle_vectors.json (no oracle call needed)."""
+    import json, os
+    v = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oracle_vectors.json")))
+    fx = lambda h: np.frombuffer(bytes.fromhex(h), dtype=np.uint8)
+    S = np.stack([fx(c["scalar"]) for c in v["varbase"]])
+    P = np.stack([fx(c["point"]) for c in v["varbase"]])
+    assert (eng.varbase_mul(S, P) == np.stack([fx(c["out"]) for c in v["varbase"]])).all()
+    assert (eng.varbase_mul_exact(S, P) == np.stack([fx(c["ext"]) for c in v["varbase"]])).all()
+    fb = v["fixedbase"]
+    tab = eng.fixedbase_table(fx(fb["base"]))
+    S = np.stack([fx(c["scalar"]) for c in fb["cases"]])
+    assert (eng.fixedbase_mul(tab, S) == np.stack([fx(c["out"]) for c in fb["cases"]])).all()
+    E = np.stack([fx(c["in"]) for c in v["decompress"]])
+    for flags in (0, 1, 3, 5, 9, 15):
+        out, ok = eng.decompress(E, flags)
+        assert list(ok) == [c["f%d" % flags]["ok"] for c in v["decompress"]], flags
+        assert (out == np.stack([fx(c["f%d" % flags]["out"]) for c in v["decompress"]])).all(), flags
+    for m in v["msm"]:
+        got = eng.msm(np.stack([fx(s) for s in m["scalars"]]), np.stack([fx(p) for p in m["points"]]))
+        assert (got == fx(m["out"])).all()

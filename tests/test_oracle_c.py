@@ -228,3 +228,25 @@ def test_decompress_flags_vs_python():
     out, ok = O.batch_from_bytes(E)
     o2, k2 = O.decompress(E, 1)
     assert (out == o2).all() and (ok == k2).all()
+
+
+def test_committed_oracle_vectors():
+    """The committed fixtures (tests/golden/oracle_vectors.json) agree with the C oracle."""
+    import json, os
+    v = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oracle_vectors.json")))
+    fx = lambda h: np.frombuffer(bytes.fromhex(h), dtype=np.uint8)
+    S = np.stack([fx(c["scalar"]) for c in v["varbase"]])
+    P = np.stack([fx(c["point"]) for c in v["varbase"]])
+    assert (O.varbase_mul(S, P) == np.stack([fx(c["out"]) for c in v["varbase"]])).all()
+    assert (O.varbase_mul_ext(S, P) == np.stack([fx(c["ext"]) for c in v["varbase"]])).all()
+    fb = v["fixedbase"]
+    S = np.stack([fx(c["scalar"]) for c in fb["cases"]])
+    assert (O.fixedbase_mul(S, fx(fb["base"])) == np.stack([fx(c["out"]) for c in fb["cases"]])).all()
+    E = np.stack([fx(c["in"]) for c in v["decompress"]])
+    for flags in (0, 1, 3, 5, 9, 15):
+        out, ok = O.decompress(E, flags)
+        assert list(ok) == [c["f%d" % flags]["ok"] for c in v["decompress"]]
+        assert (out == np.stack([fx(c["f%d" % flags]["out"]) for c in v["decompress"]])).all()
+    for m in v["msm"]:
+        got = O.msm(np.stack([fx(s) for s in m["scalars"]]), np.stack([fx(p) for p in m["points"]]))
+        assert (got == fx(m["out"])).all()
