@@ -38,8 +38,9 @@ WORK = {
     "varbase": {"S": 63 * 16 + 8, "M": 67 + 63 * 20 + 2 + 7 + 3, "bytes": 32 + 64 + 64},
     # 43 mixed adds x 7M ; normalise as above
     "fixedbase": {"S": 8, "M": 43 * 7 + 7 + 3, "bytes": 32 + 64},
-    # msm v1 = var-base terms + 10M per fold add
-    "msm": {"S": 63 * 16 + 8, "M": 67 + 63 * 20 + 2 + 10, "bytes": 32 + 64},
+    # Pippenger, c = 16: per term 2M load + 2M to_niels + 16 windows x 7M mixed add; bucket reduce 2 x 10M per bucket
+    # (2^19 buckets / 2^20 terms -> +10M); the 240-doubling Horner tail is per MSM, not per term
+    "msm": {"S": 0, "M": 2 + 2 + 16 * 7 + 10, "bytes": 32 + 64},
     # decompress: from_bytes 1M, 1S, 2M, inversion 255S+78M, sqrt ~ (222S+56M) + (528S + 64M) ; to_bytes
     "decompress": {"S": 1 + 255 + 222 + 528, "M": 1 + 2 + 78 + 56 + 64 + 4, "bytes": 32 + 65},
 }
@@ -209,7 +210,7 @@ def main():
         res["roofline"] = {
             "bound": "valu_int32", "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TIMAD32/s",
             "frac": achieved / peak, "traffic": None,
-            "kernel": {"varbase": "k_varbase", "fixedbase": "k_fixedbase", "msm": "k_varbase5", "decompress": "k_decompress"}[wl],
+            "kernel": {"varbase": "k_varbase", "fixedbase": "k_fixedbase", "msm": "k_msm_accumulate (+prepare/scatter/reduce/horner)", "decompress": "k_decompress"}[wl],
             "kernel_ms": kern_ms, "tail_ms": tail,
             "work_per_unit": {"field_squares": w["S"], "field_muls": w["M"], "imad32": imad32(w), "convention": "M=128,S=100 (SURVEY 8d)"},
             "reference_algorithm_imad32": imad32(REFERENCE_WORK[wl]) if wl in REFERENCE_WORK else None,

@@ -35,7 +35,8 @@ struct jj_ctx {
   int cus = 0, clock_khz = 0, wave = 64;
   std::string err;
   // staging for host-pointer arguments (inputs 0..3, outputs 0..1) and kernel workspaces
-  DevBuf in[4], out[2], okb, ws_ext, ws_scratch, ws_tables, ws_tmp[4];
+  DevBuf in[4], out[2], okb, ws_ext, ws_scratch, ws_tables, ws_tmp[4], msm[8];
+  int msm_min_pippenger = 512;   // below this many terms the MSM is var-base ladders + fold (JJ_MSM_NAIVE_BELOW overrides)
   // optional per-call kernel timing (HIP events on the launch stream): e0 | main kernel | e1 | normalise tail | e2
   int vb_blocks_per_cu = 2;      // var-base ladder: 2 waves/SIMD (3 blocks/CU distribute unevenly over the 4 SIMDs: measured slower)
   bool profile = false;
@@ -146,6 +147,7 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
   c->wave = prop.warpSize;
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return JJ_ERR_HIP; }
   c->stream = c->own_stream;
+  if (const char* e = getenv("JJ_MSM_NAIVE_BELOW")) { int v = atoi(e); if (v >= 0) c->msm_min_pippenger = v; }
   if (const char* e = getenv("JJ_VB_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) c->vb_blocks_per_cu = v; }
   // the fixed-base kernel needs the full 160 KiB LDS carve-out
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fixedbase), hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS_BYTES);
@@ -157,7 +159,8 @@ JJ_API int jj_ctx_destroy(jj_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   DevBuf* all[] = {&c->in[0], &c->in[1], &c->in[2], &c->in[3], &c->out[0], &c->out[1], &c->okb, &c->ws_ext, &c->ws_scratch, &c->ws_tables,
-                   &c->ws_tmp[0], &c->ws_tmp[1], &c->ws_tmp[2], &c->ws_tmp[3]};
+                   &c->ws_tmp[0], &c->ws_tmp[1], &c->ws_tmp[2], &c->ws_tmp[3], &c->msm[0], &c->msm[1], &c->msm[2], &c->msm[3],
+                   &c->msm[4], &c->msm[5], &c->msm[6], &c->msm[7]};
   for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
   for (auto& r : c->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); (void)hipEventDestroy(r.e2); }
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -504,6 +507,56 @@ JJ_API int jj_point_sum(jj_ctx* c, size_t n, const void* p, void* out64) {
   if ((rc = finish_out(c, o, &sync))) return rc;
   return finish(c, sync);
 }
+// Pippenger on the device: leaves the result (extended, coords U,V,Z of element 0) in *res.
+static int msm_pippenger(jj_ctx* c, size_t n, const void* ds, const void* dp, SoA* res) {
+  MsmParams mp;
+  mp.c = (n >= ((size_t)1 << 15)) ? 16 : (n >= ((size_t)1 << 11) ? 12 : 8);
+  mp.W = (253 + mp.c - 1) / mp.c;
+  mp.B = 1u << (mp.c - 1);
+  memset(mp.recode, 0, sizeof mp.recode);
+  for (int w = 0; w < mp.W - 1; w++) { const int bit = mp.c * w + mp.c - 1; mp.recode[bit >> 5] |= 1u << (bit & 31); }
+  const size_t nb = (size_t)mp.W * mp.B;
+  const u32 L = 32;                                   // buckets per reduce chunk
+  const size_t nchunks = nb / L;
+  int rc;
+  DevBuf &kprime = c->msm[0], &niels = c->msm[1], &cnt = c->msm[2], &idx = c->msm[3], &buckets = c->msm[4], &ra = c->msm[5], &rb = c->msm[6], &rankb = c->msm[7];
+  const size_t nscan = (nb + SCAN_TILE - 1) / SCAN_TILE;
+  const size_t max_chunks = (n * (size_t)mp.W + MSM_CHUNK - 1) / MSM_CHUNK;
+  if ((rc = ensure(c, kprime, n * 32))) return rc;
+  if ((rc = ensure(c, niels, n * (size_t)ANIELS_WORDS * 4))) return rc;
+  if ((rc = ensure(c, cnt, (2 * nb + nscan + 8) * 4))) return rc;  // count | offset (nb+1) | block sums
+  if ((rc = ensure(c, idx, n * (size_t)mp.W * 4))) return rc;
+  if ((rc = ensure(c, rankb, n * (size_t)mp.W * 4))) return rc;
+  if ((rc = ensure(c, buckets, (size_t)5 * NL * 4 * nb))) return rc;
+  if ((rc = ensure(c, ra, (size_t)5 * NL * 4 * std::max(nchunks, max_chunks)))) return rc;   // first the chunk heads, later the fold ping-pong
+  if ((rc = ensure(c, rb, (size_t)5 * NL * 4 * nchunks))) return rc;
+  u32* count = (u32*)cnt.p; u32* offset = count + nb; u32* bsum = offset + nb + 1;
+  HIPCHK(c, hipMemsetAsync(count, 0, nb * 4, c->stream));
+  hipLaunchKernelGGL(k_msm_prepare, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, ds, dp, mp, (u32*)kprime.p, (u32*)niels.p, count, (u32*)rankb.p);
+  hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)nscan), dim3(256), 0, c->stream, nb, (const u32*)count, bsum);
+  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, c->stream, nscan, bsum, offset + nb);
+  hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nscan), dim3(256), 0, c->stream, nb, (const u32*)count, (const u32*)bsum, offset);
+  hipLaunchKernelGGL(k_msm_scatter, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, mp, (const u32*)kprime.p, (const u32*)offset, (const u32*)rankb.p, (u32*)idx.p);
+  {
+    SoA head = soa_of(ra, max_chunks);
+    hipLaunchKernelGGL(k_msm_accumulate, dim3(blocks_for(max_chunks)), dim3(256), 0, c->stream, nb, (const u32*)offset, (const u32*)idx.p, (const u32*)niels.p, soa_of(buckets, nb), head);
+    hipLaunchKernelGGL(k_msm_fixup, dim3(blocks_for(nb)), dim3(256), 0, c->stream, nb, (const u32*)offset, soa_of(buckets, nb), head);
+  }
+  hipLaunchKernelGGL(k_msm_bucket_reduce, dim3(blocks_for(nchunks)), dim3(256), 0, c->stream, nchunks, L, mp.B, soa_of(buckets, nb), soa_of(ra, nchunks));
+  // fold the chunks of each window: per-window count B/L -> 1
+  size_t per_window = mp.B / L, m = nchunks;
+  DevBuf* cur = &ra; DevBuf* nxt = &rb;
+  while (per_window > 1) {
+    const int fold = (int)std::min<size_t>(per_window, 32);
+    const size_t T = m / fold;
+    hipLaunchKernelGGL(k_sum_groups, dim3(blocks_for(T)), dim3(256), 0, c->stream, m, T, fold, soa_of(*cur, m), soa_of(*nxt, T));
+    std::swap(cur, nxt); m = T; per_window /= fold;
+  }
+  // m == W window sums; Horner combine
+  hipLaunchKernelGGL(k_msm_horner, dim3(1), dim3(64), 0, c->stream, mp.W, mp.c, soa_of(*cur, m), soa_of(*nxt, 1));
+  *res = soa_of(*nxt, 1);
+  return JJ_OK;
+}
 JJ_API int jj_msm(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out64) {
   if (!c) return JJ_ERR_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
@@ -514,11 +567,18 @@ JJ_API int jj_msm(jj_ctx* c, size_t n, const void* scalars, const void* points, 
     const void *ds, *dp;
     if ((rc = stage_in(c, 0, scalars, 32 * n, &ds))) return rc;
     if ((rc = stage_in(c, 1, points, 64 * n, &dp))) return rc;
-    if ((rc = ensure(c, c->ws_tmp[2], (size_t)5 * NL * 4 * n))) return rc;
-    if ((rc = varbase_to_ext(c, n, ds, dp, soa_of(c->ws_tmp[2], n), true))) return rc;
     SoA res;
-    if ((rc = sum_reduce(c, n, &c->ws_tmp[2], &c->ws_tmp[3], &res))) return rc;
+    prof_mark(c, 0);
+    if (n >= (size_t)c->msm_min_pippenger) {
+      if ((rc = msm_pippenger(c, n, ds, dp, &res))) return rc;
+    } else {
+      if ((rc = ensure(c, c->ws_tmp[2], (size_t)5 * NL * 4 * n))) return rc;
+      if ((rc = varbase_to_ext(c, n, ds, dp, soa_of(c->ws_tmp[2], n), true))) return rc;
+      if ((rc = sum_reduce(c, n, &c->ws_tmp[2], &c->ws_tmp[3], &res))) return rc;
+    }
+    prof_mark(c, 1);
     if ((rc = normalize_launch(c, 1, res, o.dev, 0))) return rc;
+    prof_mark(c, 2);
   }
   bool sync = false;
   if ((rc = finish_out(c, o, &sync))) return rc;

@@ -509,6 +509,219 @@ __global__ void __launch_bounds__(256) k_and_bytes(size_t n, uint8_t* a, const u
   a[i] = a[i] & (negate_b ? (b[i] ^ 1) : b[i]);
 }
 
+// ------------------------------------------------------------------------------------------------ K7: Pippenger MSM
+// sum_i k_i P_i with signed c-bit windows (c <= 16): k' = k + sum_{w<W-1} 2^(cw+c-1); digit_w = window_w(k') - 2^(c-1)
+// (top window unsigned).  Terms are counting-sorted by (window, |digit|) with atomics, then one lane per bucket
+// adds its points (affine-Niels, 7M mixed addition), buckets are reduced per chunk with the running-sum trick,
+// chunks are folded, and the window sums are combined by Horner.  The group element equals the reference's
+// `sum of p * k` (src/lib.rs:183-193, 873-879); only +-P (exact on the whole curve) is used.
+struct MsmParams {
+  int c;            // window bits
+  int W;            // number of windows
+  u32 B;            // buckets per window = 2^(c-1)
+  u32 recode[8];    // sum_{w<W-1} 2^(cw+c-1)
+};
+// bits [c*w, c*w+c) of the 256-bit little-endian integer k (c <= 16)
+static JJ_DEV u32 msm_window(const u32* k, int c, int w) {
+  const int bit = c * w, wi = bit >> 5, sh = bit & 31;
+  const u64 both = ((u64)(wi < 7 ? k[wi + 1] : 0u) << 32) | k[wi];
+  return (u32)(both >> sh) & ((1u << c) - 1u);
+}
+// signed digit of window w: returns |d| (0 = skip) and sign
+static JJ_DEV u32 msm_digit(const u32* kp, const MsmParams& mp, int w, u32& neg) {
+  const u32 raw = msm_window(kp, mp.c, w);
+  if (w == mp.W - 1) { neg = 0; return raw; }
+  const int d = (int)raw - (int)mp.B;
+  neg = d < 0 ? 1u : 0u;
+  return (u32)(d < 0 ? -d : d);
+}
+// recode scalars, convert points to affine-Niels AoS (28 words), histogram the digits.  The returning atomic
+// gives every (term, window) its rank inside its bucket, so the scatter pass needs no second round of atomics.
+__global__ void __launch_bounds__(256) k_msm_prepare(size_t n, const void* scalars, const void* points, MsmParams mp,
+                                                      u32* kprime, u32* niels, u32* count, u32* rank) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 k[8];
+  load8(k, scalars, i);
+  k[7] &= 0x0fffffffu;
+  u64 cy = 0;
+  _Pragma("unroll") for (int j = 0; j < 8; j++) { const u64 t = (u64)k[j] + mp.recode[j] + cy; k[j] = (u32)t; cy = t >> 32; }
+  uint4* kp = reinterpret_cast<uint4*>(kprime + i * 8);
+  kp[0] = make_uint4(k[0], k[1], k[2], k[3]); kp[1] = make_uint4(k[4], k[5], k[6], k[7]);
+  for (int w = 0; w < mp.W; w++) {
+    u32 neg; const u32 a = msm_digit(k, mp, w, neg);
+    rank[(size_t)w * n + i] = a ? atomicAdd(&count[(size_t)w * mp.B + a - 1], 1u) : 0u;
+  }
+  const ANiels t = Curve::to_niels(load_affine(points, i));
+  u32 wv[ANIELS_WORDS];
+  _Pragma("unroll") for (int l = 0; l < NL; l++) { wv[l] = t.vpu.l[l]; wv[NL + l] = t.vmu.l[l]; wv[2 * NL + l] = t.t2d.l[l]; }
+  wv[27] = 0;
+  uint4* e = reinterpret_cast<uint4*>(niels + i * ANIELS_WORDS);
+  _Pragma("unroll") for (int v = 0; v < ANIELS_WORDS / 4; v++) e[v] = make_uint4(wv[4 * v], wv[4 * v + 1], wv[4 * v + 2], wv[4 * v + 3]);
+}
+// exclusive scan of `count` (m entries) into `offset` (m+1 entries), three small passes:
+// (1) per-block sums of SCAN_TILE entries, (2) one block scans the block sums, (3) per-block local scan + base.
+constexpr int SCAN_TILE = 2048;   // entries per 256-thread block (8 per thread)
+__global__ void __launch_bounds__(256) k_scan_block_sums(size_t m, const u32* count, u32* block_sum) {
+  __shared__ u32 red[256];
+  const size_t base = (size_t)blockIdx.x * SCAN_TILE;
+  u32 s = 0;
+  for (int j = threadIdx.x; j < SCAN_TILE; j += 256) { const size_t i = base + j; if (i < m) s += count[i]; }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) { if ((int)threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d]; __syncthreads(); }
+  if (threadIdx.x == 0) block_sum[blockIdx.x] = red[0];
+}
+__global__ void __launch_bounds__(1024) k_scan_top(size_t nblocks, u32* block_sum, u32* total_out) {
+  __shared__ u32 part[1024];
+  const size_t per = (nblocks + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < nblocks ? lo + per : nblocks;
+  u32 s = 0;
+  for (size_t j = lo; j < hi; j++) s += block_sum[j];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const u32 v = (int)threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  u32 run = part[threadIdx.x] - s;
+  for (size_t j = lo; j < hi; j++) { const u32 c = block_sum[j]; block_sum[j] = run; run += c; }
+  if (threadIdx.x == 1023) *total_out = part[1023];
+}
+__global__ void __launch_bounds__(256) k_scan_apply(size_t m, const u32* count, const u32* block_base, u32* offset) {
+  __shared__ u32 part[256];
+  const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * (SCAN_TILE / 256);
+  u32 v[SCAN_TILE / 256]; u32 s = 0;
+  _Pragma("unroll") for (int j = 0; j < SCAN_TILE / 256; j++) { v[j] = (base + j < m) ? count[base + j] : 0u; s += v[j]; }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    const u32 x = (int)threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += x;
+    __syncthreads();
+  }
+  u32 run = block_base[blockIdx.x] + part[threadIdx.x] - s;
+  _Pragma("unroll") for (int j = 0; j < SCAN_TILE / 256; j++) { if (base + j < m) offset[base + j] = run; run += v[j]; }
+}
+// idx[offset[bucket] + rank] = term | sign<<31   (no atomics: ranks were fixed by k_msm_prepare)
+__global__ void __launch_bounds__(256) k_msm_scatter(size_t n, MsmParams mp, const u32* kprime, const u32* offset, const u32* rank, u32* idx) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 k[8];
+  load8(k, kprime, i);
+  for (int w = 0; w < mp.W; w++) {
+    u32 neg; const u32 a = msm_digit(k, mp, w, neg);
+    if (a) idx[offset[(size_t)w * mp.B + a - 1] + rank[(size_t)w * n + i]] = (u32)i | (neg << 31);
+  }
+}
+// Balanced bucket accumulation: the sorted entry list (M entries, bucket-major) is cut into fixed chunks of
+// MSM_CHUNK entries, one lane per chunk, so every lane performs the same number of mixed additions whatever the
+// bucket-size distribution.  A run that starts at a bucket start is written to buckets[b]; the run a chunk
+// inherits from the previous chunk goes to head[t] and is merged by k_msm_fixup.
+constexpr int MSM_CHUNK = 32;
+static JJ_DEV void soa_put_ext(const SoA& s, size_t i, const Ext& e);
+__global__ void __launch_bounds__(256) k_msm_accumulate(size_t nb, const u32* offset, const u32* idx, const u32* niels, SoA buckets, SoA head) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t M = offset[nb];                              // number of non-zero digits
+  const size_t start = t * MSM_CHUNK;
+  if (start >= M) return;
+  const size_t end = start + MSM_CHUNK < M ? start + MSM_CHUNK : M;
+  // bucket containing `start`: largest b with offset[b] <= start
+  size_t lo = 0, hi = nb;
+  while (hi - lo > 1) { const size_t mid = (lo + hi) >> 1; if (offset[mid] <= start) lo = mid; else hi = mid; }
+  size_t b = lo;
+  u32 nxt = offset[b + 1];
+  while (nxt <= start) { b++; nxt = offset[b + 1]; }     // skip empty buckets that share the offset
+  bool inherited = offset[b] < start;                       // first run continues a bucket begun in an earlier chunk
+  Ext acc = Curve::identity();
+  bool any = false;
+  #pragma unroll 1
+  for (size_t pos = start; pos < end; pos++) {
+    if (pos >= nxt) {
+      if (inherited) { soa_put_ext(head, t, acc); inherited = false; } else if (any) soa_put_ext(buckets, b, acc);
+      acc = Curve::identity(); any = false;
+      do { b++; nxt = offset[b + 1]; } while (nxt <= pos);
+    }
+    const u32 e = idx[pos];
+    const ANiels p = lds_aniels(niels + (size_t)(e & 0x7fffffffu) * ANIELS_WORDS);
+    acc = Curve::add(acc, Curve::select(p, Curve::neg(p), (e >> 31) ? ~0u : 0u));
+    any = true;
+  }
+  if (inherited) soa_put_ext(head, t, acc); else soa_put_ext(buckets, b, acc);
+}
+// buckets[b] (+)= heads of the chunks that continue bucket b; empty buckets become the identity
+__global__ void __launch_bounds__(256) k_msm_fixup(size_t nb, const u32* offset, SoA buckets, SoA head) {
+  const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  const u32 lo = offset[b], hi = offset[b + 1];
+  if (lo == hi) { soa_put_ext(buckets, b, Curve::identity()); return; }
+  const size_t t_first = lo / MSM_CHUNK + 1, t_last = (hi - 1) / MSM_CHUNK;
+  if (t_first > t_last) return;
+  Ext acc;   // the bucket's own first run (written by the chunk that contains offset[b])
+  acc.u = buckets.get(0, b); acc.v = buckets.get(1, b); acc.z = buckets.get(2, b); acc.t1 = buckets.get(3, b); acc.t2 = buckets.get(4, b);
+  #pragma unroll 1
+  for (size_t t = t_first; t <= t_last; t++) {
+    Ext h; h.u = head.get(0, t); h.v = head.get(1, t); h.z = head.get(2, t); h.t1 = head.get(3, t); h.t2 = head.get(4, t);
+    acc = Curve::add(acc, Curve::to_niels(h));
+  }
+  soa_put_ext(buckets, b, acc);
+}
+static JJ_DEV Ext soa_ext(const SoA& s, size_t i) { Ext e; e.u = s.get(0, i); e.v = s.get(1, i); e.z = s.get(2, i); e.t1 = s.get(3, i); e.t2 = s.get(4, i); return e; }
+static JJ_DEV void soa_put_ext(const SoA& s, size_t i, const Ext& e) {
+  s.put(0, i, e.u); s.put(1, i, e.v); s.put(2, i, e.z); s.put(3, i, Fq::carry(e.t1)); s.put(4, i, Fq::carry(e.t2));
+}
+// chunk of L consecutive buckets j0..j0+L-1 of one window (bucket j holds digit value j+1):
+// sum (j+1) b_j = T + j0 * S with T = sum (j-j0+1) b_j (running sums) and S = sum b_j.
+__global__ void __launch_bounds__(256) k_msm_bucket_reduce(size_t nchunks, u32 L, u32 B, SoA buckets, SoA out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nchunks) return;
+  const size_t first = t * L;               // global bucket index (window-major)
+  const u32 j0 = (u32)(first % B);          // index inside the window
+  Ext running = Curve::identity(), total = Curve::identity();
+  #pragma unroll 1
+  for (int j = (int)L - 1; j >= 0; j--) {
+    running = Curve::add(running, Curve::to_niels(soa_ext(buckets, first + j)));
+    total = Curve::add(total, Curve::to_niels(running));
+  }
+  // total += j0 * running   (j0 < 2^15), double-and-add from the top bit
+  Ext m = Curve::identity();
+  const ENiels rn = Curve::to_niels(running);
+  #pragma unroll 1
+  for (int bit = 15; bit >= 0; bit--) {
+    m = Curve::dbl(m);
+    m = Curve::add(m, Curve::select(Curve::eniels_identity(), rn, ((j0 >> bit) & 1u) ? ~0u : 0u));
+  }
+  total = Curve::add(total, Curve::to_niels(m));
+  soa_put_ext(out, t, total);
+}
+// Horner over the W window sums (5-coordinate SoA, index w): acc = 2^c acc + S_w from the top window down
+__global__ void k_msm_horner(int W, int c, SoA wins, SoA out) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  Ext acc = soa_ext(wins, W - 1);
+  #pragma unroll 1
+  for (int w = W - 2; w >= 0; w--) {
+    #pragma unroll 1
+    for (int d = 0; d < c; d++) acc = Curve::dbl(acc);
+    acc = Curve::add(acc, Curve::to_niels(soa_ext(wins, w)));
+  }
+  soa_put_ext(out, 0, acc);
+}
+// grouped fold: out[t] = sum_{j<fold} in[t*fold + j]  (contiguous groups keep the window-major order intact)
+__global__ void __launch_bounds__(256) k_sum_groups(size_t n, size_t T, int fold, SoA in, SoA out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  Ext acc = Curve::identity();
+  #pragma unroll 1
+  for (int j = 0; j < fold; j++) {
+    const size_t i = t * (size_t)fold + j;
+    if (i >= n) break;
+    acc = Curve::add(acc, Curve::to_niels(soa_ext(in, i)));
+  }
+  soa_put_ext(out, t, acc);
+}
+
 // ------------------------------------------------------------------------------------------------ roofline probe
 // 8 independent v_mad_u64_u32 chains per lane, 64 mads per loop iteration: the measured peak IMAD32 rate.
 __global__ void __launch_bounds__(256) k_peak_mad(u32* out, int iters, u32 seed) {

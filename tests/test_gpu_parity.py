@@ -149,10 +149,24 @@ def test_fixedbase(eng):
 
 
 def test_msm(eng):
-    for n in (0, 1, 2, 33, 1000):
+    for n in (0, 1, 2, 33, 511, 512, 1000, 2048, 5000, 40000):
         S = rand_scalars(12 + n, n, full_width=True)
         P = rand_points(13 + n, n, subgroup=(n % 2 == 0))
         assert (eng.msm(S, P) == O.msm(S, P)).all(), n
+
+
+def test_msm_skewed_buckets(eng):
+    """All-equal scalars / repeated points: every term of a window lands in one bucket (worst case for bucket methods)."""
+    n = 6000
+    S = np.repeat(rand_scalars(31, 1, full_width=True), n, axis=0)
+    P = rand_points(32, n)
+    assert (eng.msm(S, P) == O.msm(S, P)).all()
+    S2 = rand_scalars(33, n)
+    S2[: n // 2] = S2[0]
+    P2 = np.repeat(rand_points(34, 3), n // 3, axis=0)
+    assert (eng.msm(S2, P2) == O.msm(S2, P2)).all()
+    Z = np.zeros((n, 32), np.uint8)                      # all-zero scalars: every digit of the recoded form cancels
+    assert to_pt(eng.msm(Z, P)) == J.AFFINE_IDENTITY
 
 
 def test_serialization_golden(eng, golden):
