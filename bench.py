@@ -41,8 +41,9 @@ WORK = {
     # Pippenger, c = 16: per term 2M load + 2M to_niels + 16 windows x 7M mixed add; bucket reduce 2 x 10M per bucket
     # (2^19 buckets / 2^20 terms -> +10M); the 240-doubling Horner tail is per MSM, not per term
     "msm": {"S": 0, "M": 2 + 2 + 16 * 7 + 10, "bytes": 32 + 64},
-    # decompress: from_bytes 1M, 1S, 2M, inversion 255S+78M, sqrt ~ (222S+56M) + (528S + 64M) ; to_bytes
-    "decompress": {"S": 1 + 255 + 222 + 528, "M": 1 + 2 + 78 + 56 + 64 + 4, "bytes": 32 + 65},
+    # decompress: two decode passes (2 x (1M + 1S + 1M)), shared inversion (3M + (255S+78M)/16), u^2 1M,
+    # sqrt = a^((t-1)/2) (221S + 69M) + 2M + 48S + 4 canon + 7M table multiplies + verify (1S + 2M), 3 to_words
+    "decompress": {"S": 2 + 16 + 221 + 48 + 1, "M": 4 + 3 + 5 + 1 + 69 + 2 + 4 + 7 + 2 + 3, "bytes": 32 + 65},
 }
 # the reference's own algorithm for comparison in the JSON
 REFERENCE_WORK = {"varbase": {"S": 1008, "M": 2774}, "fixedbase": {"S": 1008, "M": 2520}}

@@ -35,9 +35,11 @@ struct jj_ctx {
   int cus = 0, clock_khz = 0, wave = 64;
   std::string err;
   // staging for host-pointer arguments (inputs 0..3, outputs 0..1) and kernel workspaces
-  DevBuf in[4], out[2], okb, ws_ext, ws_scratch, ws_tables, ws_tmp[4], msm[8];
+  DevBuf in[4], out[2], okb, ws_ext, ws_scratch, ws_tables, ws_tmp[4], msm[8], sqrt_tabs;
+  SqrtTables sqrt_tables{nullptr, nullptr};
   int msm_min_pippenger = 512;   // below this many terms the MSM is var-base ladders + fold (JJ_MSM_NAIVE_BELOW overrides)
   // optional per-call kernel timing (HIP events on the launch stream): e0 | main kernel | e1 | normalise tail | e2
+  bool fb_const_time = true;     // fixed-base window select: true = lane-staged + ds_bpermute shuffle, false = per-lane LDS gather
   int vb_blocks_per_cu = 2;      // var-base ladder: 2 waves/SIMD (3 blocks/CU distribute unevenly over the 4 SIMDs: measured slower)
   bool profile = false;
   struct Rec { hipEvent_t e0, e1, e2; };
@@ -150,7 +152,17 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
   if (const char* e = getenv("JJ_MSM_NAIVE_BELOW")) { int v = atoi(e); if (v >= 0) c->msm_min_pippenger = v; }
   if (const char* e = getenv("JJ_VB_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) c->vb_blocks_per_cu = v; }
   // the fixed-base kernel needs the full 160 KiB LDS carve-out
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fixedbase), hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS_BYTES);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fixedbase<true>), hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS_BYTES);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fixedbase<false>), hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS_BYTES);
+  if (const char* e = getenv("JJ_FIXEDBASE_SELECT")) c->fb_const_time = strcmp(e, "gather") != 0;
+  // square-root tables (64 KiB dlog + 36 KiB powers), built on the device
+  if (hipMalloc(&c->sqrt_tabs.p, 65536 + 4 * 256 * NL * 4) != hipSuccess) { (void)hipStreamDestroy(c->own_stream); delete c; return JJ_ERR_NOMEM; }
+  c->sqrt_tabs.cap = 65536 + 4 * 256 * NL * 4;
+  (void)hipMemsetAsync(c->sqrt_tabs.p, 0, c->sqrt_tabs.cap, c->stream);
+  c->sqrt_tables.dlog = (const uint8_t*)c->sqrt_tabs.p;
+  c->sqrt_tables.npow = (const u32*)((uint8_t*)c->sqrt_tabs.p + 65536);
+  hipLaunchKernelGGL(k_sqrt_tables_init, dim3(5), dim3(256), 0, c->stream, (uint8_t*)c->sqrt_tabs.p, (u32*)((uint8_t*)c->sqrt_tabs.p + 65536));
+  if (hipStreamSynchronize(c->stream) != hipSuccess) { (void)hipFree(c->sqrt_tabs.p); (void)hipStreamDestroy(c->own_stream); delete c; return JJ_ERR_HIP; }
   *out = c;
   return JJ_OK;
 }
@@ -160,7 +172,7 @@ JJ_API int jj_ctx_destroy(jj_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   DevBuf* all[] = {&c->in[0], &c->in[1], &c->in[2], &c->in[3], &c->out[0], &c->out[1], &c->okb, &c->ws_ext, &c->ws_scratch, &c->ws_tables,
                    &c->ws_tmp[0], &c->ws_tmp[1], &c->ws_tmp[2], &c->ws_tmp[3], &c->msm[0], &c->msm[1], &c->msm[2], &c->msm[3],
-                   &c->msm[4], &c->msm[5], &c->msm[6], &c->msm[7]};
+                   &c->msm[4], &c->msm[5], &c->msm[6], &c->msm[7], &c->sqrt_tabs};
   for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
   for (auto& r : c->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); (void)hipEventDestroy(r.e2); }
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -250,7 +262,7 @@ static int field_op(jj_ctx* c, size_t n, const void* a, const void* b, void* out
   OutRef o, ok_o; ok_o.host = false; ok_o.dev = nullptr;
   if ((rc = stage_out(c, c->out[0], out, 32 * n, &o))) return rc;
   if (want_ok && (rc = stage_out(c, c->okb, ok, n, &ok_o))) return rc;
-  if (n) hipLaunchKernelGGL((k_field_op<P, OP>), dim3(blocks_for(n)), dim3(256), 0, c->stream, n, da, db, o.dev, (uint8_t*)ok_o.dev);
+  if (n) hipLaunchKernelGGL((k_field_op<P, OP>), dim3(blocks_for(n)), dim3(256), 0, c->stream, n, da, db, o.dev, (uint8_t*)ok_o.dev, c->sqrt_tables);
   bool sync = false;
   if ((rc = finish_out(c, o, &sync))) return rc;
   if (want_ok && (rc = finish_out(c, ok_o, &sync))) return rc;
@@ -457,7 +469,8 @@ JJ_API int jj_fixedbase_mul(jj_ctx* c, const jj_table* t, size_t n, const void* 
   if (n) {
     const unsigned blocks = (unsigned)std::min((size_t)c->cus, (n + 511) / 512);   // one 512-thread workgroup per CU (LDS-bound)
     prof_mark(c, 0);
-    hipLaunchKernelGGL(k_fixedbase, dim3(blocks), dim3(512), FB_LDS_BYTES, c->stream, n, ds, (const u32*)t->dev, ext);
+    if (c->fb_const_time) hipLaunchKernelGGL(k_fixedbase<true>, dim3(blocks), dim3(512), FB_LDS_BYTES, c->stream, n, ds, (const u32*)t->dev, ext);
+    else hipLaunchKernelGGL(k_fixedbase<false>, dim3(blocks), dim3(512), FB_LDS_BYTES, c->stream, n, ds, (const u32*)t->dev, ext);
     prof_mark(c, 1);
     if ((rc = normalize_launch(c, n, ext, o.dev, 0))) return rc;
     prof_mark(c, 2);
@@ -605,7 +618,13 @@ JJ_API int jj_decompress(jj_ctx* c, size_t n, const void* in32, unsigned flags, 
   if ((rc = stage_out(c, c->out[0], out64, 64 * n, &o))) return rc;
   if ((rc = stage_out(c, c->okb, ok, n, &ko))) return rc;
   if (n) {
-    hipLaunchKernelGGL(k_decompress, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, di, flags, o.dev, (uint8_t*)ko.dev);
+    if ((rc = ensure(c, c->ws_scratch, (size_t)NL * 4 * n))) return rc;
+    SoA scratch = soa_of(c->ws_scratch, n);
+    prof_mark(c, 0);
+    const size_t lanes_wanted = (size_t)c->cus * 64 * 8;
+    if (n >= lanes_wanted * 16) { size_t T = (n + 15) / 16; hipLaunchKernelGGL((k_decompress<16>), dim3(blocks_for(T)), dim3(256), 0, c->stream, n, T, di, flags, scratch, c->sqrt_tables, o.dev, (uint8_t*)ko.dev); }
+    else { size_t T = (n + 3) / 4; hipLaunchKernelGGL((k_decompress<4>), dim3(blocks_for(T)), dim3(256), 0, c->stream, n, T, di, flags, scratch, c->sqrt_tables, o.dev, (uint8_t*)ko.dev); }
+    prof_mark(c, 1); prof_mark(c, 2);
     // Invalid encodings were written as (0,0); the subgroup kernels below may compute garbage for them, the ok byte masks it.
     if (flags & JJ_DECOMPRESS_TORSION_FREE) { if ((rc = torsion_free_dev(c, n, o.dev, (uint8_t*)ko.dev, 1))) return rc; }
     if (flags & JJ_DECOMPRESS_NOT_SMALL_ORDER) {

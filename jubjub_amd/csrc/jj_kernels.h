@@ -54,42 +54,61 @@ static JJ_DEV Fe fr_sqrt(const Fe& a, bool& ok) {
   ok = Fr::eq(Fr::sqr(s), a);
   return s;
 }
-// Fq::sqrt: Tonelli-Shanks with S = 32 and ROOT_OF_UNITY = 7^t, same value as ff::helpers::sqrt_tonelli_shanks
-// (bls12_381 0.8.0 Scalar::sqrt; call sites reference src/lib.rs:515,610,1253).  x = a^((t+1)/2) * g^s.
-static JJ_DEV Fe fq_sqrt(const Fe& a, bool& ok) {
+// ---- Fq square root: the value ff::helpers::sqrt_tonelli_shanks returns (bls12_381 0.8.0 Scalar::sqrt, S = 32,
+// ROOT_OF_UNITY = 7^t; call sites reference src/lib.rs:515,610,1253), computed by a 4 x 8-bit Pohlig-Hellman discrete
+// log in the 2^32-torsion instead of Tonelli-Shanks' ~500 data-dependent squarings.  With g = ROOT_OF_UNITY, b = a^t = g^e; the digits e_i come from a 64 KiB direct table
+// keyed by 16 low bits of canon(b_i^(2^(24-8i))); Tonelli-Shanks' answer is x = a^((t+1)/2) * g^s with
+// s = ((2^32 - e) mod 2^32) / 2, i.e. x for e = 0 and -(x * g^(-e/2)) otherwise.
+struct SqrtTables {
+  const uint8_t* dlog;   // [65536]  key16 -> k   with key16 = low 16 bits of limb 0 of canon((g^(2^24))^k)
+  const u32* npow;       // [4][256][NL]  g^(-k * 2^(8i))
+};
+static JJ_DEV Fe sqrt_tab(const SqrtTables& T, int i, u32 k) {
+  const u32* p = T.npow + ((size_t)i * 256 + k) * NL;
+  Fe r; _Pragma("unroll") for (int l = 0; l < NL; l++) r.l[l] = p[l]; return r;
+}
+static JJ_DEV Fe fq_sqrt_fast(const Fe& a, bool& ok, const SqrtTables& T) {
   const Fe w = Fq::pow_words(a, FqP::TM1D2);
-  Fe x = Fq::mul(a, w);
-  Fe b = Fq::canon(Fq::mul(x, w));
-  Fe z = Fq::konst(FqP::ROOT_OF_UNITY);
-  const Fe one = Fq::canon(Fq::one());
-  int v = 32;
+  const Fe x = Fq::mul(a, w);
+  Fe bi = Fq::mul(x, w);
+  u32 e = 0;
   #pragma unroll 1
-  for (int max_v = 32; max_v >= 1; max_v--) {
-    int k = 1;
-    Fe tmp = Fq::canon(Fq::sqr(b));
-    u32 j_less_than_v = ~0u;
+  for (int i = 0; i < 4; i++) {
+    Fe y = bi;
     #pragma unroll 1
-    for (int j = 2; j < max_v; j++) {
-      const u32 tmp_is_one = Fq::eq_canon(tmp, one) ? ~0u : 0u;
-      const Fe squared = Fq::canon(Fq::sqr(Fq::select(tmp, z, tmp_is_one)));
-      tmp = Fq::select(squared, tmp, tmp_is_one);
-      const Fe new_z = Fq::select(z, squared, tmp_is_one);
-      j_less_than_v &= (j != v) ? ~0u : 0u;
-      k = tmp_is_one ? k : j;
-      z = Fq::select(z, new_z, j_less_than_v);
-    }
-    const Fe result = Fq::mul(x, z);
-    x = Fq::select(result, x, Fq::eq_canon(b, one) ? ~0u : 0u);
-    z = Fq::sqr(z);
-    b = Fq::canon(Fq::mul(b, z));
-    v = k;
+    for (int s = 0; s < 24 - 8 * i; s++) y = Fq::sqr(y);
+    const u32 ei = T.dlog[Fq::canon(y).l[0] & 0xffffu];
+    e |= ei << (8 * i);
+    if (i < 3) bi = Fq::mul(bi, sqrt_tab(T, i, ei));
   }
-  ok = Fq::eq(Fq::sqr(x), a);
-  return x;
+  const u32 h = e >> 1;
+  Fe z = Fq::mul(sqrt_tab(T, 0, h & 255u), sqrt_tab(T, 1, (h >> 8) & 255u));
+  z = Fq::mul(z, Fq::mul(sqrt_tab(T, 2, (h >> 16) & 255u), sqrt_tab(T, 3, (h >> 24) & 255u)));
+  const Fe xr = Fq::select(Fq::neg(Fq::mul(x, z)), x, e == 0 ? ~0u : 0u);
+  ok = Fq::eq(Fq::sqr(xr), a);
+  return xr;
+}
+// builds the tables once per context: thread k (< 256): dlog entry of gamma^k; thread 256 + (i*256 + k): g^(-k 2^(8i))
+__global__ void __launch_bounds__(256) k_sqrt_tables_init(uint8_t* dlog, u32* npow) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid < 256) {
+    Fe gam = Fq::konst(FqP::ROOT_POW2[24]);              // g^(2^24), order 256
+    Fe p = Fq::one();
+    for (int j = 0; j < tid; j++) p = Fq::mul(p, gam);
+    dlog[Fq::canon(p).l[0] & 0xffffu] = (uint8_t)tid;
+  } else if (tid < 256 + 1024) {
+    const int i = (tid - 256) >> 8, k = (tid - 256) & 255;
+    Fe base = Fq::konst(FqP::ROOT_OF_UNITY_INV);
+    for (int j = 0; j < 8 * i; j++) base = Fq::sqr(base);  // g^(-2^(8i))
+    Fe p = Fq::one();
+    for (int j = 0; j < k; j++) p = Fq::mul(p, base);
+    const Fe c = Fq::canon(p);
+    _Pragma("unroll") for (int l = 0; l < NL; l++) npow[((size_t)i * 256 + k) * NL + l] = c.l[l];
+  }
 }
 
 template <class P, int OP>
-__global__ void __launch_bounds__(256) k_field_op(size_t n, const void* a, const void* b, void* out, uint8_t* okp) {
+__global__ void __launch_bounds__(256) k_field_op(size_t n, const void* a, const void* b, void* out, uint8_t* okp, SqrtTables tabs) {
   typedef Field<P> F;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -117,7 +136,7 @@ __global__ void __launch_bounds__(256) k_field_op(size_t n, const void* a, const
     if constexpr (OP == OP_DOUBLE) r = F::dbl(x);
     if constexpr (OP == OP_INVERT) { ok = !F::is_zero(x); r = F::invert(x); }
     if constexpr (OP == OP_SQRT) {
-      if constexpr (P::PBITS == 255) r = fq_sqrt(x, ok); else r = fr_sqrt(x, ok);
+      if constexpr (P::PBITS == 255) r = fq_sqrt_fast(x, ok, tabs); else r = fr_sqrt(x, ok);
     }
   }
   F::to_words(wo, r);
@@ -360,6 +379,11 @@ static JJ_DEV u32 window6(const u32 (&k)[8], int i) {
   return (u32)(both >> sh) & 63u;
 }
 
+// CT = true: constant-time window select.  Lane L of every wave reads entry (L & 31) of the current window from
+// LDS (a fixed, conflict-free pattern), and each lane then pulls the entry it needs out of its neighbours'
+// registers with ds_bpermute_b32 (a crossbar shuffle: no address- or bank-dependent timing).  Sign and zero
+// digits are applied with bit masks.  CT = false reads the entry directly at a per-lane LDS address.
+template <bool CT>
 __global__ void __launch_bounds__(512) k_fixedbase(size_t n, const void* scalars, const u32* table, SoA ext) {
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
   {
@@ -369,10 +393,13 @@ __global__ void __launch_bounds__(512) k_fixedbase(size_t n, const void* scalars
   }
   __syncthreads();
   const size_t T = (size_t)gridDim.x * blockDim.x;
+  const u32 lane = threadIdx.x & 63u;
+  const size_t n_round = (n + 63) & ~(size_t)63;            // whole waves stay in the loop so shuffles see all lanes
   #pragma unroll 1
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += T) {
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n_round; idx += T) {
+    const bool live = idx < n;
     u32 k[8];
-    load8(k, scalars, idx);
+    if (live) load8(k, scalars, idx); else zero8(k);
     // recode: k' = (k mod 2^252) + sum_{i<42} 32 * 64^i
     k[7] &= 0x0fffffffu;
     {
@@ -389,12 +416,23 @@ __global__ void __launch_bounds__(512) k_fixedbase(size_t n, const void* scalars
       const int d = (int)nb - 32;
       const u32 a = (u32)(d < 0 ? -d : d);
       const u32 j = a ? a - 1 : 0;
-      const ANiels e = lds_aniels(lds + ((size_t)i * FB_ENT + j) * ANIELS_WORDS);
+      ANiels e;
+      if constexpr (CT) {
+        const ANiels mine = lds_aniels(lds + ((size_t)i * FB_ENT + (lane & 31u)) * ANIELS_WORDS);
+        const int src = (int)(j << 2);                       // byte address of lane j
+        _Pragma("unroll") for (int l = 0; l < NL; l++) {
+          e.vpu.l[l] = (u32)__builtin_amdgcn_ds_bpermute(src, (int)mine.vpu.l[l]);
+          e.vmu.l[l] = (u32)__builtin_amdgcn_ds_bpermute(src, (int)mine.vmu.l[l]);
+          e.t2d.l[l] = (u32)__builtin_amdgcn_ds_bpermute(src, (int)mine.t2d.l[l]);
+        }
+      } else {
+        e = lds_aniels(lds + ((size_t)i * FB_ENT + j) * ANIELS_WORDS);
+      }
       ANiels s = Curve::select(e, Curve::neg(e), d < 0 ? ~0u : 0u);
       s = Curve::select(s, idn, a == 0 ? ~0u : 0u);
       acc = Curve::add(acc, s);
     }
-    ext.put(0, idx, acc.u); ext.put(1, idx, acc.v); ext.put(2, idx, acc.z);
+    if (live) { ext.put(0, idx, acc.u); ext.put(1, idx, acc.v); ext.put(2, idx, acc.z); }
   }
 }
 // affine points (64 B canonical) -> table entries (AffineNiels limbs, 112 B)
@@ -447,38 +485,60 @@ __global__ void __launch_bounds__(256) k_varbase5(size_t n, const void* scalars,
 }
 
 // ------------------------------------------------------------------------------------------------ K6: decompress
-// AffinePoint::from_bytes_inner (reference src/lib.rs:492-534).  Writes the affine point in device SoA form
-// (coords 0,1 = u,v ; Z = 1) plus ok; follow-up kernels apply the subgroup options.
-__global__ void __launch_bounds__(256) k_decompress(size_t n, const void* in32, unsigned flags, void* out64, uint8_t* okp) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// AffinePoint::from_bytes_inner / batch_from_bytes (reference src/lib.rs:492-534, 541-627): u^2 = (v^2-1)/(1+d v^2).
+// Like batch_from_bytes the denominators share one inversion: each lane owns CHUNK strided encodings, multiplies
+// their (never-zero) denominators through, inverts once and walks back, recomputing v, v^2 on the way (cheaper
+// than storing them).  The square root is fq_sqrt_fast; the sign bit picks the root (lib.rs:518-520) and the
+// ZIP-216 rule rejects u = 0 with the sign bit set (lib.rs:522-531).
+static JJ_DEV void decode_v(const void* in32, size_t i, Fe& v, Fe& v2, Fe& den, u32& sign, bool& ok) {
   u32 w[8];
   load8(w, in32, i);
-  const u32 sign = w[7] >> 31;
+  sign = w[7] >> 31;
   w[7] &= 0x7fffffffu;
-  bool ok;
-  const Fe v = Fq::from_words_checked(w, ok);
-  const Fe v2 = Fq::sqr(v);
-  const Fe num = Fq::sub(v2, Fq::one());
-  const Fe den = Fq::add(Fq::one(), Fq::mul(Fq::konst(FqP::D), v2));
-  const Fe u2 = Fq::mul(num, Fq::invert(den));
-  bool sq_ok;
-  const Fe u = fq_sqrt(u2, sq_ok);
-  ok = ok && sq_ok;
-  u32 wu[8];
-  Fq::to_words(wu, u);
-  const u32 flip = (wu[0] ^ sign) & 1u;
-  u32 nz = 0; _Pragma("unroll") for (int j = 0; j < 8; j++) nz |= wu[j];
-  const bool u_is_zero = (nz == 0);
-  if ((flags & 1u) && u_is_zero && flip) ok = false;
-  u32 wn[8];
-  Fq::to_words(wn, Fq::neg(u));
-  u32 wv[8];
-  Fq::to_words(wv, v);
-  _Pragma("unroll") for (int j = 0; j < 8; j++) { wu[j] = flip ? wn[j] : wu[j]; if (!ok) { wu[j] = 0; wv[j] = 0; } }
-  store8(out64, 2 * i, wu);
-  store8(out64, 2 * i + 1, wv);
-  okp[i] = ok ? 1 : 0;
+  v = Fq::from_words_checked(w, ok);
+  v2 = Fq::sqr(v);
+  den = Fq::carry(Fq::add(Fq::one(), Fq::mul(Fq::konst(FqP::D), v2)));
+}
+template <int CHUNK>
+__global__ void __launch_bounds__(256) k_decompress(size_t n, size_t T, const void* in32, unsigned flags, SoA scratch, SqrtTables tabs,
+                                                     void* out64, uint8_t* okp) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  Fe acc = Fq::one();
+  #pragma unroll 1
+  for (int j = 0; j < CHUNK; j++) {
+    const size_t i = t + (size_t)j * T;
+    if (i >= n) break;
+    Fe v, v2, den; u32 sign; bool ok;
+    decode_v(in32, i, v, v2, den, sign, ok);
+    scratch.put(0, i, acc);
+    acc = Fq::mul(acc, den);
+  }
+  Fe inv = Fq::invert(acc);
+  #pragma unroll 1
+  for (int j = CHUNK - 1; j >= 0; j--) {
+    const size_t i = t + (size_t)j * T;
+    if (i >= n) continue;
+    Fe v, v2, den; u32 sign; bool ok;
+    decode_v(in32, i, v, v2, den, sign, ok);
+    const Fe deninv = Fq::mul(inv, scratch.get(0, i));
+    inv = Fq::mul(inv, den);
+    const Fe u2 = Fq::mul(Fq::sub(v2, Fq::one()), deninv);
+    bool sq_ok;
+    const Fe u = fq_sqrt_fast(u2, sq_ok, tabs);
+    ok = ok && sq_ok;
+    u32 wu[8], wn[8], wv[8];
+    Fq::to_words(wu, u);
+    const u32 flip = (wu[0] ^ sign) & 1u;
+    u32 nz = 0; _Pragma("unroll") for (int k = 0; k < 8; k++) nz |= wu[k];
+    if ((flags & 1u) && nz == 0 && flip) ok = false;
+    Fq::to_words(wn, Fq::neg(u));
+    Fq::to_words(wv, v);
+    _Pragma("unroll") for (int k = 0; k < 8; k++) { wu[k] = flip ? wn[k] : wu[k]; if (!ok) { wu[k] = 0; wv[k] = 0; } }
+    store8(out64, 2 * i, wu);
+    store8(out64, 2 * i + 1, wv);
+    okp[i] = ok ? 1 : 0;
+  }
 }
 // AffinePoint::to_bytes (reference src/lib.rs:455-464) for affine input
 __global__ void __launch_bounds__(256) k_compress(size_t n, const void* pts, void* out32) {
