@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--workload", default="varbase", choices=sorted(WORK))
     ap.add_argument("--log2n", type=int, default=None, help="log2 of the per-GPU batch (default: 20 varbase/msm, 24 fixedbase, 22 decompress)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target wall time of the CPU baseline sample")
     return ap.parse_args()
 
@@ -121,14 +122,18 @@ def main():
     distributed = world > 1
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if a.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=a.backend)
     n_gpus = world if distributed else 1
     if a.gpus != n_gpus and rank == 0:
         print("note: --gpus %d but WORLD_SIZE=%d; using %d" % (a.gpus, world, n_gpus), file=sys.stderr)
-    dev = torch.device("cuda", local_rank)
+    dev_index = int(os.environ.get("JJ_BENCH_FORCE_DEVICE", local_rank))   # plumbing tests: several ranks on one GPU
+    dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
-    eng = Engine(local_rank)
+    eng = Engine(dev_index)
 
     wl = a.workload
     log2n = a.log2n if a.log2n is not None else {"varbase": 20, "fixedbase": 24, "msm": 20, "decompress": 22}[wl]
@@ -157,9 +162,14 @@ def main():
             return eng.decompress(enc, 1)
         part = eng.msm(scalars, points)                             # one partial point per rank
         if distributed:
-            parts = [torch.empty_like(part) for _ in range(world)]
-            dist.all_gather(parts, part)                            # 64 B per rank over RCCL/xGMI; EC add is not a reduce op
-            part = eng.point_sum(torch.stack(parts))
+            if a.backend == "nccl":
+                parts = [torch.empty_like(part) for _ in range(world)]
+                dist.all_gather(parts, part)                        # 64 B per rank over RCCL/xGMI; EC add is not a reduce op
+                part = eng.point_sum(torch.stack(parts))
+            else:
+                parts = [torch.empty(64, dtype=torch.uint8) for _ in range(world)]
+                dist.all_gather(parts, part.cpu())
+                part = eng.point_sum(torch.stack(parts).to(dev))
         return part
 
     def barrier():
@@ -179,7 +189,7 @@ def main():
     main_ms, tail_ms = eng.profile_read()
     eng.profile(False)
     if distributed:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -210,7 +220,10 @@ def main():
         achieved = n * imad32(w) / (kern_ms * 1e-3)
         res["roofline"] = {
             "bound": "valu_int32", "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TIMAD32/s",
-            "frac": achieved / peak, "traffic": None,
+            "frac": achieved / peak,
+            # multiply-adds actually issued by the 9x29-bit representation (162 per mul, 126 per square) / measured peak
+            "mad_issue_frac": n * (162 * w["M"] + 126 * w["S"]) / (kern_ms * 1e-3) / peak,
+            "traffic": None,
             "kernel": {"varbase": "k_varbase", "fixedbase": "k_fixedbase", "msm": "k_msm_accumulate (+prepare/scatter/reduce/horner)", "decompress": "k_decompress"}[wl],
             "kernel_ms": kern_ms, "tail_ms": tail,
             "work_per_unit": {"field_squares": w["S"], "field_muls": w["M"], "imad32": imad32(w), "convention": "M=128,S=100 (SURVEY 8d)"},
@@ -218,6 +231,24 @@ def main():
             "hbm": {"achieved": n * w["bytes"] / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": n * w["bytes"] / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "bytes_per_unit": w["bytes"]},
         }
+        if wl == "varbase":
+            # the other half of BASELINE.json's metric, measured in the same process (outside the timed region above)
+            fs = scalars if log2n >= 22 else torch.randint(0, 256, (1 << 22, 32), dtype=torch.uint8, device=dev, generator=g)
+            eng.fixedbase_mul(table, fs)
+            torch.cuda.synchronize(dev)
+            eng.profile(True)
+            t1 = time.perf_counter()
+            for _ in range(5):
+                eng.fixedbase_mul(table, fs)
+            torch.cuda.synchronize(dev)
+            fdt = (time.perf_counter() - t1) / 5
+            fm, _ft = eng.profile_read()
+            eng.profile(False)
+            fw = WORK["fixedbase"]
+            res["fixed_base"] = {"value": fs.shape[0] / fdt, "unit": "scalar-muls/s per GPU", "units_per_step": int(fs.shape[0]),
+                                 "ms_per_step": fdt * 1e3, "kernel_ms": sum(fm) / max(len(fm), 1),
+                                 "roofline_frac": fs.shape[0] * imad32(fw) / (sum(fm) / max(len(fm), 1) * 1e-3) / peak,
+                                 "window_select": "LDS-staged table, ds_bpermute constant-time select"}
         if not a.no_cpu_baseline and n_gpus == 1:
             res["cpu_baseline"] = cpu_baseline(wl, a.cpu_seconds)
         print(json.dumps(res))

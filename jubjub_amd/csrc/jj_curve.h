@@ -13,7 +13,7 @@
 namespace jj {
 
 struct Affine { Fe u, v; };                 // reference AffinePoint          src/lib.rs:80-84
-struct Ext { Fe u, v, z, t1, t2; };         // reference ExtendedPoint        src/lib.rs:138-145
+struct Ext { Fe u, v, z, t1, t2; };         // reference ExtendedPoint        src/lib.rs:138-145 ; t1 is kept lazy (limbs < 2^31)
 struct ANiels { Fe vpu, vmu, t2d; };        // reference AffineNielsPoint     src/lib.rs:254-259
 struct ENiels { Fe vpu, vmu, z, t2d; };     // reference ExtendedNielsPoint   src/lib.rs:326-332
 
@@ -45,7 +45,7 @@ struct Curve {
     const Fe vpu = F::add(vv, uu);            // VV + UU   (L)
     const Fe vmu = F::sub(vv, uu);            // VV - UU   (N, +3p)
     const Fe zz2 = F::add(zz, zz);            // 2 Z^2     (L)
-    const Fe cu = F::sub(uv2, vpu);           // (U+V)^2 - (VV+UU)
+    const Fe cu = F::sub_lazy(uv2, vpu);      // (U+V)^2 - (VV+UU)   (lazy: meets the carried ct, and is T1)
     const Fe ct = F::sub_wide(zz2, vmu);      // 2Z^2 - (VV-UU)
     return into_extended(cu, vpu, vmu, ct);
   }
@@ -54,35 +54,35 @@ struct Curve {
   static JJ_DEV Ext add(const Ext& p, const ENiels& n) {
     const Fe a = F::mul(F::sub(p.v, p.u), n.vmu);
     const Fe b = F::mul(F::add(p.v, p.u), n.vpu);
-    const Fe c = F::mul(F::mul(p.t1, p.t2), n.t2d);
+    const Fe c = F::mul(F::mul(F::carry(p.t1), p.t2), n.t2d);
     const Fe zz = F::mul(p.z, n.z);
     const Fe d = F::add(zz, zz);
-    return into_extended(F::sub(b, a), F::add(b, a), F::carry(F::add(d, c)), F::sub(d, c));
+    return into_extended(F::sub_lazy(b, a), F::add(b, a), F::carry(F::add(d, c)), F::sub(d, c));
   }
   // lib.rs:922-940
   static JJ_DEV Ext sub(const Ext& p, const ENiels& n) {
     const Fe a = F::mul(F::sub(p.v, p.u), n.vpu);
     const Fe b = F::mul(F::add(p.v, p.u), n.vmu);
-    const Fe c = F::mul(F::mul(p.t1, p.t2), n.t2d);
+    const Fe c = F::mul(F::mul(F::carry(p.t1), p.t2), n.t2d);
     const Fe zz = F::mul(p.z, n.z);
     const Fe d = F::add(zz, zz);
-    return into_extended(F::sub(b, a), F::add(b, a), F::sub(d, c), F::carry(F::add(d, c)));
+    return into_extended(F::sub_lazy(b, a), F::add(b, a), F::sub(d, c), F::carry(F::add(d, c)));
   }
   // lib.rs:944-968
   static JJ_DEV Ext add(const Ext& p, const ANiels& n) {
     const Fe a = F::mul(F::sub(p.v, p.u), n.vmu);
     const Fe b = F::mul(F::add(p.v, p.u), n.vpu);
-    const Fe c = F::mul(F::mul(p.t1, p.t2), n.t2d);
+    const Fe c = F::mul(F::mul(F::carry(p.t1), p.t2), n.t2d);
     const Fe d = F::add(p.z, p.z);
-    return into_extended(F::sub(b, a), F::add(b, a), F::carry(F::add(d, c)), F::sub(d, c));
+    return into_extended(F::sub_lazy(b, a), F::add(b, a), F::carry(F::add(d, c)), F::sub(d, c));
   }
   // lib.rs:970-988
   static JJ_DEV Ext sub(const Ext& p, const ANiels& n) {
     const Fe a = F::mul(F::sub(p.v, p.u), n.vpu);
     const Fe b = F::mul(F::add(p.v, p.u), n.vmu);
-    const Fe c = F::mul(F::mul(p.t1, p.t2), n.t2d);
+    const Fe c = F::mul(F::mul(F::carry(p.t1), p.t2), n.t2d);
     const Fe d = F::add(p.z, p.z);
-    return into_extended(F::sub(b, a), F::add(b, a), F::sub(d, c), F::carry(F::add(d, c)));
+    return into_extended(F::sub_lazy(b, a), F::add(b, a), F::sub(d, c), F::carry(F::add(d, c)));
   }
 
   // lib.rs:652-658 : (v+u, v-u, u*v*2d), all N
@@ -99,14 +99,14 @@ struct Curve {
     n.vpu = F::carry(F::add(p.v, p.u));
     n.vmu = F::sub(p.v, p.u);
     n.z = p.z;
-    n.t2d = F::mul(F::mul(p.t1, p.t2), F::konst(FqP::D2));
+    n.t2d = F::mul(F::mul(F::carry(p.t1), p.t2), F::konst(FqP::D2));
     return n;
   }
   // -(vpu, vmu, t2d) = (vmu, vpu, -t2d)   (negation of the underlying point, lib.rs:92-104)
   static JJ_DEV ENiels neg(const ENiels& n) { ENiels r; r.vpu = n.vmu; r.vmu = n.vpu; r.z = n.z; r.t2d = F::neg(n.t2d); return r; }
   static JJ_DEV ANiels neg(const ANiels& n) { ANiels r; r.vpu = n.vmu; r.vmu = n.vpu; r.t2d = F::neg(n.t2d); return r; }
   // lib.rs:195-211
-  static JJ_DEV Ext neg(const Ext& p) { Ext r; r.u = F::neg(p.u); r.v = p.v; r.z = p.z; r.t1 = F::neg(p.t1); r.t2 = p.t2; return r; }
+  static JJ_DEV Ext neg(const Ext& p) { Ext r; r.u = F::neg(p.u); r.v = p.v; r.z = p.z; r.t1 = F::neg(F::carry(p.t1)); r.t2 = p.t2; return r; }
 
   // masked select: mask all-ones -> b
   static JJ_DEV ENiels select(const ENiels& a, const ENiels& b, u32 mask) {
@@ -127,17 +127,6 @@ struct Curve {
     return F::eq(lhs, rhs);
   }
 
-  // exact reference ladder: 252 iterations of double + add-select, bits 251..0 (lib.rs:357-379)
-  static JJ_DEV Ext ladder_exact(const ENiels& n, const u32 (&k)[8]) {
-    const ENiels zero = eniels_identity();
-    Ext acc = identity();
-    for (int i = 251; i >= 0; i--) {
-      acc = dbl(acc);
-      const u32 bit = (k[i >> 5] >> (i & 31)) & 1u;
-      acc = add(acc, select(zero, n, 0u - bit));
-    }
-    return acc;
-  }
 };
 
 }  // namespace jj

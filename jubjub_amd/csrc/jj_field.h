@@ -224,6 +224,11 @@ struct Field {
     Fe t; _Pragma("unroll") for (int i = 0; i < NL; i++) t.l[i] = a.l[i] + P::BIAS_N[i] - b.l[i];
     return carry(t);
   }
+  // same without the carry step: limbs < 2^31 (a N-like), for operands that meet a carried partner in their next multiply
+  static JJ_DEV Fe sub_lazy(const Fe& a, const Fe& b) {
+    Fe t; _Pragma("unroll") for (int i = 0; i < NL; i++) t.l[i] = a.l[i] + P::BIAS_N[i] - b.l[i];
+    return t;
+  }
   // r = a - b (+ 5p), b with limbs <= 2^31, value(b) < 5p.
   static JJ_DEV Fe sub_wide(const Fe& a, const Fe& b) {
     Fe t; _Pragma("unroll") for (int i = 0; i < NL; i++) t.l[i] = a.l[i] + P::BIAS_L[i] - b.l[i];

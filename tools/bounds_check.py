@@ -90,6 +90,14 @@ class FieldModel:
     def sub(self, a, b, what="sub"):
         return self._sub(a, b, self.BIAS_N, 3, what)
 
+    def sub_lazy(self, a, b, what="sub_lazy"):
+        B = self.BIAS_N
+        for i in range(NL):
+            assert b[0][i] <= B[i], f"{what}: limb {i} of subtrahend may exceed bias"
+        t = [a[0][i] + B[i] for i in range(NL)]
+        assert max(t) < (1 << 32), f"{what}: limb overflow"
+        return (t, a[1] + 3 * self.p)
+
     def sub_wide(self, a, b, what="sub_wide"):
         return self._sub(a, b, self.BIAS_L, 5, what)
 
@@ -117,7 +125,7 @@ def check_curve(verbose=True):
         vpu = F.add(vv, uu)
         vmu = F.sub(vv, uu, w + ".vmu")
         zz2 = F.add(zz, zz)
-        cu = F.sub(uv2, vpu, w + ".cu")
+        cu = F.sub_lazy(uv2, vpu, w + ".cu")
         ct = F.sub_wide(zz2, vmu, w + ".ct")
         return into_extended(cu, vpu, vmu, ct, w)
 
@@ -125,7 +133,7 @@ def check_curve(verbose=True):
         vmu, vpu = (n["vpu"], n["vmu"]) if negate else (n["vmu"], n["vpu"])
         a = F.mul(F.sub(p["v"], p["u"], w + ".v-u"), vmu, w + ".a")
         b = F.mul(F.add(p["v"], p["u"]), vpu, w + ".b")
-        c = F.mul(F.mul(p["t1"], p["t2"], w + ".tt"), n["t2d"], w + ".c")
+        c = F.mul(F.mul(F.carry(p["t1"]), p["t2"], w + ".tt"), n["t2d"], w + ".c")
         if affine:
             d = F.add(p["z"], p["z"])
         else:
@@ -133,11 +141,11 @@ def check_curve(verbose=True):
             d = F.add(zz, zz)
         plus, minus = F.carry(F.add(d, c)), F.sub(d, c, w + ".d-c")
         cz, ct = (minus, plus) if negate else (plus, minus)
-        return into_extended(F.sub(b, a, w + ".b-a"), F.add(b, a), cz, ct, w)
+        return into_extended(F.sub_lazy(b, a, w + ".b-a"), F.add(b, a), cz, ct, w)
 
     def to_niels_ext(p, w="to_niels"):
         return dict(vpu=F.carry(F.add(p["v"], p["u"])), vmu=F.sub(p["v"], p["u"], w + ".vmu"), z=p["z"],
-                    t2d=F.mul(F.mul(p["t1"], p["t2"], w + ".tt"), D2, w + ".t2d"))
+                    t2d=F.mul(F.mul(F.carry(p["t1"]), p["t2"], w + ".tt"), D2, w + ".t2d"))
 
     # Inputs: affine points loaded through from_words (mul by R2): N with value < 2p
     N2 = F.N(2.0)
