@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--workload", default="varbase", choices=sorted(WORK))
     ap.add_argument("--log2n", type=int, default=None, help="log2 of the per-GPU batch (default: 20 varbase/msm, 24 fixedbase, 22 decompress)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fb-window", type=int, default=0, help="fixed-base window bits: 0/6 = LDS-staged constant-time table (default), 8..12 = L2-resident table")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target wall time of the CPU baseline sample")
     return ap.parse_args()
@@ -145,7 +146,7 @@ def main():
     scalars = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
     scalars[:, 31] &= 0x0F                                          # uniform below 2^252 (reference ladder width)
     base = torch.from_numpy(np.frombuffer(J.GENERATOR[0].to_bytes(32, "little") + J.GENERATOR[1].to_bytes(32, "little"), dtype=np.uint8).copy()).to(dev)
-    table = eng.fixedbase_table(base)
+    table = eng.fixedbase_table(base, a.fb_window)
     points = None
     if wl in ("varbase", "msm", "decompress"):
         ks = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
@@ -210,7 +211,9 @@ def main():
             "parallelism": "independent shards, one process per GPU" + ("; all_gather of 64 B partial points" if wl == "msm" else "")},
     }
     if rank == 0:
-        w = WORK[wl]
+        w = dict(WORK[wl])
+        if wl == "fixedbase" and a.fb_window >= 8:
+            w["M"] = -(-253 // a.fb_window) * 7 + 10          # ceil(253/w) mixed additions + normalise
         if main_ms:
             kern_ms = sum(main_ms) / len(main_ms)
             tail = sum(tail_ms) / len(tail_ms)
@@ -224,7 +227,7 @@ def main():
             # multiply-adds actually issued by the 9x29-bit representation (162 per mul, 126 per square) / measured peak
             "mad_issue_frac": n * (162 * w["M"] + 126 * w["S"]) / (kern_ms * 1e-3) / peak,
             "traffic": None,
-            "kernel": {"varbase": "k_varbase", "fixedbase": "k_fixedbase", "msm": "k_msm_accumulate (+prepare/scatter/reduce/horner)", "decompress": "k_decompress"}[wl],
+            "kernel": {"varbase": "k_varbase", "fixedbase": "k_fixedbase" if a.fb_window < 8 else "k_fixedbase_gather(w=%d)" % a.fb_window, "msm": "k_msm_accumulate (+prepare/scatter/reduce/horner)", "decompress": "k_decompress"}[wl],
             "kernel_ms": kern_ms, "tail_ms": tail,
             "work_per_unit": {"field_squares": w["S"], "field_muls": w["M"], "imad32": imad32(w), "convention": "M=128,S=100 (SURVEY 8d)"},
             "reference_algorithm_imad32": imad32(REFERENCE_WORK[wl]) if wl in REFERENCE_WORK else None,
@@ -249,6 +252,16 @@ def main():
                                  "ms_per_step": fdt * 1e3, "kernel_ms": sum(fm) / max(len(fm), 1),
                                  "roofline_frac": fs.shape[0] * imad32(fw) / (sum(fm) / max(len(fm), 1) * 1e-3) / peak,
                                  "window_select": "LDS-staged table, ds_bpermute constant-time select"}
+            wt = eng.fixedbase_table(base, 12)                      # wide-window alternative (5 MB table in L2, per-lane gather)
+            eng.fixedbase_mul(wt, fs)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(5):
+                eng.fixedbase_mul(wt, fs)
+            torch.cuda.synchronize(dev)
+            res["fixed_base_wide_window"] = {"value": fs.shape[0] * 5 / (time.perf_counter() - t1), "unit": "scalar-muls/s per GPU",
+                                              "window_bits": 12, "table": "5 MB, L2-resident, variable-time gather"}
+            wt.close()
         if not a.no_cpu_baseline and n_gpus == 1:
             res["cpu_baseline"] = cpu_baseline(wl, a.cpu_seconds)
         print(json.dumps(res))

@@ -24,8 +24,9 @@ struct DevBuf {
 };
 
 struct jj_table {
-  u32* dev = nullptr;      // FB_ENTRIES x ANIELS_WORDS
-  int window_bits = FB_W;
+  u32* dev = nullptr;      // entries x ANIELS_WORDS
+  int window_bits = FB_W;  // 6: LDS-staged table (k_fixedbase); 8..12: L2-resident table (k_fixedbase_gather)
+  FbParams fp;
 };
 
 struct jj_ctx {
@@ -413,40 +414,61 @@ JJ_API int jj_is_torsion_free(jj_ctx* c, size_t n, const void* p, uint8_t* out) 
 JJ_API int jj_is_prime_order(jj_ctx* c, size_t n, const void* p, uint8_t* out) { return torsion_pred(c, n, p, out, true); }
 
 // ---------------------------------------------------------------------------------------------------- fixed-base
+// entries (i, j) = (j+1) * 2^(w i) * B for i < W, j < E, built on the GPU in two var-base passes
+// (Q_i = 2^(w i) B, then (j+1) Q_i) so that no scalar ever reaches bit 252, which the ladder ignores.
+static int build_window_table(jj_ctx* c, const uint8_t base[64], int w, int W, u32 E, size_t extra_top_entry, u32** out_dev, size_t* out_entries) {
+  std::vector<uint8_t> s1((size_t)W * 32, 0), p1((size_t)W * 64), q((size_t)W * 64);
+  for (int i = 0; i < W; i++) {
+    const int bit = w * i;
+    if (bit < 252) s1[(size_t)i * 32 + (bit >> 3)] = (uint8_t)(1u << (bit & 7));
+    else { const int b2 = bit - 1; s1[(size_t)i * 32 + (b2 >> 3)] = (uint8_t)(1u << (b2 & 7)); }   // 2^(bit-1), doubled below
+    memcpy(&p1[(size_t)i * 64], base, 64);
+  }
+  int rc = jj_varbase_mul(c, W, s1.data(), p1.data(), q.data()); if (rc) return rc;
+  for (int i = 0; i < W; i++) if (w * i >= 252) { rc = jj_point_double(c, 1, &q[(size_t)i * 64], &q[(size_t)i * 64]); if (rc) return rc; }
+  const size_t ne = (size_t)W * E + extra_top_entry;
+  std::vector<uint8_t> s2(ne * 32, 0), p2(ne * 64), aff(ne * 64);
+  for (size_t e = 0; e < (size_t)W * E; e++) {
+    const size_t i = e / E; const u32 mult = (u32)(e % E) + 1;
+    s2[e * 32] = (uint8_t)mult; s2[e * 32 + 1] = (uint8_t)(mult >> 8); s2[e * 32 + 2] = (uint8_t)(mult >> 16);
+    memcpy(&p2[e * 64], &q[i * 64], 64);
+  }
+  rc = jj_varbase_mul(c, (size_t)W * E, s2.data(), p2.data(), aff.data()); if (rc) return rc;
+  if (extra_top_entry) {                       // LDS layout: one extra entry 2^(w W) B = 2^w * Q_{W-1}
+    uint8_t sc[32] = {0}; sc[w >> 3] = (uint8_t)(1u << (w & 7));
+    rc = jj_varbase_mul(c, 1, sc, &q[(size_t)(W - 1) * 64], &aff[(size_t)W * E * 64]); if (rc) return rc;
+  }
+  u32* dev = nullptr;
+  if (hipMalloc((void**)&dev, ne * (size_t)ANIELS_WORDS * 4) != hipSuccess) { c->err = "hipMalloc(table) failed"; return JJ_ERR_NOMEM; }
+  const void* dpts;
+  if ((rc = stage_in(c, 0, aff.data(), ne * 64, &dpts))) { (void)hipFree(dev); return rc; }
+  hipLaunchKernelGGL(k_affine_to_table, dim3(blocks_for(ne)), dim3(256), 0, c->stream, ne, dpts, dev);
+  rc = finish(c, true);
+  if (rc) { (void)hipFree(dev); return rc; }
+  *out_dev = dev; *out_entries = ne;
+  return JJ_OK;
+}
 JJ_API int jj_fixedbase_table_create(jj_ctx* c, const void* base64, int window_bits, jj_table** out) {
   if (!c || !out || !base64) return JJ_ERR_INVALID;
-  if (window_bits != 0 && window_bits != FB_W) { c->err = "only window_bits = 6 (or 0 = default) is built"; return JJ_ERR_INVALID; }
+  if (window_bits == 0) window_bits = FB_W;
+  if (window_bits != FB_W && (window_bits < 8 || window_bits > 16)) { c->err = "window_bits must be 0/6 (LDS table) or 8..16 (L2/MALL-resident table)"; return JJ_ERR_INVALID; }
   HIPCHK(c, hipSetDevice(c->device));
   uint8_t base[64];
   if (is_device_ptr(base64)) { HIPCHK(c, hipMemcpy(base, base64, 64, hipMemcpyDeviceToHost)); } else memcpy(base, base64, 64);
-  // entry (i, j) = (j+1) * 64^i * B ; entry FB_NWIN*FB_ENT = 64^42 * B.  Build the scalars on the host, multiply on the GPU.
-  const size_t ne = FB_ENTRIES;
-  std::vector<uint8_t> scal(ne * 32, 0), pts(ne * 64);
-  for (size_t e = 0; e < ne; e++) {
-    const int i = (int)(e / FB_ENT), j = (int)(e % FB_ENT);
-    const unsigned mult = (e == (size_t)FB_NWIN * FB_ENT) ? 1u : (unsigned)(j + 1);
-    const int bit = 6 * i;                                   // mult << bit, mult <= 32 (6 bits)
-    uint8_t* s = &scal[e * 32];
-    unsigned long long v = (unsigned long long)mult << (bit & 7);
-    for (int b = 0; b < 3 && (bit >> 3) + b < 32; b++) s[(bit >> 3) + b] = (uint8_t)(v >> (8 * b));
-    memcpy(&pts[e * 64], base, 64);
-  }
-  // NB: 64^42 = 2^252 has bit 252 set, which the ladder ignores (top four bits); build it as 2 * (2^251 * B) instead.
-  {
-    uint8_t* s = &scal[(size_t)FB_NWIN * FB_ENT * 32];
-    memset(s, 0, 32); s[31] = 0x08;                          // 2^251
-  }
-  std::vector<uint8_t> aff(ne * 64);
-  int rc = jj_varbase_mul(c, ne, scal.data(), pts.data(), aff.data()); if (rc) return rc;
-  // double the last entry: 2^252 B
-  rc = jj_point_double(c, 1, &aff[(size_t)FB_NWIN * FB_ENT * 64], &aff[(size_t)FB_NWIN * FB_ENT * 64]); if (rc) return rc;
   jj_table* t = new jj_table();
-  if (hipMalloc((void**)&t->dev, (size_t)FB_LDS_BYTES) != hipSuccess) { delete t; c->err = "hipMalloc(table) failed"; return JJ_ERR_NOMEM; }
-  const void* dpts;
-  if ((rc = stage_in(c, 0, aff.data(), ne * 64, &dpts))) { (void)hipFree(t->dev); delete t; return rc; }
-  hipLaunchKernelGGL(k_affine_to_table, dim3(blocks_for(ne)), dim3(256), 0, c->stream, ne, dpts, t->dev);
-  rc = finish(c, true);
-  if (rc) { (void)hipFree(t->dev); delete t; return rc; }
+  t->window_bits = window_bits;
+  size_t ne = 0; int rc;
+  if (window_bits == FB_W) {
+    // 42 windows x 32 entries + the carry entry 2^252 B  (layout of k_fixedbase)
+    rc = build_window_table(c, base, FB_W, FB_NWIN, FB_ENT, 1, &t->dev, &ne);
+  } else {
+    FbParams& fp = t->fp;
+    fp.w = window_bits; fp.W = (253 + window_bits - 1) / window_bits; fp.E = 1u << (window_bits - 1);
+    memset(fp.recode, 0, sizeof fp.recode);
+    for (int i = 0; i < fp.W - 1; i++) { const int bit = fp.w * i + fp.w - 1; fp.recode[bit >> 5] |= 1u << (bit & 31); }
+    rc = build_window_table(c, base, fp.w, fp.W, fp.E, 0, &t->dev, &ne);
+  }
+  if (rc) { delete t; return rc; }
   *out = t;
   return JJ_OK;
 }
@@ -469,6 +491,10 @@ JJ_API int jj_fixedbase_mul(jj_ctx* c, const jj_table* t, size_t n, const void* 
   if (n) {
     const unsigned blocks = (unsigned)std::min((size_t)c->cus, (n + 511) / 512);   // one 512-thread workgroup per CU (LDS-bound)
     prof_mark(c, 0);
+    if (t->window_bits != FB_W) {
+      const unsigned gblocks = (unsigned)std::min((size_t)c->cus * 2, (n + 255) / 256);
+      hipLaunchKernelGGL(k_fixedbase_gather, dim3(gblocks), dim3(256), 0, c->stream, n, ds, (const u32*)t->dev, t->fp, ext);
+    } else
     if (c->fb_const_time) hipLaunchKernelGGL(k_fixedbase<true>, dim3(blocks), dim3(512), FB_LDS_BYTES, c->stream, n, ds, (const u32*)t->dev, ext);
     else hipLaunchKernelGGL(k_fixedbase<false>, dim3(blocks), dim3(512), FB_LDS_BYTES, c->stream, n, ds, (const u32*)t->dev, ext);
     prof_mark(c, 1);

@@ -240,6 +240,9 @@ __global__ void __launch_bounds__(256) k_ext160_to_soa(size_t n, const void* ext
 // The lane's table {1..8}P (ExtendedNiels, 144 B each) lives in a per-lane slot of a global workspace (L2/MALL
 // resident); the entry for the next window is fetched before the four doublings that precede its use.
 // Group element equals the reference ladder's (src/lib.rs:357-379, 831-833); negation is exact on the whole curve.
+#ifndef JJ_VB_MINWAVES
+#define JJ_VB_MINWAVES 2
+#endif
 constexpr int VB_TABLE = 8;
 constexpr int ENIELS_WORDS = 4 * NL;   // 36 words = 144 B
 
@@ -311,7 +314,7 @@ static JJ_DEV Ext varbase_windowed(const Affine& P, u32 (&k)[8], u32* slot) {
 }
 
 // grid-stride over scalars; each thread owns one table slot
-__global__ void __launch_bounds__(256) k_varbase(size_t n, const void* scalars, const void* points, u32* tables, SoA ext) {
+__global__ void __launch_bounds__(256, JJ_VB_MINWAVES) k_varbase(size_t n, const void* scalars, const void* points, u32* tables, SoA ext) {
   const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t T = (size_t)gridDim.x * blockDim.x;
   u32* slot = tables + gtid * (size_t)(VB_TABLE * ENIELS_WORDS);
@@ -433,6 +436,51 @@ __global__ void __launch_bounds__(512) k_fixedbase(size_t n, const void* scalars
       acc = Curve::add(acc, s);
     }
     if (live) { ext.put(0, idx, acc.u); ext.put(1, idx, acc.v); ext.put(2, idx, acc.z); }
+  }
+}
+// Wide-window variant: table of (j+1) * 2^(w i) * B for w = 8..12 (0.5 - 5 MB) kept in global memory, L2-resident;
+// each lane gathers its 112-byte entry (7 x dwordx4) one window ahead of its use.  Fewer additions than the LDS
+// kernel (w = 10: 26 instead of 43) at the price of a secret-dependent address (documented as variable-time).
+struct FbParams {
+  int w, W;          // window bits, number of windows = ceil(253 / w)
+  u32 E;             // entries per window = 2^(w-1)
+  u32 recode[8];     // sum_{i<W-1} 2^(w i + w - 1)
+};
+static JJ_DEV u32 fb_window(const u32 (&k)[8], int w, int i) {
+  const int bit = w * i, wi = bit >> 5, sh = bit & 31;
+  u32 lo = k[0], hi = k[1];
+  _Pragma("unroll") for (int q = 1; q < 8; q++) { lo = (wi == q) ? k[q] : lo; hi = (wi == q) ? (q < 7 ? k[q + 1] : 0u) : hi; }
+  const u64 both = ((u64)hi << 32) | lo;
+  return (u32)(both >> sh) & ((1u << w) - 1u);
+}
+__global__ void __launch_bounds__(256) k_fixedbase_gather(size_t n, const void* scalars, const u32* table, FbParams fp, SoA ext) {
+  const size_t T = (size_t)gridDim.x * blockDim.x;
+  #pragma unroll 1
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += T) {
+    u32 k[8];
+    load8(k, scalars, idx);
+    k[7] &= 0x0fffffffu;
+    {
+      u64 c = 0;
+      _Pragma("unroll") for (int i = 0; i < 8; i++) { const u64 t = (u64)k[i] + fp.recode[i] + c; k[i] = (u32)t; c = t >> 32; }
+    }
+    const ANiels idn = Curve::aniels_identity();
+    Ext acc = Curve::identity();
+    // top window: unsigned digit
+    u32 a = fb_window(k, fp.w, fp.W - 1), neg = 0;
+    ANiels e = lds_aniels(table + ((size_t)(fp.W - 1) * fp.E + (a ? a - 1 : 0)) * ANIELS_WORDS);
+    #pragma unroll 1
+    for (int i = fp.W - 1; i >= 0; i--) {
+      ANiels s = Curve::select(e, Curve::neg(e), neg ? ~0u : 0u);
+      s = Curve::select(s, idn, a == 0 ? ~0u : 0u);
+      if (i > 0) {                                           // fetch the next window's entry before this addition
+        const int d = (int)fb_window(k, fp.w, i - 1) - (int)fp.E;
+        neg = d < 0; a = (u32)(d < 0 ? -d : d);
+        e = lds_aniels(table + ((size_t)(i - 1) * fp.E + (a ? a - 1 : 0)) * ANIELS_WORDS);
+      }
+      acc = Curve::add(acc, s);
+    }
+    ext.put(0, idx, acc.u); ext.put(1, idx, acc.v); ext.put(2, idx, acc.z);
   }
 }
 // affine points (64 B canonical) -> table entries (AffineNiels limbs, 112 B)

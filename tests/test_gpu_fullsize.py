@@ -1,0 +1,127 @@
+"""
+Full-size GPU parity (BASELINE.json sizes) through size-independent properties, plus strided oracle samples:
+linearity of scalar multiplication, agreement of independent algorithms (windowed ladder vs LDS fixed-base table
+vs Pippenger), encode -> decode round trips, and a strided bit-exact comparison with the CPU oracle.
+Inputs are generated on the device (torch), so nothing large crosses PCIe.
+"""
+import numpy as np
+import pytest
+
+from oracle import c_oracle as O
+from oracle import jubjub_ref as J
+from util import pt64
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def env():
+    from jubjub_amd import Engine
+
+    eng = Engine(0)
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(0x4A55424A5542)
+    base = torch.from_numpy(pt64(J.GENERATOR).copy()).to(dev)
+    table = eng.fixedbase_table(base)
+    yield eng, dev, g, base, table
+    table.close()
+    eng.close()
+
+
+def rand_scalars(dev, g, n, bits252=True):
+    s = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
+    if bits252:
+        s[:, 31] &= 0x0F
+    return s
+
+
+def sample_vs_oracle(fn_oracle, got, idx, *inputs):
+    want = fn_oracle(*[x[idx].cpu().numpy() for x in inputs])
+    assert (got[idx].cpu().numpy() == want).all()
+
+
+def test_varbase_2p20(env):
+    eng, dev, g, base, table = env
+    n = 1 << 20
+    P = eng.fixedbase_mul(table, rand_scalars(dev, g, n))          # random points of the full group
+    k1, k2 = rand_scalars(dev, g, n), rand_scalars(dev, g, n)
+    k1[:, 31] &= 0x07
+    k2[:, 31] &= 0x07                                              # k1 + k2 < 2^252: integer addition, no wrap
+    a, b = eng.varbase_mul(k1, P), eng.varbase_mul(k2, P)
+    s = np.zeros((n, 32), np.uint8)                                # add the 256-bit integers on the host (cheap)
+    carry = np.zeros(n, np.uint16)
+    k1h, k2h = k1.cpu().numpy(), k2.cpu().numpy()
+    for j in range(32):
+        t = k1h[:, j].astype(np.uint16) + k2h[:, j] + carry
+        s[:, j] = t & 0xFF
+        carry = t >> 8
+    c = eng.varbase_mul(torch.from_numpy(s).to(dev), P)
+    assert bool((eng.point_add(a, b) == c).all())                  # (k1 + k2) P == k1 P + k2 P for all 2^20 units
+    idx = torch.arange(0, n, 1 << 10, device=dev)                  # 2^10 strided sample, bit-exact vs the oracle ladder
+    sample_vs_oracle(O.varbase_mul, a, idx, k1, P)
+    enc = eng.compress(a)
+    back, ok = eng.decompress(enc, 1)
+    assert bool(ok.all()) and bool((back == a).all())              # encode -> decode round trip over all outputs
+    assert bool(eng.predicate("is_on_curve", a).all())
+
+
+def test_fixedbase_2p24(env):
+    eng, dev, g, base, table = env
+    n = 1 << 24
+    k1, k2 = rand_scalars(dev, g, n), rand_scalars(dev, g, n)
+    a = eng.fixedbase_mul(table, k1)
+    idx = torch.arange(0, n, 1 << 12, device=dev)                  # 2^12 strided sample vs the reference ladder (oracle)
+    want = O.fixedbase_mul(k1[idx].cpu().numpy(), base.cpu().numpy())
+    assert (a[idx].cpu().numpy() == want).all()
+    # independent algorithm: windowed var-base ladder on the same base, 2^18 sample
+    m = 1 << 18
+    pb = base.reshape(1, 64).expand(m, 64).contiguous()
+    assert bool((eng.varbase_mul(k1[:m], pb) == a[:m]).all())
+    # linearity over the whole batch with Fr arithmetic on the device: (k1 + k2 mod r) G == k1 G + k2 G is only
+    # valid on the prime-order subgroup, so use 8G-scaled results: 8 (k1 G) + 8 (k2 G) == 8 ((k1+k2 mod r) G)
+    b = eng.fixedbase_mul(table, k2)
+    ks = eng.field_binary("fr", "add", k1, k2)
+    c = eng.fixedbase_mul(table, ks)
+    lhs = eng.mul_by_cofactor(eng.point_add(a, b))
+    assert bool((lhs == eng.mul_by_cofactor(c)).all())
+
+
+def test_msm_2p20(env):
+    eng, dev, g, base, table = env
+    n = 1 << 20
+    S = rand_scalars(dev, g, n)
+    P = eng.fixedbase_mul(table, rand_scalars(dev, g, n))
+    total = eng.msm(S, P)
+    assert bool((total == eng.point_sum(eng.varbase_mul(S, P))).all())       # Pippenger == sum of ladders (independent algorithms)
+    h = n // 3
+    parts = torch.stack([eng.msm(S[:h], P[:h]), eng.msm(S[h:], P[h:])])
+    assert bool((eng.point_sum(parts) == total).all())                         # additivity over a split (the multi-GPU combine)
+    m = 1 << 12
+    assert (eng.msm(S[:m], P[:m]).cpu().numpy() == O.msm(S[:m].cpu().numpy(), P[:m].cpu().numpy())).all()
+
+
+def test_decompress_2p22(env):
+    eng, dev, g, base, table = env
+    n = 1 << 22
+    P = eng.fixedbase_mul(table, rand_scalars(dev, g, n))
+    enc = eng.compress(P)
+    junk = torch.randint(0, 256, (n // 16, 32), dtype=torch.uint8, device=dev, generator=g)
+    enc[::16] = junk                                               # 1/16 raw bytes: off-curve, >= q, sign-bit noise
+    out, ok = eng.decompress(enc, 1)
+    valid = torch.ones(n, dtype=torch.bool, device=dev)
+    valid[::16] = False
+    assert bool(ok[valid].all()) and bool((out[valid] == P[valid]).all())
+    re = eng.compress(out)
+    good = ok.bool()
+    assert bool((re[good] == enc[good]).all())                     # every accepted encoding re-encodes to itself (canonical)
+    assert bool((out[~good] == 0).all())
+    idx = torch.arange(0, n, 16, device=dev)[:4096]                # the junk lanes, checked against the oracle decode
+    eo, ek = O.decompress(enc[idx].cpu().numpy(), 1)
+    assert (ok[idx].cpu().numpy() == ek).all() and (out[idx].cpu().numpy() == eo).all()
+    # subgroup variant on a 2^16 slice: decode + [r]P == O, vs oracle on a sample
+    m = 1 << 16
+    o2, k2 = eng.decompress(enc[:m], 1 | 2)
+    eo, ek = O.decompress(enc[:512].cpu().numpy(), 1 | 2)
+    assert (k2[:512].cpu().numpy() == ek).all() and (o2[:512].cpu().numpy() == eo).all()

@@ -140,12 +140,16 @@ def test_eight_torsion_through_gpu(eng, golden):
 
 def test_fixedbase(eng):
     for base in (J.GENERATOR, to_pt(O.point_op("mul_by_cofactor", arr64([J.GENERATOR]))[0]), to_pt(rand_points(9, 1)[0])):
-        tab = eng.fixedbase_table(pt64(base))
         S = np.concatenate([arr32(EDGE_SCALARS), rand_scalars(10, 2500, full_width=True)])
-        got = eng.fixedbase_mul(tab, S)
-        assert (got == O.fixedbase_mul(S, pt64(base))).all()
-        assert eng.fixedbase_mul(tab, S[:0]).shape == (0, 64)
-        tab.close()
+        want = O.fixedbase_mul(S, pt64(base))
+        for wbits in (0, 8, 10, 12):          # 0/6: LDS-staged constant-time table; 8..12: L2-resident wide windows
+            tab = eng.fixedbase_table(pt64(base), wbits)
+            got = eng.fixedbase_mul(tab, S)
+            assert (got == want).all(), wbits
+            assert eng.fixedbase_mul(tab, S[:0]).shape == (0, 64)
+            tab.close()
+    with pytest.raises(Exception):
+        eng.fixedbase_table(pt64(J.GENERATOR), 7)
 
 
 def test_msm(eng):
