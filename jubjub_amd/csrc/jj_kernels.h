@@ -804,17 +804,50 @@ __global__ void __launch_bounds__(256) k_msm_bucket_reduce(size_t nchunks, u32 L
   total = Curve::add(total, Curve::to_niels(m));
   soa_put_ext(out, t, total);
 }
-// Horner over the W window sums (5-coordinate SoA, index w): acc = 2^c acc + S_w from the top window down
-__global__ void k_msm_horner(int W, int c, SoA wins, SoA out) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+// Horner over the W window sums (5-coordinate SoA, index w): acc = 2^c acc + S_w from the top window down.
+// This is a strictly serial chain of (W-1)*c doublings, and a lone wave issues only one VALU instruction per ~9
+// cycles, so the doubling is spread over the four lanes of a quad: lane r squares {U, V, Z, U+V}[r], the four
+// squares are broadcast inside the quad with DPP quad_perm moves, every lane forms the completed point, and lane r
+// multiplies one of (cu*ct, cv*cz, cz*ct).  Same formulas as Curve::dbl (reference src/lib.rs:739-828), ~2.4x fewer
+// instructions on the critical path.
+template <int K>
+static JJ_DEV Fe quad_bcast(const Fe& a) {   // value held by lane K of each quad -> all four lanes
+  Fe r;
+  _Pragma("unroll") for (int l = 0; l < NL; l++) r.l[l] = (u32)__builtin_amdgcn_mov_dpp((int)a.l[l], K * 0x55, 0xf, 0xf, false);
+  return r;
+}
+static JJ_DEV Fe role_select4(const Fe& a0, const Fe& a1, const Fe& a2, const Fe& a3, u32 role) {
+  Fe r = Fq::select(a0, a1, role == 1 ? ~0u : 0u);
+  r = Fq::select(r, a2, role == 2 ? ~0u : 0u);
+  return Fq::select(r, a3, role == 3 ? ~0u : 0u);
+}
+static JJ_DEV Ext quad_dbl(const Ext& p, u32 role) {
+  const Fe sq = Fq::sqr(role_select4(p.u, p.v, p.z, Fq::add(p.u, p.v), role));
+  const Fe uu = quad_bcast<0>(sq), vv = quad_bcast<1>(sq), zz = quad_bcast<2>(sq), uv2 = quad_bcast<3>(sq);
+  const Fe vpu = Fq::add(vv, uu);
+  const Fe vmu = Fq::sub(vv, uu);
+  const Fe zz2 = Fq::add(zz, zz);
+  const Fe cu = Fq::sub_lazy(uv2, vpu);
+  const Fe ct = Fq::sub_wide(zz2, vmu);
+  // lane 0: cu*ct   lane 1: cv*cz   lane 2,3: cz*ct
+  const Fe a = role_select4(cu, vpu, vmu, vmu, role);
+  const Fe b = role_select4(ct, vmu, ct, ct, role);
+  const Fe pr = Fq::mul(a, b);
+  Ext r;
+  r.u = quad_bcast<0>(pr); r.v = quad_bcast<1>(pr); r.z = quad_bcast<2>(pr); r.t1 = cu; r.t2 = vpu;
+  return r;
+}
+__global__ void __launch_bounds__(64) k_msm_horner(int W, int c, SoA wins, SoA out) {
+  if (blockIdx.x != 0) return;
+  const u32 role = threadIdx.x & 3u;
   Ext acc = soa_ext(wins, W - 1);
   #pragma unroll 1
   for (int w = W - 2; w >= 0; w--) {
     #pragma unroll 1
-    for (int d = 0; d < c; d++) acc = Curve::dbl(acc);
+    for (int d = 0; d < c; d++) acc = quad_dbl(acc, role);
     acc = Curve::add(acc, Curve::to_niels(soa_ext(wins, w)));
   }
-  soa_put_ext(out, 0, acc);
+  if (threadIdx.x == 0) soa_put_ext(out, 0, acc);
 }
 // grouped fold: out[t] = sum_{j<fold} in[t*fold + j]  (contiguous groups keep the window-major order intact)
 __global__ void __launch_bounds__(256) k_sum_groups(size_t n, size_t T, int fold, SoA in, SoA out) {
