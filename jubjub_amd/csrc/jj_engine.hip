@@ -38,6 +38,7 @@ struct jj_ctx {
   // staging for host-pointer arguments (inputs 0..3, outputs 0..1) and kernel workspaces
   DevBuf in[4], out[2], okb, ws_ext, ws_scratch, ws_tables, ws_tmp[4], msm[8], sqrt_tabs;
   SqrtTables sqrt_tables{nullptr, nullptr};
+  int msm_pass_log2 = 24;        // terms per Pippenger pass (JJ_MSM_PASS_LOG2 overrides; for tests)
   int msm_min_pippenger = 512;   // below this many terms the MSM is var-base ladders + fold (JJ_MSM_NAIVE_BELOW overrides)
   // optional per-call kernel timing (HIP events on the launch stream): e0 | main kernel | e1 | normalise tail | e2
   bool fb_const_time = true;     // fixed-base window select: true = lane-staged + ds_bpermute shuffle, false = per-lane LDS gather
@@ -150,6 +151,7 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
   c->wave = prop.warpSize;
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return JJ_ERR_HIP; }
   c->stream = c->own_stream;
+  if (const char* e = getenv("JJ_MSM_PASS_LOG2")) { int v = atoi(e); if (v >= 10 && v <= 24) c->msm_pass_log2 = v; }
   if (const char* e = getenv("JJ_MSM_NAIVE_BELOW")) { int v = atoi(e); if (v >= 0) c->msm_min_pippenger = v; }
   if (const char* e = getenv("JJ_VB_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) c->vb_blocks_per_cu = v; }
   // the fixed-base kernel needs the full 160 KiB LDS carve-out
@@ -609,7 +611,23 @@ JJ_API int jj_msm(jj_ctx* c, size_t n, const void* scalars, const void* points, 
     SoA res;
     prof_mark(c, 0);
     if (n >= (size_t)c->msm_min_pippenger) {
-      if ((rc = msm_pippenger(c, n, ds, dp, &res))) return rc;
+      // 32-bit sort indices: at most 2^24 terms per Pippenger pass; larger inputs are folded pass by pass
+      const size_t PASS = (size_t)1 << c->msm_pass_log2;
+      if (n <= PASS) {
+        if ((rc = msm_pippenger(c, n, ds, dp, &res))) return rc;
+      } else {
+        const size_t npass = (n + PASS - 1) / PASS;
+        if ((rc = ensure(c, c->ws_tmp[2], (size_t)5 * NL * 4 * npass))) return rc;
+        if ((rc = ensure(c, c->ws_tmp[3], (size_t)5 * NL * 4 * npass))) return rc;
+        SoA parts = soa_of(c->ws_tmp[2], npass);
+        for (size_t k = 0; k < npass; k++) {
+          const size_t lo = k * PASS, cnt = std::min(PASS, n - lo);
+          SoA r1;
+          if ((rc = msm_pippenger(c, cnt, (const uint8_t*)ds + lo * 32, (const uint8_t*)dp + lo * 64, &r1))) return rc;
+          hipLaunchKernelGGL(k_soa_copy5, dim3(1), dim3(64), 0, c->stream, r1, (size_t)0, parts, k);
+        }
+        if ((rc = sum_reduce(c, npass, &c->ws_tmp[2], &c->ws_tmp[3], &res))) return rc;
+      }
     } else {
       if ((rc = ensure(c, c->ws_tmp[2], (size_t)5 * NL * 4 * n))) return rc;
       if ((rc = varbase_to_ext(c, n, ds, dp, soa_of(c->ws_tmp[2], n), true))) return rc;

@@ -849,6 +849,9 @@ __global__ void __launch_bounds__(64) k_msm_horner(int W, int c, SoA wins, SoA o
   }
   if (threadIdx.x == 0) soa_put_ext(out, 0, acc);
 }
+__global__ void k_soa_copy5(SoA src, size_t i, SoA dst, size_t j) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) soa_put_ext(dst, j, soa_ext(src, i));
+}
 // grouped fold: out[t] = sum_{j<fold} in[t*fold + j]  (contiguous groups keep the window-major order intact)
 __global__ void __launch_bounds__(256) k_sum_groups(size_t n, size_t T, int fold, SoA in, SoA out) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -173,6 +173,18 @@ def test_msm_skewed_buckets(eng):
     assert to_pt(eng.msm(Z, P)) == J.AFFINE_IDENTITY
 
 
+def test_msm_multipass(monkeypatch):
+    """Inputs larger than one Pippenger pass are folded pass by pass (pass size shrunk here via the env knob)."""
+    from jubjub_amd import Engine
+
+    monkeypatch.setenv("JJ_MSM_PASS_LOG2", "12")
+    e2 = Engine(0)
+    n = 10000
+    S, P = rand_scalars(41, n, full_width=True), rand_points(42, n)
+    assert (e2.msm(S, P) == O.msm(S, P)).all()
+    e2.close()
+
+
 def test_serialization_golden(eng, golden):
     encs = np.array(golden["serialization_16"]["encodings"], np.uint8)
     gen8 = eng.mul_by_cofactor(arr64([J.GENERATOR]))
