@@ -100,7 +100,7 @@ def cpu_baseline(workload, target_s):
 
     probe = max(64, 16 * cores)
     t = run(probe)
-    n = int(max(probe, min(1 << 18, probe * target_s / max(t, 1e-6))))
+    n = int(max(probe, min(1 << 22, probe * target_s / max(t, 1e-6))))
     t = run(n)
     unit = {"varbase": "scalar-muls/s", "fixedbase": "scalar-muls/s", "msm": "terms/s", "decompress": "points/s"}[workload]
     return {"value": n / t, "unit": unit, "cores": cores, "kind": "port",

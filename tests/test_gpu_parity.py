@@ -258,3 +258,37 @@ def test_committed_oracle_vectors_gpu(eng):
     for m in v["msm"]:
         got = eng.msm(np.stack([fx(s) for s in m["scalars"]]), np.stack([fx(p) for p in m["points"]]))
         assert (got == fx(m["out"])).all()
+
+
+def test_reference_style_api(eng, golden):
+    """The reference's test_mul_consistency / test_assoc / test_zip_216 written against jubjub_amd.group
+    (reference src/lib.rs:1504-1527, 1756-1804, 1892-1935)."""
+    from jubjub_amd.group import FixedBase, Fr, Points, msm
+
+    tp = golden["TEST_POINT_raw"]
+    from conftest import limbs
+    p = Points(eng, arr64([(limbs(tp["u"]) % Q, limbs(tp["v"]) % Q)])).mul_by_cofactor()
+    assert p.is_on_curve().all()
+    k1, k2 = Fr.from_u64(eng, [1000]), Fr.from_u64(eng, [3938])
+    assert (p * k1) * k2 == p * (k1 * k2)
+    t = golden["fr_mul_consistency_mont"]
+    a, b, c = (Fr(eng, arr32([J.FR.from_mont_limbs([int(x, 16) for x in t[k]])])) for k in "abc")
+    assert a * b == c
+    assert p * c == (p * a) * b
+    fb = FixedBase(eng, p.data[0])
+    assert fb * c == (p * a) * b and p * c == (fb * a) * b
+    assert msm(Points(eng, np.concatenate([p.data, p.data])), Fr(eng, np.concatenate([a.data, b.data]))) == p * (a + b)
+    for enc in golden["zip216_noncanonical"]["encodings"]:
+        e = np.array([enc], np.uint8)
+        assert not Points.from_bytes(eng, e)[1].any()
+        pts, ok = Points.from_bytes(eng, e, zip216=False)
+        assert ok.all()
+        re = pts.to_bytes()
+        re[:, 31] |= 0x80
+        assert (re == e).all()
+    with pytest.raises(ValueError):
+        Points.generator(eng, 2) * Fr.from_u64(eng, [1])
+    g = Points.generator(eng)
+    assert not g.is_torsion_free().any() and g.clear_cofactor().is_prime_order().all()
+    sub, ok = Points.from_bytes(eng, g.to_bytes(), subgroup=True)
+    assert not ok.any() and (sub.data == 0).all()
