@@ -583,14 +583,14 @@ static int msm_pippenger(jj_ctx* c, size_t n, const void* ds, const void* dp, So
     hipLaunchKernelGGL(k_msm_accumulate, dim3(blocks_for(max_chunks)), dim3(256), 0, c->stream, nb, (const u32*)offset, (const u32*)idx.p, (const u32*)niels.p, soa_of(buckets, nb), head);
     hipLaunchKernelGGL(k_msm_fixup, dim3(blocks_for(nb)), dim3(256), 0, c->stream, nb, (const u32*)offset, soa_of(buckets, nb), head);
   }
-  hipLaunchKernelGGL(k_msm_bucket_reduce, dim3(blocks_for(nchunks)), dim3(256), 0, c->stream, nchunks, L, mp.B, soa_of(buckets, nb), soa_of(ra, nchunks));
+  hipLaunchKernelGGL(k_msm_bucket_reduce, dim3(blocks_for(nchunks * 4)), dim3(256), 0, c->stream, nchunks, L, mp.B, soa_of(buckets, nb), soa_of(ra, nchunks));
   // fold the chunks of each window: per-window count B/L -> 1
   size_t per_window = mp.B / L, m = nchunks;
   DevBuf* cur = &ra; DevBuf* nxt = &rb;
   while (per_window > 1) {
     const int fold = (int)std::min<size_t>(per_window, 32);
     const size_t T = m / fold;
-    hipLaunchKernelGGL(k_sum_groups, dim3(blocks_for(T)), dim3(256), 0, c->stream, m, T, fold, soa_of(*cur, m), soa_of(*nxt, T));
+    hipLaunchKernelGGL(k_sum_groups, dim3(blocks_for(T * 4)), dim3(256), 0, c->stream, m, T, fold, soa_of(*cur, m), soa_of(*nxt, T));
     std::swap(cur, nxt); m = T; per_window /= fold;
   }
   // m == W window sums; Horner combine

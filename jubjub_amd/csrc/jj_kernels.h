@@ -780,30 +780,6 @@ static JJ_DEV Ext soa_ext(const SoA& s, size_t i) { Ext e; e.u = s.get(0, i); e.
 static JJ_DEV void soa_put_ext(const SoA& s, size_t i, const Ext& e) {
   s.put(0, i, e.u); s.put(1, i, e.v); s.put(2, i, e.z); s.put(3, i, Fq::carry(e.t1)); s.put(4, i, Fq::carry(e.t2));
 }
-// chunk of L consecutive buckets j0..j0+L-1 of one window (bucket j holds digit value j+1):
-// sum (j+1) b_j = T + j0 * S with T = sum (j-j0+1) b_j (running sums) and S = sum b_j.
-__global__ void __launch_bounds__(256) k_msm_bucket_reduce(size_t nchunks, u32 L, u32 B, SoA buckets, SoA out) {
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nchunks) return;
-  const size_t first = t * L;               // global bucket index (window-major)
-  const u32 j0 = (u32)(first % B);          // index inside the window
-  Ext running = Curve::identity(), total = Curve::identity();
-  #pragma unroll 1
-  for (int j = (int)L - 1; j >= 0; j--) {
-    running = Curve::add(running, Curve::to_niels(soa_ext(buckets, first + j)));
-    total = Curve::add(total, Curve::to_niels(running));
-  }
-  // total += j0 * running   (j0 < 2^15), double-and-add from the top bit
-  Ext m = Curve::identity();
-  const ENiels rn = Curve::to_niels(running);
-  #pragma unroll 1
-  for (int bit = 15; bit >= 0; bit--) {
-    m = Curve::dbl(m);
-    m = Curve::add(m, Curve::select(Curve::eniels_identity(), rn, ((j0 >> bit) & 1u) ? ~0u : 0u));
-  }
-  total = Curve::add(total, Curve::to_niels(m));
-  soa_put_ext(out, t, total);
-}
 // Horner over the W window sums (5-coordinate SoA, index w): acc = 2^c acc + S_w from the top window down.
 // This is a strictly serial chain of (W-1)*c doublings, and a lone wave issues only one VALU instruction per ~9
 // cycles, so the doubling is spread over the four lanes of a quad: lane r squares {U, V, Z, U+V}[r], the four
@@ -837,6 +813,26 @@ static JJ_DEV Ext quad_dbl(const Ext& p, u32 role) {
   r.u = quad_bcast<0>(pr); r.v = quad_bcast<1>(pr); r.z = quad_bcast<2>(pr); r.t1 = cu; r.t2 = vpu;
   return r;
 }
+// Extended + Extended on a quad (reference src/lib.rs:992-999 = to_niels + Add<&ExtendedNielsPoint>, 883-920):
+// four multiplication rounds instead of ten serial multiplications.
+static JJ_DEV Ext quad_add_ext(const Ext& p, const Ext& q, u32 role) {
+  // round 1: lane0 p.t1*p.t2, lane1 q.t1*q.t2, lane2/3 p.z*q.z
+  const Fe r1 = Fq::mul(role_select4(Fq::carry(p.t1), Fq::carry(q.t1), p.z, p.z, role), role_select4(p.t2, q.t2, q.z, q.z, role));
+  const Fe ttp = quad_bcast<0>(r1), ttq = quad_bcast<1>(r1), zz = quad_bcast<2>(r1);
+  // round 2: lane0 (Vp-Up)(Vq-Uq), lane1 (Vp+Up)(Vq+Uq), lane2/3 ttp*ttq
+  const Fe r2 = Fq::mul(role_select4(Fq::sub(p.v, p.u), Fq::add(p.v, p.u), ttp, ttp, role),
+                        role_select4(Fq::sub(q.v, q.u), Fq::carry(Fq::add(q.v, q.u)), ttq, ttq, role));
+  const Fe a = quad_bcast<0>(r2), b = quad_bcast<1>(r2), tpq = quad_bcast<2>(r2);
+  // round 3: c = 2d * ttp * ttq  (every lane)
+  const Fe c = Fq::mul(tpq, Fq::konst(FqP::D2));
+  const Fe d = Fq::add(zz, zz);
+  const Fe cu = Fq::sub_lazy(b, a), cv = Fq::add(b, a), cz = Fq::carry(Fq::add(d, c)), ct = Fq::sub(d, c);
+  // round 4: lane0 cu*ct, lane1 cv*cz, lane2/3 cz*ct
+  const Fe r4 = Fq::mul(role_select4(cu, cv, cz, cz, role), role_select4(ct, cz, ct, ct, role));
+  Ext r;
+  r.u = quad_bcast<0>(r4); r.v = quad_bcast<1>(r4); r.z = quad_bcast<2>(r4); r.t1 = cu; r.t2 = cv;
+  return r;
+}
 __global__ void __launch_bounds__(64) k_msm_horner(int W, int c, SoA wins, SoA out) {
   if (blockIdx.x != 0) return;
   const u32 role = threadIdx.x & 3u;
@@ -845,25 +841,56 @@ __global__ void __launch_bounds__(64) k_msm_horner(int W, int c, SoA wins, SoA o
   for (int w = W - 2; w >= 0; w--) {
     #pragma unroll 1
     for (int d = 0; d < c; d++) acc = quad_dbl(acc, role);
-    acc = Curve::add(acc, Curve::to_niels(soa_ext(wins, w)));
+    acc = quad_add_ext(acc, soa_ext(wins, w), role);
   }
   if (threadIdx.x == 0) soa_put_ext(out, 0, acc);
 }
 __global__ void k_soa_copy5(SoA src, size_t i, SoA dst, size_t j) {
   if (blockIdx.x == 0 && threadIdx.x == 0) soa_put_ext(dst, j, soa_ext(src, i));
 }
+// The reduction kernels below are short and latency-bound (few independent chains), so each logical thread is a
+// quad of lanes running quad_dbl / quad_add_ext.
+// chunk of L consecutive buckets j0..j0+L-1 of one window (bucket j holds digit value j+1):
+// sum (j+1) b_j = T + j0 * S with T = sum (j-j0+1) b_j (running sums) and S = sum b_j.
+__global__ void __launch_bounds__(256) k_msm_bucket_reduce(size_t nchunks, u32 L, u32 B, SoA buckets, SoA out) {
+  const size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  const u32 role = threadIdx.x & 3u;
+  if (t >= nchunks) return;
+  const size_t first = t * L;               // global bucket index (window-major)
+  const u32 j0 = (u32)(first % B);          // index inside the window
+  Ext running = Curve::identity(), total = Curve::identity();
+  #pragma unroll 1
+  for (int j = (int)L - 1; j >= 0; j--) {
+    running = quad_add_ext(running, soa_ext(buckets, first + j), role);
+    total = quad_add_ext(total, running, role);
+  }
+  // total += j0 * running   (j0 < 2^15), double-and-add from the top bit
+  Ext m = Curve::identity();
+  #pragma unroll 1
+  for (int bit = 15; bit >= 0; bit--) {
+    m = quad_dbl(m, role);
+    Ext sel = Curve::identity();
+    const u32 mask = ((j0 >> bit) & 1u) ? ~0u : 0u;
+    sel.u = Fq::select(sel.u, running.u, mask); sel.v = Fq::select(sel.v, running.v, mask); sel.z = Fq::select(sel.z, running.z, mask);
+    sel.t1 = Fq::select(sel.t1, Fq::carry(running.t1), mask); sel.t2 = Fq::select(sel.t2, running.t2, mask);
+    m = quad_add_ext(m, sel, role);
+  }
+  total = quad_add_ext(total, m, role);
+  if (role == 0) soa_put_ext(out, t, total);
+}
 // grouped fold: out[t] = sum_{j<fold} in[t*fold + j]  (contiguous groups keep the window-major order intact)
 __global__ void __launch_bounds__(256) k_sum_groups(size_t n, size_t T, int fold, SoA in, SoA out) {
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  const u32 role = threadIdx.x & 3u;
   if (t >= T) return;
   Ext acc = Curve::identity();
   #pragma unroll 1
   for (int j = 0; j < fold; j++) {
     const size_t i = t * (size_t)fold + j;
     if (i >= n) break;
-    acc = Curve::add(acc, Curve::to_niels(soa_ext(in, i)));
+    acc = quad_add_ext(acc, soa_ext(in, i), role);
   }
-  soa_put_ext(out, t, acc);
+  if (role == 0) soa_put_ext(out, t, acc);
 }
 
 // ------------------------------------------------------------------------------------------------ roofline probe
