@@ -114,6 +114,8 @@ int jj_point_sum(jj_ctx*, size_t n, const void* p, void* out64);
  * scalars are raw 32-byte patterns; only the low 252 bits are used, as in the reference ladder.
  * Windowed signed-digit ladder with a per-lane table; results are specified for on-curve points. */
 int jj_varbase_mul(jj_ctx*, size_t n, const void* scalars32, const void* points64, void* out64);
+/* same, result written as 32-byte compressed encodings (to_bytes of the product, src/lib.rs:455-464, 1419-1421) */
+int jj_varbase_mul_compressed(jj_ctx*, size_t n, const void* scalars32, const void* points64, void* out32);
 /* Same group element, but computed with the reference's exact 252-step double-and-add-always ladder and
  * returned in projective form: out = 160 bytes (U,V,Z,T1,T2 canonical LE) matching the Rust ExtendedPoint
  * fields bit for bit.  For parity testing, not for throughput. */
@@ -128,6 +130,7 @@ int jj_varbase_mul_exact(jj_ctx*, size_t n, const void* scalars32, const void* p
 int jj_fixedbase_table_create(jj_ctx*, const void* base64, int window_bits /* 0 = default */, jj_table** out);
 int jj_fixedbase_table_destroy(jj_ctx*, jj_table* t);
 int jj_fixedbase_mul(jj_ctx*, const jj_table* t, size_t n, const void* scalars32, void* out64);
+int jj_fixedbase_mul_compressed(jj_ctx*, const jj_table* t, size_t n, const void* scalars32, void* out32);
 
 /* Multi-scalar multiplication: out = to_affine(sum_i points[i] * scalars[i])  (semantics: iterator Sum of
  * `p * k`, src/lib.rs:183-193 + 873-879; the reference has no MSM algorithm).  n = 0 gives the identity. */

@@ -347,26 +347,28 @@ static int varbase_to_ext(jj_ctx* c, size_t n, const void* ds, const void* dp, S
   else hipLaunchKernelGGL(k_varbase, dim3(blocks), dim3(256), 0, c->stream, n, ds, dp, (u32*)c->ws_tables.p, ext);
   return JJ_OK;
 }
-JJ_API int jj_varbase_mul(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out) {
+static int varbase_api(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out, int mode) {
   if (!c) return JJ_ERR_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
   const void *ds, *dp; int rc; OutRef o;
   if ((rc = stage_in(c, 0, scalars, 32 * n, &ds))) return rc;
   if ((rc = stage_in(c, 1, points, 64 * n, &dp))) return rc;
-  if ((rc = stage_out(c, c->out[0], out, 64 * n, &o))) return rc;
+  if ((rc = stage_out(c, c->out[0], out, (mode ? 32 : 64) * n, &o))) return rc;
   if ((rc = ensure_ext(c, n, 3))) return rc;
   SoA ext = soa_of(c->ws_ext, n);
   if (n) {
     prof_mark(c, 0);
     if ((rc = varbase_to_ext(c, n, ds, dp, ext, false))) return rc;
     prof_mark(c, 1);
-    if ((rc = normalize_launch(c, n, ext, o.dev, 0))) return rc;
+    if ((rc = normalize_launch(c, n, ext, o.dev, mode))) return rc;
     prof_mark(c, 2);
   }
   bool sync = false;
   if ((rc = finish_out(c, o, &sync))) return rc;
   return finish(c, sync);
 }
+JJ_API int jj_varbase_mul(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out) { return varbase_api(c, n, scalars, points, out, 0); }
+JJ_API int jj_varbase_mul_compressed(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out32) { return varbase_api(c, n, scalars, points, out32, 1); }
 JJ_API int jj_varbase_mul_exact(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out160) {
   if (!c) return JJ_ERR_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
@@ -482,12 +484,12 @@ JJ_API int jj_fixedbase_table_destroy(jj_ctx* c, jj_table* t) {
   delete t;
   return JJ_OK;
 }
-JJ_API int jj_fixedbase_mul(jj_ctx* c, const jj_table* t, size_t n, const void* scalars, void* out) {
+static int fixedbase_api(jj_ctx* c, const jj_table* t, size_t n, const void* scalars, void* out, int mode) {
   if (!c || !t) return JJ_ERR_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
   const void* ds; int rc; OutRef o;
   if ((rc = stage_in(c, 0, scalars, 32 * n, &ds))) return rc;
-  if ((rc = stage_out(c, c->out[0], out, 64 * n, &o))) return rc;
+  if ((rc = stage_out(c, c->out[0], out, (mode ? 32 : 64) * n, &o))) return rc;
   if ((rc = ensure_ext(c, n, 3))) return rc;
   SoA ext = soa_of(c->ws_ext, n);
   if (n) {
@@ -500,13 +502,16 @@ JJ_API int jj_fixedbase_mul(jj_ctx* c, const jj_table* t, size_t n, const void* 
     if (c->fb_const_time) hipLaunchKernelGGL(k_fixedbase<true>, dim3(blocks), dim3(512), FB_LDS_BYTES, c->stream, n, ds, (const u32*)t->dev, ext);
     else hipLaunchKernelGGL(k_fixedbase<false>, dim3(blocks), dim3(512), FB_LDS_BYTES, c->stream, n, ds, (const u32*)t->dev, ext);
     prof_mark(c, 1);
-    if ((rc = normalize_launch(c, n, ext, o.dev, 0))) return rc;
+    if ((rc = normalize_launch(c, n, ext, o.dev, mode))) return rc;
     prof_mark(c, 2);
   }
   bool sync = false;
   if ((rc = finish_out(c, o, &sync))) return rc;
   return finish(c, sync);
 }
+
+JJ_API int jj_fixedbase_mul(jj_ctx* c, const jj_table* t, size_t n, const void* scalars, void* out) { return fixedbase_api(c, t, n, scalars, out, 0); }
+JJ_API int jj_fixedbase_mul_compressed(jj_ctx* c, const jj_table* t, size_t n, const void* scalars, void* out32) { return fixedbase_api(c, t, n, scalars, out32, 1); }
 
 // ---------------------------------------------------------------------------------------------------- sums / MSM
 // folds a 5-coordinate SoA of n extended points down to one, result left in (U,V,Z) coords of the returned SoA

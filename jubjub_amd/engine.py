@@ -212,6 +212,12 @@ class Engine:
     def varbase_mul(self, scalars, points):
         return self._call("jj_varbase_mul", [scalars, points], [32, 64], [64])
 
+    def varbase_mul_compressed(self, scalars, points):
+        return self._call("jj_varbase_mul_compressed", [scalars, points], [32, 64], [32])
+
+    def fixedbase_mul_compressed(self, table, scalars):
+        return self._call("jj_fixedbase_mul_compressed", [scalars], [32], [32], extra_before=(table._h,))
+
     def varbase_mul_exact(self, scalars, points):
         return self._call("jj_varbase_mul_exact", [scalars, points], [32, 64], [160])
 

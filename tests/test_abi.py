@@ -1,0 +1,54 @@
+"""CPU-side checks of the C-ABI boundary: the library loads without a GPU, exports every symbol that
+include/jubjub_hip.h declares, refuses to create a context without a gfx950 device (no CPU fallback), and the
+product package never touches the oracle."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "jubjub_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(jj_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as ge
+
+    ge.build()
+    lib = ctypes.CDLL(os.path.join(ROOT, "jubjub_amd", "lib", "libjubjub_hip.so"))
+    names = declared_symbols()
+    assert len(names) >= 50
+    for n in names:
+        assert hasattr(lib, n), "missing export: " + n
+    from jubjub_amd import _lib
+
+    for n in _lib.EXPORTS:
+        assert n in names, "python binding uses an undeclared symbol: " + n
+    assert lib.jj_version() >= 100
+
+
+def test_no_cpu_fallback():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from jubjub_amd import Engine, JubjubError
+
+    with pytest.raises(JubjubError):
+        Engine(0)
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "jubjub_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".hpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle|#include\s+[\"<].*oracle|libjj_oracle", src, re.M), os.path.join(dirpath, f)
+    for f in ("include/jubjub_hip.h", "include/jubjub_hip.hpp"):
+        assert "oracle" not in open(os.path.join(ROOT, f)).read()

@@ -118,6 +118,10 @@ def test_varbase_random(eng):
     assert (got == O.varbase_mul(S, P)).all()
     assert eng.varbase_mul(S[:0], P[:0]).shape == (0, 64)
     assert (eng.varbase_mul(S[:1], P[:1]) == got[:1]).all()
+    assert (eng.varbase_mul_compressed(S, P) == O.compress(got)).all()
+    tab = eng.fixedbase_table(P[0])
+    assert (eng.fixedbase_mul_compressed(tab, S) == O.compress(O.fixedbase_mul(S, P[0]))).all()
+    tab.close()
 
 
 def test_varbase_exact_projective(eng):
