@@ -53,6 +53,8 @@ int jj_ctx_use_own_stream(jj_ctx* ctx);
 int jj_ctx_sync(jj_ctx* ctx);
 const char* jj_last_error(jj_ctx* ctx);
 int jj_version(void);
+/* WnafGroup::recommended_wnaf_for_num_scalars (src/lib.rs:1320-1335) */
+int jj_recommended_wnaf_for_num_scalars(size_t num_scalars);
 /* Device properties used for roofline accounting: out[0]=CU count, out[1]=clock kHz, out[2]=wavefront size. */
 int jj_device_info(jj_ctx* ctx, int64_t out[4]);
 

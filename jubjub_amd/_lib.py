@@ -45,7 +45,7 @@ _SIGS.update({
     "jj_peak_imad32": [C.POINTER(C.c_double)],
 })
 
-EXPORTS = sorted(list(_SIGS) + ["jj_ctx_create", "jj_ctx_destroy", "jj_last_error", "jj_version", "jj_device_info",
+EXPORTS = sorted(list(_SIGS) + ["jj_ctx_create", "jj_ctx_destroy", "jj_last_error", "jj_version", "jj_device_info", "jj_recommended_wnaf_for_num_scalars",
                                 "jj_fixedbase_table_create"])
 
 _lib = None
@@ -96,6 +96,8 @@ def load():
     lib.jj_last_error.argtypes = [_vp]
     lib.jj_version.restype = C.c_int
     lib.jj_version.argtypes = []
+    lib.jj_recommended_wnaf_for_num_scalars.restype = C.c_int
+    lib.jj_recommended_wnaf_for_num_scalars.argtypes = [C.c_size_t]
     lib.jj_device_info.restype = C.c_int
     lib.jj_device_info.argtypes = [_vp, C.POINTER(C.c_int64)]
     lib.jj_fixedbase_table_create.restype = C.c_int

@@ -134,6 +134,13 @@ static inline unsigned blocks_for(size_t n, unsigned bs = 256) { return (unsigne
 
 // ---------------------------------------------------------------------------------------------------- context
 JJ_API int jj_version(void) { return JJ_VERSION; }
+// WnafGroup::recommended_wnaf_for_num_scalars (reference src/lib.rs:1320-1335): same thresholds, same result.
+JJ_API int jj_recommended_wnaf_for_num_scalars(size_t num_scalars) {
+  static const size_t rec[12] = {1, 3, 7, 20, 43, 120, 273, 563, 1630, 3128, 7933, 62569};
+  int ret = 4;
+  for (size_t r : rec) { if (num_scalars > r) ret++; else break; }
+  return ret;
+}
 
 JJ_API int jj_ctx_create(int device, jj_ctx** out) {
   if (!out) return JJ_ERR_INVALID;

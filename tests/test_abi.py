@@ -52,3 +52,15 @@ def test_product_does_not_import_the_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle|#include\s+[\"<].*oracle|libjj_oracle", src, re.M), os.path.join(dirpath, f)
     for f in ("include/jubjub_hip.h", "include/jubjub_hip.hpp"):
         assert "oracle" not in open(os.path.join(ROOT, f)).read()
+
+
+def test_wnaf_recommendation_matches_reference(golden):
+    """reference src/lib.rs:1320-1335 through the C ABI (host-only function, no GPU needed)."""
+    from jubjub_amd import _lib
+
+    lib = _lib.load()
+    tab = golden["wnaf_recommendations"]["table"]
+    assert lib.jj_recommended_wnaf_for_num_scalars(0) == 4
+    for i, r in enumerate(tab):
+        assert lib.jj_recommended_wnaf_for_num_scalars(r) == 4 + i
+        assert lib.jj_recommended_wnaf_for_num_scalars(r + 1) == 5 + i
