@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="varbase", choices=sorted(WORK))
-    ap.add_argument("--log2n", type=int, default=None, help="log2 of the per-GPU batch (default: 20 varbase/msm, 24 fixedbase, 22 decompress)")
+    ap.add_argument("--log2n", type=int, default=None, help="log2 of the per-GPU batch (default: 20 varbase/msm, 24 fixedbase, 23 decompress = 2^26 over 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fb-window", type=int, default=0, help="fixed-base window bits: 0/6 = LDS-staged constant-time table (default), 8..12 = L2-resident table")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for plumbing tests)")
@@ -137,7 +137,7 @@ def main():
     eng = Engine(dev_index)
 
     wl = a.workload
-    log2n = a.log2n if a.log2n is not None else {"varbase": 20, "fixedbase": 24, "msm": 20, "decompress": 22}[wl]
+    log2n = a.log2n if a.log2n is not None else {"varbase": 20, "fixedbase": 24, "msm": 20, "decompress": 23}[wl]
     n = 1 << log2n
 
     # ---- synthetic inputs, generated on the device, resident in HBM before the timed region
