@@ -86,6 +86,9 @@ int jj_fr_square(jj_ctx*, size_t n, const void* a, void* out);
 int jj_fr_double(jj_ctx*, size_t n, const void* a, void* out);
 int jj_fr_invert(jj_ctx*, size_t n, const void* a, void* out, uint8_t* ok);
 int jj_fr_sqrt(jj_ctx*, size_t n, const void* a, void* out, uint8_t* ok);
+/* pow (src/fr.rs:403-414): out[i] = a[i] ^ exp[i], exponent = 32-byte little-endian integer, constant-time ladder */
+int jj_fq_pow(jj_ctx*, size_t n, const void* a, const void* exp32, void* out);
+int jj_fr_pow(jj_ctx*, size_t n, const void* a, const void* exp32, void* out);
 /* from_bytes: ok=0 (and out=0) when the integer is >= p (src/fr.rs:268-292).  from_bytes_wide: 64-byte input
  * reduced mod p (src/fr.rs:312-343). */
 int jj_fq_from_bytes(jj_ctx*, size_t n, const void* in32, void* out, uint8_t* ok);

@@ -13,7 +13,7 @@ _vp, _sz, _u8p = C.c_void_p, C.c_size_t, C.c_void_p
 # name -> argtypes after the context pointer
 _SIGS = {}
 for _f in ("fq", "fr"):
-    for _op in ("add", "sub", "mul"):
+    for _op in ("add", "sub", "mul", "pow"):
         _SIGS["jj_%s_%s" % (_f, _op)] = [_sz, _vp, _vp, _vp]
     for _op in ("neg", "square", "double", "from_bytes_wide"):
         _SIGS["jj_%s_%s" % (_f, _op)] = [_sz, _vp, _vp]

@@ -290,6 +290,22 @@ FIELD_UN(jj_fr_neg, FrP, OP_NEG) FIELD_UN(jj_fr_square, FrP, OP_SQUARE) FIELD_UN
 FIELD_UN_OK(jj_fr_invert, FrP, OP_INVERT) FIELD_UN_OK(jj_fr_sqrt, FrP, OP_SQRT) FIELD_UN_OK(jj_fr_from_bytes, FrP, OP_FROM_BYTES)
 FIELD_UN(jj_fr_from_bytes_wide, FrP, OP_FROM_WIDE)
 
+template <class P>
+static int field_pow(jj_ctx* c, size_t n, const void* a, const void* e, void* out) {
+  if (!c) return JJ_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  const void *da, *de; int rc; OutRef o;
+  if ((rc = stage_in(c, 0, a, 32 * n, &da))) return rc;
+  if ((rc = stage_in(c, 1, e, 32 * n, &de))) return rc;
+  if ((rc = stage_out(c, c->out[0], out, 32 * n, &o))) return rc;
+  if (n) hipLaunchKernelGGL((k_field_pow<P>), dim3(blocks_for(n)), dim3(256), 0, c->stream, n, da, de, o.dev);
+  bool sync = false;
+  if ((rc = finish_out(c, o, &sync))) return rc;
+  return finish(c, sync);
+}
+JJ_API int jj_fq_pow(jj_ctx* c, size_t n, const void* a, const void* exp32, void* out) { return field_pow<FqP>(c, n, a, exp32, out); }
+JJ_API int jj_fr_pow(jj_ctx* c, size_t n, const void* a, const void* exp32, void* out) { return field_pow<FrP>(c, n, a, exp32, out); }
+
 // ---------------------------------------------------------------------------------------------------- normalisation
 static SoA soa_of(DevBuf& b, size_t n) { SoA s; s.base = (u32*)b.p; s.n = n; return s; }
 static int ensure_ext(jj_ctx* c, size_t n, int coords) { return ensure(c, c->ws_ext, (size_t)coords * NL * 4 * std::max(n, (size_t)1)); }

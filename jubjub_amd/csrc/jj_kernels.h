@@ -145,6 +145,29 @@ __global__ void __launch_bounds__(256) k_field_op(size_t n, const void* a, const
   if (okp) okp[i] = ok ? 1 : 0;
 }
 
+// Fr::pow / Fq::pow (reference src/fr.rs:403-414): constant-time square-and-multiply over all 256 exponent bits,
+// one (base, exponent) pair per lane; the exponent is a little-endian 256-bit integer.
+template <class P>
+__global__ void __launch_bounds__(256) k_field_pow(size_t n, const void* a, const void* e, void* out) {
+  typedef Field<P> F;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 wa[8], we[8], wo[8];
+  load8(wa, a, i); load8(we, e, i);
+  const Fe x = F::from_words(wa);
+  Fe res = F::one();
+  #pragma unroll 1
+  for (int bit = 255; bit >= 0; bit--) {
+    u32 word = we[0];
+    _Pragma("unroll") for (int w = 1; w < 8; w++) word = ((bit >> 5) == w) ? we[w] : word;
+    res = F::sqr(res);
+    const Fe t = F::mul(res, x);
+    res = F::select(res, t, 0u - ((word >> (bit & 31)) & 1u));
+  }
+  F::to_words(wo, res);
+  store8(out, i, wo);
+}
+
 // ------------------------------------------------------------------------------------------------ K2: point ops
 enum PointOp { PT_DOUBLE = 0, PT_ADD, PT_SUB, PT_NEG, PT_COFACTOR, PT_TO_NIELS,
                PT_IS_IDENTITY, PT_IS_SMALL_ORDER, PT_IS_ON_CURVE };

@@ -62,6 +62,22 @@ def test_field_sqrt(eng, fname, which, p):
     assert ok[len(a):].all()
 
 
+@pytest.mark.parametrize("fname,p", [("fq", Q), ("fr", R)])
+def test_field_pow(eng, fname, p):
+    rng = np.random.default_rng(55)
+    a = rng.integers(0, 256, size=(300, 32), dtype=np.uint8)
+    e = rng.integers(0, 256, size=(300, 32), dtype=np.uint8)
+    e[0] = 0
+    e[1] = b32(p - 2)                       # inversion exponent (reference test_invert_is_pow, src/fr.rs:1177-1202)
+    e[2] = b32(1)
+    a[3] = 0
+    got = eng.field_binary(fname, "pow", a, e)
+    want = [pow(to_int(x) % p, to_int(y), p) for x, y in zip(a, e)]
+    assert [to_int(r) for r in got] == want
+    inv, ok = eng.field_unary_ok(fname, "invert", a[1:2])
+    assert (inv == got[1:2]).all() and ok.all()
+
+
 def test_fr_golden_vectors(eng, golden):
     # reference src/fr.rs:856-961 and src/lib.rs:1758-1776 through the GPU path
     tb = golden["fr"]["to_bytes"]
