@@ -38,6 +38,7 @@ struct jj_ctx {
   // staging for host-pointer arguments (inputs 0..3, outputs 0..1) and kernel workspaces
   DevBuf in[4], out[2], okb, ws_ext, ws_scratch, ws_tables, ws_tmp[4], msm[8], sqrt_tabs;
   SqrtTables sqrt_tables{nullptr, nullptr};
+  int msm_window = 0;            // 0 = choose from n (JJ_MSM_WINDOW overrides; 8..22)
   int msm_pass_log2 = 24;        // terms per Pippenger pass (JJ_MSM_PASS_LOG2 overrides; for tests)
   int msm_min_pippenger = 512;   // below this many terms the MSM is var-base ladders + fold (JJ_MSM_NAIVE_BELOW overrides)
   // optional per-call kernel timing (HIP events on the launch stream): e0 | main kernel | e1 | normalise tail | e2
@@ -158,6 +159,7 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
   c->wave = prop.warpSize;
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return JJ_ERR_HIP; }
   c->stream = c->own_stream;
+  if (const char* e = getenv("JJ_MSM_WINDOW")) c->msm_window = atoi(e);
   if (const char* e = getenv("JJ_MSM_PASS_LOG2")) { int v = atoi(e); if (v >= 10 && v <= 24) c->msm_pass_log2 = v; }
   if (const char* e = getenv("JJ_MSM_NAIVE_BELOW")) { int v = atoi(e); if (v >= 0) c->msm_min_pippenger = v; }
   if (const char* e = getenv("JJ_VB_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) c->vb_blocks_per_cu = v; }
@@ -579,7 +581,10 @@ JJ_API int jj_point_sum(jj_ctx* c, size_t n, const void* p, void* out64) {
 // Pippenger on the device: leaves the result (extended, coords U,V,Z of element 0) in *res.
 static int msm_pippenger(jj_ctx* c, size_t n, const void* ds, const void* dp, SoA* res) {
   MsmParams mp;
-  mp.c = (n >= ((size_t)1 << 15)) ? 16 : (n >= ((size_t)1 << 11) ? 12 : 8);
+  // window sizes whose top window keeps >= 10 scalar bits (or is short only for small n): a 1-2 bit top window would
+  // put n/2 terms into one bucket
+  mp.c = (n >= ((size_t)1 << 23)) ? 20 : (n >= ((size_t)1 << 15)) ? 16 : (n >= ((size_t)1 << 11) ? 11 : 8);
+  if (c->msm_window >= 8 && c->msm_window <= 22) mp.c = c->msm_window;
   mp.W = (253 + mp.c - 1) / mp.c;
   mp.B = 1u << (mp.c - 1);
   memset(mp.recode, 0, sizeof mp.recode);
@@ -594,6 +599,8 @@ static int msm_pippenger(jj_ctx* c, size_t n, const void* ds, const void* dp, So
   if ((rc = ensure(c, kprime, n * 32))) return rc;
   if ((rc = ensure(c, niels, n * (size_t)ANIELS_WORDS * 4))) return rc;
   if ((rc = ensure(c, cnt, (2 * nb + nscan + 8) * 4))) return rc;  // count | offset (nb+1) | block sums
+  if ((rc = ensure(c, c->ws_tmp[1], 64 + sizeof(BigBucket) * FIXUP_BIG_MAX))) return rc;              // big-bucket work list
+  if ((rc = ensure(c, c->ws_tmp[0], (size_t)5 * NL * 4 * FIXUP_BIG_MAX * FIXUP_BIG_QUADS))) return rc;   // their partial sums
   if ((rc = ensure(c, idx, n * (size_t)mp.W * 4))) return rc;
   if ((rc = ensure(c, rankb, n * (size_t)mp.W * 4))) return rc;
   if ((rc = ensure(c, buckets, (size_t)5 * NL * 4 * nb))) return rc;
@@ -609,9 +616,14 @@ static int msm_pippenger(jj_ctx* c, size_t n, const void* ds, const void* dp, So
   {
     SoA head = soa_of(ra, max_chunks);
     hipLaunchKernelGGL(k_msm_accumulate, dim3(blocks_for(max_chunks)), dim3(256), 0, c->stream, nb, (const u32*)offset, (const u32*)idx.p, (const u32*)niels.p, soa_of(buckets, nb), head);
-    hipLaunchKernelGGL(k_msm_fixup, dim3(blocks_for(nb)), dim3(256), 0, c->stream, nb, (const u32*)offset, soa_of(buckets, nb), head);
+    u32* big_count = (u32*)c->ws_tmp[1].p; BigBucket* big = (BigBucket*)((uint8_t*)c->ws_tmp[1].p + 64);
+    SoA partial = soa_of(c->ws_tmp[0], (size_t)FIXUP_BIG_MAX * FIXUP_BIG_QUADS);
+    HIPCHK(c, hipMemsetAsync(big_count, 0, 4, c->stream));
+    hipLaunchKernelGGL(k_msm_fixup, dim3(blocks_for(nb)), dim3(256), 0, c->stream, nb, (const u32*)offset, soa_of(buckets, nb), head, big_count, big);
+    hipLaunchKernelGGL(k_msm_fixup_big, dim3(256), dim3(256), 0, c->stream, (const u32*)big_count, (const BigBucket*)big, soa_of(buckets, nb), head, partial, 0);
+    hipLaunchKernelGGL(k_msm_fixup_big, dim3(256), dim3(256), 0, c->stream, (const u32*)big_count, (const BigBucket*)big, soa_of(buckets, nb), head, partial, 1);
   }
-  hipLaunchKernelGGL(k_msm_bucket_reduce, dim3(blocks_for(nchunks * 4)), dim3(256), 0, c->stream, nchunks, L, mp.B, soa_of(buckets, nb), soa_of(ra, nchunks));
+  hipLaunchKernelGGL(k_msm_bucket_reduce, dim3(blocks_for(nchunks * 4)), dim3(256), 0, c->stream, nchunks, L, mp.B, mp.c - 1, soa_of(buckets, nb), soa_of(ra, nchunks));
   // fold the chunks of each window: per-window count B/L -> 1
   size_t per_window = mp.B / L, m = nchunks;
   DevBuf* cur = &ra; DevBuf* nxt = &rb;

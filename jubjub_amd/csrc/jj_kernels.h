@@ -782,14 +782,27 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(size_t nb, const u32* of
   }
   if (inherited) soa_put_ext(head, t, acc); else soa_put_ext(buckets, b, acc);
 }
-// buckets[b] (+)= heads of the chunks that continue bucket b; empty buckets become the identity
-__global__ void __launch_bounds__(256) k_msm_fixup(size_t nb, const u32* offset, SoA buckets, SoA head) {
+// buckets[b] (+)= heads of the chunks that continue bucket b; empty buckets become the identity.
+// A bucket with more than FIXUP_SERIAL_MAX heads (heavily skewed digit distribution: repeated scalars, or a narrow
+// top window) is appended to a work list instead and reduced by a whole workgroup in k_msm_fixup_big; if the list is
+// full the lane falls back to the serial loop (slow but correct).
+constexpr u32 FIXUP_SERIAL_MAX = 32;
+constexpr u32 FIXUP_BIG_MAX = 2048;       // work-list capacity
+constexpr u32 FIXUP_BIG_QUADS = 64;       // quads (of 4 lanes) per big bucket
+struct BigBucket { u32 bucket, t_first, t_last, pad; };
+static JJ_DEV Ext soa_ext(const SoA& s, size_t i);
+static JJ_DEV Ext quad_add_ext(const Ext& p, const Ext& q, u32 role);
+__global__ void __launch_bounds__(256) k_msm_fixup(size_t nb, const u32* offset, SoA buckets, SoA head, u32* big_count, BigBucket* big) {
   const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nb) return;
   const u32 lo = offset[b], hi = offset[b + 1];
   if (lo == hi) { soa_put_ext(buckets, b, Curve::identity()); return; }
   const size_t t_first = lo / MSM_CHUNK + 1, t_last = (hi - 1) / MSM_CHUNK;
   if (t_first > t_last) return;
+  if (t_last - t_first + 1 > FIXUP_SERIAL_MAX) {
+    const u32 slot = atomicAdd(big_count, 1u);
+    if (slot < FIXUP_BIG_MAX) { big[slot].bucket = (u32)b; big[slot].t_first = (u32)t_first; big[slot].t_last = (u32)t_last; big[slot].pad = 0; return; }
+  }
   Ext acc;   // the bucket's own first run (written by the chunk that contains offset[b])
   acc.u = buckets.get(0, b); acc.v = buckets.get(1, b); acc.z = buckets.get(2, b); acc.t1 = buckets.get(3, b); acc.t2 = buckets.get(4, b);
   #pragma unroll 1
@@ -856,6 +869,28 @@ static JJ_DEV Ext quad_add_ext(const Ext& p, const Ext& q, u32 role) {
   r.u = quad_bcast<0>(r4); r.v = quad_bcast<1>(r4); r.z = quad_bcast<2>(r4); r.t1 = cu; r.t2 = cv;
   return r;
 }
+// One workgroup per listed big bucket: FIXUP_BIG_QUADS quads each fold a strided share of the bucket's heads into a
+// partial (stage 0, written to `partial[item][quad]`); stage 1 (one quad per item) folds the partials into the bucket.
+__global__ void __launch_bounds__(256) k_msm_fixup_big(const u32* big_count, const BigBucket* big, SoA buckets, SoA head, SoA partial, int stage) {
+  u32 cnt = *big_count; if (cnt > FIXUP_BIG_MAX) cnt = FIXUP_BIG_MAX;
+  const u32 role = threadIdx.x & 3u, quad = threadIdx.x >> 2;
+  #pragma unroll 1
+  for (u32 item = blockIdx.x; item < cnt; item += gridDim.x) {     // usually cnt == 0: the launch is a no-op
+    const BigBucket bb = big[item];
+    if (stage == 0) {
+      Ext acc = Curve::identity();
+      #pragma unroll 1
+      for (size_t t = (size_t)bb.t_first + quad; t <= bb.t_last; t += FIXUP_BIG_QUADS) acc = quad_add_ext(acc, soa_ext(head, t), role);
+      if (role == 0) soa_put_ext(partial, (size_t)item * FIXUP_BIG_QUADS + quad, acc);
+    } else if (quad == 0) {
+      Ext acc = soa_ext(buckets, bb.bucket);
+      const u32 nh = bb.t_last - bb.t_first + 1, used = nh < FIXUP_BIG_QUADS ? nh : FIXUP_BIG_QUADS;
+      #pragma unroll 1
+      for (u32 q = 0; q < used; q++) acc = quad_add_ext(acc, soa_ext(partial, (size_t)item * FIXUP_BIG_QUADS + q), role);
+      if (role == 0) soa_put_ext(buckets, bb.bucket, acc);
+    }
+  }
+}
 __global__ void __launch_bounds__(64) k_msm_horner(int W, int c, SoA wins, SoA out) {
   if (blockIdx.x != 0) return;
   const u32 role = threadIdx.x & 3u;
@@ -875,7 +910,7 @@ __global__ void k_soa_copy5(SoA src, size_t i, SoA dst, size_t j) {
 // quad of lanes running quad_dbl / quad_add_ext.
 // chunk of L consecutive buckets j0..j0+L-1 of one window (bucket j holds digit value j+1):
 // sum (j+1) b_j = T + j0 * S with T = sum (j-j0+1) b_j (running sums) and S = sum b_j.
-__global__ void __launch_bounds__(256) k_msm_bucket_reduce(size_t nchunks, u32 L, u32 B, SoA buckets, SoA out) {
+__global__ void __launch_bounds__(256) k_msm_bucket_reduce(size_t nchunks, u32 L, u32 B, int jbits, SoA buckets, SoA out) {
   const size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
   const u32 role = threadIdx.x & 3u;
   if (t >= nchunks) return;
@@ -887,10 +922,10 @@ __global__ void __launch_bounds__(256) k_msm_bucket_reduce(size_t nchunks, u32 L
     running = quad_add_ext(running, soa_ext(buckets, first + j), role);
     total = quad_add_ext(total, running, role);
   }
-  // total += j0 * running   (j0 < 2^15), double-and-add from the top bit
+  // total += j0 * running   (j0 < B = 2^jbits), double-and-add from the top bit
   Ext m = Curve::identity();
   #pragma unroll 1
-  for (int bit = 15; bit >= 0; bit--) {
+  for (int bit = jbits - 1; bit >= 0; bit--) {
     m = quad_dbl(m, role);
     Ext sel = Curve::identity();
     const u32 mask = ((j0 >> bit) & 1u) ? ~0u : 0u;
