@@ -64,3 +64,15 @@ def test_wnaf_recommendation_matches_reference(golden):
     for i, r in enumerate(tab):
         assert lib.jj_recommended_wnaf_for_num_scalars(r) == 4 + i
         assert lib.jj_recommended_wnaf_for_num_scalars(r + 1) == 5 + i
+
+
+def test_c_example_compiles(tmp_path):
+    """The plain-C caller in examples/ compiles against the header and links the library (C, not C++: checks the ABI is C)."""
+    import subprocess
+
+    out = tmp_path / "scalar_mul"
+    lib = os.path.join(ROOT, "jubjub_amd", "lib")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "scalar_mul.c"), "-L", lib, "-ljubjub_hip",
+                           "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined", "-o", str(out)])
+    assert out.exists()

@@ -61,3 +61,18 @@ def test_reference_suite_through_cpp_host(tmp_path):
     print(r.stderr)
     assert r.returncode == 0, r.stdout[-2000:]
     assert "ALL PASSED" in r.stdout
+
+
+@pytest.mark.gpu
+def test_c_example_runs(tmp_path):
+    """examples/scalar_mul.c prints the 16 golden encodings of the reference's test_serialization_consistency."""
+    lib = os.path.join(ROOT, "jubjub_amd", "lib")
+    out = tmp_path / "scalar_mul"
+    subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "scalar_mul.c"),
+                           "-L", lib, "-ljubjub_hip", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined", "-o", str(out)])
+    r = subprocess.run([str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    g = json.load(open(os.path.join(GOLDEN_DIR, "reference_vectors.json")))
+    want = [bytes(e).hex() for e in g["serialization_16"]["encodings"]]
+    got = [line.split("= ")[1].strip() for line in r.stdout.splitlines() if "*(8G)" in line]
+    assert got == want
