@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Static instruction mix of the shipped kernels, straight from hipcc's gfx950 assembly (-save-temps): how many
+v_mad_u64_u32 / other VALU / SALU / memory instructions each kernel (and each of its loops) contains.
+This is where the per-field-op numbers in DESIGN.md (162 multiply-adds + ~61 other VALU per multiplication) come from.
+Usage: python tools/instr_mix.py [kernel-substring ...]      (default: k_varbase k_fixedbase k_field_op)"""
+import collections
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+SRC = os.path.join(ROOT, "jubjub_amd", "csrc", "jj_engine.hip")
+
+
+def main():
+    want = sys.argv[1:] or ["k_varbaseEm", "k_fixedbaseILb1", "k_field_opINS_3FqPELi2", "k_field_opINS_3FqPELi4"]
+    with tempfile.TemporaryDirectory() as td:
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-save-temps", "-c", "-x", "hip", SRC,
+                               "-I", os.path.dirname(SRC), "-o", os.path.join(td, "e.o")], cwd=td, stderr=subprocess.DEVNULL)
+        asm = open(os.path.join(td, "jj_engine-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
+    kernels = re.split(r"\n(?=_Z\w+:\s)", asm)
+    for k in kernels:
+        name = k.split(":", 1)[0]
+        if not name.startswith("_Z") or not any(w in name for w in want):
+            continue
+        body = k.split("s_endpgm")[0]
+        print("==", name)
+        blocks = re.split(r"\n(?=\.LBB\d+_\d+:)", body)
+        total = collections.Counter()
+        for b in blocks:
+            label = b.split(":", 1)[0] if b.startswith(".LBB") else "entry"
+            ops = [l.split()[0] for l in b.splitlines() if re.match(r"^\s+[vsdgb][a-z0-9_]*_", l)]
+            total.update(ops)
+            if len(ops) >= 400:
+                c = collections.Counter(ops)
+                mad = c["v_mad_u64_u32"]
+                valu = sum(v for o, v in c.items() if o.startswith("v_"))
+                print("   block %-10s %5d instr: %5d v_mad_u64_u32, %5d other VALU, %4d SALU, %4d memory/LDS" % (
+                    label, len(ops), mad, valu - mad, sum(v for o, v in c.items() if o.startswith("s_")),
+                    sum(v for o, v in c.items() if o.startswith(("global_", "ds_", "buffer_", "scratch_", "flat_")))))
+        mad = total["v_mad_u64_u32"]
+        valu = sum(v for o, v in total.items() if o.startswith("v_"))
+        print("   TOTAL %d instr: %d v_mad_u64_u32 (%.0f%% of VALU), %d other VALU; top other ops: %s" % (
+            sum(total.values()), mad, 100.0 * mad / max(valu, 1), valu - mad,
+            ", ".join("%s x%d" % (o, v) for o, v in total.most_common(8) if o != "v_mad_u64_u32")))
+
+
+if __name__ == "__main__":
+    main()

@@ -16,13 +16,14 @@ from oracle import jubjub_ref as J  # noqa: E402
 from util import pt64  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+SEED0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 eng = Engine(0)
 base = pt64(J.GENERATOR)
 t_end = time.time() + budget
 rnd = 0
 checked = 0
 while time.time() < t_end:
-    rng = np.random.default_rng(1000 + rnd)
+    rng = np.random.default_rng(SEED0 + rnd)
     n = int(rng.integers(1, 20000))
     S = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
     K = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
