@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <time.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -42,6 +43,14 @@ struct jj_ctx {
   int msm_pass_log2 = 24;        // terms per Pippenger pass (JJ_MSM_PASS_LOG2 overrides; for tests)
   int msm_min_pippenger = 512;   // below this many terms the MSM is var-base ladders + fold (JJ_MSM_NAIVE_BELOW overrides)
   // optional per-call kernel timing (HIP events on the launch stream): e0 | main kernel | e1 | normalise tail | e2
+  // pipelined host-buffer path: copy streams + two device slots (caller buffers are page-locked in place)
+  struct Pipe {
+    hipStream_t h2d = nullptr, d2h = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+    DevBuf din[2], dout[2];
+    bool ready = false;
+  } pipe;
+  size_t pipe_chunk = (size_t)1 << 18;   // elements per pipeline chunk (JJ_PIPE_CHUNK_LOG2)
   bool fb_const_time = true;     // fixed-base window select: true = lane-staged + ds_bpermute shuffle, false = per-lane LDS gather
   int vb_blocks_per_cu = 2;      // var-base ladder: 2 waves/SIMD (3 blocks/CU distribute unevenly over the 4 SIMDs: measured slower)
   bool profile = false;
@@ -133,6 +142,100 @@ static int finish(jj_ctx* c, bool need_sync) {
 }
 static inline unsigned blocks_for(size_t n, unsigned bs = 256) { return (unsigned)((n + bs - 1) / bs); }
 
+// ---------------------------------------------------------------------------------------------------- host-buffer pipeline
+// When every array argument is a host pointer and the batch is large, the caller's buffers are page-locked in place
+// (hipHostRegister: ~1 ms per 100 MB, measured) and the batch is cut into chunks that flow over two copy streams
+// while the kernels of the neighbouring chunk run:  H2D (h2d stream) -> kernels (compute stream) -> D2H (d2h stream),
+// two device slots, all ordering by events (no host synchronisation inside the loop, no CPU bounce copies).
+// If registration fails (e.g. overlapping or already registered buffers) the caller falls back to plain staging.
+struct HostIn { const void* p; size_t elem; };
+struct HostOut { void* p; size_t elem; };
+static int pipe_prepare(jj_ctx* c, size_t in_bytes, size_t out_bytes) {
+  jj_ctx::Pipe& P = c->pipe;
+  if (!P.ready) {
+    HIPCHK(c, hipStreamCreateWithFlags(&P.h2d, hipStreamNonBlocking));
+    HIPCHK(c, hipStreamCreateWithFlags(&P.d2h, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) {
+      HIPCHK(c, hipEventCreateWithFlags(&P.ev_in[i], hipEventDisableTiming));
+      HIPCHK(c, hipEventCreateWithFlags(&P.ev_done[i], hipEventDisableTiming));
+      HIPCHK(c, hipEventCreateWithFlags(&P.ev_out[i], hipEventDisableTiming));
+    }
+    P.ready = true;
+  }
+  for (int i = 0; i < 2; i++) {
+    int rc;
+    if ((rc = ensure(c, P.din[i], in_bytes))) return rc;
+    if ((rc = ensure(c, P.dout[i], out_bytes))) return rc;
+  }
+  return JJ_OK;
+}
+static bool all_host(std::initializer_list<const void*> ptrs) { for (const void* p : ptrs) if (!p || is_device_ptr(p)) return false; return true; }
+
+// body(cn, dev_in[k], dev_out[k]) must enqueue the chunk's kernels on c->stream.
+// Returns JJ_OK, an error, or +1 when the buffers could not be page-locked (caller uses the staging path).
+template <int NIN, int NOUT, class Body>
+static int run_pipelined(jj_ctx* c, size_t n, const HostIn (&in)[NIN], const HostOut (&out)[NOUT], Body body) {
+  const size_t CH = c->pipe_chunk;
+  size_t in_stride = 0, out_stride = 0;
+  for (int k = 0; k < NIN; k++) in_stride += in[k].elem;
+  for (int k = 0; k < NOUT; k++) out_stride += out[k].elem;
+  int rc = pipe_prepare(c, in_stride * CH, out_stride * CH); if (rc) return rc;
+  // page-lock the caller's buffers in place
+  const bool dbg = getenv("JJ_PIPE_DEBUG") != nullptr;
+  timespec ts0, ts1, ts2, ts3; clock_gettime(CLOCK_MONOTONIC, &ts0);
+  void* locked[NIN + NOUT]; int nlocked = 0; bool ok = true;
+  for (int k = 0; k < NIN && ok; k++) { if (hipHostRegister(const_cast<void*>(in[k].p), n * in[k].elem, hipHostRegisterDefault) == hipSuccess) locked[nlocked++] = const_cast<void*>(in[k].p); else ok = false; }
+  for (int k = 0; k < NOUT && ok; k++) { if (hipHostRegister(out[k].p, n * out[k].elem, hipHostRegisterDefault) == hipSuccess) locked[nlocked++] = out[k].p; else ok = false; }
+  auto unlock = [&]() { for (int k = 0; k < nlocked; k++) (void)hipHostUnregister(locked[k]); };
+  if (!ok) { (void)hipGetLastError(); unlock(); return 1; }
+  clock_gettime(CLOCK_MONOTONIC, &ts1);
+  jj_ctx::Pipe& P = c->pipe;
+  hipStream_t saved = c->stream;
+  c->stream = c->own_stream;
+  const size_t nchunks = (n + CH - 1) / CH;
+  rc = JJ_OK;
+  #define PIPE_CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { c->err = std::string(#call) + " failed: " + hipGetErrorString(e_); rc = JJ_ERR_HIP; goto done; } } while (0)
+  for (size_t k = 0; k < nchunks; k++) {
+    const int s = (int)(k & 1); const size_t lo = k * CH, cn = std::min(CH, n - lo);
+    const void* din[NIN]; void* dout[NOUT];
+    size_t off = 0;
+    if (k >= 2) PIPE_CHK(hipStreamWaitEvent(P.h2d, P.ev_done[s], 0));            // slot's previous kernels have consumed din[s]
+    for (int j = 0; j < NIN; j++) {
+      din[j] = (uint8_t*)P.din[s].p + off;
+      PIPE_CHK(hipMemcpyAsync((uint8_t*)P.din[s].p + off, (const uint8_t*)in[j].p + lo * in[j].elem, cn * in[j].elem, hipMemcpyHostToDevice, P.h2d));
+      off += CH * in[j].elem;
+    }
+    PIPE_CHK(hipEventRecord(P.ev_in[s], P.h2d));
+    PIPE_CHK(hipStreamWaitEvent(c->stream, P.ev_in[s], 0));
+    if (k >= 2) PIPE_CHK(hipStreamWaitEvent(c->stream, P.ev_out[s], 0));         // slot's previous results have left dout[s]
+    off = 0;
+    for (int j = 0; j < NOUT; j++) { dout[j] = (uint8_t*)P.dout[s].p + off; off += CH * out[j].elem; }
+    if ((rc = body(cn, din, dout))) goto done;
+    PIPE_CHK(hipEventRecord(P.ev_done[s], c->stream));
+    PIPE_CHK(hipStreamWaitEvent(P.d2h, P.ev_done[s], 0));
+    off = 0;
+    for (int j = 0; j < NOUT; j++) {
+      PIPE_CHK(hipMemcpyAsync((uint8_t*)out[j].p + lo * out[j].elem, (uint8_t*)P.dout[s].p + off, cn * out[j].elem, hipMemcpyDeviceToHost, P.d2h));
+      off += CH * out[j].elem;
+    }
+    PIPE_CHK(hipEventRecord(P.ev_out[s], P.d2h));
+  }
+  clock_gettime(CLOCK_MONOTONIC, &ts2);
+  PIPE_CHK(hipStreamSynchronize(P.d2h));
+  PIPE_CHK(hipGetLastError());
+  clock_gettime(CLOCK_MONOTONIC, &ts3);
+  if (dbg) {
+    auto ms = [](const timespec& a, const timespec& b) { return (b.tv_sec - a.tv_sec) * 1e3 + (b.tv_nsec - a.tv_nsec) * 1e-6; };
+    fprintf(stderr, "[jj pipe] n=%zu chunks=%zu register %.2f ms, enqueue %.2f ms, drain %.2f ms\n", n, nchunks, ms(ts0, ts1), ms(ts1, ts2), ms(ts2, ts3));
+  }
+done:
+  #undef PIPE_CHK
+  if (rc != JJ_OK) { (void)hipStreamSynchronize(P.h2d); (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(P.d2h); }
+  c->stream = saved;
+  unlock();
+  return rc;
+}
+
 // ---------------------------------------------------------------------------------------------------- context
 JJ_API int jj_version(void) { return JJ_VERSION; }
 // WnafGroup::recommended_wnaf_for_num_scalars (reference src/lib.rs:1320-1335): same thresholds, same result.
@@ -159,6 +262,7 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
   c->wave = prop.warpSize;
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return JJ_ERR_HIP; }
   c->stream = c->own_stream;
+  if (const char* e = getenv("JJ_PIPE_CHUNK_LOG2")) { int v = atoi(e); if (v >= 8 && v <= 24) c->pipe_chunk = (size_t)1 << v; }
   if (const char* e = getenv("JJ_MSM_WINDOW")) c->msm_window = atoi(e);
   if (const char* e = getenv("JJ_MSM_PASS_LOG2")) { int v = atoi(e); if (v >= 10 && v <= 24) c->msm_pass_log2 = v; }
   if (const char* e = getenv("JJ_MSM_NAIVE_BELOW")) { int v = atoi(e); if (v >= 0) c->msm_min_pippenger = v; }
@@ -186,6 +290,14 @@ JJ_API int jj_ctx_destroy(jj_ctx* c) {
                    &c->ws_tmp[0], &c->ws_tmp[1], &c->ws_tmp[2], &c->ws_tmp[3], &c->msm[0], &c->msm[1], &c->msm[2], &c->msm[3],
                    &c->msm[4], &c->msm[5], &c->msm[6], &c->msm[7], &c->sqrt_tabs};
   for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
+  if (c->pipe.ready) {
+    for (int i = 0; i < 2; i++) {
+      (void)hipEventDestroy(c->pipe.ev_in[i]); (void)hipEventDestroy(c->pipe.ev_done[i]); (void)hipEventDestroy(c->pipe.ev_out[i]);
+      if (c->pipe.din[i].p) (void)hipFree(c->pipe.din[i].p);
+      if (c->pipe.dout[i].p) (void)hipFree(c->pipe.dout[i].p);
+    }
+    (void)hipStreamDestroy(c->pipe.h2d); (void)hipStreamDestroy(c->pipe.d2h);
+  }
   for (auto& r : c->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); (void)hipEventDestroy(r.e2); }
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -375,6 +487,18 @@ static int varbase_to_ext(jj_ctx* c, size_t n, const void* ds, const void* dp, S
 static int varbase_api(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out, int mode) {
   if (!c) return JJ_ERR_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
+  if (n >= 2 * c->pipe_chunk && all_host({scalars, points, out})) {
+    const HostIn in[2] = {{scalars, 32}, {points, 64}};
+    const HostOut ho[1] = {{out, (size_t)(mode ? 32 : 64)}};
+    const int prc = run_pipelined(c, n, in, ho, [&](size_t cn, const void* const* di, void* const* dout) -> int {
+      int rc2;
+      if ((rc2 = ensure_ext(c, cn, 3))) return rc2;
+      SoA ext = soa_of(c->ws_ext, cn);
+      if ((rc2 = varbase_to_ext(c, cn, di[0], di[1], ext, false))) return rc2;
+      return normalize_launch(c, cn, ext, dout[0], mode);
+    });
+    if (prc <= 0) return prc;      // +1: buffers could not be page-locked -> plain staging below
+  }
   const void *ds, *dp; int rc; OutRef o;
   if ((rc = stage_in(c, 0, scalars, 32 * n, &ds))) return rc;
   if ((rc = stage_in(c, 1, points, 64 * n, &dp))) return rc;
@@ -509,23 +633,38 @@ JJ_API int jj_fixedbase_table_destroy(jj_ctx* c, jj_table* t) {
   delete t;
   return JJ_OK;
 }
+static int fixedbase_launch(jj_ctx* c, const jj_table* t, size_t n, const void* ds, SoA ext) {
+  const unsigned blocks = (unsigned)std::min((size_t)c->cus, (n + 511) / 512);   // one 512-thread workgroup per CU (LDS-bound)
+  if (t->window_bits != FB_W) {
+    const unsigned gblocks = (unsigned)std::min((size_t)c->cus * 2, (n + 255) / 256);
+    hipLaunchKernelGGL(k_fixedbase_gather, dim3(gblocks), dim3(256), 0, c->stream, n, ds, (const u32*)t->dev, t->fp, ext);
+  } else if (c->fb_const_time) hipLaunchKernelGGL(k_fixedbase<true>, dim3(blocks), dim3(512), FB_LDS_BYTES, c->stream, n, ds, (const u32*)t->dev, ext);
+  else hipLaunchKernelGGL(k_fixedbase<false>, dim3(blocks), dim3(512), FB_LDS_BYTES, c->stream, n, ds, (const u32*)t->dev, ext);
+  return JJ_OK;
+}
 static int fixedbase_api(jj_ctx* c, const jj_table* t, size_t n, const void* scalars, void* out, int mode) {
   if (!c || !t) return JJ_ERR_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
+  if (n >= 2 * c->pipe_chunk && all_host({scalars, out})) {
+    const HostIn in[1] = {{scalars, 32}};
+    const HostOut ho[1] = {{out, (size_t)(mode ? 32 : 64)}};
+    const int prc = run_pipelined(c, n, in, ho, [&](size_t cn, const void* const* di, void* const* dout) -> int {
+      int rc2;
+      if ((rc2 = ensure_ext(c, cn, 3))) return rc2;
+      SoA ext = soa_of(c->ws_ext, cn);
+      if ((rc2 = fixedbase_launch(c, t, cn, di[0], ext))) return rc2;
+      return normalize_launch(c, cn, ext, dout[0], mode);
+    });
+    if (prc <= 0) return prc;
+  }
   const void* ds; int rc; OutRef o;
   if ((rc = stage_in(c, 0, scalars, 32 * n, &ds))) return rc;
   if ((rc = stage_out(c, c->out[0], out, (mode ? 32 : 64) * n, &o))) return rc;
   if ((rc = ensure_ext(c, n, 3))) return rc;
   SoA ext = soa_of(c->ws_ext, n);
   if (n) {
-    const unsigned blocks = (unsigned)std::min((size_t)c->cus, (n + 511) / 512);   // one 512-thread workgroup per CU (LDS-bound)
     prof_mark(c, 0);
-    if (t->window_bits != FB_W) {
-      const unsigned gblocks = (unsigned)std::min((size_t)c->cus * 2, (n + 255) / 256);
-      hipLaunchKernelGGL(k_fixedbase_gather, dim3(gblocks), dim3(256), 0, c->stream, n, ds, (const u32*)t->dev, t->fp, ext);
-    } else
-    if (c->fb_const_time) hipLaunchKernelGGL(k_fixedbase<true>, dim3(blocks), dim3(512), FB_LDS_BYTES, c->stream, n, ds, (const u32*)t->dev, ext);
-    else hipLaunchKernelGGL(k_fixedbase<false>, dim3(blocks), dim3(512), FB_LDS_BYTES, c->stream, n, ds, (const u32*)t->dev, ext);
+    if ((rc = fixedbase_launch(c, t, n, ds, ext))) return rc;
     prof_mark(c, 1);
     if ((rc = normalize_launch(c, n, ext, o.dev, mode))) return rc;
     prof_mark(c, 2);
