@@ -34,8 +34,9 @@ HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s 
 # Field-operation counts of the algorithms the kernels actually run, per unit.
 # IMAD32 convention: M = 128, S = 100.
 WORK = {
-    # table build 67M; 63 windows x (4 dbl (4S+3M) + 8M add) ; load 2M ; normalise 7M + (255S+78M)/32 inversion share
-    "varbase": {"S": 63 * 16 + 8, "M": 67 + 63 * 20 + 2 + 7 + 3, "bytes": 32 + 64 + 64},
+    # signed 5-bit windows: table {1..16}P 139M (15 mixed adds + 17 to_niels); 51 adds x 8M; 250 dbl x (4S+3M); load 2M;
+    # normalise 7M + (255S+78M)/32 inversion share
+    "varbase": {"S": 250 * 4 + 8, "M": 139 + 51 * 8 + 250 * 3 + 2 + 7 + 3, "bytes": 32 + 64 + 64},
     # 43 mixed adds x 7M ; normalise as above
     "fixedbase": {"S": 8, "M": 43 * 7 + 7 + 3, "bytes": 32 + 64},
     # Pippenger, c = 16: per term 2M load + 2M to_niels + 16 windows x 7M mixed add; bucket reduce 2 x 10M per bucket

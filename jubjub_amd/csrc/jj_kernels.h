@@ -258,15 +258,21 @@ __global__ void __launch_bounds__(256) k_ext160_to_soa(size_t n, const void* ext
 }
 
 // ------------------------------------------------------------------------------------------------ K3: variable-base
-// Signed 4-bit fixed-window ladder, one scalar-mul per lane.  k (low 252 bits) is recoded as
-// k = sum_{i<63} d_i 16^i + d_63 16^63, d_i in [-8,7], d_63 in {0,1}, via k' = k + 0x888..8 (digit = nibble(k') - 8).
-// The lane's table {1..8}P (ExtendedNiels, 144 B each) lives in a per-lane slot of a global workspace (L2/MALL
-// resident); the entry for the next window is fetched before the four doublings that precede its use.
+// Signed fixed-window ladder (w = 5 by default), one scalar-mul per lane.  k (low 252 bits) is recoded as
+// k = sum_i d_i 2^(w i) with signed w-bit digits d_i in [-2^(w-1), 2^(w-1)) (top digit unsigned), obtained from
+// k' = k + sum 2^(w i + w - 1) as digit = window(k') - 2^(w-1).
+// The lane's table {1..2^(w-1)}P (ExtendedNiels, 144 B each) lives in a per-lane slot of a global workspace (L2/MALL
+// resident); the entry for the next window is fetched before the w doublings that precede its use.
 // Group element equals the reference ladder's (src/lib.rs:357-379, 831-833); negation is exact on the whole curve.
 #ifndef JJ_VB_MINWAVES
 #define JJ_VB_MINWAVES 2
 #endif
-constexpr int VB_TABLE = 8;
+#ifndef JJ_VB_W
+#define JJ_VB_W 5
+#endif
+constexpr int VB_W = JJ_VB_W;                       // signed window width of the var-base ladder (4 or 5)
+constexpr int VB_TABLE = 1 << (VB_W - 1);           // table entries {1 .. 2^(w-1)} P
+constexpr int VB_NWIN = (253 + VB_W - 1) / VB_W;    // windows; the top one is unsigned (it holds the recoding carry)
 constexpr int ENIELS_WORDS = 4 * NL;   // 36 words = 144 B
 
 static JJ_DEV void store_eniels(u32* slot, const ENiels& n) {
@@ -284,26 +290,29 @@ static JJ_DEV ENiels load_eniels(const u32* slot) {
   _Pragma("unroll") for (int l = 0; l < NL; l++) { n.vpu.l[l] = w[l]; n.vmu.l[l] = w[NL + l]; n.z.l[l] = w[2 * NL + l]; n.t2d.l[l] = w[3 * NL + l]; }
   return n;
 }
-// recode: k' = (k & (2^252-1)) + 0x0888...8 (63 nibbles of 8)
-static JJ_DEV void recode_signed4(u32 (&k)[8]) {
+// recode: k' = (k & (2^252-1)) + sum_{i < NWIN-1} 2^(w i + w - 1); digit_i = window_i(k') - 2^(w-1), top window unsigned
+static JJ_DEV void recode_signed(u32 (&k)[8]) {
   k[7] &= 0x0fffffffu;
   u64 c = 0;
   _Pragma("unroll") for (int i = 0; i < 8; i++) {
-    const u64 t = (u64)k[i] + RECODE4[i] + c;
+    u32 rc = 0;
+    _Pragma("unroll") for (int j = 0; j < VB_NWIN - 1; j++) { const int bit = VB_W * j + VB_W - 1; if ((bit >> 5) == i) rc |= 1u << (bit & 31); }
+    const u64 t = (u64)k[i] + rc + c;
     k[i] = (u32)t; c = t >> 32;
   }
 }
-// apply sign / zero to a table entry: digit d in [-8,7] given as nibble nb = d + 8
-static JJ_DEV ENiels signed_entry(const ENiels& e, u32 nb) {
-  const u32 is_neg = (nb < 8u) ? ~0u : 0u;
-  const u32 is_zero = (nb == 8u) ? ~0u : 0u;
-  ENiels r = Curve::select(e, Curve::neg(e), is_neg);
-  return Curve::select(r, Curve::eniels_identity(), is_zero);
+// bits [w i, w i + w) of k'
+static JJ_DEV u32 vb_window(const u32 (&k)[8], int i) {
+  const int bit = VB_W * i, wi = bit >> 5, sh = bit & 31;
+  u32 lo = k[0], hi = k[1];
+  _Pragma("unroll") for (int q = 1; q < 8; q++) { lo = (wi == q) ? k[q] : lo; hi = (wi == q) ? (q < 7 ? k[q + 1] : 0u) : hi; }
+  const u64 both = ((u64)hi << 32) | lo;
+  return (u32)(both >> sh) & ((1u << VB_W) - 1u);
 }
-static JJ_DEV u32 table_index(u32 nb) {   // |d| - 1, clamped to 0 for d == 0
-  const int d = (int)nb - 8;
-  const int a = d < 0 ? -d : d;
-  return (u32)(a > 0 ? a - 1 : 0);
+// apply sign / zero to a table entry
+static JJ_DEV ENiels signed_entry(const ENiels& e, u32 neg, u32 zero) {
+  ENiels r = Curve::select(e, Curve::neg(e), neg ? ~0u : 0u);
+  return Curve::select(r, Curve::eniels_identity(), zero ? ~0u : 0u);
 }
 
 static JJ_DEV Ext varbase_windowed(const Affine& P, u32 (&k)[8], u32* slot) {
@@ -316,22 +325,24 @@ static JJ_DEV Ext varbase_windowed(const Affine& P, u32 (&k)[8], u32* slot) {
     cur = Curve::add(cur, pn);
     store_eniels(slot + j * ENIELS_WORDS, Curve::to_niels(cur));
   }
-  recode_signed4(k);
-  // top digit d_63 in {0,1}
-  const u32 top = (k[7] >> 28) & 1u;
-  const Ext Pe = Curve::from_affine(P), id = Curve::identity();
-  Ext acc;
-  acc.u = Fq::select(id.u, Pe.u, 0u - top); acc.v = Fq::select(id.v, Pe.v, 0u - top); acc.z = Pe.z;
-  acc.t1 = Fq::select(id.t1, Pe.t1, 0u - top); acc.t2 = Fq::select(id.t2, Pe.t2, 0u - top);
+  recode_signed(k);
+  // top window: unsigned digit (0 .. 2^(253 - w (NWIN-1)))
+  u32 a = vb_window(k, VB_NWIN - 1), neg = 0;
+  ENiels e = load_eniels(slot + (a ? a - 1 : 0) * ENIELS_WORDS);
+  Ext acc = Curve::identity();
   #pragma unroll 1
-  for (int i = 62; i >= 0; i--) {
-    u32 word = k[0];
-    _Pragma("unroll") for (int w = 1; w < 8; w++) word = ((i >> 3) == w) ? k[w] : word;
-    const u32 nb = (word >> ((i & 7) * 4)) & 15u;
-    const ENiels e = load_eniels(slot + table_index(nb) * ENIELS_WORDS);
-    #pragma unroll 1
-    for (int d = 0; d < 4; d++) acc = Curve::dbl(acc);
-    acc = Curve::add(acc, signed_entry(e, nb));
+  for (int i = VB_NWIN - 1; i >= 0; i--) {
+    const ENiels s = signed_entry(e, neg, a == 0);
+    if (i > 0) {                                             // fetch the next window's entry before the doublings
+      const int d = (int)vb_window(k, i - 1) - VB_TABLE;
+      neg = d < 0; a = (u32)(d < 0 ? -d : d);
+      e = load_eniels(slot + (a ? a - 1 : 0) * ENIELS_WORDS);
+    }
+    acc = Curve::add(acc, s);
+    if (i > 0) {
+      #pragma unroll 1
+      for (int d = 0; d < VB_W; d++) acc = Curve::dbl(acc);
+    }
   }
   return acc;
 }
