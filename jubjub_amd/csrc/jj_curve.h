@@ -44,9 +44,8 @@ struct Curve {
     const Fe uv2 = F::sqr(F::add(p.u, p.v));
     const Fe vpu = F::add(vv, uu);            // VV + UU   (L)
     const Fe vmu = F::sub(vv, uu);            // VV - UU   (N, +3p)
-    const Fe zz2 = F::add(zz, zz);            // 2 Z^2     (L)
     const Fe cu = F::sub_lazy(uv2, vpu);      // (U+V)^2 - (VV+UU)   (lazy: meets the carried ct, and is T1)
-    const Fe ct = F::sub_wide(zz2, vmu);      // 2Z^2 - (VV-UU)
+    const Fe ct = F::dbl_sub_wide(zz, vmu);   // 2Z^2 - (VV-UU)
     return into_extended(cu, vpu, vmu, ct);
   }
 

@@ -234,6 +234,11 @@ struct Field {
     Fe t; _Pragma("unroll") for (int i = 0; i < NL; i++) t.l[i] = a.l[i] + P::BIAS_L[i] - b.l[i];
     return carry(t);
   }
+  // r = 2a - b (+ 5p) in one pass (the doubling's 2Z^2 - (VV - UU)); same bounds as sub_wide(add(a, a), b)
+  static JJ_DEV Fe dbl_sub_wide(const Fe& a, const Fe& b) {
+    Fe t; _Pragma("unroll") for (int i = 0; i < NL; i++) t.l[i] = (a.l[i] << 1) + P::BIAS_L[i] - b.l[i];
+    return carry(t);
+  }
   // r = -a (+3p).  reference Fr::neg src/fr.rs:651-665.
   static JJ_DEV Fe neg(const Fe& a) {
     Fe t; _Pragma("unroll") for (int i = 0; i < NL; i++) t.l[i] = P::BIAS_N[i] - a.l[i];

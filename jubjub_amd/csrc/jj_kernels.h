@@ -849,9 +849,8 @@ static JJ_DEV Ext quad_dbl(const Ext& p, u32 role) {
   const Fe uu = quad_bcast<0>(sq), vv = quad_bcast<1>(sq), zz = quad_bcast<2>(sq), uv2 = quad_bcast<3>(sq);
   const Fe vpu = Fq::add(vv, uu);
   const Fe vmu = Fq::sub(vv, uu);
-  const Fe zz2 = Fq::add(zz, zz);
   const Fe cu = Fq::sub_lazy(uv2, vpu);
-  const Fe ct = Fq::sub_wide(zz2, vmu);
+  const Fe ct = Fq::dbl_sub_wide(zz, vmu);
   // lane 0: cu*ct   lane 1: cv*cz   lane 2,3: cz*ct
   const Fe a = role_select4(cu, vpu, vmu, vmu, role);
   const Fe b = role_select4(ct, vmu, ct, ct, role);
