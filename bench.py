@@ -102,8 +102,10 @@ def cpu_baseline(workload, target_s):
         t0 = time.perf_counter(); O.varbase_mul(s, pts); return time.perf_counter() - t0
 
     probe = max(64, 16 * cores)
-    t = run(probe)
-    n = int(max(probe, min(1 << 22, probe * target_s / max(t, 1e-6))))
+    t = run(probe)                                                  # warm-up + first calibration
+    n = int(max(probe, min(1 << 18, probe * 1.0 / max(t, 1e-6))))   # ~1 s sample for a stable rate estimate
+    t = run(n)
+    n = int(max(probe, min(1 << 22, n * target_s / max(t, 1e-6))))  # the reported sample: ~target_s of wall time
     t = run(n)
     unit = {"varbase": "scalar-muls/s", "fixedbase": "scalar-muls/s", "msm": "terms/s", "decompress": "points/s"}[workload]
     return {"value": n / t, "unit": unit, "cores": cores, "kind": "port",
