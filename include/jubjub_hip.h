@@ -117,7 +117,8 @@ int jj_point_sum(jj_ctx*, size_t n, const void* p, void* out64);
 /* ---- scalar multiplication ----------------------------------------------------------------------------- */
 /* out[i] = to_affine(points[i] * scalars[i])   (`ExtendedPoint * Fr`, src/lib.rs:873-879 -> 831-833 -> 357-379).
  * scalars are raw 32-byte patterns; only the low 252 bits are used, as in the reference ladder.
- * Windowed signed-digit ladder with a per-lane table; results are specified for on-curve points. */
+ * Windowed signed-digit ladder with a per-lane table; results are specified for on-curve points.
+ * Scalar-independent instruction stream; the per-lane table lookups use digit-dependent addresses. */
 int jj_varbase_mul(jj_ctx*, size_t n, const void* scalars32, const void* points64, void* out64);
 /* same, result written as 32-byte compressed encodings (to_bytes of the product, src/lib.rs:455-464, 1419-1421) */
 int jj_varbase_mul_compressed(jj_ctx*, size_t n, const void* scalars32, const void* points64, void* out32);
