@@ -108,6 +108,8 @@ int jj_point_to_niels(jj_ctx*, size_t n, const void* p, void* out96);
 /* predicates -> uint8_t; src/lib.rs:691-719 and (is_on_curve) 670-675 */
 int jj_is_identity(jj_ctx*, size_t n, const void* p, uint8_t* out);
 int jj_is_small_order(jj_ctx*, size_t n, const void* p, uint8_t* out);
+/* is_torsion_free: same predicate as [r]P == O (lib.rs:709-711) for points on the curve, computed with the order-8
+ * Tate pairing (one exponentiation) instead of the 252-step ladder; JJ_TORSION_CHECK=ladder selects the ladder. */
 int jj_is_torsion_free(jj_ctx*, size_t n, const void* p, uint8_t* out);
 int jj_is_prime_order(jj_ctx*, size_t n, const void* p, uint8_t* out);
 int jj_is_on_curve(jj_ctx*, size_t n, const void* p, uint8_t* out);

@@ -51,6 +51,7 @@ struct jj_ctx {
     bool ready = false;
   } pipe;
   size_t pipe_chunk = (size_t)1 << 18;   // elements per pipeline chunk (JJ_PIPE_CHUNK_LOG2)
+  bool torsion_ladder = false;   // subgroup test: false = Tate pairing (k_torsion_free), true = multiply by r (reference definition)
   bool fb_const_time = true;     // fixed-base window select: true = lane-staged + ds_bpermute shuffle, false = per-lane LDS gather
   int vb_blocks_per_cu = 2;      // var-base ladder: 2 waves/SIMD (3 blocks/CU distribute unevenly over the 4 SIMDs: measured slower)
   bool profile = false;
@@ -270,6 +271,7 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
   // the fixed-base kernel needs the full 160 KiB LDS carve-out
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fixedbase<true>), hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS_BYTES);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fixedbase<false>), hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS_BYTES);
+  if (const char* e = getenv("JJ_TORSION_CHECK")) c->torsion_ladder = strcmp(e, "ladder") == 0;
   if (const char* e = getenv("JJ_FIXEDBASE_SELECT")) c->fb_const_time = strcmp(e, "gather") != 0;
   // square-root tables (64 KiB dlog + 36 KiB powers), built on the device
   if (hipMalloc(&c->sqrt_tabs.p, 65536 + 4 * 256 * NL * 4) != hipSuccess) { (void)hipStreamDestroy(c->own_stream); delete c; return JJ_ERR_NOMEM; }
@@ -531,9 +533,14 @@ JJ_API int jj_varbase_mul_exact(jj_ctx* c, size_t n, const void* scalars, const 
   return finish(c, sync);
 }
 
-// [r]P == O for affine device points -> ok bytes (combine: 0 set, 1 and)
+// [r]P == O for affine device points -> ok bytes (combine: 0 set, 1 and).  Default: order-8 Tate pairing
+// (k_torsion_free); JJ_TORSION_CHECK=ladder runs the reference's definition, a var-base multiplication by r.
 static int torsion_free_dev(jj_ctx* c, size_t n, const void* dpts, uint8_t* dok, int combine) {
   int rc;
+  if (!c->torsion_ladder) {
+    hipLaunchKernelGGL(k_torsion_free, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, dpts, dok, combine);
+    return JJ_OK;
+  }
   if ((rc = ensure(c, c->ws_tmp[0], 32 * std::max(n, (size_t)1)))) return rc;
   if ((rc = ensure(c, c->ws_tmp[1], 32))) return rc;
   HIPCHK(c, hipMemcpyAsync(c->ws_tmp[1].p, FR_MODULUS_BYTES, 32, hipMemcpyHostToDevice, c->stream));

@@ -249,6 +249,14 @@ __global__ void __launch_bounds__(256) k_is_identity_ext(size_t n, SoA ext, uint
   else out[i] = out[i] & (id ? 0 : 1);
 }
 
+// subgroup test by Tate pairing (Curve::is_torsion_free); combine: 0 set, 1 and
+__global__ void __launch_bounds__(256) k_torsion_free(size_t n, const void* pts, uint8_t* out, int combine) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool tf = Curve::is_torsion_free(load_affine(pts, i));
+  out[i] = combine ? (out[i] & (tf ? 1 : 0)) : (tf ? 1 : 0);
+}
+
 // user-facing batch_normalize input: 160-byte canonical (U,V,Z,T1,T2) -> SoA
 __global__ void __launch_bounds__(256) k_ext160_to_soa(size_t n, const void* ext160, SoA ext) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -127,6 +127,32 @@ def test_decompress_2p22(env):
     assert (k2[:512].cpu().numpy() == ek).all() and (o2[:512].cpu().numpy() == eo).all()
 
 
+def test_subgroup_check_2p20(env, monkeypatch):
+    """2^20 points with a known torsion component: P_i = 8*A_i + (i mod 8)*T for a generator T of the 8-torsion.
+    The pairing test must accept exactly the lanes with i = 0 mod 8, and must agree with the ladder mode."""
+    from jubjub_amd import Engine
+
+    eng, dev, g, base, table = env
+    n = 1 << 20
+    A = eng.mul_by_cofactor(eng.fixedbase_mul(table, rand_scalars(dev, g, n)))
+    G8 = J.scalar_mul_fast(J.GENERATOR, J.R_MOD)                    # order-8 component of the generator
+    assert J.scalar_mul_fast(G8, 4) != J.AFFINE_IDENTITY
+    tors = np.stack([pt64(J.scalar_mul_fast(G8, j) if j else J.AFFINE_IDENTITY) for j in range(8)])
+    T = torch.from_numpy(tors).to(dev)[torch.arange(n, device=dev) % 8]
+    P = eng.point_add(A, T)
+    tf = eng.predicate("is_torsion_free", P)
+    want = (torch.arange(n, device=dev) % 8 == 0)
+    assert bool((tf.bool() == want).all())
+    monkeypatch.setenv("JJ_TORSION_CHECK", "ladder")
+    e2 = Engine(0)
+    m = 1 << 17
+    assert bool((e2.predicate("is_torsion_free", P[:m]) == tf[:m]).all())
+    e2.close()
+    enc = eng.compress(P)
+    out, ok = eng.decompress(enc, 1 | 2)
+    assert bool((ok.bool() == want).all()) and bool((out[want] == P[want]).all()) and bool((out[~want] == 0).all())
+
+
 @pytest.mark.parametrize("fname,which,p", [("fq", O.FQ, J.Q), ("fr", O.FR, J.R_MOD)])
 def test_field_ops_2p20_vs_oracle(env, fname, which, p):
     """2^20 random pairs plus structured operands (2^k, 2^k - 1, p - 2^k, saturated 29-bit limb patterns) through

@@ -115,6 +115,31 @@ def test_point_ops(eng, golden):
     assert to_pt(eng.point_sum(P[:0])) == J.AFFINE_IDENTITY
 
 
+def test_torsion_free_pairing_vs_reference_ladder(eng, golden, monkeypatch):
+    """The default subgroup test (order-8 Tate pairing) against the reference's definition [r]P == O, computed by the
+    C oracle's ladder and by this library's own ladder mode: random points of every coset of the subgroup, the
+    small-order points, the identity."""
+    from jubjub_amd import Engine
+
+    tors = torsion_points(golden)
+    sub = rand_points(71, 512, subgroup=True)
+    cosets = np.concatenate([O.point_op("add", sub[64 * j:64 * (j + 1)], np.repeat(tors[j:j + 1], 64, axis=0)) for j in range(8)])
+    P = np.concatenate([rand_points(72, 1500), cosets, tors, arr64([J.AFFINE_IDENTITY])])
+    want = O.predicate("is_torsion_free", P)
+    assert 0 < int(want.sum()) < len(P)
+    assert (eng.predicate("is_torsion_free", P) == want).all()
+    assert (eng.predicate("is_prime_order", P) == O.predicate("is_prime_order", P)).all()
+    monkeypatch.setenv("JJ_TORSION_CHECK", "ladder")
+    e2 = Engine(0)
+    assert (e2.predicate("is_torsion_free", P) == want).all()
+    enc = O.compress(P)
+    for flags in (1 | 2, 1 | 2 | 4 | 8):
+        a, ka = eng.decompress(enc, flags)
+        b, kb = e2.decompress(enc, flags)
+        assert (ka == kb).all() and (a == b).all()
+    e2.close()
+
+
 def test_varbase_edges(eng, golden):
     pts = np.concatenate([rand_points(3, 8), torsion_points(golden), arr64([J.GENERATOR, J.AFFINE_IDENTITY])])
     S, Pn = [], []

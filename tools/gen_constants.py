@@ -69,6 +69,82 @@ def field_block(name, p, extra=""):
     return s
 
 
+def sqrt_mod(a, p):
+    """Tonelli-Shanks; returns the smaller root or None."""
+    a %= p
+    if a == 0:
+        return 0
+    if pow(a, (p - 1) // 2, p) != 1:
+        return None
+    s, t = 0, p - 1
+    while t % 2 == 0:
+        s, t = s + 1, t // 2
+    z = 2
+    while pow(z, (p - 1) // 2, p) == 1:
+        z += 1
+    c, x, b, m = pow(z, t, p), pow(a, (t + 1) // 2, p), pow(a, t, p), s
+    while b != 1:
+        i, b2 = 0, b
+        while b2 != 1:
+            b2, i = b2 * b2 % p, i + 1
+        g = pow(c, 1 << (m - i - 1), p)
+        x, c = x * g % p, g * g % p
+        b, m = b * c % p, i
+    return min(x, p - x)
+
+
+def torsion_pairing_constants(d):
+    """Constants of the Tate-pairing subgroup test (jj_curve.h Curve::is_torsion_free).
+
+    E(Fq) is cyclic of order 8r, so P is in the prime-order subgroup iff the order-8 Tate pairing
+    t_8(T, P) = f_{8,T}(P)^((q-1)/8) is 1 for a generator T of the 8-torsion.  On the Montgomery model
+    B y^2 = x^3 + A x^2 + x (x = (1+v)/(1-v), y = x/u) three Miller doubling steps give
+        f_{8,T} = L1^4 L2^2 / (V1^4 X Z) / B,   L_i = Y - l_i X - n_i Z  (tangents at T and 2T),  V1 = X - Z,
+    with (X:Y:Z) = ((1+v)u : 1+v : (1-v)u).  Modulo 8th powers that is C g^4 L2^2 k^7 with g = L1 u v,
+    k = u^2 (1-v^2), C = 16 B^7, and L_i = (1+v) - u (a_i v + b_i), a_i = l_i - n_i, b_i = l_i + n_i."""
+    q = Q
+    inv = lambda x: pow(x, -1, q)
+
+    def add(P, S):
+        (u1, v1), (u2, v2) = P, S
+        k = d * u1 * u2 * v1 * v2 % q
+        return ((u1 * v2 + v1 * u2) * inv(1 + k) % q, (v1 * v2 + u1 * u2) * inv(1 - k) % q)
+
+    def mul(P, k):
+        acc = (0, 1)
+        while k:
+            if k & 1:
+                acc = add(acc, P)
+            P, k = add(P, P), k >> 1
+        return acc
+
+    v = 2
+    while True:  # smallest v whose point has an order-8 component
+        u = sqrt_mod((v * v - 1) * inv(1 + d * v * v), q)
+        if u:
+            T = mul((u, v), R)
+            if mul(T, 4) != (0, 1):
+                break
+        v += 1
+    assert mul(T, 8) == (0, 1)
+    A = 2 * (d - 1) * inv(-1 - d) % q
+    B = 4 * inv(-1 - d) % q
+
+    def to_mont(P):
+        x = (1 + P[1]) * inv(1 - P[1]) % q
+        return x, x * inv(P[0]) % q
+
+    def tangent(M):
+        lam = (3 * M[0] * M[0] + 2 * A * M[0] + 1) * inv(2 * B * M[1]) % q
+        return lam, (M[1] - lam * M[0]) % q
+
+    T2 = add(T, T)
+    assert to_mont(T2)[0] == 1 and add(T2, T2) == (0, q - 1)
+    (l1, n1), (l2, n2) = tangent(to_mont(T)), tangent(to_mont(T2))
+    return {"TP_A1": (l1 - n1) % q, "TP_B1": (l1 + n1) % q, "TP_A2": (l2 - n2) % q, "TP_B2": (l2 + n2) % q,
+            "TP_C": 16 * pow(B, 7, q) % q}
+
+
 def main():
     d = (-10240 * pow(10241, -1, Q)) % Q
     d2 = (2 * d) % Q
@@ -89,6 +165,10 @@ def main():
     pw = [mont(pow(root, 1 << i, Q), Q) for i in range(32)]
     fq_extra += "  static constexpr u32 ROOT_POW2[32][9] = {\n" + ",\n".join(
         "    {" + ", ".join("0x%08xu" % v for v in limbs(x)) + "}" for x in pw) + "};\n"
+
+    fq_extra += "  // Tate-pairing subgroup test (see torsion_pairing_constants in tools/gen_constants.py)\n"
+    for nm, val in torsion_pairing_constants(d).items():
+        fq_extra += arr(nm, limbs(mont(val, Q)))
 
     fr_extra = ""
     fr_extra += arr("SQRT_EXP", words32((R + 1) // 4, 8))  # src/fr.rs:388-393
