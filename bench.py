@@ -43,9 +43,10 @@ WORK = {
     # (2^19 buckets / 2^20 terms -> +10M); the 240-doubling Horner tail is per MSM, not per term
     "msm": {"S": 0, "M": 2 + 2 + 16 * 7 + 10, "bytes": 32 + 64},
     # decode kernel only (roofline.kernel_ms is k_decompress; the flag kernels run after it and show up in tail_ms):
-    # two decode passes (2 x (1M + 1S + 1M)), shared inversion (3M + (255S+78M)/16), u^2 1M,
-    # sqrt = a^((t-1)/2) (221S + 69M) + 2M + 48S + 4 canon + 7M table multiplies + verify (1S + 2M), 3 to_words
-    "decompress": {"S": 2 + 16 + 221 + 48 + 1, "M": 4 + 3 + 5 + 1 + 69 + 2 + 4 + 7 + 2 + 3, "bytes": 32 + 65},
+    # two decode passes (2 x (1M + 1S + 1M)), shared inversion (3M + (253S+61M)/32), u^2 1M,
+    # sqrt = a^((t-1)/2) (220S + 52M, sliding windows) + 2M + 24S + 6M digit extraction + 4 canon + 4M table multiplies
+    # + verify (1S + 2M), 3 to_words
+    "decompress": {"S": 2 + 8 + 220 + 24 + 1, "M": 4 + 3 + 2 + 1 + 52 + 2 + 6 + 4 + 4 + 2 + 3, "bytes": 32 + 65},
 }
 # the reference's own algorithm for comparison in the JSON
 REFERENCE_WORK = {"varbase": {"S": 1008, "M": 2774}, "fixedbase": {"S": 1008, "M": 2520}}

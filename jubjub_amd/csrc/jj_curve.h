@@ -139,7 +139,7 @@ struct Curve {
     const Fe k7 = F::mul(F::mul(k, k2), F::sqr(k2));
     const Fe z = F::mul(F::mul(F::konst(FqP::TP_C), g4), F::mul(F::sqr(l2), k7));
     // z^((q-1)/8) = (z^t)^(2^29),  z^t = z * (z^((t-1)/2))^2
-    const Fe w = F::pow_words(z, FqP::TM1D2);
+    const Fe w = F::pow_const<8, FqP::TM1D2>(z);
     Fe b = F::mul(F::mul(z, w), w);
     #pragma unroll 1
     for (int i = 0; i < FqP::TWO_ADICITY - 3; i++) b = F::sqr(b);

@@ -332,25 +332,48 @@ struct Field {
   // ---------------------------------------------------------------- exponentiation
   // a^e for a public fixed exponent given as 8 x 32-bit words (4-bit fixed windows).
   // reference Fr::pow_vartime src/fr.rs:422-434 (same value; exponent is public so no select needed).
+  // a^E for a public compile-time exponent E (32-bit words, little-endian): sliding 4-bit windows over odd powers
+  // a, a^3 .. a^15; the window program (squarings before each multiplication, table index) is built at compile time
+  // so the run-time loop reads two bytes per window.  Wave-uniform control flow.
+  struct PowProg { uint8_t nsq[80]; uint8_t idx[80]; int len; int first; };
   template <int NW>
-  static JJ_DEV Fe pow_words(const Fe& a, const u32 (&e)[NW]) {
-    Fe tab[16];
-    tab[0] = one(); tab[1] = a;
-    for (int i = 2; i < 16; i++) tab[i] = mul(tab[i - 1], a);
-    Fe r = one();
+  static constexpr PowProg make_prog(const u32 (&e)[NW]) {
+    PowProg p{};
     bool started = false;
-    for (int wi = NW - 1; wi >= 0; wi--) {
-      const u32 word = e[wi];
-      for (int n = 7; n >= 0; n--) {
-        const u32 d = (word >> (4 * n)) & 15u;   // wave-uniform (public exponent)
-        if (started) { r = sqr(r); r = sqr(r); r = sqr(r); r = sqr(r); }
-        if (d) { r = started ? mul(r, tab[d]) : tab[d]; started = true; }
-      }
+    int pend = 0, i = 32 * NW - 1;
+    while (i >= 0) {
+      if (!((e[i >> 5] >> (i & 31)) & 1u)) { if (started) pend++; i--; continue; }
+      int j = i >= 3 ? i - 3 : 0;
+      while (!((e[j >> 5] >> (j & 31)) & 1u)) j++;          // window e[i..j] ends in a set bit
+      u32 val = 0;
+      for (int b = i; b >= j; b--) val = (val << 1) | ((e[b >> 5] >> (b & 31)) & 1u);
+      if (started) { p.nsq[p.len] = (uint8_t)(pend + (i - j + 1)); p.idx[p.len] = (uint8_t)(val >> 1); p.len++; }
+      else { p.first = (int)(val >> 1); started = true; }
+      pend = 0;
+      i = j - 1;
+    }
+    if (pend) { p.nsq[p.len] = (uint8_t)pend; p.idx[p.len] = 255; p.len++; }
+    return p;
+  }
+  template <int NW, const u32 (&E)[NW]>
+  static JJ_DEV Fe pow_const(const Fe& a) {
+    static constexpr PowProg prog = make_prog(E);
+    Fe tab[8];
+    const Fe a2 = sqr(a);
+    tab[0] = a;
+    for (int i = 1; i < 8; i++) tab[i] = mul(tab[i - 1], a2);
+    Fe r = tab[prog.first];
+    #pragma unroll 1
+    for (int s = 0; s < prog.len; s++) {
+      const int nsq = prog.nsq[s], idx = prog.idx[s];
+      #pragma unroll 1
+      for (int q = 0; q < nsq; q++) r = sqr(r);
+      if (idx != 255) r = mul(r, tab[idx]);
     }
     return r;
   }
   // reference Fr::invert src/fr.rs:438-540 : a^(p-2); ok = (a != 0); returns 0 when a == 0
-  static JJ_DEV Fe invert(const Fe& a) { return pow_words(a, P::PM2); }
+  static JJ_DEV Fe invert(const Fe& a) { return pow_const<8, P::PM2>(a); }
 };
 
 typedef Field<FqP> Fq;

@@ -50,7 +50,7 @@ enum FieldOp { OP_ADD = 0, OP_SUB, OP_MUL, OP_NEG, OP_SQUARE, OP_DOUBLE, OP_INVE
 
 // Fr::sqrt: a^((r+1)/4), Some iff it squares back (reference src/fr.rs:384-399)
 static JJ_DEV Fe fr_sqrt(const Fe& a, bool& ok) {
-  const Fe s = Fr::pow_words(a, FrP::SQRT_EXP);
+  const Fe s = Fr::pow_const<8, FrP::SQRT_EXP>(a);
   ok = Fr::eq(Fr::sqr(s), a);
   return s;
 }
@@ -68,19 +68,25 @@ static JJ_DEV Fe sqrt_tab(const SqrtTables& T, int i, u32 k) {
   Fe r; _Pragma("unroll") for (int l = 0; l < NL; l++) r.l[l] = p[l]; return r;
 }
 static JJ_DEV Fe fq_sqrt_fast(const Fe& a, bool& ok, const SqrtTables& T) {
-  const Fe w = Fq::pow_words(a, FqP::TM1D2);
+  const Fe w = Fq::pow_const<8, FqP::TM1D2>(a);
   const Fe x = Fq::mul(a, w);
-  Fe bi = Fq::mul(x, w);
-  u32 e = 0;
+  const Fe b = Fq::mul(x, w);                          // a^t = g^e
+  // digits of e, least significant first: b^(2^24) = gamma^e0; then strip the known digits from b^(2^16), b^(2^8), b
+  // with table entries g^(-k 2^(8i)) instead of squaring a reduced b again (24 squarings in all)
+  Fe c1 = b;
   #pragma unroll 1
-  for (int i = 0; i < 4; i++) {
-    Fe y = bi;
-    #pragma unroll 1
-    for (int s = 0; s < 24 - 8 * i; s++) y = Fq::sqr(y);
-    const u32 ei = T.dlog[Fq::canon(y).l[0] & 0xffffu];
-    e |= ei << (8 * i);
-    if (i < 3) bi = Fq::mul(bi, sqrt_tab(T, i, ei));
-  }
+  for (int s = 0; s < 8; s++) c1 = Fq::sqr(c1);
+  Fe c2 = c1;
+  #pragma unroll 1
+  for (int s = 0; s < 8; s++) c2 = Fq::sqr(c2);
+  Fe c3 = c2;
+  #pragma unroll 1
+  for (int s = 0; s < 8; s++) c3 = Fq::sqr(c3);
+  const u32 e0 = T.dlog[Fq::canon(c3).l[0] & 0xffffu];
+  const u32 e1 = T.dlog[Fq::canon(Fq::mul(c2, sqrt_tab(T, 2, e0))).l[0] & 0xffffu];
+  const u32 e2 = T.dlog[Fq::canon(Fq::mul(Fq::mul(c1, sqrt_tab(T, 1, e0)), sqrt_tab(T, 2, e1))).l[0] & 0xffffu];
+  const u32 e3 = T.dlog[Fq::canon(Fq::mul(Fq::mul(b, sqrt_tab(T, 0, e0)), Fq::mul(sqrt_tab(T, 1, e1), sqrt_tab(T, 2, e2)))).l[0] & 0xffffu];
+  const u32 e = e0 | (e1 << 8) | (e2 << 16) | (e3 << 24);
   const u32 h = e >> 1;
   Fe z = Fq::mul(sqrt_tab(T, 0, h & 255u), sqrt_tab(T, 1, (h >> 8) & 255u));
   z = Fq::mul(z, Fq::mul(sqrt_tab(T, 2, (h >> 16) & 255u), sqrt_tab(T, 3, (h >> 24) & 255u)));
