@@ -39,7 +39,7 @@ struct jj_ctx {
   // staging for host-pointer arguments (inputs 0..3, outputs 0..1) and kernel workspaces
   DevBuf in[4], out[2], okb, ws_ext, ws_scratch, ws_tables, ws_tmp[4], msm[8], sqrt_tabs;
   SqrtTables sqrt_tables{nullptr, nullptr};
-  int msm_window = 0;            // 0 = choose from n (JJ_MSM_WINDOW overrides; 8..22)
+  int msm_window = 0;            // 0 = choose from n (JJ_MSM_WINDOW overrides; 8..16)
   int msm_pass_log2 = 24;        // terms per Pippenger pass (JJ_MSM_PASS_LOG2 overrides; for tests)
   int msm_min_pippenger = 512;   // below this many terms the MSM is var-base ladders + fold (JJ_MSM_NAIVE_BELOW overrides)
   // optional per-call kernel timing (HIP events on the launch stream): e0 | main kernel | e1 | normalise tail | e2
@@ -271,6 +271,8 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
   // the fixed-base kernel needs the full 160 KiB LDS carve-out
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fixedbase<true>), hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS_BYTES);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fixedbase<false>), hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS_BYTES);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_hist), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4);
   if (const char* e = getenv("JJ_TORSION_CHECK")) c->torsion_ladder = strcmp(e, "ladder") == 0;
   if (const char* e = getenv("JJ_FIXEDBASE_SELECT")) c->fb_const_time = strcmp(e, "gather") != 0;
   // square-root tables (64 KiB dlog + 36 KiB powers), built on the device
@@ -729,8 +731,8 @@ static int msm_pippenger(jj_ctx* c, size_t n, const void* ds, const void* dp, So
   MsmParams mp;
   // window sizes whose top window keeps >= 10 scalar bits (or is short only for small n): a 1-2 bit top window would
   // put n/2 terms into one bucket
-  mp.c = (n >= ((size_t)1 << 23)) ? 20 : (n >= ((size_t)1 << 15)) ? 16 : (n >= ((size_t)1 << 11) ? 11 : 8);
-  if (c->msm_window >= 8 && c->msm_window <= 22) mp.c = c->msm_window;
+  mp.c = (n >= ((size_t)1 << 15)) ? 16 : (n >= ((size_t)1 << 11) ? 11 : 8);
+  if (c->msm_window >= 8 && c->msm_window <= 16) mp.c = c->msm_window;      // one window's histogram must fit LDS
   mp.W = (253 + mp.c - 1) / mp.c;
   mp.B = 1u << (mp.c - 1);
   memset(mp.recode, 0, sizeof mp.recode);
@@ -739,7 +741,7 @@ static int msm_pippenger(jj_ctx* c, size_t n, const void* ds, const void* dp, So
   const u32 L = 32;                                   // buckets per reduce chunk
   const size_t nchunks = nb / L;
   int rc;
-  DevBuf &kprime = c->msm[0], &niels = c->msm[1], &cnt = c->msm[2], &idx = c->msm[3], &buckets = c->msm[4], &ra = c->msm[5], &rb = c->msm[6], &rankb = c->msm[7];
+  DevBuf &kprime = c->msm[0], &niels = c->msm[1], &cnt = c->msm[2], &idx = c->msm[3], &buckets = c->msm[4], &ra = c->msm[5], &rb = c->msm[6], &tcnt = c->msm[7];
   const size_t nscan = (nb + SCAN_TILE - 1) / SCAN_TILE;
   const size_t max_chunks = (n * (size_t)mp.W + MSM_CHUNK - 1) / MSM_CHUNK;
   if ((rc = ensure(c, kprime, n * 32))) return rc;
@@ -748,17 +750,22 @@ static int msm_pippenger(jj_ctx* c, size_t n, const void* ds, const void* dp, So
   if ((rc = ensure(c, c->ws_tmp[1], 64 + sizeof(BigBucket) * FIXUP_BIG_MAX))) return rc;              // big-bucket work list
   if ((rc = ensure(c, c->ws_tmp[0], (size_t)5 * NL * 4 * FIXUP_BIG_MAX * FIXUP_BIG_QUADS))) return rc;   // their partial sums
   if ((rc = ensure(c, idx, n * (size_t)mp.W * 4))) return rc;
-  if ((rc = ensure(c, rankb, n * (size_t)mp.W * 4))) return rc;
+  // sort tiles: enough (tile, window) blocks to fill the GPU, each at least 4096 terms
+  const u32 ntiles = (u32)std::max<size_t>(1, std::min<size_t>((size_t)(c->cus + mp.W - 1) / mp.W, (n + 4095) / 4096));
+  const size_t tile = (n + ntiles - 1) / ntiles;
+  if ((rc = ensure(c, tcnt, (size_t)mp.W * ntiles * mp.B * 4))) return rc;
   if ((rc = ensure(c, buckets, (size_t)5 * NL * 4 * nb))) return rc;
   if ((rc = ensure(c, ra, (size_t)5 * NL * 4 * std::max(nchunks, max_chunks)))) return rc;   // first the chunk heads, later the fold ping-pong
   if ((rc = ensure(c, rb, (size_t)5 * NL * 4 * nchunks))) return rc;
   u32* count = (u32*)cnt.p; u32* offset = count + nb; u32* bsum = offset + nb + 1;
-  HIPCHK(c, hipMemsetAsync(count, 0, nb * 4, c->stream));
-  hipLaunchKernelGGL(k_msm_prepare, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, ds, dp, mp, (u32*)kprime.p, (u32*)niels.p, count, (u32*)rankb.p);
+  hipLaunchKernelGGL(k_msm_convert, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, ds, dp, mp, (u32*)kprime.p, (u32*)niels.p);
+  hipLaunchKernelGGL(k_msm_hist, dim3(ntiles, mp.W), dim3(MSM_SORT_THREADS), mp.B * 4, c->stream, n, tile, mp, (const u32*)kprime.p, (u32*)tcnt.p);
+  hipLaunchKernelGGL(k_msm_tile_totals, dim3(blocks_for(nb)), dim3(256), 0, c->stream, nb, mp.B, ntiles, (const u32*)tcnt.p, count);
   hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)nscan), dim3(256), 0, c->stream, nb, (const u32*)count, bsum);
   hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, c->stream, nscan, bsum, offset + nb);
   hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nscan), dim3(256), 0, c->stream, nb, (const u32*)count, (const u32*)bsum, offset);
-  hipLaunchKernelGGL(k_msm_scatter, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, mp, (const u32*)kprime.p, (const u32*)offset, (const u32*)rankb.p, (u32*)idx.p);
+  hipLaunchKernelGGL(k_msm_tile_bases, dim3(blocks_for(nb)), dim3(256), 0, c->stream, nb, mp.B, ntiles, (const u32*)offset, (u32*)tcnt.p);
+  hipLaunchKernelGGL(k_msm_scatter, dim3(ntiles, mp.W), dim3(MSM_SORT_THREADS), mp.B * 4, c->stream, n, tile, mp, (const u32*)kprime.p, (const u32*)tcnt.p, (u32*)idx.p);
   {
     SoA head = soa_of(ra, max_chunks);
     hipLaunchKernelGGL(k_msm_accumulate, dim3(blocks_for(max_chunks)), dim3(256), 0, c->stream, nb, (const u32*)offset, (const u32*)idx.p, (const u32*)niels.p, soa_of(buckets, nb), head);

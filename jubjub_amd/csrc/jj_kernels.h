@@ -667,8 +667,8 @@ __global__ void __launch_bounds__(256) k_and_bytes(size_t n, uint8_t* a, const u
 
 // ------------------------------------------------------------------------------------------------ K7: Pippenger MSM
 // sum_i k_i P_i with signed c-bit windows (c <= 16): k' = k + sum_{w<W-1} 2^(cw+c-1); digit_w = window_w(k') - 2^(c-1)
-// (top window unsigned).  Terms are counting-sorted by (window, |digit|) with atomics, then one lane per bucket
-// adds its points (affine-Niels, 7M mixed addition), buckets are reduced per chunk with the running-sum trick,
+// (top window unsigned).  Terms are counting-sorted by (window, |digit|) with LDS histograms, then fixed-size chunks of the
+// sorted list are accumulated per lane (affine-Niels, 7M mixed addition), buckets are reduced per chunk with the running-sum trick,
 // chunks are folded, and the window sums are combined by Horner.  The group element equals the reference's
 // `sum of p * k` (src/lib.rs:183-193, 873-879); only +-P (exact on the whole curve) is used.
 struct MsmParams {
@@ -677,43 +677,86 @@ struct MsmParams {
   u32 B;            // buckets per window = 2^(c-1)
   u32 recode[8];    // sum_{w<W-1} 2^(cw+c-1)
 };
-// bits [c*w, c*w+c) of the 256-bit little-endian integer k (c <= 16)
-static JJ_DEV u32 msm_window(const u32* k, int c, int w) {
-  const int bit = c * w, wi = bit >> 5, sh = bit & 31;
-  const u64 both = ((u64)(wi < 7 ? k[wi + 1] : 0u) << 32) | k[wi];
-  return (u32)(both >> sh) & ((1u << c) - 1u);
-}
 // signed digit of window w: returns |d| (0 = skip) and sign
-static JJ_DEV u32 msm_digit(const u32* kp, const MsmParams& mp, int w, u32& neg) {
-  const u32 raw = msm_window(kp, mp.c, w);
+static JJ_DEV u32 msm_digit_raw(u32 raw, const MsmParams& mp, int w, u32& neg) {
   if (w == mp.W - 1) { neg = 0; return raw; }
   const int d = (int)raw - (int)mp.B;
   neg = d < 0 ? 1u : 0u;
   return (u32)(d < 0 ? -d : d);
 }
-// recode scalars, convert points to affine-Niels AoS (28 words), histogram the digits.  The returning atomic
-// gives every (term, window) its rank inside its bucket, so the scatter pass needs no second round of atomics.
-__global__ void __launch_bounds__(256) k_msm_prepare(size_t n, const void* scalars, const void* points, MsmParams mp,
-                                                      u32* kprime, u32* niels, u32* count, u32* rank) {
+// the recoded scalars k' are kept word-major (kp[j * n + i] = word j of term i) so that a block working on one
+// window reads just the one or two words that hold it, coalesced
+static JJ_DEV u32 msm_digit_wm(const u32* kp, size_t n, size_t i, const MsmParams& mp, int w, u32& neg) {
+  const int bit = mp.c * w, wi = bit >> 5, sh = bit & 31;
+  u64 both = kp[(size_t)wi * n + i];
+  if (sh + mp.c > 32 && wi < 7) both |= (u64)kp[(size_t)(wi + 1) * n + i] << 32;
+  return msm_digit_raw((u32)(both >> sh) & ((1u << mp.c) - 1u), mp, w, neg);
+}
+// recode scalars (k' = k + recode, word-major) and convert points to affine-Niels AoS (28 words)
+__global__ void __launch_bounds__(256) k_msm_convert(size_t n, const void* scalars, const void* points, MsmParams mp, u32* kprime, u32* niels) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   u32 k[8];
   load8(k, scalars, i);
   k[7] &= 0x0fffffffu;
   u64 cy = 0;
-  _Pragma("unroll") for (int j = 0; j < 8; j++) { const u64 t = (u64)k[j] + mp.recode[j] + cy; k[j] = (u32)t; cy = t >> 32; }
-  uint4* kp = reinterpret_cast<uint4*>(kprime + i * 8);
-  kp[0] = make_uint4(k[0], k[1], k[2], k[3]); kp[1] = make_uint4(k[4], k[5], k[6], k[7]);
-  for (int w = 0; w < mp.W; w++) {
-    u32 neg; const u32 a = msm_digit(k, mp, w, neg);
-    rank[(size_t)w * n + i] = a ? atomicAdd(&count[(size_t)w * mp.B + a - 1], 1u) : 0u;
-  }
+  _Pragma("unroll") for (int j = 0; j < 8; j++) { const u64 t = (u64)k[j] + mp.recode[j] + cy; kprime[(size_t)j * n + i] = (u32)t; cy = t >> 32; }
   const ANiels t = Curve::to_niels(load_affine(points, i));
   u32 wv[ANIELS_WORDS];
   _Pragma("unroll") for (int l = 0; l < NL; l++) { wv[l] = t.vpu.l[l]; wv[NL + l] = t.vmu.l[l]; wv[2 * NL + l] = t.t2d.l[l]; }
   wv[27] = 0;
   uint4* e = reinterpret_cast<uint4*>(niels + i * ANIELS_WORDS);
   _Pragma("unroll") for (int v = 0; v < ANIELS_WORDS / 4; v++) e[v] = make_uint4(wv[4 * v], wv[4 * v + 1], wv[4 * v + 2], wv[4 * v + 3]);
+}
+// Counting sort of the (term, window) pairs by (window, |digit|), tile by tile with the histogram of one window
+// (B <= 32768 counters) in LDS: block (t, w) handles terms [t*tile, (t+1)*tile) of window w.
+//   k_msm_hist       : LDS histogram of the tile -> tcount[w][t][b]                      (LDS atomics only)
+//   k_msm_tile_totals: count[w][b] = sum_t tcount[w][t][b]; the usual scan turns count into bucket offsets
+//   k_msm_tile_bases : tcount[w][t][b] <- offset[w][b] + sum_{t' < t} tcount[w][t'][b]   (first slot of the tile's run)
+//   k_msm_scatter    : LDS cursors start at the tile bases; every term takes the next slot of its bucket
+// No global atomics, and the global traffic is coalesced except the final 4-byte index writes.
+constexpr int MSM_SORT_THREADS = 1024;
+__global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_hist(size_t n, size_t tile, MsmParams mp, const u32* kp, u32* tcount) {
+  extern __shared__ u32 msm_lds[];
+  const int w = blockIdx.y;
+  for (u32 b = threadIdx.x; b < mp.B; b += MSM_SORT_THREADS) msm_lds[b] = 0;
+  __syncthreads();
+  const size_t lo = (size_t)blockIdx.x * tile, hi = lo + tile < n ? lo + tile : n;
+  for (size_t i = lo + threadIdx.x; i < hi; i += MSM_SORT_THREADS) {
+    u32 neg; const u32 a = msm_digit_wm(kp, n, i, mp, w, neg);
+    if (a) atomicAdd(&msm_lds[a - 1], 1u);
+  }
+  __syncthreads();
+  u32* out = tcount + ((size_t)w * gridDim.x + blockIdx.x) * mp.B;
+  for (u32 b = threadIdx.x; b < mp.B; b += MSM_SORT_THREADS) out[b] = msm_lds[b];
+}
+__global__ void __launch_bounds__(256) k_msm_tile_totals(size_t nb, u32 B, u32 ntiles, const u32* tcount, u32* count) {
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nb) return;
+  const size_t w = g / B, b = g % B;
+  u32 s = 0;
+  for (u32 t = 0; t < ntiles; t++) s += tcount[(w * ntiles + t) * B + b];
+  count[g] = s;
+}
+__global__ void __launch_bounds__(256) k_msm_tile_bases(size_t nb, u32 B, u32 ntiles, const u32* offset, u32* tcount) {
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nb) return;
+  const size_t w = g / B, b = g % B;
+  u32 run = offset[g];
+  for (u32 t = 0; t < ntiles; t++) { u32* p = tcount + (w * ntiles + t) * B + b; const u32 c = *p; *p = run; run += c; }
+}
+// idx[slot] = term | sign<<31
+__global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_scatter(size_t n, size_t tile, MsmParams mp, const u32* kp, const u32* tbase, u32* idx) {
+  extern __shared__ u32 msm_lds[];
+  const int w = blockIdx.y;
+  const u32* base = tbase + ((size_t)w * gridDim.x + blockIdx.x) * mp.B;
+  for (u32 b = threadIdx.x; b < mp.B; b += MSM_SORT_THREADS) msm_lds[b] = base[b];
+  __syncthreads();
+  const size_t lo = (size_t)blockIdx.x * tile, hi = lo + tile < n ? lo + tile : n;
+  for (size_t i = lo + threadIdx.x; i < hi; i += MSM_SORT_THREADS) {
+    u32 neg; const u32 a = msm_digit_wm(kp, n, i, mp, w, neg);
+    if (a) idx[atomicAdd(&msm_lds[a - 1], 1u)] = (u32)i | (neg << 31);
+  }
 }
 // exclusive scan of `count` (m entries) into `offset` (m+1 entries), three small passes:
 // (1) per-block sums of SCAN_TILE entries, (2) one block scans the block sums, (3) per-block local scan + base.
@@ -760,17 +803,6 @@ __global__ void __launch_bounds__(256) k_scan_apply(size_t m, const u32* count, 
   }
   u32 run = block_base[blockIdx.x] + part[threadIdx.x] - s;
   _Pragma("unroll") for (int j = 0; j < SCAN_TILE / 256; j++) { if (base + j < m) offset[base + j] = run; run += v[j]; }
-}
-// idx[offset[bucket] + rank] = term | sign<<31   (no atomics: ranks were fixed by k_msm_prepare)
-__global__ void __launch_bounds__(256) k_msm_scatter(size_t n, MsmParams mp, const u32* kprime, const u32* offset, const u32* rank, u32* idx) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  u32 k[8];
-  load8(k, kprime, i);
-  for (int w = 0; w < mp.W; w++) {
-    u32 neg; const u32 a = msm_digit(k, mp, w, neg);
-    if (a) idx[offset[(size_t)w * mp.B + a - 1] + rank[(size_t)w * n + i]] = (u32)i | (neg << 31);
-  }
 }
 // Balanced bucket accumulation: the sorted entry list (M entries, bucket-major) is cut into fixed chunks of
 // MSM_CHUNK entries, one lane per chunk, so every lane performs the same number of mixed additions whatever the
