@@ -805,17 +805,17 @@ __global__ void __launch_bounds__(256) k_scan_apply(size_t m, const u32* count, 
   _Pragma("unroll") for (int j = 0; j < SCAN_TILE / 256; j++) { if (base + j < m) offset[base + j] = run; run += v[j]; }
 }
 // Balanced bucket accumulation: the sorted entry list (M entries, bucket-major) is cut into fixed chunks of
-// MSM_CHUNK entries, one lane per chunk, so every lane performs the same number of mixed additions whatever the
+// `chunk` entries, one lane per chunk, so every lane performs the same number of mixed additions whatever the
 // bucket-size distribution.  A run that starts at a bucket start is written to buckets[b]; the run a chunk
 // inherits from the previous chunk goes to head[t] and is merged by k_msm_fixup.
-constexpr int MSM_CHUNK = 32;
+constexpr int MSM_CHUNK_MIN = 32;   // entries per lane; the host scales it with n so that the narrow top window keeps few heads per bucket
 static JJ_DEV void soa_put_ext(const SoA& s, size_t i, const Ext& e);
-__global__ void __launch_bounds__(256) k_msm_accumulate(size_t nb, const u32* offset, const u32* idx, const u32* niels, SoA buckets, SoA head) {
+__global__ void __launch_bounds__(256) k_msm_accumulate(size_t nb, u32 chunk, const u32* offset, const u32* idx, const u32* niels, SoA buckets, SoA head) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t M = offset[nb];                              // number of non-zero digits
-  const size_t start = t * MSM_CHUNK;
+  const size_t start = t * chunk;
   if (start >= M) return;
-  const size_t end = start + MSM_CHUNK < M ? start + MSM_CHUNK : M;
+  const size_t end = start + chunk < M ? start + chunk : M;
   // bucket containing `start`: largest b with offset[b] <= start
   size_t lo = 0, hi = nb;
   while (hi - lo > 1) { const size_t mid = (lo + hi) >> 1; if (offset[mid] <= start) lo = mid; else hi = mid; }
@@ -849,12 +849,12 @@ constexpr u32 FIXUP_BIG_QUADS = 64;       // quads (of 4 lanes) per big bucket
 struct BigBucket { u32 bucket, t_first, t_last, pad; };
 static JJ_DEV Ext soa_ext(const SoA& s, size_t i);
 static JJ_DEV Ext quad_add_ext(const Ext& p, const Ext& q, u32 role);
-__global__ void __launch_bounds__(256) k_msm_fixup(size_t nb, const u32* offset, SoA buckets, SoA head, u32* big_count, BigBucket* big) {
+__global__ void __launch_bounds__(256) k_msm_fixup(size_t nb, u32 chunk, const u32* offset, SoA buckets, SoA head, u32* big_count, BigBucket* big) {
   const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nb) return;
   const u32 lo = offset[b], hi = offset[b + 1];
   if (lo == hi) { soa_put_ext(buckets, b, Curve::identity()); return; }
-  const size_t t_first = lo / MSM_CHUNK + 1, t_last = (hi - 1) / MSM_CHUNK;
+  const size_t t_first = lo / chunk + 1, t_last = (hi - 1) / chunk;
   if (t_first > t_last) return;
   if (t_last - t_first + 1 > FIXUP_SERIAL_MAX) {
     const u32 slot = atomicAdd(big_count, 1u);
@@ -958,6 +958,18 @@ __global__ void __launch_bounds__(64) k_msm_horner(int W, int c, SoA wins, SoA o
     acc = quad_add_ext(acc, soa_ext(wins, w), role);
   }
   if (threadIdx.x == 0) soa_put_ext(out, 0, acc);
+}
+// window sums -> canonical 160-byte extended points for the host-side Horner (jj_host_tail.h)
+__global__ void __launch_bounds__(64) k_soa_to_ext160(size_t n, SoA src, void* out160) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Ext e = soa_ext(src, i);
+  u32 w[8];
+  Fq::to_words(w, e.u); store8(out160, 5 * i, w);
+  Fq::to_words(w, e.v); store8(out160, 5 * i + 1, w);
+  Fq::to_words(w, e.z); store8(out160, 5 * i + 2, w);
+  Fq::to_words(w, Fq::carry(e.t1)); store8(out160, 5 * i + 3, w);
+  Fq::to_words(w, e.t2); store8(out160, 5 * i + 4, w);
 }
 __global__ void k_soa_copy5(SoA src, size_t i, SoA dst, size_t j) {
   if (blockIdx.x == 0 && threadIdx.x == 0) soa_put_ext(dst, j, soa_ext(src, i));
