@@ -41,6 +41,8 @@ struct jj_ctx {
   DevBuf in[4], out[2], okb, ws_ext, ws_scratch, ws_tables, ws_tmp[4], msm[8], sqrt_tabs;
   SqrtTables sqrt_tables{nullptr, nullptr};
   int msm_window = 0;            // 0 = choose from n (JJ_MSM_WINDOW overrides; 8..16)
+  int msm_chunk = 0;             // accumulation chunk override (JJ_MSM_CHUNK; 0 = scale with n)
+  int msm_reduce_chunk = 32, msm_fold = 4;   // bucket-reduce chunk length / fan-in of the chunk folds (powers of two)
   int msm_pass_log2 = 24;        // terms per Pippenger pass (JJ_MSM_PASS_LOG2 overrides; for tests)
   int msm_min_pippenger = 512;   // below this many terms the MSM is var-base ladders + fold (JJ_MSM_NAIVE_BELOW overrides)
   // optional per-call kernel timing (HIP events on the launch stream): e0 | main kernel | e1 | normalise tail | e2
@@ -268,6 +270,9 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
   c->stream = c->own_stream;
   if (const char* e = getenv("JJ_PIPE_CHUNK_LOG2")) { int v = atoi(e); if (v >= 8 && v <= 24) c->pipe_chunk = (size_t)1 << v; }
   if (const char* e = getenv("JJ_MSM_WINDOW")) c->msm_window = atoi(e);
+  if (const char* e = getenv("JJ_MSM_CHUNK")) { int v = atoi(e); if (v >= 8 && v <= 1024) c->msm_chunk = v; }
+  if (const char* e = getenv("JJ_MSM_REDUCE_CHUNK")) { int v = atoi(e); if (v >= 2 && v <= 256 && (v & (v - 1)) == 0) c->msm_reduce_chunk = v; }
+  if (const char* e = getenv("JJ_MSM_FOLD")) { int v = atoi(e); if (v >= 2 && v <= 64 && (v & (v - 1)) == 0) c->msm_fold = v; }
   if (const char* e = getenv("JJ_MSM_PASS_LOG2")) { int v = atoi(e); if (v >= 10 && v <= 24) c->msm_pass_log2 = v; }
   if (const char* e = getenv("JJ_MSM_NAIVE_BELOW")) { int v = atoi(e); if (v >= 0) c->msm_min_pippenger = v; }
   if (const char* e = getenv("JJ_VB_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) c->vb_blocks_per_cu = v; }
@@ -743,13 +748,14 @@ static int msm_pippenger(jj_ctx* c, size_t n, const void* ds, const void* dp, jj
   memset(mp.recode, 0, sizeof mp.recode);
   for (int w = 0; w < mp.W - 1; w++) { const int bit = mp.c * w + mp.c - 1; mp.recode[bit >> 5] |= 1u << (bit & 31); }
   const size_t nb = (size_t)mp.W * mp.B;
-  const u32 L = 32;                                   // buckets per reduce chunk
+  const u32 L = c->msm_reduce_chunk;                  // buckets per reduce chunk (serial depth 2L + ~2c; JJ_MSM_REDUCE_CHUNK)
   const size_t nchunks = nb / L;
   int rc;
   DevBuf &kprime = c->msm[0], &niels = c->msm[1], &cnt = c->msm[2], &idx = c->msm[3], &buckets = c->msm[4], &ra = c->msm[5], &rb = c->msm[6], &tcnt = c->msm[7];
   const size_t nscan = (nb + SCAN_TILE - 1) / SCAN_TILE;
-  u32 chunk = MSM_CHUNK_MIN;                           // 32 entries per lane up to 2^20 terms, then proportional to n
+  u32 chunk = MSM_CHUNK_MIN;                           // 16 entries per lane up to 2^19 terms, 32 at 2^20, then proportional to n (measured)
   while (chunk < 256 && ((size_t)chunk << 15) < n) chunk <<= 1;
+  if (c->msm_chunk) chunk = (u32)c->msm_chunk;
   const size_t max_chunks = (n * (size_t)mp.W + chunk - 1) / chunk;
   if ((rc = ensure(c, kprime, n * 32))) return rc;
   if ((rc = ensure(c, niels, n * (size_t)ANIELS_WORDS * 4))) return rc;
@@ -788,7 +794,7 @@ static int msm_pippenger(jj_ctx* c, size_t n, const void* ds, const void* dp, jj
   size_t per_window = mp.B / L, m = nchunks;
   DevBuf* cur = &ra; DevBuf* nxt = &rb;
   while (per_window > 1) {
-    const int fold = (int)std::min<size_t>(per_window, 32);
+    const int fold = (int)std::min<size_t>(per_window, (size_t)c->msm_fold);
     const size_t T = m / fold;
     hipLaunchKernelGGL(k_sum_groups, dim3(blocks_for(T * 4)), dim3(256), 0, c->stream, m, T, fold, soa_of(*cur, m), soa_of(*nxt, T));
     std::swap(cur, nxt); m = T; per_window /= fold;

@@ -808,7 +808,7 @@ __global__ void __launch_bounds__(256) k_scan_apply(size_t m, const u32* count, 
 // `chunk` entries, one lane per chunk, so every lane performs the same number of mixed additions whatever the
 // bucket-size distribution.  A run that starts at a bucket start is written to buckets[b]; the run a chunk
 // inherits from the previous chunk goes to head[t] and is merged by k_msm_fixup.
-constexpr int MSM_CHUNK_MIN = 32;   // entries per lane; the host scales it with n so that the narrow top window keeps few heads per bucket
+constexpr int MSM_CHUNK_MIN = 16;   // entries per lane; the host scales it with n so that the narrow top window keeps few heads per bucket
 static JJ_DEV void soa_put_ext(const SoA& s, size_t i, const Ext& e);
 __global__ void __launch_bounds__(256) k_msm_accumulate(size_t nb, u32 chunk, const u32* offset, const u32* idx, const u32* niels, SoA buckets, SoA head) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -873,9 +873,8 @@ static JJ_DEV Ext soa_ext(const SoA& s, size_t i) { Ext e; e.u = s.get(0, i); e.
 static JJ_DEV void soa_put_ext(const SoA& s, size_t i, const Ext& e) {
   s.put(0, i, e.u); s.put(1, i, e.v); s.put(2, i, e.z); s.put(3, i, Fq::carry(e.t1)); s.put(4, i, Fq::carry(e.t2));
 }
-// Horner over the W window sums (5-coordinate SoA, index w): acc = 2^c acc + S_w from the top window down.
-// This is a strictly serial chain of (W-1)*c doublings, and a lone wave issues only one VALU instruction per ~9
-// cycles, so the doubling is spread over the four lanes of a quad: lane r squares {U, V, Z, U+V}[r], the four
+// Latency-bound tails (bucket reduce, folds, big-bucket fix-up) are serial chains of point operations, and a lone
+// wave issues only one VALU instruction per ~9 cycles, so each point operation is spread over the four lanes of a quad: lane r squares {U, V, Z, U+V}[r], the four
 // squares are broadcast inside the quad with DPP quad_perm moves, every lane forms the completed point, and lane r
 // multiplies one of (cu*ct, cv*cz, cz*ct).  Same formulas as Curve::dbl (reference src/lib.rs:739-828), ~2.4x fewer
 // instructions on the critical path.
@@ -946,18 +945,6 @@ __global__ void __launch_bounds__(256) k_msm_fixup_big(const u32* big_count, con
       if (role == 0) soa_put_ext(buckets, bb.bucket, acc);
     }
   }
-}
-__global__ void __launch_bounds__(64) k_msm_horner(int W, int c, SoA wins, SoA out) {
-  if (blockIdx.x != 0) return;
-  const u32 role = threadIdx.x & 3u;
-  Ext acc = soa_ext(wins, W - 1);
-  #pragma unroll 1
-  for (int w = W - 2; w >= 0; w--) {
-    #pragma unroll 1
-    for (int d = 0; d < c; d++) acc = quad_dbl(acc, role);
-    acc = quad_add_ext(acc, soa_ext(wins, w), role);
-  }
-  if (threadIdx.x == 0) soa_put_ext(out, 0, acc);
 }
 // window sums -> canonical 160-byte extended points for the host-side Horner (jj_host_tail.h)
 __global__ void __launch_bounds__(64) k_soa_to_ext160(size_t n, SoA src, void* out160) {
