@@ -19,6 +19,8 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 SEED0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 eng = Engine(0)
 base = pt64(J.GENERATOR)
+G8 = J.scalar_mul_fast(J.GENERATOR, J.R_MOD)             # order-8 component of the generator
+TORS = np.stack([pt64(J.scalar_mul_fast(G8, j) if j else J.AFFINE_IDENTITY) for j in range(8)])
 t_end = time.time() + budget
 rnd = 0
 checked = 0
@@ -37,13 +39,13 @@ while time.time() < t_end:
     tab = eng.fixedbase_table(bp, wbits)
     assert (eng.fixedbase_mul(tab, S) == O.fixedbase_mul(S, bp)).all(), ("fixedbase", rnd, wbits)
     tab.close()
-    m = min(n, 3000)
+    m = n
     assert (eng.msm(S[:m], P[:m]) == O.msm(S[:m], P[:m])).all(), ("msm", rnd)
     enc = O.compress(P)
     bad = rng.integers(0, n, size=max(1, n // 10))
     enc[bad] = rng.integers(0, 256, size=(len(bad), 32), dtype=np.uint8)
     flags = int(rng.choice([0, 1, 3, 5, 9, 13, 15]))
-    mm = n if not (flags & 2) else min(n, 2000)
+    mm = n
     o1, k1 = eng.decompress(enc[:mm], flags)
     o2, k2 = O.decompress(enc[:mm], flags)
     assert (k1 == k2).all() and (o1 == o2).all(), ("decompress", rnd, flags)
@@ -60,6 +62,9 @@ while time.time() < t_end:
     Qp = O.fixedbase_mul(S, base)
     assert (eng.point_add(P, Qp) == O.point_op("add", P, Qp)).all() and (eng.point_sub(P, Qp) == O.point_op("sub", P, Qp)).all()
     assert (eng.point_double(P) == O.point_op("double", P)).all()
+    Pm = P if rnd % 3 else O.point_op("add", P, np.repeat(TORS[rnd % 8:rnd % 8 + 1], n, axis=0))   # shift whole batch into another coset
+    for pred in ("is_torsion_free", "is_prime_order", "is_small_order"):
+        assert (eng.predicate(pred, Pm) == O.predicate(pred, Pm)).all(), (pred, rnd)
     checked += n
     rnd += 1
     print("round %d ok: n=%d flags=%d window_bits=%d  (%d units so far, %.0f s left)" % (rnd, n, flags, wbits, checked, t_end - time.time()), flush=True)
