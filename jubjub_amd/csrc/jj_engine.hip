@@ -767,8 +767,8 @@ static int msm_pippenger(jj_ctx* c, size_t n, const void* ds, const void* dp, jj
   const u32 ntiles = (u32)std::max<size_t>(1, std::min<size_t>((size_t)(c->cus + mp.W - 1) / mp.W, (n + 4095) / 4096));
   const size_t tile = (n + ntiles - 1) / ntiles;
   if ((rc = ensure(c, tcnt, (size_t)mp.W * ntiles * mp.B * 4))) return rc;
-  if ((rc = ensure(c, buckets, (size_t)5 * NL * 4 * nb))) return rc;
-  if ((rc = ensure(c, ra, (size_t)5 * NL * 4 * std::max(nchunks, max_chunks)))) return rc;   // first the chunk heads, later the fold ping-pong
+  if ((rc = ensure(c, buckets, (size_t)EXT_AOS_WORDS * 4 * nb))) return rc;
+  if ((rc = ensure(c, ra, (size_t)EXT_AOS_WORDS * 4 * std::max(nchunks, max_chunks)))) return rc;   // first the chunk heads, later the fold ping-pong
   if ((rc = ensure(c, rb, (size_t)5 * NL * 4 * nchunks))) return rc;
   u32* count = (u32*)cnt.p; u32* offset = count + nb; u32* bsum = offset + nb + 1;
   hipLaunchKernelGGL(k_msm_convert, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, ds, dp, mp, (u32*)kprime.p, (u32*)niels.p);
@@ -780,16 +780,16 @@ static int msm_pippenger(jj_ctx* c, size_t n, const void* ds, const void* dp, jj
   hipLaunchKernelGGL(k_msm_tile_bases, dim3(blocks_for(nb)), dim3(256), 0, c->stream, nb, mp.B, ntiles, (const u32*)offset, (u32*)tcnt.p);
   hipLaunchKernelGGL(k_msm_scatter, dim3(ntiles, mp.W), dim3(MSM_SORT_THREADS), mp.B * 4, c->stream, n, tile, mp, (const u32*)kprime.p, (const u32*)tcnt.p, (u32*)idx.p);
   {
-    SoA head = soa_of(ra, max_chunks);
-    hipLaunchKernelGGL(k_msm_accumulate, dim3(blocks_for(max_chunks)), dim3(256), 0, c->stream, nb, chunk, (const u32*)offset, (const u32*)idx.p, (const u32*)niels.p, soa_of(buckets, nb), head);
+    const ExtAoS head{(u32*)ra.p}, bk{(u32*)buckets.p};
+    hipLaunchKernelGGL(k_msm_accumulate, dim3(blocks_for(max_chunks)), dim3(256), 0, c->stream, nb, chunk, (const u32*)offset, (const u32*)idx.p, (const u32*)niels.p, bk, head);
     u32* big_count = (u32*)c->ws_tmp[1].p; BigBucket* big = (BigBucket*)((uint8_t*)c->ws_tmp[1].p + 64);
     SoA partial = soa_of(c->ws_tmp[0], (size_t)FIXUP_BIG_MAX * FIXUP_BIG_QUADS);
     HIPCHK(c, hipMemsetAsync(big_count, 0, 4, c->stream));
-    hipLaunchKernelGGL(k_msm_fixup, dim3(blocks_for(nb)), dim3(256), 0, c->stream, nb, chunk, (const u32*)offset, soa_of(buckets, nb), head, big_count, big);
-    hipLaunchKernelGGL(k_msm_fixup_big, dim3(256), dim3(256), 0, c->stream, (const u32*)big_count, (const BigBucket*)big, soa_of(buckets, nb), head, partial, 0);
-    hipLaunchKernelGGL(k_msm_fixup_big, dim3(256), dim3(256), 0, c->stream, (const u32*)big_count, (const BigBucket*)big, soa_of(buckets, nb), head, partial, 1);
+    hipLaunchKernelGGL(k_msm_fixup, dim3(blocks_for(nb)), dim3(256), 0, c->stream, nb, chunk, (const u32*)offset, bk, head, big_count, big);
+    hipLaunchKernelGGL(k_msm_fixup_big, dim3(256), dim3(256), 0, c->stream, (const u32*)big_count, (const BigBucket*)big, bk, head, partial, 0);
+    hipLaunchKernelGGL(k_msm_fixup_big, dim3(256), dim3(256), 0, c->stream, (const u32*)big_count, (const BigBucket*)big, bk, head, partial, 1);
   }
-  hipLaunchKernelGGL(k_msm_bucket_reduce, dim3(blocks_for(nchunks * 4)), dim3(256), 0, c->stream, nchunks, L, mp.B, mp.c - 1, soa_of(buckets, nb), soa_of(ra, nchunks));
+  hipLaunchKernelGGL(k_msm_bucket_reduce, dim3(blocks_for(nchunks * 4)), dim3(256), 0, c->stream, nchunks, L, mp.B, mp.c - 1, ExtAoS{(u32*)buckets.p}, soa_of(ra, nchunks));
   // fold the chunks of each window: per-window count B/L -> 1
   size_t per_window = mp.B / L, m = nchunks;
   DevBuf* cur = &ra; DevBuf* nxt = &rb;

@@ -810,7 +810,28 @@ __global__ void __launch_bounds__(256) k_scan_apply(size_t m, const u32* count, 
 // inherits from the previous chunk goes to head[t] and is merged by k_msm_fixup.
 constexpr int MSM_CHUNK_MIN = 16;   // entries per lane; the host scales it with n so that the narrow top window keeps few heads per bucket
 static JJ_DEV void soa_put_ext(const SoA& s, size_t i, const Ext& e);
-__global__ void __launch_bounds__(256) k_msm_accumulate(size_t nb, u32 chunk, const u32* offset, const u32* idx, const u32* niels, SoA buckets, SoA head) {
+// Buckets and chunk heads are written from divergent code (a lane flushes whenever its run of equal buckets ends), so
+// they are kept as one 192-byte record per point (U V Z T1 T2, 9 limbs each, 3 words of padding): 12 16-byte
+// stores from one base address instead of 45 strided dword stores.
+constexpr int EXT_AOS_WORDS = 48;
+struct ExtAoS { u32* p; };
+static JJ_DEV void aos_put_ext(const ExtAoS& a, size_t i, const Ext& e) {
+  const Fe t1 = Fq::carry(e.t1), t2 = Fq::carry(e.t2);
+  u32 w[EXT_AOS_WORDS];
+  _Pragma("unroll") for (int l = 0; l < NL; l++) { w[l] = e.u.l[l]; w[NL + l] = e.v.l[l]; w[2 * NL + l] = e.z.l[l]; w[3 * NL + l] = t1.l[l]; w[4 * NL + l] = t2.l[l]; }
+  w[45] = w[46] = w[47] = 0;
+  uint4* d = reinterpret_cast<uint4*>(a.p + i * EXT_AOS_WORDS);
+  _Pragma("unroll") for (int v = 0; v < EXT_AOS_WORDS / 4; v++) d[v] = make_uint4(w[4 * v], w[4 * v + 1], w[4 * v + 2], w[4 * v + 3]);
+}
+static JJ_DEV Ext aos_ext(const ExtAoS& a, size_t i) {
+  const uint4* d = reinterpret_cast<const uint4*>(a.p + i * EXT_AOS_WORDS);
+  u32 w[EXT_AOS_WORDS];
+  _Pragma("unroll") for (int v = 0; v < EXT_AOS_WORDS / 4; v++) { const uint4 x = d[v]; w[4 * v] = x.x; w[4 * v + 1] = x.y; w[4 * v + 2] = x.z; w[4 * v + 3] = x.w; }
+  Ext e;
+  _Pragma("unroll") for (int l = 0; l < NL; l++) { e.u.l[l] = w[l]; e.v.l[l] = w[NL + l]; e.z.l[l] = w[2 * NL + l]; e.t1.l[l] = w[3 * NL + l]; e.t2.l[l] = w[4 * NL + l]; }
+  return e;
+}
+__global__ void __launch_bounds__(256) k_msm_accumulate(size_t nb, u32 chunk, const u32* offset, const u32* idx, const u32* niels, ExtAoS buckets, ExtAoS head) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t M = offset[nb];                              // number of non-zero digits
   const size_t start = t * chunk;
@@ -828,7 +849,7 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(size_t nb, u32 chunk, co
   #pragma unroll 1
   for (size_t pos = start; pos < end; pos++) {
     if (pos >= nxt) {
-      if (inherited) { soa_put_ext(head, t, acc); inherited = false; } else if (any) soa_put_ext(buckets, b, acc);
+      if (inherited) { aos_put_ext(head, t, acc); inherited = false; } else if (any) aos_put_ext(buckets, b, acc);
       acc = Curve::identity(); any = false;
       do { b++; nxt = offset[b + 1]; } while (nxt <= pos);
     }
@@ -837,7 +858,7 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(size_t nb, u32 chunk, co
     acc = Curve::add(acc, Curve::select(p, Curve::neg(p), (e >> 31) ? ~0u : 0u));
     any = true;
   }
-  if (inherited) soa_put_ext(head, t, acc); else soa_put_ext(buckets, b, acc);
+  if (inherited) aos_put_ext(head, t, acc); else aos_put_ext(buckets, b, acc);
 }
 // buckets[b] (+)= heads of the chunks that continue bucket b; empty buckets become the identity.
 // A bucket with more than FIXUP_SERIAL_MAX heads (heavily skewed digit distribution: repeated scalars, or a narrow
@@ -849,11 +870,11 @@ constexpr u32 FIXUP_BIG_QUADS = 64;       // quads (of 4 lanes) per big bucket
 struct BigBucket { u32 bucket, t_first, t_last, pad; };
 static JJ_DEV Ext soa_ext(const SoA& s, size_t i);
 static JJ_DEV Ext quad_add_ext(const Ext& p, const Ext& q, u32 role);
-__global__ void __launch_bounds__(256) k_msm_fixup(size_t nb, u32 chunk, const u32* offset, SoA buckets, SoA head, u32* big_count, BigBucket* big) {
+__global__ void __launch_bounds__(256) k_msm_fixup(size_t nb, u32 chunk, const u32* offset, ExtAoS buckets, ExtAoS head, u32* big_count, BigBucket* big) {
   const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nb) return;
   const u32 lo = offset[b], hi = offset[b + 1];
-  if (lo == hi) { soa_put_ext(buckets, b, Curve::identity()); return; }
+  if (lo == hi) { aos_put_ext(buckets, b, Curve::identity()); return; }
   const size_t t_first = lo / chunk + 1, t_last = (hi - 1) / chunk;
   if (t_first > t_last) return;
   if (t_last - t_first + 1 > FIXUP_SERIAL_MAX) {
@@ -861,13 +882,12 @@ __global__ void __launch_bounds__(256) k_msm_fixup(size_t nb, u32 chunk, const u
     if (slot < FIXUP_BIG_MAX) { big[slot].bucket = (u32)b; big[slot].t_first = (u32)t_first; big[slot].t_last = (u32)t_last; big[slot].pad = 0; return; }
   }
   Ext acc;   // the bucket's own first run (written by the chunk that contains offset[b])
-  acc.u = buckets.get(0, b); acc.v = buckets.get(1, b); acc.z = buckets.get(2, b); acc.t1 = buckets.get(3, b); acc.t2 = buckets.get(4, b);
+  acc = aos_ext(buckets, b);
   #pragma unroll 1
   for (size_t t = t_first; t <= t_last; t++) {
-    Ext h; h.u = head.get(0, t); h.v = head.get(1, t); h.z = head.get(2, t); h.t1 = head.get(3, t); h.t2 = head.get(4, t);
-    acc = Curve::add(acc, Curve::to_niels(h));
+    acc = Curve::add(acc, Curve::to_niels(aos_ext(head, t)));
   }
-  soa_put_ext(buckets, b, acc);
+  aos_put_ext(buckets, b, acc);
 }
 static JJ_DEV Ext soa_ext(const SoA& s, size_t i) { Ext e; e.u = s.get(0, i); e.v = s.get(1, i); e.z = s.get(2, i); e.t1 = s.get(3, i); e.t2 = s.get(4, i); return e; }
 static JJ_DEV void soa_put_ext(const SoA& s, size_t i, const Ext& e) {
@@ -926,7 +946,7 @@ static JJ_DEV Ext quad_add_ext(const Ext& p, const Ext& q, u32 role) {
 }
 // One workgroup per listed big bucket: FIXUP_BIG_QUADS quads each fold a strided share of the bucket's heads into a
 // partial (stage 0, written to `partial[item][quad]`); stage 1 (one quad per item) folds the partials into the bucket.
-__global__ void __launch_bounds__(256) k_msm_fixup_big(const u32* big_count, const BigBucket* big, SoA buckets, SoA head, SoA partial, int stage) {
+__global__ void __launch_bounds__(256) k_msm_fixup_big(const u32* big_count, const BigBucket* big, ExtAoS buckets, ExtAoS head, SoA partial, int stage) {
   u32 cnt = *big_count; if (cnt > FIXUP_BIG_MAX) cnt = FIXUP_BIG_MAX;
   const u32 role = threadIdx.x & 3u, quad = threadIdx.x >> 2;
   #pragma unroll 1
@@ -935,14 +955,14 @@ __global__ void __launch_bounds__(256) k_msm_fixup_big(const u32* big_count, con
     if (stage == 0) {
       Ext acc = Curve::identity();
       #pragma unroll 1
-      for (size_t t = (size_t)bb.t_first + quad; t <= bb.t_last; t += FIXUP_BIG_QUADS) acc = quad_add_ext(acc, soa_ext(head, t), role);
+      for (size_t t = (size_t)bb.t_first + quad; t <= bb.t_last; t += FIXUP_BIG_QUADS) acc = quad_add_ext(acc, aos_ext(head, t), role);
       if (role == 0) soa_put_ext(partial, (size_t)item * FIXUP_BIG_QUADS + quad, acc);
     } else if (quad == 0) {
-      Ext acc = soa_ext(buckets, bb.bucket);
+      Ext acc = aos_ext(buckets, bb.bucket);
       const u32 nh = bb.t_last - bb.t_first + 1, used = nh < FIXUP_BIG_QUADS ? nh : FIXUP_BIG_QUADS;
       #pragma unroll 1
       for (u32 q = 0; q < used; q++) acc = quad_add_ext(acc, soa_ext(partial, (size_t)item * FIXUP_BIG_QUADS + q), role);
-      if (role == 0) soa_put_ext(buckets, bb.bucket, acc);
+      if (role == 0) aos_put_ext(buckets, bb.bucket, acc);
     }
   }
 }
@@ -965,7 +985,7 @@ __global__ void k_soa_copy5(SoA src, size_t i, SoA dst, size_t j) {
 // quad of lanes running quad_dbl / quad_add_ext.
 // chunk of L consecutive buckets j0..j0+L-1 of one window (bucket j holds digit value j+1):
 // sum (j+1) b_j = T + j0 * S with T = sum (j-j0+1) b_j (running sums) and S = sum b_j.
-__global__ void __launch_bounds__(256) k_msm_bucket_reduce(size_t nchunks, u32 L, u32 B, int jbits, SoA buckets, SoA out) {
+__global__ void __launch_bounds__(256) k_msm_bucket_reduce(size_t nchunks, u32 L, u32 B, int jbits, ExtAoS buckets, SoA out) {
   const size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
   const u32 role = threadIdx.x & 3u;
   if (t >= nchunks) return;
@@ -974,7 +994,7 @@ __global__ void __launch_bounds__(256) k_msm_bucket_reduce(size_t nchunks, u32 L
   Ext running = Curve::identity(), total = Curve::identity();
   #pragma unroll 1
   for (int j = (int)L - 1; j >= 0; j--) {
-    running = quad_add_ext(running, soa_ext(buckets, first + j), role);
+    running = quad_add_ext(running, aos_ext(buckets, first + j), role);
     total = quad_add_ext(total, running, role);
   }
   // total += j0 * running   (j0 < B = 2^jbits), double-and-add from the top bit
