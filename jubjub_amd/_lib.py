@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libjubjub_hip.so")
+LIB_PATH = os.environ.get("JJ_LIB_PATH") or os.path.join(HERE, "lib", "libjubjub_hip.so")   # JJ_LIB_PATH: A/B builds of the same library
 
 JJ_OK, JJ_ERR_INVALID, JJ_ERR_HIP, JJ_ERR_NOMEM, JJ_ERR_NODEVICE = 0, -1, -2, -3, -4
 

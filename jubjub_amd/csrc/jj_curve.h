@@ -17,8 +17,10 @@ struct Ext { Fe u, v, z, t1, t2; };         // reference ExtendedPoint        sr
 struct ANiels { Fe vpu, vmu, t2d; };        // reference AffineNielsPoint     src/lib.rs:254-259
 struct ENiels { Fe vpu, vmu, z, t2d; };     // reference ExtendedNielsPoint   src/lib.rs:326-332
 
-struct Curve {
-  typedef Fq F;
+// FT: the field flavour (Field<FqP, PIN>); Curve = CurveT<Fq> everywhere except register-bound kernels.
+template <class FT>
+struct CurveT {
+  typedef FT F;
 
   static JJ_DEV Ext identity() { Ext p; p.u = F::zero(); p.v = F::one(); p.z = F::one(); p.t1 = F::zero(); p.t2 = F::zero(); return p; }  // lib.rs:680-688
   static JJ_DEV ANiels aniels_identity() { ANiels n; n.vpu = F::one(); n.vmu = F::one(); n.t2d = F::zero(); return n; }                      // lib.rs:263-269
@@ -139,7 +141,7 @@ struct Curve {
     const Fe k7 = F::mul(F::mul(k, k2), F::sqr(k2));
     const Fe z = F::mul(F::mul(F::konst(FqP::TP_C), g4), F::mul(F::sqr(l2), k7));
     // z^((q-1)/8) = (z^t)^(2^29),  z^t = z * (z^((t-1)/2))^2
-    const Fe w = F::pow_const<8, FqP::TM1D2>(z);
+    const Fe w = F::template pow_const<8, FqP::TM1D2>(z);
     Fe b = F::mul(F::mul(z, w), w);
     #pragma unroll 1
     for (int i = 0; i < FqP::TWO_ADICITY - 3; i++) b = F::sqr(b);
@@ -154,5 +156,7 @@ struct Curve {
   }
 
 };
+typedef CurveT<Fq> Curve;
+typedef CurveT<Field<FqP, 0>> CurveNP;   // products without association pins (see JJ_MUL_PIN in jj_field.h)
 
 }  // namespace jj

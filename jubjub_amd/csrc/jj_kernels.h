@@ -844,18 +844,18 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(size_t nb, u32 chunk, co
   u32 nxt = offset[b + 1];
   while (nxt <= start) { b++; nxt = offset[b + 1]; }     // skip empty buckets that share the offset
   bool inherited = offset[b] < start;                       // first run continues a bucket begun in an earlier chunk
-  Ext acc = Curve::identity();
+  Ext acc = CurveNP::identity();
   bool any = false;
   #pragma unroll 1
   for (size_t pos = start; pos < end; pos++) {
     if (pos >= nxt) {
       if (inherited) { aos_put_ext(head, t, acc); inherited = false; } else if (any) aos_put_ext(buckets, b, acc);
-      acc = Curve::identity(); any = false;
+      acc = CurveNP::identity(); any = false;
       do { b++; nxt = offset[b + 1]; } while (nxt <= pos);
     }
     const u32 e = idx[pos];
     const ANiels p = lds_aniels(niels + (size_t)(e & 0x7fffffffu) * ANIELS_WORDS);
-    acc = Curve::add(acc, Curve::select(p, Curve::neg(p), (e >> 31) ? ~0u : 0u));
+    acc = CurveNP::add(acc, CurveNP::select(p, CurveNP::neg(p), (e >> 31) ? ~0u : 0u));
     any = true;
   }
   if (inherited) aos_put_ext(head, t, acc); else aos_put_ext(buckets, b, acc);

@@ -18,7 +18,7 @@ def main():
     want = sys.argv[1:] or ["k_varbaseEm", "k_fixedbaseILb1", "k_field_opINS_3FqPELi2", "k_field_opINS_3FqPELi4"]
     with tempfile.TemporaryDirectory() as td:
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-save-temps", "-c", "-x", "hip", SRC,
-                               "-I", os.path.dirname(SRC), "-o", os.path.join(td, "e.o")], cwd=td, stderr=subprocess.DEVNULL)
+                               "-I", os.path.dirname(SRC), "-o", os.path.join(td, "e.o")] + os.environ.get("JJ_CXXFLAGS", "").split(), cwd=td, stderr=subprocess.DEVNULL)
         asm = open(os.path.join(td, "jj_engine-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
     kernels = re.split(r"\n(?=_Z\w+:\s)", asm)
     for k in kernels:
