@@ -39,9 +39,9 @@ WORK = {
     "varbase": {"S": 250 * 4 + 8, "M": 139 + 51 * 8 + 250 * 3 + 2 + 7 + 3, "bytes": 32 + 64 + 64},
     # 43 mixed adds x 7M ; normalise as above
     "fixedbase": {"S": 8, "M": 43 * 7 + 7 + 3, "bytes": 32 + 64},
-    # Pippenger, c = 15: per term 2M load + 2M to_niels + 17 windows x 7M mixed add; bucket reduce 2 x 10M per bucket
-    # (17 x 2^14 buckets / 2^20 terms -> +5M); the 240-doubling Horner tail is per MSM (on the host), not per term
-    "msm": {"S": 0, "M": 2 + 2 + 17 * 7 + 5, "bytes": 32 + 64},
+    # Pippenger, c = 16: per term 2M load + 2M to_niels + 16 windows x 7M mixed add; bucket reduce 2 x 10M per bucket
+    # (16 x 2^15 buckets / 2^20 terms -> +10M); the 240-doubling Horner tail is per MSM (on the host), not per term
+    "msm": {"S": 0, "M": 2 + 2 + 16 * 7 + 10, "bytes": 32 + 64},
     # decode kernel only (roofline.kernel_ms is k_decompress; the flag kernels run after it and show up in tail_ms):
     # two decode passes (2 x (1M + 1S + 1M)), shared inversion (3M + (253S+61M)/32), u^2 1M,
     # sqrt = a^((t-1)/2) (220S + 52M, sliding windows) + 2M + 24S + 6M digit extraction + 4 canon + 4M table multiplies
