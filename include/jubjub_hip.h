@@ -141,7 +141,10 @@ int jj_fixedbase_mul(jj_ctx*, const jj_table* t, size_t n, const void* scalars32
 int jj_fixedbase_mul_compressed(jj_ctx*, const jj_table* t, size_t n, const void* scalars32, void* out32);
 
 /* Multi-scalar multiplication: out = to_affine(sum_i points[i] * scalars[i])  (semantics: iterator Sum of
- * `p * k`, src/lib.rs:183-193 + 873-879; the reference has no MSM algorithm).  n = 0 gives the identity. */
+ * `p * k`, src/lib.rs:183-193 + 873-879; the reference has no MSM algorithm).  n = 0 gives the identity.
+ * Pippenger on the device; the last step (Horner over the 16-17 window sums and one inversion, a chain of ~250
+ * dependent doublings) runs on the calling host thread, so for n >= 512 this call synchronises the stream even when
+ * all pointers are device pointers (the 64-byte result is then copied back to out64 asynchronously). */
 int jj_msm(jj_ctx*, size_t n, const void* scalars32, const void* points64, void* out64);
 
 /* ---- encodings ----------------------------------------------------------------------------------------- */
