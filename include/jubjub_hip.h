@@ -133,7 +133,7 @@ int jj_varbase_mul_exact(jj_ctx*, size_t n, const void* scalars32, const void* p
  * The table holds signed-window multiples (j+1) * 2^(w i) * B of the base as affine-Niels triples.
  *   window_bits 0 or 6 : 147 KiB table staged in LDS, window entry selected with a ds_bpermute shuffle
  *                        (constant-time: no secret-dependent address) — 43 mixed additions per scalar;
- *   window_bits 8..16  : wider windows (0.5 MB .. 59 MB table) kept in L2/MALL and gathered per lane
+ *   window_bits 8..16  : wider windows (0.6 MB .. 64 MB table, one 128-byte line per entry) kept in L2 / Infinity Cache and gathered per lane
  *                        (variable-time addressing) — ceil(253/w) additions per scalar. */
 int jj_fixedbase_table_create(jj_ctx*, const void* base64, int window_bits /* 0 = default */, jj_table** out);
 int jj_fixedbase_table_destroy(jj_ctx*, jj_table* t);

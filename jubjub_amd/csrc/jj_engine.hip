@@ -610,10 +610,11 @@ static int build_window_table(jj_ctx* c, const uint8_t base[64], int w, int W, u
     rc = jj_varbase_mul(c, 1, sc, &q[(size_t)(W - 1) * 64], &aff[(size_t)W * E * 64]); if (rc) return rc;
   }
   u32* dev = nullptr;
-  if (hipMalloc((void**)&dev, ne * (size_t)ANIELS_WORDS * 4) != hipSuccess) { c->err = "hipMalloc(table) failed"; return JJ_ERR_NOMEM; }
+  const int stride = extra_top_entry ? ANIELS_WORDS : GNIELS_WORDS;      // LDS-staged table: packed; gathered table: one line per entry
+  if (hipMalloc((void**)&dev, ne * (size_t)stride * 4) != hipSuccess) { c->err = "hipMalloc(table) failed"; return JJ_ERR_NOMEM; }
   const void* dpts;
   if ((rc = stage_in(c, 0, aff.data(), ne * 64, &dpts))) { (void)hipFree(dev); return rc; }
-  hipLaunchKernelGGL(k_affine_to_table, dim3(blocks_for(ne)), dim3(256), 0, c->stream, ne, dpts, dev);
+  hipLaunchKernelGGL(k_affine_to_table, dim3(blocks_for(ne)), dim3(256), 0, c->stream, ne, dpts, dev, stride);
   rc = finish(c, true);
   if (rc) { (void)hipFree(dev); return rc; }
   *out_dev = dev; *out_entries = ne;
@@ -758,7 +759,7 @@ static int msm_pippenger(jj_ctx* c, size_t n, const void* ds, const void* dp, jj
   if (c->msm_chunk) chunk = (u32)c->msm_chunk;
   const size_t max_chunks = (n * (size_t)mp.W + chunk - 1) / chunk;
   if ((rc = ensure(c, kprime, n * 32))) return rc;
-  if ((rc = ensure(c, niels, n * (size_t)ANIELS_WORDS * 4))) return rc;
+  if ((rc = ensure(c, niels, n * (size_t)GNIELS_WORDS * 4))) return rc;
   if ((rc = ensure(c, cnt, (2 * nb + nscan + 8) * 4))) return rc;  // count | offset (nb+1) | block sums
   if ((rc = ensure(c, c->ws_tmp[1], 64 + sizeof(BigBucket) * FIXUP_BIG_MAX))) return rc;              // big-bucket work list
   if ((rc = ensure(c, c->ws_tmp[0], (size_t)5 * NL * 4 * FIXUP_BIG_MAX * FIXUP_BIG_QUADS))) return rc;   // their partial sums

@@ -410,7 +410,8 @@ constexpr int FB_W = 6;
 constexpr int FB_NWIN = 42;
 constexpr int FB_ENT = 32;
 constexpr int FB_ENTRIES = FB_NWIN * FB_ENT + 1;
-constexpr int ANIELS_WORDS = 28;   // 27 + 1 pad, 16-byte multiple
+constexpr int ANIELS_WORDS = 28;   // 27 + 1 pad, 16-byte multiple: entry stride of the LDS table
+constexpr int GNIELS_WORDS = 32;   // entry stride of tables gathered from global memory: one 128-byte line per entry
 constexpr int FB_LDS_BYTES = FB_ENTRIES * ANIELS_WORDS * 4;
 
 static JJ_DEV ANiels lds_aniels(const u32* e) {
@@ -487,7 +488,7 @@ __global__ void __launch_bounds__(512) k_fixedbase(size_t n, const void* scalars
   }
 }
 // Wide-window variant: table of (j+1) * 2^(w i) * B for w = 8..12 (0.5 - 5 MB) kept in global memory, L2-resident;
-// each lane gathers its 112-byte entry (7 x dwordx4) one window ahead of its use.  Fewer additions than the LDS
+// each lane gathers its entry (7 x dwordx4 of one 128-byte line) one window ahead of its use.  Fewer additions than the LDS
 // kernel (w = 10: 26 instead of 43) at the price of a secret-dependent address (documented as variable-time).
 struct FbParams {
   int w, W;          // window bits, number of windows = ceil(253 / w)
@@ -516,7 +517,7 @@ __global__ void __launch_bounds__(256) k_fixedbase_gather(size_t n, const void* 
     Ext acc = Curve::identity();
     // top window: unsigned digit
     u32 a = fb_window(k, fp.w, fp.W - 1), neg = 0;
-    ANiels e = lds_aniels(table + ((size_t)(fp.W - 1) * fp.E + (a ? a - 1 : 0)) * ANIELS_WORDS);
+    ANiels e = lds_aniels(table + ((size_t)(fp.W - 1) * fp.E + (a ? a - 1 : 0)) * GNIELS_WORDS);
     #pragma unroll 1
     for (int i = fp.W - 1; i >= 0; i--) {
       ANiels s = Curve::select(e, Curve::neg(e), neg ? ~0u : 0u);
@@ -524,7 +525,7 @@ __global__ void __launch_bounds__(256) k_fixedbase_gather(size_t n, const void* 
       if (i > 0) {                                           // fetch the next window's entry before this addition
         const int d = (int)fb_window(k, fp.w, i - 1) - (int)fp.E;
         neg = d < 0; a = (u32)(d < 0 ? -d : d);
-        e = lds_aniels(table + ((size_t)(i - 1) * fp.E + (a ? a - 1 : 0)) * ANIELS_WORDS);
+        e = lds_aniels(table + ((size_t)(i - 1) * fp.E + (a ? a - 1 : 0)) * GNIELS_WORDS);
       }
       acc = Curve::add(acc, s);
     }
@@ -532,15 +533,15 @@ __global__ void __launch_bounds__(256) k_fixedbase_gather(size_t n, const void* 
   }
 }
 // affine points (64 B canonical) -> table entries (AffineNiels limbs, 112 B)
-__global__ void __launch_bounds__(256) k_affine_to_table(size_t n, const void* pts, u32* table) {
+__global__ void __launch_bounds__(256) k_affine_to_table(size_t n, const void* pts, u32* table, int stride) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const ANiels t = Curve::to_niels(load_affine(pts, i));
-  u32* e = table + i * ANIELS_WORDS;
+  u32* e = table + i * (size_t)stride;
   // canonical Montgomery limbs so the table is a deterministic function of the base point
   const Fe a = Fq::canon(t.vpu), b = Fq::canon(t.vmu), c = Fq::canon(t.t2d);
   _Pragma("unroll") for (int l = 0; l < NL; l++) { e[l] = a.l[l]; e[NL + l] = b.l[l]; e[2 * NL + l] = c.l[l]; }
-  e[27] = 0;
+  for (int l = 27; l < stride; l++) e[l] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------ sums (MSM tail, point_sum)
@@ -692,7 +693,7 @@ static JJ_DEV u32 msm_digit_wm(const u32* kp, size_t n, size_t i, const MsmParam
   if (sh + mp.c > 32 && wi < 7) both |= (u64)kp[(size_t)(wi + 1) * n + i] << 32;
   return msm_digit_raw((u32)(both >> sh) & ((1u << mp.c) - 1u), mp, w, neg);
 }
-// recode scalars (k' = k + recode, word-major) and convert points to affine-Niels AoS (28 words)
+// recode scalars (k' = k + recode, word-major) and convert points to affine-Niels AoS (27 words in a 128-byte record)
 __global__ void __launch_bounds__(256) k_msm_convert(size_t n, const void* scalars, const void* points, MsmParams mp, u32* kprime, u32* niels) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -705,7 +706,7 @@ __global__ void __launch_bounds__(256) k_msm_convert(size_t n, const void* scala
   u32 wv[ANIELS_WORDS];
   _Pragma("unroll") for (int l = 0; l < NL; l++) { wv[l] = t.vpu.l[l]; wv[NL + l] = t.vmu.l[l]; wv[2 * NL + l] = t.t2d.l[l]; }
   wv[27] = 0;
-  uint4* e = reinterpret_cast<uint4*>(niels + i * ANIELS_WORDS);
+  uint4* e = reinterpret_cast<uint4*>(niels + i * GNIELS_WORDS);
   _Pragma("unroll") for (int v = 0; v < ANIELS_WORDS / 4; v++) e[v] = make_uint4(wv[4 * v], wv[4 * v + 1], wv[4 * v + 2], wv[4 * v + 3]);
 }
 // Counting sort of the (term, window) pairs by (window, |digit|), tile by tile with the histogram of one window
@@ -854,7 +855,7 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(size_t nb, u32 chunk, co
       do { b++; nxt = offset[b + 1]; } while (nxt <= pos);
     }
     const u32 e = idx[pos];
-    const ANiels p = lds_aniels(niels + (size_t)(e & 0x7fffffffu) * ANIELS_WORDS);
+    const ANiels p = lds_aniels(niels + (size_t)(e & 0x7fffffffu) * GNIELS_WORDS);
     acc = CurveNP::add(acc, CurveNP::select(p, CurveNP::neg(p), (e >> 31) ? ~0u : 0u));
     any = true;
   }
