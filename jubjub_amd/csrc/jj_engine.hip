@@ -58,6 +58,7 @@ struct jj_ctx {
   uint8_t host_out[64];
   bool torsion_ladder = false;   // subgroup test: false = Tate pairing (k_torsion_free), true = multiply by r (reference definition)
   bool fb_const_time = true;     // fixed-base window select: true = lane-staged + ds_bpermute shuffle, false = per-lane LDS gather
+  int vb_quad_max = 32768;       // batches up to this size run one scalar-mul per quad of lanes (JJ_VB_QUAD_MAX; 0 = never)
   int vb_blocks_per_cu = 2;      // var-base ladder: 2 waves/SIMD (3 blocks/CU distribute unevenly over the 4 SIMDs: measured slower)
   bool profile = false;
   struct Rec { hipEvent_t e0, e1, e2; };
@@ -275,6 +276,7 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
   if (const char* e = getenv("JJ_MSM_FOLD")) { int v = atoi(e); if (v >= 2 && v <= 64 && (v & (v - 1)) == 0) c->msm_fold = v; }
   if (const char* e = getenv("JJ_MSM_PASS_LOG2")) { int v = atoi(e); if (v >= 10 && v <= 24) c->msm_pass_log2 = v; }
   if (const char* e = getenv("JJ_MSM_NAIVE_BELOW")) { int v = atoi(e); if (v >= 0) c->msm_min_pippenger = v; }
+  if (const char* e = getenv("JJ_VB_QUAD_MAX")) { int v = atoi(e); if (v >= 0 && v <= (1 << 20)) c->vb_quad_max = v; }
   if (const char* e = getenv("JJ_VB_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) c->vb_blocks_per_cu = v; }
   // the fixed-base kernel needs the full 160 KiB LDS carve-out
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fixedbase<true>), hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS_BYTES);
@@ -490,6 +492,12 @@ static void varbase_geometry(jj_ctx* c, size_t n, unsigned* blocks, size_t* thre
   *blocks = (unsigned)(t / 256); *threads = t;
 }
 static int varbase_to_ext(jj_ctx* c, size_t n, const void* ds, const void* dp, SoA ext, bool five) {
+  if (n <= (size_t)c->vb_quad_max) {      // small batch: one scalar multiplication per quad of lanes (3x lower latency)
+    int rc = ensure(c, c->ws_tables, n * (size_t)(VB_TABLE * ENIELS_WORDS) * 4); if (rc) return rc;
+    if (five) hipLaunchKernelGGL(k_varbase_quad<true>, dim3(blocks_for(4 * n)), dim3(256), 0, c->stream, n, ds, dp, (u32*)c->ws_tables.p, ext);
+    else hipLaunchKernelGGL(k_varbase_quad<false>, dim3(blocks_for(4 * n)), dim3(256), 0, c->stream, n, ds, dp, (u32*)c->ws_tables.p, ext);
+    return JJ_OK;
+  }
   unsigned blocks; size_t threads;
   varbase_geometry(c, n, &blocks, &threads);
   int rc = ensure(c, c->ws_tables, threads * (size_t)(VB_TABLE * ENIELS_WORDS) * 4); if (rc) return rc;

@@ -945,6 +945,105 @@ static JJ_DEV Ext quad_add_ext(const Ext& p, const Ext& q, u32 role) {
   r.u = quad_bcast<0>(r4); r.v = quad_bcast<1>(r4); r.z = quad_bcast<2>(r4); r.t1 = cu; r.t2 = cv;
   return r;
 }
+// ---- quad variants that keep T = t1*t2 alongside the point, for adding table entries in two rounds
+// doubling; lane 3 multiplies carry(cu)*cv so the caller also gets T of the result
+static JJ_DEV Ext quad_dbl_t(const Ext& p, u32 role, Fe& T) {
+  const Fe sq = Fq::sqr(role_select4(p.u, p.v, p.z, Fq::add(p.u, p.v), role));
+  const Fe uu = quad_bcast<0>(sq), vv = quad_bcast<1>(sq), zz = quad_bcast<2>(sq), uv2 = quad_bcast<3>(sq);
+  const Fe vpu = Fq::add(vv, uu);
+  const Fe vmu = Fq::sub(vv, uu);
+  const Fe cu = Fq::sub_lazy(uv2, vpu);
+  const Fe ct = Fq::dbl_sub_wide(zz, vmu);
+  const Fe pr = Fq::mul(role_select4(cu, vpu, vmu, Fq::carry(cu), role), role_select4(ct, vmu, ct, vpu, role));
+  Ext r;
+  r.u = quad_bcast<0>(pr); r.v = quad_bcast<1>(pr); r.z = quad_bcast<2>(pr); r.t1 = cu; r.t2 = vpu;
+  T = quad_bcast<3>(pr);
+  return r;
+}
+// p (+/-) n for an extended-Niels operand, given T = p.t1*p.t2 (reference src/lib.rs:883-940): round 1 a, b, c = T*t2d,
+// zz on the four lanes; round 2 U, V, Z, T.  neg selects the subtraction formula (swap v+u / v-u, swap d+c / d-c).
+static JJ_DEV Ext quad_add_eniels(const Ext& p, const Fe& T, const ENiels& n, u32 neg, u32 role, Fe& Tout) {
+  const u32 nm = neg ? ~0u : 0u;
+  const Fe fa = Fq::select(n.vmu, n.vpu, nm), fb = Fq::select(n.vpu, n.vmu, nm);
+  const Fe r1 = Fq::mul(role_select4(Fq::sub(p.v, p.u), Fq::add(p.v, p.u), T, p.z, role), role_select4(fa, fb, n.t2d, n.z, role));
+  const Fe a = quad_bcast<0>(r1), b = quad_bcast<1>(r1), c = quad_bcast<2>(r1), zz = quad_bcast<3>(r1);
+  const Fe d = Fq::add(zz, zz);
+  const Fe plus = Fq::carry(Fq::add(d, c)), minus = Fq::sub(d, c);
+  const Fe cu = Fq::sub_lazy(b, a), cv = Fq::add(b, a), cz = Fq::select(plus, minus, nm), ct = Fq::select(minus, plus, nm);
+  const Fe r2 = Fq::mul(role_select4(cu, cv, cz, Fq::carry(cu), role), role_select4(ct, cz, ct, cv, role));
+  Ext r;
+  r.u = quad_bcast<0>(r2); r.v = quad_bcast<1>(r2); r.z = quad_bcast<2>(r2); r.t1 = cu; r.t2 = cv;
+  Tout = quad_bcast<3>(r2);
+  return r;
+}
+// p + n for an affine-Niels operand (Z2 = 1: d = 2 Z1; reference src/lib.rs:944-968)
+static JJ_DEV Ext quad_add_aniels(const Ext& p, const Fe& T, const ANiels& n, u32 role, Fe& Tout) {
+  const Fe r1 = Fq::mul(role_select4(Fq::sub(p.v, p.u), Fq::add(p.v, p.u), T, T, role), role_select4(n.vmu, n.vpu, n.t2d, n.t2d, role));
+  const Fe a = quad_bcast<0>(r1), b = quad_bcast<1>(r1), c = quad_bcast<2>(r1);
+  const Fe d = Fq::add(p.z, p.z);
+  const Fe cu = Fq::sub_lazy(b, a), cv = Fq::add(b, a), cz = Fq::carry(Fq::add(d, c)), ct = Fq::sub(d, c);
+  const Fe r2 = Fq::mul(role_select4(cu, cv, cz, Fq::carry(cu), role), role_select4(ct, cz, ct, cv, role));
+  Ext r;
+  r.u = quad_bcast<0>(r2); r.v = quad_bcast<1>(r2); r.z = quad_bcast<2>(r2); r.t1 = cu; r.t2 = cv;
+  Tout = quad_bcast<3>(r2);
+  return r;
+}
+// Small batches: one scalar multiplication per quad of lanes.  Same signed-window ladder and table as
+// varbase_windowed, but every point operation is two multiplication rounds on four lanes (12 rounds per 5-bit window
+// instead of 43 dependent products), which is what matters when the batch cannot fill the SIMDs anyway.
+// All four lanes hold the same point; each lane stores / loads whole table entries itself.
+static JJ_DEV Ext varbase_windowed_quad(const Affine& P, u32 (&k)[8], u32* slot, u32 role) {
+  const ANiels pn = Curve::to_niels(P);
+  Ext cur = Curve::from_affine(P);
+  Fe T = Fq::mul(P.u, P.v);
+  ENiels en;
+  en.vpu = pn.vpu; en.vmu = pn.vmu; en.z = Fq::one(); en.t2d = pn.t2d;
+  store_eniels(slot, en);
+  #pragma unroll 1
+  for (int j = 1; j < VB_TABLE; j++) {
+    cur = quad_add_aniels(cur, T, pn, role, T);
+    en.vpu = Fq::carry(Fq::add(cur.v, cur.u)); en.vmu = Fq::sub(cur.v, cur.u); en.z = cur.z;
+    en.t2d = Fq::mul(T, Fq::konst(FqP::D2));
+    store_eniels(slot + j * ENIELS_WORDS, en);
+  }
+  recode_signed(k);
+  u32 a = vb_window(k, VB_NWIN - 1), neg = 0;
+  ENiels e = load_eniels(slot + (a ? a - 1 : 0) * ENIELS_WORDS);
+  Ext acc = Curve::identity();
+  T = Fq::zero();
+  #pragma unroll 1
+  for (int i = VB_NWIN - 1; i >= 0; i--) {
+    const ENiels s = Curve::select(e, Curve::eniels_identity(), a == 0 ? ~0u : 0u);
+    const u32 sneg = neg;
+    if (i > 0) {
+      const int d = (int)vb_window(k, i - 1) - VB_TABLE;
+      neg = d < 0; a = (u32)(d < 0 ? -d : d);
+      e = load_eniels(slot + (a ? a - 1 : 0) * ENIELS_WORDS);
+    }
+    acc = quad_add_eniels(acc, T, s, sneg, role, T);
+    if (i > 0) {
+      #pragma unroll 1
+      for (int d = 0; d < VB_W - 1; d++) acc = quad_dbl(acc, role);
+      acc = quad_dbl_t(acc, role, T);
+    }
+  }
+  return acc;
+}
+template <bool FIVE>
+__global__ void __launch_bounds__(256) k_varbase_quad(size_t n, const void* scalars, const void* points, u32* tables, SoA ext) {
+  const size_t q = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  const u32 role = threadIdx.x & 3u;
+  if (q >= n) return;                                       // whole quads leave together
+  u32 k[8];
+  load8(k, scalars, q);
+  const Affine P = load_affine(points, q);
+  const Ext r = varbase_windowed_quad(P, k, tables + q * (size_t)(VB_TABLE * ENIELS_WORDS), role);
+  if (role == 0) {
+    ext.put(0, q, r.u); ext.put(1, q, r.v); ext.put(2, q, r.z);
+    if constexpr (FIVE) { ext.put(3, q, Fq::carry(r.t1)); ext.put(4, q, Fq::carry(r.t2)); }
+  }
+}
+
 // One workgroup per listed big bucket: FIXUP_BIG_QUADS quads each fold a strided share of the bucket's heads into a
 // partial (stage 0, written to `partial[item][quad]`); stage 1 (one quad per item) folds the partials into the bucket.
 __global__ void __launch_bounds__(256) k_msm_fixup_big(const u32* big_count, const BigBucket* big, ExtAoS buckets, ExtAoS head, SoA partial, int stage) {

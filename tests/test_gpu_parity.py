@@ -151,6 +151,27 @@ def test_varbase_edges(eng, golden):
     assert (eng.varbase_mul(S, Pn) == O.varbase_mul(S, Pn)).all()
 
 
+def test_varbase_per_lane_and_per_quad_kernels(golden, monkeypatch):
+    """Batches up to JJ_VB_QUAD_MAX run one scalar multiplication per quad of lanes, larger ones one per lane; both
+    kernels on the same inputs (edge scalars x special points, random, sizes around the wave/quad granularity)."""
+    from jubjub_amd import Engine
+
+    pts = np.concatenate([rand_points(3, 8), torsion_points(golden), arr64([J.GENERATOR, J.AFFINE_IDENTITY])])
+    S = np.stack([b32(k) for k in EDGE_SCALARS for _ in pts])
+    Pn = np.stack([p for _ in EDGE_SCALARS for p in pts])
+    S = np.concatenate([S, rand_scalars(51, 1500, full_width=True)])
+    Pn = np.concatenate([Pn, rand_points(52, 1500)])
+    want = O.varbase_mul(S, Pn)
+    for quad_max in ("0", "1048576"):
+        monkeypatch.setenv("JJ_VB_QUAD_MAX", quad_max)
+        e2 = Engine(0)
+        assert (e2.varbase_mul(S, Pn) == want).all(), quad_max
+        for m in (1, 3, 15, 16, 17, 63, 64, 65, 255, 257):
+            assert (e2.varbase_mul(S[:m], Pn[:m]) == want[:m]).all(), (quad_max, m)
+        assert (e2.msm(S[:300], Pn[:300]) == O.msm(S[:300], Pn[:300])).all()       # below 512 terms: ladders (5 coordinates) + fold
+        e2.close()
+
+
 def test_varbase_random(eng):
     n = 3000   # not a multiple of the block size; exercises the grid-stride tail
     S = rand_scalars(5, n, full_width=True)
