@@ -44,7 +44,7 @@ struct jj_ctx {
   int msm_chunk = 0;             // accumulation chunk override (JJ_MSM_CHUNK; 0 = scale with n)
   int msm_reduce_chunk = 32, msm_fold = 4;   // bucket-reduce chunk length / fan-in of the chunk folds (powers of two)
   int msm_pass_log2 = 24;        // terms per Pippenger pass (JJ_MSM_PASS_LOG2 overrides; for tests)
-  int msm_min_pippenger = 512;   // below this many terms the MSM is var-base ladders + fold (JJ_MSM_NAIVE_BELOW overrides)
+  int msm_min_pippenger = 1;     // below this many terms the MSM is var-base ladders + fold (JJ_MSM_NAIVE_BELOW; Pippenger is faster at every size, measured)
   // optional per-call kernel timing (HIP events on the launch stream): e0 | main kernel | e1 | normalise tail | e2
   // pipelined host-buffer path: copy streams + two device slots (caller buffers are page-locked in place)
   struct Pipe {

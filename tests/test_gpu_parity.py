@@ -168,7 +168,6 @@ def test_varbase_per_lane_and_per_quad_kernels(golden, monkeypatch):
         assert (e2.varbase_mul(S, Pn) == want).all(), quad_max
         for m in (1, 3, 15, 16, 17, 63, 64, 65, 255, 257):
             assert (e2.varbase_mul(S[:m], Pn[:m]) == want[:m]).all(), (quad_max, m)
-        assert (e2.msm(S[:300], Pn[:300]) == O.msm(S[:300], Pn[:300])).all()       # below 512 terms: ladders (5 coordinates) + fold
         e2.close()
 
 
@@ -219,10 +218,23 @@ def test_fixedbase(eng):
 
 
 def test_msm(eng):
-    for n in (0, 1, 2, 33, 511, 512, 1000, 2048, 5000, 40000):
+    for n in (0, 1, 2, 3, 7, 33, 127, 511, 512, 1000, 2047, 2048, 5000, 32767, 32768, 40000):
         S = rand_scalars(12 + n, n, full_width=True)
         P = rand_points(13 + n, n, subgroup=(n % 2 == 0))
         assert (eng.msm(S, P) == O.msm(S, P)).all(), n
+
+
+def test_msm_ladder_fold_path(monkeypatch):
+    """JJ_MSM_NAIVE_BELOW: sizes below the threshold use var-base ladders (five coordinates) and a fold instead of Pippenger."""
+    from jubjub_amd import Engine
+
+    monkeypatch.setenv("JJ_MSM_NAIVE_BELOW", "100000")
+    e2 = Engine(0)
+    for n in (1, 2, 33, 700, 40000):
+        S = rand_scalars(112 + n, n, full_width=True)
+        P = rand_points(113 + n, n, subgroup=(n % 2 == 0))
+        assert (e2.msm(S, P) == O.msm(S, P)).all(), n
+    e2.close()
 
 
 def test_msm_skewed_buckets(eng):
