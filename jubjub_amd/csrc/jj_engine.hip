@@ -882,6 +882,7 @@ JJ_API int jj_decompress(jj_ctx* c, size_t n, const void* in32, unsigned flags, 
     const size_t lanes_wanted = (size_t)c->cus * 64 * 8;
     if (n >= lanes_wanted * 32) { size_t T = (n + 31) / 32; hipLaunchKernelGGL((k_decompress<32>), dim3(blocks_for(T)), dim3(256), 0, c->stream, n, T, di, flags, scratch, c->sqrt_tables, o.dev, (uint8_t*)ko.dev); }
     else if (n >= lanes_wanted * 8) { size_t T = (n + 15) / 16; hipLaunchKernelGGL((k_decompress<16>), dim3(blocks_for(T)), dim3(256), 0, c->stream, n, T, di, flags, scratch, c->sqrt_tables, o.dev, (uint8_t*)ko.dev); }
+    else if (n <= 16384) { hipLaunchKernelGGL((k_decompress<1>), dim3(blocks_for(n)), dim3(256), 0, c->stream, n, n, di, flags, scratch, c->sqrt_tables, o.dev, (uint8_t*)ko.dev); }   // latency: no shared inversion
     else { size_t T = (n + 3) / 4; hipLaunchKernelGGL((k_decompress<4>), dim3(blocks_for(T)), dim3(256), 0, c->stream, n, T, di, flags, scratch, c->sqrt_tables, o.dev, (uint8_t*)ko.dev); }
     prof_mark(c, 1); prof_mark(c, 2);
     // Invalid encodings were written as (0,0); the subgroup kernels below may compute garbage for them, the ok byte masks it.
