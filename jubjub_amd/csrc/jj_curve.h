@@ -86,6 +86,26 @@ struct CurveT {
     return into_extended(F::sub_lazy(b, a), F::add(b, a), F::sub(d, c), F::carry(F::add(d, c)));
   }
 
+  // p + n (negmask = 0) or p - n (negmask = ~0) without negating the operand: the subtraction formulas (lib.rs:922-940,
+  // 970-988) swap v+u / v-u and d+c / d-c, so four selects replace a field negation and three selects.
+  static JJ_DEV Ext add_signed(const Ext& p, const ENiels& n, u32 negmask) {
+    const Fe a = F::mul(F::sub(p.v, p.u), F::select(n.vmu, n.vpu, negmask));
+    const Fe b = F::mul(F::add(p.v, p.u), F::select(n.vpu, n.vmu, negmask));
+    const Fe c = F::mul(F::mul(F::carry(p.t1), p.t2), n.t2d);
+    const Fe zz = F::mul(p.z, n.z);
+    const Fe d = F::add(zz, zz);
+    const Fe plus = F::carry(F::add(d, c)), minus = F::sub(d, c);
+    return into_extended(F::sub_lazy(b, a), F::add(b, a), F::select(plus, minus, negmask), F::select(minus, plus, negmask));
+  }
+  static JJ_DEV Ext add_signed(const Ext& p, const ANiels& n, u32 negmask) {
+    const Fe a = F::mul(F::sub(p.v, p.u), F::select(n.vmu, n.vpu, negmask));
+    const Fe b = F::mul(F::add(p.v, p.u), F::select(n.vpu, n.vmu, negmask));
+    const Fe c = F::mul(F::mul(F::carry(p.t1), p.t2), n.t2d);
+    const Fe d = F::add(p.z, p.z);
+    const Fe plus = F::carry(F::add(d, c)), minus = F::sub(d, c);
+    return into_extended(F::sub_lazy(b, a), F::add(b, a), F::select(plus, minus, negmask), F::select(minus, plus, negmask));
+  }
+
   // lib.rs:652-658 : (v+u, v-u, u*v*2d), all N
   static JJ_DEV ANiels to_niels(const Affine& a) {
     ANiels n;

@@ -323,10 +323,9 @@ static JJ_DEV u32 vb_window(const u32 (&k)[8], int i) {
   const u64 both = ((u64)hi << 32) | lo;
   return (u32)(both >> sh) & ((1u << VB_W) - 1u);
 }
-// apply sign / zero to a table entry
-static JJ_DEV ENiels signed_entry(const ENiels& e, u32 neg, u32 zero) {
-  ENiels r = Curve::select(e, Curve::neg(e), neg ? ~0u : 0u);
-  return Curve::select(r, Curve::eniels_identity(), zero ? ~0u : 0u);
+// zero digit -> identity entry (the sign is applied inside Curve::add_signed)
+static JJ_DEV ENiels zeroed_entry(const ENiels& e, u32 zero) {
+  return Curve::select(e, Curve::eniels_identity(), zero ? ~0u : 0u);
 }
 
 static JJ_DEV Ext varbase_windowed(const Affine& P, u32 (&k)[8], u32* slot) {
@@ -346,13 +345,14 @@ static JJ_DEV Ext varbase_windowed(const Affine& P, u32 (&k)[8], u32* slot) {
   Ext acc = Curve::identity();
   #pragma unroll 1
   for (int i = VB_NWIN - 1; i >= 0; i--) {
-    const ENiels s = signed_entry(e, neg, a == 0);
+    const ENiels s = zeroed_entry(e, a == 0);
+    const u32 smask = neg ? ~0u : 0u;
     if (i > 0) {                                             // fetch the next window's entry before the doublings
       const int d = (int)vb_window(k, i - 1) - VB_TABLE;
       neg = d < 0; a = (u32)(d < 0 ? -d : d);
       e = load_eniels(slot + (a ? a - 1 : 0) * ENIELS_WORDS);
     }
-    acc = Curve::add(acc, s);
+    acc = Curve::add_signed(acc, s, smask);
     if (i > 0) {
       #pragma unroll 1
       for (int d = 0; d < VB_W; d++) acc = Curve::dbl(acc);
@@ -480,9 +480,7 @@ __global__ void __launch_bounds__(512) k_fixedbase(size_t n, const void* scalars
       } else {
         e = lds_aniels(lds + ((size_t)i * FB_ENT + j) * ANIELS_WORDS);
       }
-      ANiels s = Curve::select(e, Curve::neg(e), d < 0 ? ~0u : 0u);
-      s = Curve::select(s, idn, a == 0 ? ~0u : 0u);
-      acc = Curve::add(acc, s);
+      acc = Curve::add_signed(acc, Curve::select(e, idn, a == 0 ? ~0u : 0u), d < 0 ? ~0u : 0u);
     }
     if (live) { ext.put(0, idx, acc.u); ext.put(1, idx, acc.v); ext.put(2, idx, acc.z); }
   }
@@ -520,14 +518,14 @@ __global__ void __launch_bounds__(256) k_fixedbase_gather(size_t n, const void* 
     ANiels e = lds_aniels(table + ((size_t)(fp.W - 1) * fp.E + (a ? a - 1 : 0)) * GNIELS_WORDS);
     #pragma unroll 1
     for (int i = fp.W - 1; i >= 0; i--) {
-      ANiels s = Curve::select(e, Curve::neg(e), neg ? ~0u : 0u);
-      s = Curve::select(s, idn, a == 0 ? ~0u : 0u);
+      const ANiels s = Curve::select(e, idn, a == 0 ? ~0u : 0u);
+      const u32 smask = neg ? ~0u : 0u;
       if (i > 0) {                                           // fetch the next window's entry before this addition
         const int d = (int)fb_window(k, fp.w, i - 1) - (int)fp.E;
         neg = d < 0; a = (u32)(d < 0 ? -d : d);
         e = lds_aniels(table + ((size_t)(i - 1) * fp.E + (a ? a - 1 : 0)) * GNIELS_WORDS);
       }
-      acc = Curve::add(acc, s);
+      acc = Curve::add_signed(acc, s, smask);
     }
     ext.put(0, idx, acc.u); ext.put(1, idx, acc.v); ext.put(2, idx, acc.z);
   }
@@ -856,7 +854,7 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(size_t nb, u32 chunk, co
     }
     const u32 e = idx[pos];
     const ANiels p = lds_aniels(niels + (size_t)(e & 0x7fffffffu) * GNIELS_WORDS);
-    acc = CurveNP::add(acc, CurveNP::select(p, CurveNP::neg(p), (e >> 31) ? ~0u : 0u));
+    acc = CurveNP::add_signed(acc, p, (e >> 31) ? ~0u : 0u);
     any = true;
   }
   if (inherited) aos_put_ext(head, t, acc); else aos_put_ext(buckets, b, acc);
