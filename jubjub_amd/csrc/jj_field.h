@@ -54,6 +54,8 @@ static JJ_DEV u64 mad_vs(u32 a, u32 k, u64 c) {
 //   dummy SGPR token (no code, no hazard padding, ordered only inside one product so that independent products still
 //   interleave): 205 instead of 223 instructions per product.  Measured +5..7 % on the ladders and the decoder.  The
 //   pins lengthen live ranges, so kernels that are already register-bound (k_msm_accumulate) instantiate PIN = 0.
+//   4 = as 3, plus the column shift amount routed through the token chain, which retires a column's pins before the
+//   next column starts: fits k_msm_accumulate in 97 VGPRs, but measured 1-3 % slower than 3 everywhere (kept for reference).
 #ifndef JJ_MUL_PIN
 #define JJ_MUL_PIN 3
 #endif
@@ -178,7 +180,8 @@ struct Field {
     u32 p0 = P::P[0];
     asm("" : "+s"(p0));   // opaque to the optimiser
     [[maybe_unused]] u32 pin_tok = 0;
-#define JJ_PIN(x) do { if constexpr (PIN == 3) asm("" : "+s"(pin_tok) : "v"(x)); } while (0)
+    [[maybe_unused]] u32 pin_sh = LB;     // PIN == 4: the column shift amount, routed through the token chain
+#define JJ_PIN(x) do { if constexpr (PIN == 3 || PIN == 4) asm("" : "+s"(pin_tok) : "v"(x)); } while (0)
     _Pragma("unroll") for (int k = 0; k < 2 * NL - 1; k++) {
       _Pragma("unroll") for (int i = 0; i < NL; i++) {
         const int j = k - i;
@@ -206,10 +209,11 @@ struct Field {
       } else {
         r.l[k - NL] = (u32)acc & LMASK;
       }
-      acc >>= LB;
+      if constexpr (PIN == 4) { asm("" : "+s"(pin_sh), "+s"(pin_tok)); acc >>= pin_sh; }   // all pins of this column retire before the next one starts
+      else acc >>= LB;
     }
     r.l[NL - 1] = (u32)acc;
-    if constexpr (PIN == 3) asm volatile("" ::"s"(pin_tok));
+    if constexpr (PIN == 3 || PIN == 4) asm volatile("" ::"s"(pin_tok));
 #undef JJ_PIN
     return r;
   }
