@@ -887,17 +887,11 @@ JJ_API int jj_decompress(jj_ctx* c, size_t n, const void* in32, unsigned flags, 
     prof_mark(c, 1); prof_mark(c, 2);
     // Invalid encodings were written as (0,0); the subgroup kernels below may compute garbage for them, the ok byte masks it.
     if (flags & JJ_DECOMPRESS_TORSION_FREE) { if ((rc = torsion_free_dev(c, n, o.dev, (uint8_t*)ko.dev, 1))) return rc; }
-    if (flags & JJ_DECOMPRESS_NOT_SMALL_ORDER) {
-      if ((rc = ensure(c, c->ws_tmp[2], n))) return rc;
-      if ((rc = ensure_ext(c, n, 3))) return rc;
-      hipLaunchKernelGGL((k_point_op<PT_IS_SMALL_ORDER>), dim3(blocks_for(n)), dim3(256), 0, c->stream, n, (const void*)o.dev, (const void*)nullptr, soa_of(c->ws_ext, n), c->ws_tmp[2].p);
-      hipLaunchKernelGGL(k_and_bytes, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, (uint8_t*)ko.dev, (const uint8_t*)c->ws_tmp[2].p, 1);
-    }
-    if (flags & JJ_DECOMPRESS_CLEAR_COFACTOR) {
+    if (flags & (JJ_DECOMPRESS_NOT_SMALL_ORDER | JJ_DECOMPRESS_CLEAR_COFACTOR)) {
       if ((rc = ensure_ext(c, n, 3))) return rc;
       SoA ext = soa_of(c->ws_ext, n);
-      hipLaunchKernelGGL((k_point_op<PT_COFACTOR>), dim3(blocks_for(n)), dim3(256), 0, c->stream, n, (const void*)o.dev, (const void*)nullptr, ext, o.dev);
-      if ((rc = normalize_launch(c, n, ext, o.dev, 0))) return rc;
+      hipLaunchKernelGGL(k_small_order_cofactor, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, (const void*)o.dev, flags, ext, (uint8_t*)ko.dev);
+      if (flags & JJ_DECOMPRESS_CLEAR_COFACTOR) { if ((rc = normalize_launch(c, n, ext, o.dev, 0))) return rc; }
     }
     if (flags & (JJ_DECOMPRESS_TORSION_FREE | JJ_DECOMPRESS_NOT_SMALL_ORDER | JJ_DECOMPRESS_CLEAR_COFACTOR))
       hipLaunchKernelGGL(k_mask_outputs, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, o.dev, (const uint8_t*)ko.dev);

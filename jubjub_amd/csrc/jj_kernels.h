@@ -204,6 +204,16 @@ __global__ void __launch_bounds__(256) k_point_op(size_t n, const void* p, const
   if constexpr (OP == PT_IS_ON_CURVE) static_cast<uint8_t*>(out)[i] = Curve::is_on_curve(a);
 }
 
+// decode follow-up for jj_decompress flags 4 (reject small order: U([4]P) == 0, reference src/lib.rs:699-705) and 8 (clear
+// the cofactor, src/lib.rs:722-724) in one pass over the decoded points: the two tests share the first two doublings.
+__global__ void __launch_bounds__(256) k_small_order_cofactor(size_t n, const void* pts, unsigned flags, SoA ext, uint8_t* ok) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Ext e = Curve::dbl(Curve::dbl(Curve::from_affine(load_affine(pts, i))));
+  if ((flags & 4u) && Fq::is_zero(e.u)) ok[i] = 0;
+  if (flags & 8u) { e = Curve::dbl(e); ext.put(0, i, e.u); ext.put(1, i, e.v); ext.put(2, i, e.z); }
+}
+
 // ------------------------------------------------------------------------------------------------ K5: normalise
 // batch_normalize (reference src/lib.rs:1084-1107, ff::BatchInverter): each lane owns CHUNK elements
 // (element j of lane t is index t + j*T, so every access is coalesced), multiplies their Z's through, inverts
