@@ -750,7 +750,7 @@ static int msm_pippenger(jj_ctx* c, size_t n, const void* ds, const void* dp, jj
   MsmParams mp;
   // window sizes whose top window keeps >= 10 scalar bits (or is short only for small n): a 1-2 bit top window would
   // put n/2 terms into one bucket
-  mp.c = (n >= ((size_t)1 << 18)) ? 16 : (n >= ((size_t)1 << 15)) ? 15 : (n >= ((size_t)1 << 11) ? 11 : 8);   // measured
+  mp.c = (n >= ((size_t)1 << 18)) ? 16 : (n >= ((size_t)1 << 11) ? 11 : 8);   // measured; 11 | 253, so its top window is a full one
   if (c->msm_window >= 8 && c->msm_window <= 16) mp.c = c->msm_window;      // one window's histogram must fit LDS
   mp.W = (253 + mp.c - 1) / mp.c;
   mp.B = 1u << (mp.c - 1);
