@@ -59,7 +59,7 @@ struct jj_ctx {
   bool torsion_ladder = false;   // subgroup test: false = Tate pairing (k_torsion_free), true = multiply by r (reference definition)
   bool fb_const_time = true;     // fixed-base window select: true = lane-staged + ds_bpermute shuffle, false = per-lane LDS gather
   int vb_quad_max = 32768;       // batches up to this size run one scalar-mul per quad of lanes (JJ_VB_QUAD_MAX; 0 = never)
-  int vb_blocks_per_cu = 2;      // var-base ladder: 2 waves/SIMD (3 blocks/CU distribute unevenly over the 4 SIMDs: measured slower)
+  int vb_blocks_per_cu = 3;      // var-base ladder: 3 resident blocks of 256 per CU (156 VGPRs); measured 2 % faster than 2 with the pinned products
   bool profile = false;
   struct Rec { hipEvent_t e0, e1, e2; };
   std::vector<Rec> recs;
