@@ -59,6 +59,7 @@ struct jj_ctx {
   bool torsion_ladder = false;   // subgroup test: false = Tate pairing (k_torsion_free), true = multiply by r (reference definition)
   bool fb_const_time = true;     // fixed-base window select: true = lane-staged + ds_bpermute shuffle, false = per-lane LDS gather
   int vb_quad_max = 32768;       // batches up to this size run one scalar-mul per quad of lanes (JJ_VB_QUAD_MAX; 0 = never)
+  int fb_gather_blocks_per_cu = 3;   // wide-window fixed-base kernel: resident blocks of 256 per CU (JJ_FB_GATHER_BLOCKS_PER_CU)
   int vb_blocks_per_cu = 3;      // var-base ladder: 3 resident blocks of 256 per CU (156 VGPRs); measured 2 % faster than 2 with the pinned products
   bool profile = false;
   struct Rec { hipEvent_t e0, e1, e2; };
@@ -277,6 +278,7 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
   if (const char* e = getenv("JJ_MSM_PASS_LOG2")) { int v = atoi(e); if (v >= 10 && v <= 24) c->msm_pass_log2 = v; }
   if (const char* e = getenv("JJ_MSM_NAIVE_BELOW")) { int v = atoi(e); if (v >= 0) c->msm_min_pippenger = v; }
   if (const char* e = getenv("JJ_VB_QUAD_MAX")) { int v = atoi(e); if (v >= 0 && v <= (1 << 20)) c->vb_quad_max = v; }
+  if (const char* e = getenv("JJ_FB_GATHER_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) c->fb_gather_blocks_per_cu = v; }
   if (const char* e = getenv("JJ_VB_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) c->vb_blocks_per_cu = v; }
   // the fixed-base kernel needs the full 160 KiB LDS carve-out
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fixedbase<true>), hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS_BYTES);
@@ -663,7 +665,7 @@ JJ_API int jj_fixedbase_table_destroy(jj_ctx* c, jj_table* t) {
 static int fixedbase_launch(jj_ctx* c, const jj_table* t, size_t n, const void* ds, SoA ext) {
   const unsigned blocks = (unsigned)std::min((size_t)c->cus, (n + 511) / 512);   // one 512-thread workgroup per CU (LDS-bound)
   if (t->window_bits != FB_W) {
-    const unsigned gblocks = (unsigned)std::min((size_t)c->cus * 2, (n + 255) / 256);
+    const unsigned gblocks = (unsigned)std::min((size_t)c->cus * c->fb_gather_blocks_per_cu, (n + 255) / 256);
     hipLaunchKernelGGL(k_fixedbase_gather, dim3(gblocks), dim3(256), 0, c->stream, n, ds, (const u32*)t->dev, t->fp, ext);
   } else if (c->fb_const_time) hipLaunchKernelGGL(k_fixedbase<true>, dim3(blocks), dim3(512), FB_LDS_BYTES, c->stream, n, ds, (const u32*)t->dev, ext);
   else hipLaunchKernelGGL(k_fixedbase<false>, dim3(blocks), dim3(512), FB_LDS_BYTES, c->stream, n, ds, (const u32*)t->dev, ext);
