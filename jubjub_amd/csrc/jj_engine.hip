@@ -38,9 +38,12 @@ struct jj_ctx {
   int cus = 0, clock_khz = 0, wave = 64;
   std::string err;
   // staging for host-pointer arguments (inputs 0..3, outputs 0..1) and kernel workspaces
-  DevBuf in[4], out[2], okb, ws_ext, ws_scratch, ws_tables, ws_tmp[4], msm[8], sqrt_tabs;
+  DevBuf in[4], out[2], okb, ws_ext, msm_seg, ws_scratch, ws_tables, ws_tmp[4], msm[8], sqrt_tabs;
   SqrtTables sqrt_tables{nullptr, nullptr};
   int msm_window = 0;            // 0 = choose from n (JJ_MSM_WINDOW overrides; 8..16)
+  int msm_segments = -1;         // bucket accumulation: 1 = length-sorted segments, 0 = fixed chunks + fix-up, -1 = segments from 2^19 terms
+                                 // (2-4 % faster there, slower below: more launches) (JJ_MSM_ACCUM=segments|chunks)
+  int msm_seg_len = 0;           // segment length override (JJ_MSM_SEG_LEN; 0 = n / 2^14 clamped to [32, 1024])
   int msm_chunk = 0;             // accumulation chunk override (JJ_MSM_CHUNK; 0 = scale with n)
   int msm_reduce_chunk = 32, msm_fold = 4;   // bucket-reduce chunk length / fan-in of the chunk folds (powers of two)
   int msm_pass_log2 = 24;        // terms per Pippenger pass (JJ_MSM_PASS_LOG2 overrides; for tests)
@@ -272,6 +275,8 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
   c->stream = c->own_stream;
   if (const char* e = getenv("JJ_PIPE_CHUNK_LOG2")) { int v = atoi(e); if (v >= 8 && v <= 24) c->pipe_chunk = (size_t)1 << v; }
   if (const char* e = getenv("JJ_MSM_WINDOW")) c->msm_window = atoi(e);
+  if (const char* e = getenv("JJ_MSM_ACCUM")) c->msm_segments = strcmp(e, "chunks") == 0 ? 0 : strcmp(e, "segments") == 0 ? 1 : -1;
+  if (const char* e = getenv("JJ_MSM_SEG_LEN")) c->msm_seg_len = atoi(e);
   if (const char* e = getenv("JJ_MSM_CHUNK")) { int v = atoi(e); if (v >= 8 && v <= 1024) c->msm_chunk = v; }
   if (const char* e = getenv("JJ_MSM_REDUCE_CHUNK")) { int v = atoi(e); if (v >= 2 && v <= 256 && (v & (v - 1)) == 0) c->msm_reduce_chunk = v; }
   if (const char* e = getenv("JJ_MSM_FOLD")) { int v = atoi(e); if (v >= 2 && v <= 64 && (v & (v - 1)) == 0) c->msm_fold = v; }
@@ -284,6 +289,7 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fixedbase<true>), hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS_BYTES);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fixedbase<false>), hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS_BYTES);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_hist), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_seg_plan), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4);
   if (const char* e = getenv("JJ_TORSION_CHECK")) c->torsion_ladder = strcmp(e, "ladder") == 0;
   if (const char* e = getenv("JJ_FIXEDBASE_SELECT")) c->fb_const_time = strcmp(e, "gather") != 0;
@@ -302,7 +308,7 @@ JJ_API int jj_ctx_destroy(jj_ctx* c) {
   if (!c) return JJ_ERR_INVALID;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  DevBuf* all[] = {&c->in[0], &c->in[1], &c->in[2], &c->in[3], &c->out[0], &c->out[1], &c->okb, &c->ws_ext, &c->ws_scratch, &c->ws_tables,
+  DevBuf* all[] = {&c->in[0], &c->in[1], &c->in[2], &c->in[3], &c->out[0], &c->out[1], &c->okb, &c->ws_ext, &c->msm_seg, &c->ws_scratch, &c->ws_tables,
                    &c->ws_tmp[0], &c->ws_tmp[1], &c->ws_tmp[2], &c->ws_tmp[3], &c->msm[0], &c->msm[1], &c->msm[2], &c->msm[3],
                    &c->msm[4], &c->msm[5], &c->msm[6], &c->msm[7], &c->sqrt_tabs};
   for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
@@ -779,7 +785,7 @@ static int msm_pippenger(jj_ctx* c, size_t n, const void* ds, const void* dp, jj
   const size_t tile = (n + ntiles - 1) / ntiles;
   if ((rc = ensure(c, tcnt, (size_t)mp.W * ntiles * mp.B * 4))) return rc;
   if ((rc = ensure(c, buckets, (size_t)EXT_AOS_WORDS * 4 * nb))) return rc;
-  if ((rc = ensure(c, ra, (size_t)EXT_AOS_WORDS * 4 * std::max(nchunks, max_chunks)))) return rc;   // first the chunk heads, later the fold ping-pong
+  if ((rc = ensure(c, ra, (size_t)EXT_AOS_WORDS * 4 * std::max(nchunks, std::max(max_chunks, (n * (size_t)mp.W) / 8 + 1))))) return rc;   // first the chunk heads, later the fold ping-pong
   if ((rc = ensure(c, rb, (size_t)5 * NL * 4 * nchunks))) return rc;
   u32* count = (u32*)cnt.p; u32* offset = count + nb; u32* bsum = offset + nb + 1;
   hipLaunchKernelGGL(k_msm_convert, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, ds, dp, mp, (u32*)kprime.p, (u32*)niels.p);
@@ -792,11 +798,32 @@ static int msm_pippenger(jj_ctx* c, size_t n, const void* ds, const void* dp, jj
   hipLaunchKernelGGL(k_msm_scatter, dim3(ntiles, mp.W), dim3(MSM_SORT_THREADS), mp.B * 4, c->stream, n, tile, mp, (const u32*)kprime.p, (const u32*)tcnt.p, (u32*)idx.p);
   {
     const ExtAoS head{(u32*)ra.p}, bk{(u32*)buckets.p};
-    hipLaunchKernelGGL(k_msm_accumulate, dim3(blocks_for(max_chunks)), dim3(256), 0, c->stream, nb, chunk, (const u32*)offset, (const u32*)idx.p, (const u32*)niels.p, bk, head);
-    u32* big_count = (u32*)c->ws_tmp[1].p; BigBucket* big = (BigBucket*)((uint8_t*)c->ws_tmp[1].p + 64);
+    u32* counters = (u32*)c->ws_tmp[1].p;                   // [0] heads, [1] merge items, [2] big buckets (work list follows at +64)
+    u32* big_count = counters + 2; BigBucket* big = (BigBucket*)((uint8_t*)c->ws_tmp[1].p + 64);
     SoA partial = soa_of(c->ws_tmp[0], (size_t)FIXUP_BIG_MAX * FIXUP_BIG_QUADS);
-    HIPCHK(c, hipMemsetAsync(big_count, 0, 4, c->stream));
-    hipLaunchKernelGGL(k_msm_fixup, dim3(blocks_for(nb)), dim3(256), 0, c->stream, nb, chunk, (const u32*)offset, bk, head, big_count, big);
+    HIPCHK(c, hipMemsetAsync(counters, 0, 16, c->stream));
+    if (c->msm_segments == 1 || (c->msm_segments < 0 && n >= ((size_t)1 << 19))) {
+      // segments of at most P entries, sorted by length; P bounds the serial depth of one lane (~ n / 2^14 additions)
+      u32 P = (u32)std::min<size_t>(SEG_PMAX, std::max<size_t>(32, n >> 14));
+      if (c->msm_seg_len >= 8 && c->msm_seg_len <= SEG_PMAX) P = (u32)c->msm_seg_len;
+      const u32 stiles = (u32)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(256, 15000 / (P + 1)), (nb + 255) / 256));   // the plan kernel keeps the tiles x (P+1) matrix in LDS
+      const u32 per_tile = (u32)((nb + stiles - 1) / stiles);
+      const size_t max_segs = nb + (n * (size_t)mp.W) / P + 1;
+      DevBuf& sb = c->msm_seg;                                // bh [stiles][P+1] | count [P+1] | offset [P+2] | block sums | merge list | segments
+      const size_t bh_words = (size_t)stiles * (P + 1), hdr_words = bh_words + 2 * (P + 2) + 16;
+      if ((rc = ensure(c, sb, hdr_words * 4 + 16 + nb * sizeof(MergeItem) + max_segs * sizeof(Seg)))) return rc;
+      u32* bh = (u32*)sb.p; u32* soff = bh + bh_words + (P + 1);
+      MergeItem* merge = (MergeItem*)(((uintptr_t)(bh + hdr_words) + 15) & ~(uintptr_t)15);
+      Seg* seg = (Seg*)(merge + nb);
+      hipLaunchKernelGGL(k_seg_hist, dim3(stiles), dim3(256), 0, c->stream, nb, per_tile, P, (const u32*)offset, bk, bh);
+      hipLaunchKernelGGL(k_seg_plan, dim3(1), dim3(1024), (bh_words + P + 2) * 4, c->stream, stiles, P, bh, soff + (P + 1));
+      hipLaunchKernelGGL(k_seg_scatter, dim3(stiles), dim3(256), 0, c->stream, nb, per_tile, P, (const u32*)offset, (const u32*)bh, seg, counters, merge, big);
+      hipLaunchKernelGGL(k_msm_accumulate_seg, dim3(blocks_for(max_segs)), dim3(256), 0, c->stream, (const u32*)(soff + (P + 1)), (const Seg*)seg, (const u32*)idx.p, (const u32*)niels.p, bk, head);
+      hipLaunchKernelGGL(k_msm_merge, dim3(blocks_for(std::min(nb, max_segs))), dim3(256), 0, c->stream, (const u32*)counters, (const MergeItem*)merge, bk, head);
+    } else {
+      hipLaunchKernelGGL(k_msm_accumulate, dim3(blocks_for(max_chunks)), dim3(256), 0, c->stream, nb, chunk, (const u32*)offset, (const u32*)idx.p, (const u32*)niels.p, bk, head);
+      hipLaunchKernelGGL(k_msm_fixup, dim3(blocks_for(nb)), dim3(256), 0, c->stream, nb, chunk, (const u32*)offset, bk, head, big_count, big);
+    }
     hipLaunchKernelGGL(k_msm_fixup_big, dim3(256), dim3(256), 0, c->stream, (const u32*)big_count, (const BigBucket*)big, bk, head, partial, 0);
     hipLaunchKernelGGL(k_msm_fixup_big, dim3(256), dim3(256), 0, c->stream, (const u32*)big_count, (const BigBucket*)big, bk, head, partial, 1);
   }

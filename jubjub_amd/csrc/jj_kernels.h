@@ -898,6 +898,104 @@ __global__ void __launch_bounds__(256) k_msm_fixup(size_t nb, u32 chunk, const u
   }
   aos_put_ext(buckets, b, acc);
 }
+// ---- Segment-sorted accumulation (default).  Every non-empty bucket is cut into segments of at most P entries, the
+// segments are counting-sorted by length (longest first), and each lane adds up one segment: lanes of a wave run the
+// same number of iterations, no lane ever switches buckets inside its loop, and a bucket with a single segment (the
+// common case) is finished by its lane.  Buckets with several segments (narrow top window, repeated scalars) get their
+// extra segments as `head` partials that k_msm_merge (few) or k_msm_fixup_big (many) folds in.
+constexpr int SEG_PMAX = 1024;
+struct Seg { u32 start, len, dst, pad; };            // dst: bucket index, or 0x80000000 | head index
+struct MergeItem { u32 bucket, h0, k, pad; };         // buckets[bucket] += head[h0 .. h0 + k)
+// pass 1: per-block histogram of segment lengths, key = P - len (longer first); empty buckets become the identity
+__global__ void __launch_bounds__(256) k_seg_hist(size_t nb, u32 per_tile, u32 P, const u32* offset, ExtAoS buckets, u32* bh) {
+  __shared__ u32 hist[SEG_PMAX + 1];
+  for (u32 k = threadIdx.x; k <= P; k += 256) hist[k] = 0;
+  __syncthreads();
+  const size_t base = (size_t)blockIdx.x * per_tile;
+  for (u32 j = threadIdx.x; j < per_tile; j += 256) {
+    const size_t b = base + j;
+    if (b >= nb) break;
+    const u32 c = offset[b + 1] - offset[b];
+    if (c == 0) { aos_put_ext(buckets, b, Curve::identity()); continue; }
+    const u32 full = c / P, rem = c - full * P;
+    if (full) atomicAdd(&hist[0], full);
+    if (rem) atomicAdd(&hist[P - rem], 1u);
+  }
+  __syncthreads();
+  for (u32 k = threadIdx.x; k <= P; k += 256) bh[(size_t)blockIdx.x * (P + 1) + k] = hist[k];
+}
+// between the passes, one workgroup: per-key totals over the blocks, exclusive scan over the keys, and each block's
+// first slot per key written back into bh (the whole matrix, tiles x (P+1) <= 16384 words, sits in LDS)
+__global__ void __launch_bounds__(1024) k_seg_plan(u32 tiles, u32 P, u32* bh, u32* total_out) {
+  extern __shared__ u32 msm_lds[];
+  u32* m = msm_lds;                       // [tiles][P+1]
+  u32* off = msm_lds + (size_t)tiles * (P + 1);   // [P+2]
+  const u32 K = P + 1;
+  for (u32 i = threadIdx.x; i < tiles * K; i += 1024) m[i] = bh[i];
+  __syncthreads();
+  for (u32 k = threadIdx.x; k < K; k += 1024) { u32 s = 0; for (u32 t = 0; t < tiles; t++) s += m[t * K + k]; off[k] = s; }
+  __syncthreads();
+  if (threadIdx.x == 0) { u32 run = 0; for (u32 k = 0; k < K; k++) { const u32 c = off[k]; off[k] = run; run += c; } *total_out = run; }
+  __syncthreads();
+  for (u32 k = threadIdx.x; k < K; k += 1024) { u32 run = off[k]; for (u32 t = 0; t < tiles; t++) { const u32 c = m[t * K + k]; m[t * K + k] = run; run += c; } }
+  __syncthreads();
+  for (u32 i = threadIdx.x; i < tiles * K; i += 1024) bh[i] = m[i];
+}
+// pass 2: bh now holds each block's first slot per key; every segment takes the next slot of its key
+__global__ void __launch_bounds__(256) k_seg_scatter(size_t nb, u32 per_tile, u32 P, const u32* offset, const u32* bh, Seg* seg,
+                                                      u32* counters /* [0] heads, [1] merge items, [2] big buckets */, MergeItem* merge, BigBucket* big) {
+  __shared__ u32 cur[SEG_PMAX + 1];
+  for (u32 k = threadIdx.x; k <= P; k += 256) cur[k] = bh[(size_t)blockIdx.x * (P + 1) + k];
+  __syncthreads();
+  const size_t base = (size_t)blockIdx.x * per_tile;
+  for (u32 j = threadIdx.x; j < per_tile; j += 256) {
+    const size_t b = base + j;
+    if (b >= nb) break;
+    const u32 lo = offset[b], c = offset[b + 1] - lo;
+    if (c == 0) continue;
+    const u32 full = c / P, rem = c - full * P, nseg = full + (rem ? 1u : 0u);
+    u32 h0 = 0;
+    if (nseg > 1) {
+      h0 = atomicAdd(&counters[0], nseg - 1);
+      bool listed = false;
+      if (nseg - 1 > FIXUP_SERIAL_MAX) {
+        const u32 slot = atomicAdd(&counters[2], 1u);
+        if (slot < FIXUP_BIG_MAX) { big[slot].bucket = (u32)b; big[slot].t_first = h0; big[slot].t_last = h0 + nseg - 2; big[slot].pad = 0; listed = true; }
+      }
+      if (!listed) { const u32 m = atomicAdd(&counters[1], 1u); merge[m].bucket = (u32)b; merge[m].h0 = h0; merge[m].k = nseg - 1; merge[m].pad = 0; }
+    }
+    for (u32 sgi = 0; sgi < nseg; sgi++) {
+      const u32 len = sgi < full ? P : rem;
+      const u32 slot = atomicAdd(&cur[P - len], 1u);
+      Seg sg; sg.start = lo + sgi * P; sg.len = len; sg.dst = sgi == 0 ? (u32)b : (0x80000000u | (h0 + sgi - 1)); sg.pad = 0;
+      seg[slot] = sg;
+    }
+  }
+}
+__global__ void __launch_bounds__(256) k_msm_accumulate_seg(const u32* nseg_total, const Seg* seg, const u32* idx, const u32* niels, ExtAoS buckets, ExtAoS head) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= *nseg_total) return;
+  const Seg sg = seg[t];
+  Ext acc = CurveNP::identity();
+  const u32* ip = idx + sg.start;
+  #pragma unroll 1
+  for (u32 k = 0; k < sg.len; k++) {
+    const u32 e = ip[k];
+    const ANiels p = lds_aniels(niels + (size_t)(e & 0x7fffffffu) * GNIELS_WORDS);
+    acc = CurveNP::add_signed(acc, p, (e >> 31) ? ~0u : 0u);
+  }
+  if (sg.dst >> 31) aos_put_ext(head, sg.dst & 0x7fffffffu, acc); else aos_put_ext(buckets, sg.dst, acc);
+}
+// buckets with a few extra segments: one lane folds them in
+__global__ void __launch_bounds__(256) k_msm_merge(const u32* counters, const MergeItem* merge, ExtAoS buckets, ExtAoS head) {
+  const size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= counters[1]) return;
+  const MergeItem it = merge[m];
+  Ext acc = aos_ext(buckets, it.bucket);
+  #pragma unroll 1
+  for (u32 j = 0; j < it.k; j++) acc = Curve::add(acc, Curve::to_niels(aos_ext(head, (size_t)it.h0 + j)));
+  aos_put_ext(buckets, it.bucket, acc);
+}
 static JJ_DEV Ext soa_ext(const SoA& s, size_t i) { Ext e; e.u = s.get(0, i); e.v = s.get(1, i); e.z = s.get(2, i); e.t1 = s.get(3, i); e.t2 = s.get(4, i); return e; }
 static JJ_DEV void soa_put_ext(const SoA& s, size_t i, const Ext& e) {
   s.put(0, i, e.u); s.put(1, i, e.v); s.put(2, i, e.z); s.put(3, i, Fq::carry(e.t1)); s.put(4, i, Fq::carry(e.t2));

@@ -237,6 +237,29 @@ def test_msm_ladder_fold_path(monkeypatch):
     e2.close()
 
 
+@pytest.mark.parametrize("mode", ["segments", "chunks"])
+def test_msm_both_accumulation_schemes(monkeypatch, mode):
+    """Bucket accumulation by length-sorted segments (default from 2^19 terms) and by fixed chunks + fix-up (below),
+    forced in turn on the same inputs, including skewed digit distributions and short segments."""
+    from jubjub_amd import Engine
+
+    monkeypatch.setenv("JJ_MSM_ACCUM", mode)
+    monkeypatch.setenv("JJ_MSM_SEG_LEN", "8")
+    e2 = Engine(0)
+    for n in (1, 5, 300, 4099, 70000):
+        S = rand_scalars(212 + n, n, full_width=True)
+        P = rand_points(213 + n, n)
+        assert (e2.msm(S, P) == O.msm(S, P)).all(), (mode, n)
+    n = 6000
+    S = np.repeat(rand_scalars(31, 1, full_width=True), n, axis=0)      # every term in the same bucket of every window
+    P = rand_points(32, n)
+    assert (e2.msm(S, P) == O.msm(S, P)).all()
+    S2 = rand_scalars(33, n)
+    S2[: n // 2] = S2[0]
+    assert (e2.msm(S2, P) == O.msm(S2, P)).all()
+    e2.close()
+
+
 def test_msm_skewed_buckets(eng):
     """All-equal scalars / repeated points: every term of a window lands in one bucket (worst case for bucket methods)."""
     n = 6000
