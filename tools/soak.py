@@ -18,6 +18,10 @@ from util import pt64  # noqa: E402
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 SEED0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 eng = Engine(0)
+os.environ["JJ_MSM_ACCUM"] = "segments"      # second context: the large-input MSM accumulation scheme forced on small inputs
+os.environ["JJ_VB_QUAD_MAX"] = "0"           # ... and the per-lane var-base kernel instead of the per-quad one
+eng_alt = Engine(0)
+del os.environ["JJ_MSM_ACCUM"], os.environ["JJ_VB_QUAD_MAX"]
 base = pt64(J.GENERATOR)
 G8 = J.scalar_mul_fast(J.GENERATOR, J.R_MOD)             # order-8 component of the generator
 TORS = np.stack([pt64(J.scalar_mul_fast(G8, j) if j else J.AFFINE_IDENTITY) for j in range(8)])
@@ -33,14 +37,18 @@ while time.time() < t_end:
     P = O.fixedbase_mul(K, base)
     if rnd % 3 == 0:
         P = O.point_op("mul_by_cofactor", P)
-    assert (eng.varbase_mul(S, P) == O.varbase_mul(S, P)).all(), ("varbase", rnd)
+    want_vb = O.varbase_mul(S, P)
+    assert (eng.varbase_mul(S, P) == want_vb).all(), ("varbase", rnd)
+    assert (eng_alt.varbase_mul(S, P) == want_vb).all(), ("varbase per-lane", rnd)
     bp = P[int(rng.integers(0, n))]
     wbits = [0, 8, 10, 12][rnd % 4]
     tab = eng.fixedbase_table(bp, wbits)
     assert (eng.fixedbase_mul(tab, S) == O.fixedbase_mul(S, bp)).all(), ("fixedbase", rnd, wbits)
     tab.close()
     m = n
-    assert (eng.msm(S[:m], P[:m]) == O.msm(S[:m], P[:m])).all(), ("msm", rnd)
+    want_msm = O.msm(S[:m], P[:m])
+    assert (eng.msm(S[:m], P[:m]) == want_msm).all(), ("msm", rnd)
+    assert (eng_alt.msm(S[:m], P[:m]) == want_msm).all(), ("msm segments", rnd)
     enc = O.compress(P)
     bad = rng.integers(0, n, size=max(1, n // 10))
     enc[bad] = rng.integers(0, 256, size=(len(bad), 32), dtype=np.uint8)
