@@ -795,7 +795,7 @@ static int msm_pippenger(jj_ctx* c, size_t n, const void* ds, const void* dp, jj
   hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, c->stream, nscan, bsum, offset + nb);
   hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nscan), dim3(256), 0, c->stream, nb, (const u32*)count, (const u32*)bsum, offset);
   hipLaunchKernelGGL(k_msm_tile_bases, dim3(blocks_for(nb)), dim3(256), 0, c->stream, nb, mp.B, ntiles, (const u32*)offset, (u32*)tcnt.p);
-  hipLaunchKernelGGL(k_msm_scatter, dim3(ntiles, mp.W), dim3(MSM_SORT_THREADS), mp.B * 4, c->stream, n, tile, mp, (const u32*)kprime.p, (const u32*)tcnt.p, (u32*)idx.p);
+  hipLaunchKernelGGL(k_msm_scatter, dim3(ntiles * 8 * ((mp.W + 7) / 8)), dim3(MSM_SORT_THREADS), mp.B * 4, c->stream, n, tile, ntiles, mp, (const u32*)kprime.p, (const u32*)tcnt.p, (u32*)idx.p);
   {
     const ExtAoS head{(u32*)ra.p}, bk{(u32*)buckets.p};
     u32* counters = (u32*)c->ws_tmp[1].p;                   // [0] heads, [1] merge items, [2] big buckets (work list follows at +64)

@@ -731,9 +731,13 @@ __global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_hist(size_t n, size_t 
   for (u32 b = threadIdx.x; b < mp.B; b += MSM_SORT_THREADS) msm_lds[b] = 0;
   __syncthreads();
   const size_t lo = (size_t)blockIdx.x * tile, hi = lo + tile < n ? lo + tile : n;
-  for (size_t i = lo + threadIdx.x; i < hi; i += MSM_SORT_THREADS) {
-    u32 neg; const u32 a = msm_digit_wm(kp, n, i, mp, w, neg);
-    if (a) atomicAdd(&msm_lds[a - 1], 1u);
+  for (size_t i0 = lo + threadIdx.x; i0 < hi; i0 += 4 * MSM_SORT_THREADS) {
+    u32 a[4];
+    _Pragma("unroll") for (int q = 0; q < 4; q++) {
+      const size_t i = i0 + (size_t)q * MSM_SORT_THREADS;
+      u32 neg; a[q] = i < hi ? msm_digit_wm(kp, n, i, mp, w, neg) : 0u;
+    }
+    _Pragma("unroll") for (int q = 0; q < 4; q++) if (a[q]) atomicAdd(&msm_lds[a[q] - 1], 1u);
   }
   __syncthreads();
   u32* out = tcount + ((size_t)w * gridDim.x + blockIdx.x) * mp.B;
@@ -755,16 +759,30 @@ __global__ void __launch_bounds__(256) k_msm_tile_bases(size_t nb, u32 B, u32 nt
   for (u32 t = 0; t < ntiles; t++) { u32* p = tcount + (w * ntiles + t) * B + b; const u32 c = *p; *p = run; run += c; }
 }
 // idx[slot] = term | sign<<31
-__global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_scatter(size_t n, size_t tile, MsmParams mp, const u32* kp, const u32* tbase, u32* idx) {
+// XCD-aware block mapping: workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  All tiles of one window
+// write into that window's 4-byte index segment, so a window is given to ONE XCD (window = 8 * (j / ntiles) + xcd): the
+// partial-line writes of its tiles then meet in the same L2 and leave it as full lines.
+__global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_scatter(size_t n, size_t tile, u32 ntiles, MsmParams mp, const u32* kp, const u32* tbase, u32* idx) {
   extern __shared__ u32 msm_lds[];
-  const int w = blockIdx.y;
-  const u32* base = tbase + ((size_t)w * gridDim.x + blockIdx.x) * mp.B;
+  const u32 xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+  const int w = (int)((j / ntiles) * 8 + xcd);
+  const u32 tile_id = j % ntiles;
+  if (w >= mp.W) return;
+  const u32* base = tbase + ((size_t)w * ntiles + tile_id) * mp.B;
   for (u32 b = threadIdx.x; b < mp.B; b += MSM_SORT_THREADS) msm_lds[b] = base[b];
   __syncthreads();
-  const size_t lo = (size_t)blockIdx.x * tile, hi = lo + tile < n ? lo + tile : n;
-  for (size_t i = lo + threadIdx.x; i < hi; i += MSM_SORT_THREADS) {
-    u32 neg; const u32 a = msm_digit_wm(kp, n, i, mp, w, neg);
-    if (a) idx[atomicAdd(&msm_lds[a - 1], 1u)] = (u32)i | (neg << 31);
+  const size_t lo = (size_t)tile_id * tile, hi = lo + tile < n ? lo + tile : n;
+  // four terms per trip: the digit loads, then the LDS cursor updates, then the stores (more memory operations in flight)
+  for (size_t i0 = lo + threadIdx.x; i0 < hi; i0 += 4 * MSM_SORT_THREADS) {
+    u32 a[4], neg[4];
+    _Pragma("unroll") for (int q = 0; q < 4; q++) {
+      const size_t i = i0 + (size_t)q * MSM_SORT_THREADS;
+      a[q] = 0; neg[q] = 0;
+      if (i < hi) a[q] = msm_digit_wm(kp, n, i, mp, w, neg[q]);
+    }
+    u32 slot[4];
+    _Pragma("unroll") for (int q = 0; q < 4; q++) slot[q] = a[q] ? atomicAdd(&msm_lds[a[q] - 1], 1u) : 0u;
+    _Pragma("unroll") for (int q = 0; q < 4; q++) if (a[q]) idx[slot[q]] = (u32)(i0 + (size_t)q * MSM_SORT_THREADS) | (neg[q] << 31);
   }
 }
 // exclusive scan of `count` (m entries) into `offset` (m+1 entries), three small passes:
