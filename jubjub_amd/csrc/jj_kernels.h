@@ -1112,6 +1112,25 @@ static JJ_DEV Ext quad_add_aniels(const Ext& p, const Fe& T, const ANiels& n, u3
   Tout = quad_bcast<3>(r2);
   return r;
 }
+// Extended + Extended with both T = t1*t2 known: round 1 a, b, T1*T2, Z1*Z2; round 2 c = 2d*T1*T2 (lane 0 used; lane 1
+// does a side product sa*sb for the caller, typically T of the NEXT operand); round 3 U, V, Z, T.  Three rounds
+// instead of the four of quad_add_ext.
+static JJ_DEV Ext quad_add_ext_t(const Ext& p, const Fe& Tp, const Ext& q, const Fe& Tq, u32 role, Fe& Tout,
+                                 const Fe& sa, const Fe& sb, Fe& sout) {
+  const Fe r1 = Fq::mul(role_select4(Fq::sub(p.v, p.u), Fq::add(p.v, p.u), Tp, p.z, role),
+                        role_select4(Fq::sub(q.v, q.u), Fq::carry(Fq::add(q.v, q.u)), Tq, q.z, role));
+  const Fe a = quad_bcast<0>(r1), b = quad_bcast<1>(r1), tt = quad_bcast<2>(r1), zz = quad_bcast<3>(r1);
+  const Fe r2 = Fq::mul(role_select4(tt, sa, tt, tt, role), role_select4(Fq::konst(FqP::D2), sb, Fq::konst(FqP::D2), Fq::konst(FqP::D2), role));
+  const Fe c = quad_bcast<0>(r2);
+  sout = quad_bcast<1>(r2);
+  const Fe d = Fq::add(zz, zz);
+  const Fe cu = Fq::sub_lazy(b, a), cv = Fq::add(b, a), cz = Fq::carry(Fq::add(d, c)), ct = Fq::sub(d, c);
+  const Fe r3 = Fq::mul(role_select4(cu, cv, cz, Fq::carry(cu), role), role_select4(ct, cz, ct, cv, role));
+  Ext r;
+  r.u = quad_bcast<0>(r3); r.v = quad_bcast<1>(r3); r.z = quad_bcast<2>(r3); r.t1 = cu; r.t2 = cv;
+  Tout = quad_bcast<3>(r3);
+  return r;
+}
 // Small batches: one scalar multiplication per quad of lanes.  Same signed-window ladder and table as
 // varbase_windowed, but every point operation is two multiplication rounds on four lanes (12 rounds per 5-bit window
 // instead of 43 dependent products), which is what matters when the batch cannot fill the SIMDs anyway.
@@ -1215,24 +1234,32 @@ __global__ void __launch_bounds__(256) k_msm_bucket_reduce(size_t nchunks, u32 L
   if (t >= nchunks) return;
   const size_t first = t * L;               // global bucket index (window-major)
   const u32 j0 = (u32)(first % B);          // index inside the window
+  // every point travels with T = t1*t2; T of the next bucket is the side product of the current addition
   Ext running = Curve::identity(), total = Curve::identity();
+  Fe Tr = Fq::zero(), Tt = Fq::zero(), dummy;
+  Ext bk = aos_ext(buckets, first + L - 1);
+  Fe Tb = Fq::mul(bk.t1, bk.t2);                       // stored t1, t2 are carried
   #pragma unroll 1
   for (int j = (int)L - 1; j >= 0; j--) {
-    running = quad_add_ext(running, aos_ext(buckets, first + j), role);
-    total = quad_add_ext(total, running, role);
+    const Ext nx = aos_ext(buckets, first + (j > 0 ? j - 1 : 0));
+    Fe Tn;
+    running = quad_add_ext_t(running, Tr, bk, Tb, role, Tr, nx.t1, nx.t2, Tn);
+    total = quad_add_ext_t(total, Tt, running, Tr, role, Tt, Tr, Tr, dummy);
+    bk = nx; Tb = Tn;
   }
   // total += j0 * running   (j0 < B = 2^jbits), double-and-add from the top bit
   Ext m = Curve::identity();
+  Fe Tm = Fq::zero();
   #pragma unroll 1
   for (int bit = jbits - 1; bit >= 0; bit--) {
-    m = quad_dbl(m, role);
+    m = quad_dbl_t(m, role, Tm);
     Ext sel = Curve::identity();
     const u32 mask = ((j0 >> bit) & 1u) ? ~0u : 0u;
     sel.u = Fq::select(sel.u, running.u, mask); sel.v = Fq::select(sel.v, running.v, mask); sel.z = Fq::select(sel.z, running.z, mask);
-    sel.t1 = Fq::select(sel.t1, Fq::carry(running.t1), mask); sel.t2 = Fq::select(sel.t2, running.t2, mask);
-    m = quad_add_ext(m, sel, role);
+    const Fe Ts = Fq::select(Fq::zero(), Tr, mask);
+    m = quad_add_ext_t(m, Tm, sel, Ts, role, Tm, Tr, Tr, dummy);
   }
-  total = quad_add_ext(total, m, role);
+  total = quad_add_ext_t(total, Tt, m, Tm, role, Tt, Tr, Tr, dummy);
   if (role == 0) soa_put_ext(out, t, total);
 }
 // grouped fold: out[t] = sum_{j<fold} in[t*fold + j]  (contiguous groups keep the window-major order intact)
@@ -1241,11 +1268,18 @@ __global__ void __launch_bounds__(256) k_sum_groups(size_t n, size_t T, int fold
   const u32 role = threadIdx.x & 3u;
   if (t >= T) return;
   Ext acc = Curve::identity();
+  Fe Ta = Fq::zero();
+  const size_t i0 = t * (size_t)fold;
+  Ext q = soa_ext(in, i0 < n ? i0 : 0);
+  Fe Tq = Fq::mul(q.t1, q.t2);                          // stored t1, t2 are carried
   #pragma unroll 1
   for (int j = 0; j < fold; j++) {
-    const size_t i = t * (size_t)fold + j;
+    const size_t i = i0 + j;
     if (i >= n) break;
-    acc = quad_add_ext(acc, soa_ext(in, i), role);
+    const Ext nx = soa_ext(in, i + 1 < n ? i + 1 : i);
+    Fe Tn;
+    acc = quad_add_ext_t(acc, Ta, q, Tq, role, Ta, nx.t1, nx.t2, Tn);
+    q = nx; Tq = Tn;
   }
   if (role == 0) soa_put_ext(out, t, acc);
 }
