@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised differential soak: every C-ABI entry point against the C oracle on fresh seeds for a wall-clock
-budget.  Usage: python tools/soak.py [seconds]   (needs an MI355X).  Prints one summary line per round."""
+budget.  Usage: python tests/soak.py [seconds]   (needs an MI355X).  Prints one summary line per round."""
 import os
 import sys
 import time

@@ -52,6 +52,12 @@ def test_product_does_not_import_the_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle|#include\s+[\"<].*oracle|libjj_oracle", src, re.M), os.path.join(dirpath, f)
     for f in ("include/jubjub_hip.h", "include/jubjub_hip.hpp"):
         assert "oracle" not in open(os.path.join(ROOT, f)).read()
+    # tools/ and examples/ are product-side helpers too: only tests/, smoke() and bench.py's cpu_baseline use the oracle
+    for sub in ("tools", "examples"):
+        for f in os.listdir(os.path.join(ROOT, sub)):
+            if f.endswith((".py", ".c", ".cpp", ".h")):
+                src = open(os.path.join(ROOT, sub, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle|#include\s+[\"<].*oracle|libjj_oracle", src, re.M), os.path.join(sub, f)
 
 
 def test_wnaf_recommendation_matches_reference(golden):
