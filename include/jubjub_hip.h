@@ -139,6 +139,11 @@ int jj_fixedbase_table_create(jj_ctx*, const void* base64, int window_bits /* 0 
 int jj_fixedbase_table_destroy(jj_ctx*, jj_table* t);
 int jj_fixedbase_mul(jj_ctx*, const jj_table* t, size_t n, const void* scalars32, void* out64);
 int jj_fixedbase_mul_compressed(jj_ctx*, const jj_table* t, size_t n, const void* scalars32, void* out32);
+/* Sums over several fixed bases (the primitive is AffineNielsPoint::multiply_bits, src/lib.rs:297-301):
+ *   out[i] = sum_{j < nbases} tables[j] * scalars32[j * n + i]      (base-major scalar array, nbases * n * 32 bytes)
+ * e.g. value commitments v*G_v + r*G_r or windowed Pedersen sums.  One pass per base; the accumulator stays in
+ * extended coordinates between the passes, so there is a single normalisation. */
+int jj_fixedbase_multi_mul(jj_ctx*, const jj_table* const* tables, int nbases, size_t n, const void* scalars32, void* out64);
 
 /* Multi-scalar multiplication: out = to_affine(sum_i points[i] * scalars[i])  (semantics: iterator Sum of
  * `p * k`, src/lib.rs:183-193 + 873-879; the reference has no MSM algorithm).  n = 0 gives the identity.

@@ -217,11 +217,30 @@ class FixedBase {
     return AffineBatch(*c_, std::move(out));
   }
   AffineBatch operator*(const FrBatch& k) const { return multiply_bits(k.to_bytes()); }
+  const jj_table* raw() const { return t_; }
+  const Context& context() const { return *c_; }
 
  private:
   const Context* c_;
   jj_table* t_ = nullptr;
 };
+// sum_j bases[j] * scalars[j][i] for every i: sums of AffineNielsPoint::multiply_bits over several fixed generators
+inline AffineBatch fixedbase_multi_mul(const std::vector<const FixedBase*>& bases, const std::vector<std::vector<Bytes32>>& scalars) {
+  if (bases.empty() || bases.size() != scalars.size()) throw Error(JJ_ERR_INVALID, "bases / scalars mismatch");
+  const size_t n = scalars[0].size();
+  std::vector<const jj_table*> tabs;
+  std::vector<Bytes32> flat;
+  flat.reserve(n * bases.size());
+  for (size_t j = 0; j < bases.size(); j++) {
+    if (scalars[j].size() != n) throw Error(JJ_ERR_INVALID, "length mismatch");          // cf. lib.rs:841
+    tabs.push_back(bases[j]->raw());
+    flat.insert(flat.end(), scalars[j].begin(), scalars[j].end());
+  }
+  const Context& c = bases[0]->context();
+  std::vector<Bytes64> out(n);
+  c.check(jj_fixedbase_multi_mul(c.raw(), tabs.data(), (int)tabs.size(), n, flat.data(), out.data()));
+  return AffineBatch(c, std::move(out));
+}
 
 // batch_normalize (lib.rs:1084-1107): (U,V,Z,T1,T2) canonical 160-byte records -> affine
 inline AffineBatch batch_normalize(const Context& c, const std::vector<std::array<uint8_t, 160>>& ext) {

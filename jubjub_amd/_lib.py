@@ -33,6 +33,7 @@ _SIGS.update({
     "jj_fixedbase_mul_compressed": [_vp, _sz, _vp, _vp],
     "jj_fixedbase_table_destroy": [_vp],
     "jj_fixedbase_mul": [_vp, _sz, _vp, _vp],
+    "jj_fixedbase_multi_mul": [_vp, C.c_int, _sz, _vp, _vp],
     "jj_msm": [_sz, _vp, _vp, _vp],
     "jj_decompress": [_sz, _vp, C.c_uint, _vp, _u8p],
     "jj_compress": [_sz, _vp, _vp],

@@ -668,13 +668,13 @@ JJ_API int jj_fixedbase_table_destroy(jj_ctx* c, jj_table* t) {
   delete t;
   return JJ_OK;
 }
-static int fixedbase_launch(jj_ctx* c, const jj_table* t, size_t n, const void* ds, SoA ext) {
+static int fixedbase_launch(jj_ctx* c, const jj_table* t, size_t n, const void* ds, SoA ext, int chain = 0) {
   const unsigned blocks = (unsigned)std::min((size_t)c->cus, (n + 511) / 512);   // one 512-thread workgroup per CU (LDS-bound)
   if (t->window_bits != FB_W) {
     const unsigned gblocks = (unsigned)std::min((size_t)c->cus * c->fb_gather_blocks_per_cu, (n + 255) / 256);
-    hipLaunchKernelGGL(k_fixedbase_gather, dim3(gblocks), dim3(256), 0, c->stream, n, ds, (const u32*)t->dev, t->fp, ext);
-  } else if (c->fb_const_time) hipLaunchKernelGGL(k_fixedbase<true>, dim3(blocks), dim3(512), FB_LDS_BYTES, c->stream, n, ds, (const u32*)t->dev, ext);
-  else hipLaunchKernelGGL(k_fixedbase<false>, dim3(blocks), dim3(512), FB_LDS_BYTES, c->stream, n, ds, (const u32*)t->dev, ext);
+    hipLaunchKernelGGL(k_fixedbase_gather, dim3(gblocks), dim3(256), 0, c->stream, n, ds, (const u32*)t->dev, t->fp, ext, chain);
+  } else if (c->fb_const_time) hipLaunchKernelGGL(k_fixedbase<true>, dim3(blocks), dim3(512), FB_LDS_BYTES, c->stream, n, ds, (const u32*)t->dev, ext, chain);
+  else hipLaunchKernelGGL(k_fixedbase<false>, dim3(blocks), dim3(512), FB_LDS_BYTES, c->stream, n, ds, (const u32*)t->dev, ext, chain);
   return JJ_OK;
 }
 static int fixedbase_api(jj_ctx* c, const jj_table* t, size_t n, const void* scalars, void* out, int mode) {
@@ -710,6 +710,30 @@ static int fixedbase_api(jj_ctx* c, const jj_table* t, size_t n, const void* sca
 }
 
 JJ_API int jj_fixedbase_mul(jj_ctx* c, const jj_table* t, size_t n, const void* scalars, void* out) { return fixedbase_api(c, t, n, scalars, out, 0); }
+// out[i] = sum_j tables[j] * scalars[j * n + i]: the accumulator stays extended between the bases (one normalisation in all)
+JJ_API int jj_fixedbase_multi_mul(jj_ctx* c, const jj_table* const* tables, int nbases, size_t n, const void* scalars, void* out64) {
+  if (!c || !tables || nbases < 1) return JJ_ERR_INVALID;
+  for (int j = 0; j < nbases; j++) if (!tables[j]) return JJ_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  const void* ds; int rc; OutRef o;
+  if ((rc = stage_in(c, 0, scalars, 32 * n * (size_t)nbases, &ds))) return rc;
+  if ((rc = stage_out(c, c->out[0], out64, 64 * n, &o))) return rc;
+  if ((rc = ensure_ext(c, n, 5))) return rc;
+  SoA ext = soa_of(c->ws_ext, n);
+  if (n) {
+    prof_mark(c, 0);
+    for (int j = 0; j < nbases; j++) {
+      const int chain = (j > 0 ? 1 : 0) | (j + 1 < nbases ? 2 : 0);
+      if ((rc = fixedbase_launch(c, tables[j], n, (const uint8_t*)ds + (size_t)j * n * 32, ext, chain))) return rc;
+    }
+    prof_mark(c, 1);
+    if ((rc = normalize_launch(c, n, ext, o.dev, 0))) return rc;
+    prof_mark(c, 2);
+  }
+  bool sync = false;
+  if ((rc = finish_out(c, o, &sync))) return rc;
+  return finish(c, sync);
+}
 JJ_API int jj_fixedbase_mul_compressed(jj_ctx* c, const jj_table* t, size_t n, const void* scalars, void* out32) { return fixedbase_api(c, t, n, scalars, out32, 1); }
 
 // ---------------------------------------------------------------------------------------------------- sums / MSM

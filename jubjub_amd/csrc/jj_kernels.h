@@ -445,8 +445,10 @@ static JJ_DEV u32 window6(const u32 (&k)[8], int i) {
 // LDS (a fixed, conflict-free pattern), and each lane then pulls the entry it needs out of its neighbours'
 // registers with ds_bpermute_b32 (a crossbar shuffle: no address- or bank-dependent timing).  Sign and zero
 // digits are applied with bit masks.  CT = false reads the entry directly at a per-lane LDS address.
+static JJ_DEV Ext soa_ext(const SoA& s, size_t i);
+// chain: bit 0 = start from the point already in `ext` (sums over several fixed bases), bit 1 = also write t1, t2
 template <bool CT>
-__global__ void __launch_bounds__(512) k_fixedbase(size_t n, const void* scalars, const u32* table, SoA ext) {
+__global__ void __launch_bounds__(512) k_fixedbase(size_t n, const void* scalars, const u32* table, SoA ext, int chain) {
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
   {
     const uint4* src = reinterpret_cast<const uint4*>(table);
@@ -471,6 +473,7 @@ __global__ void __launch_bounds__(512) k_fixedbase(size_t n, const void* scalars
     const u32 top = (k[7] >> 28) & 1u;                      // d_42
     const ANiels idn = Curve::aniels_identity();
     Ext acc = Curve::identity();
+    if ((chain & 1) && live) acc = soa_ext(ext, idx);
     acc = Curve::add(acc, Curve::select(idn, lds_aniels(lds + (size_t)(FB_NWIN * FB_ENT) * ANIELS_WORDS), 0u - top));
     #pragma unroll 1
     for (int i = FB_NWIN - 1; i >= 0; i--) {
@@ -492,7 +495,10 @@ __global__ void __launch_bounds__(512) k_fixedbase(size_t n, const void* scalars
       }
       acc = Curve::add_signed(acc, Curve::select(e, idn, a == 0 ? ~0u : 0u), d < 0 ? ~0u : 0u);
     }
-    if (live) { ext.put(0, idx, acc.u); ext.put(1, idx, acc.v); ext.put(2, idx, acc.z); }
+    if (live) {
+      ext.put(0, idx, acc.u); ext.put(1, idx, acc.v); ext.put(2, idx, acc.z);
+      if (chain & 2) { ext.put(3, idx, Fq::carry(acc.t1)); ext.put(4, idx, Fq::carry(acc.t2)); }
+    }
   }
 }
 // Wide-window variant: table of (j+1) * 2^(w i) * B for w = 8..12 (0.5 - 5 MB) kept in global memory, L2-resident;
@@ -510,7 +516,7 @@ static JJ_DEV u32 fb_window(const u32 (&k)[8], int w, int i) {
   const u64 both = ((u64)hi << 32) | lo;
   return (u32)(both >> sh) & ((1u << w) - 1u);
 }
-__global__ void __launch_bounds__(256) k_fixedbase_gather(size_t n, const void* scalars, const u32* table, FbParams fp, SoA ext) {
+__global__ void __launch_bounds__(256) k_fixedbase_gather(size_t n, const void* scalars, const u32* table, FbParams fp, SoA ext, int chain) {
   const size_t T = (size_t)gridDim.x * blockDim.x;
   #pragma unroll 1
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += T) {
@@ -523,6 +529,7 @@ __global__ void __launch_bounds__(256) k_fixedbase_gather(size_t n, const void* 
     }
     const ANiels idn = Curve::aniels_identity();
     Ext acc = Curve::identity();
+    if (chain & 1) acc = soa_ext(ext, idx);
     // top window: unsigned digit
     u32 a = fb_window(k, fp.w, fp.W - 1), neg = 0;
     ANiels e = lds_aniels(table + ((size_t)(fp.W - 1) * fp.E + (a ? a - 1 : 0)) * GNIELS_WORDS);
@@ -538,6 +545,7 @@ __global__ void __launch_bounds__(256) k_fixedbase_gather(size_t n, const void* 
       acc = Curve::add_signed(acc, s, smask);
     }
     ext.put(0, idx, acc.u); ext.put(1, idx, acc.v); ext.put(2, idx, acc.z);
+    if (chain & 2) { ext.put(3, idx, Fq::carry(acc.t1)); ext.put(4, idx, Fq::carry(acc.t2)); }
   }
 }
 // affine points (64 B canonical) -> table entries (AffineNiels limbs, 112 B)

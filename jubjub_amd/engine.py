@@ -233,6 +233,19 @@ class Engine:
     def fixedbase_mul(self, table, scalars):
         return self._call("jj_fixedbase_mul", [scalars], [32], [64], extra_before=(table._h,))
 
+    def fixedbase_multi_mul(self, tables, scalars):
+        """out[i] = sum_j tables[j] * scalars[j][i]; scalars: (len(tables), n, 32) bytes, base-major."""
+        nb = len(tables)
+        a = _Arg(scalars, 32)
+        if nb < 1 or a.n % nb:
+            raise ValueError("scalars must hold len(tables) x n x 32 bytes")
+        n = a.n // nb
+        self._bind_stream([a])
+        out, optr = self._alloc(a, n, 64)
+        handles = (C.c_void_p * nb)(*[t._h for t in tables])
+        self._check(self._lib.jj_fixedbase_multi_mul(self._ctx, handles, C.c_int(nb), C.c_size_t(n), a.ptr, optr))
+        return out
+
     def msm(self, scalars, points):
         return self._sum_like("jj_msm", [scalars, points], [32, 64])
 

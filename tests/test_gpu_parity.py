@@ -217,6 +217,27 @@ def test_fixedbase(eng):
         eng.fixedbase_table(pt64(J.GENERATOR), 7)
 
 
+def test_fixedbase_multi_base_sums(eng):
+    """jj_fixedbase_multi_mul: sum_j k_ij * B_j for LDS tables, wide-window tables and a mix, against the oracle's
+    AffineNielsPoint ladders folded with point additions."""
+    n = 1500
+    bases = rand_points(81, 3)
+    S = np.stack([rand_scalars(82 + j, n, full_width=(j == 1)) for j in range(3)])
+    S[0, :len(EDGE_SCALARS)] = arr32(EDGE_SCALARS)
+    want = O.fixedbase_mul(S[0], bases[0])
+    for j in (1, 2):
+        want = O.point_op("add", want, O.fixedbase_mul(S[j], bases[j]))
+    for widths in ((0, 0, 0), (10, 10, 10), (0, 12, 0)):
+        tabs = [eng.fixedbase_table(bases[j], widths[j]) for j in range(3)]
+        assert (eng.fixedbase_multi_mul(tabs, S) == want).all(), widths
+        assert (eng.fixedbase_multi_mul(tabs[:1], S[:1]) == O.fixedbase_mul(S[0], bases[0])).all()
+        for t in tabs:
+            t.close()
+    tab = eng.fixedbase_table(bases[0])
+    assert eng.fixedbase_multi_mul([tab, tab], S[:2, :0]).shape == (0, 64)
+    tab.close()
+
+
 def test_msm(eng):
     for n in (0, 1, 2, 3, 7, 33, 127, 511, 512, 1000, 2047, 2048, 5000, 32767, 32768, 40000):
         S = rand_scalars(12 + n, n, full_width=True)
