@@ -124,6 +124,9 @@ int jj_point_sum(jj_ctx*, size_t n, const void* p, void* out64);
 int jj_varbase_mul(jj_ctx*, size_t n, const void* scalars32, const void* points64, void* out64);
 /* same, result written as 32-byte compressed encodings (to_bytes of the product, src/lib.rs:455-464, 1419-1421) */
 int jj_varbase_mul_compressed(jj_ctx*, size_t n, const void* scalars32, const void* points64, void* out32);
+/* One scalar, many bases: out[i] = points[i] * scalar (the `Wnaf::scalar(..).base(..)` reuse pattern of the group crate,
+ * cf. WnafGroup src/lib.rs:1318-1336).  Same kernel as jj_varbase_mul after broadcasting the 32-byte scalar. */
+int jj_varbase_mul_scalar(jj_ctx*, size_t n, const void* scalar32, const void* points64, void* out64);
 /* Same group element, but computed with the reference's exact 252-step double-and-add-always ladder and
  * returned in projective form: out = 160 bytes (U,V,Z,T1,T2 canonical LE) matching the Rust ExtendedPoint
  * fields bit for bit.  For parity testing, not for throughput. */

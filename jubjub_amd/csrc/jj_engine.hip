@@ -547,6 +547,27 @@ static int varbase_api(jj_ctx* c, size_t n, const void* scalars, const void* poi
 }
 JJ_API int jj_varbase_mul(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out) { return varbase_api(c, n, scalars, points, out, 0); }
 JJ_API int jj_varbase_mul_compressed(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out32) { return varbase_api(c, n, scalars, points, out32, 1); }
+// one scalar, many bases (group::Wnaf's `scalar(..).base(..)` reuse pattern): the scalar is broadcast on the device
+JJ_API int jj_varbase_mul_scalar(jj_ctx* c, size_t n, const void* scalar32, const void* points, void* out) {
+  if (!c || !scalar32) return JJ_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  const void* dp; int rc; OutRef o;
+  if ((rc = stage_in(c, 1, points, 64 * n, &dp))) return rc;
+  if ((rc = stage_out(c, c->out[0], out, 64 * n, &o))) return rc;
+  if ((rc = ensure(c, c->ws_tmp[0], 32 * std::max(n, (size_t)1)))) return rc;
+  if ((rc = ensure(c, c->ws_tmp[1], 32))) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->ws_tmp[1].p, scalar32, 32, is_device_ptr(scalar32) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+  if ((rc = ensure_ext(c, n, 3))) return rc;
+  SoA ext = soa_of(c->ws_ext, n);
+  if (n) {
+    hipLaunchKernelGGL(k_fill_scalar, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, c->ws_tmp[0].p, (const uint8_t*)c->ws_tmp[1].p);
+    if ((rc = varbase_to_ext(c, n, c->ws_tmp[0].p, dp, ext, false))) return rc;
+    if ((rc = normalize_launch(c, n, ext, o.dev, 0))) return rc;
+  }
+  bool sync = false;
+  if ((rc = finish_out(c, o, &sync))) return rc;
+  return finish(c, sync);
+}
 JJ_API int jj_varbase_mul_exact(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out160) {
   if (!c) return JJ_ERR_INVALID;
   HIPCHK(c, hipSetDevice(c->device));

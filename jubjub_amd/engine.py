@@ -212,6 +212,16 @@ class Engine:
     def varbase_mul(self, scalars, points):
         return self._call("jj_varbase_mul", [scalars, points], [32, 64], [64])
 
+    def varbase_mul_scalar(self, scalar, points):
+        """points[i] * scalar for one 32-byte scalar (numpy or torch), every point of the batch."""
+        a, p = _Arg(scalar, 32), _Arg(points, 64)
+        if a.n != 1:
+            raise ValueError("scalar must be 32 bytes")
+        self._bind_stream([a, p])
+        out, optr = self._alloc(p, p.n, 64)
+        self._check(self._lib.jj_varbase_mul_scalar(self._ctx, C.c_size_t(p.n), a.ptr, p.ptr, optr))
+        return out
+
     def varbase_mul_compressed(self, scalars, points):
         return self._call("jj_varbase_mul_compressed", [scalars, points], [32, 64], [32])
 

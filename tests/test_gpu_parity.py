@@ -185,6 +185,14 @@ def test_varbase_random(eng):
     tab.close()
 
 
+def test_varbase_shared_scalar(eng, golden):
+    pts = np.concatenate([rand_points(91, 700), torsion_points(golden), arr64([J.GENERATOR, J.AFFINE_IDENTITY])])
+    for k in (0, 1, R - 1, (1 << 252) - 1, to_int(rand_scalars(92, 1, full_width=True)[0])):
+        S = np.repeat(b32(k)[None, :], len(pts), axis=0)
+        assert (eng.varbase_mul_scalar(b32(k), pts) == O.varbase_mul(S, pts)).all(), k
+    assert eng.varbase_mul_scalar(b32(5), pts[:0]).shape == (0, 64)
+
+
 def test_varbase_exact_projective(eng):
     n = 200
     S = np.concatenate([arr32(EDGE_SCALARS), rand_scalars(7, n)])
