@@ -65,6 +65,7 @@ def parse():
     ap.add_argument("--workload", default="varbase", choices=sorted(WORK))
     ap.add_argument("--log2n", type=int, default=None, help="log2 of the per-GPU batch (default: 20 varbase/msm, 24 fixedbase, 23 decompress = 2^26 over 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="varbase workload: skip the fixed-base side measurements (clean per-kernel profiles)")
     ap.add_argument("--fb-window", type=int, default=0, help="fixed-base window bits: 0/6 = LDS-staged constant-time table (default), 8..12 = L2-resident table")
     ap.add_argument("--decompress-flags", type=int, default=13,
                     help="jj_decompress flags: 1 ZIP-216 | 2 torsion-free (order-8 Tate pairing; JJ_TORSION_CHECK=ladder for the [r]P ladder) | 4 reject small order | 8 clear cofactor (default 13 = BASELINE config 5: decode + small-order check + mul_by_cofactor)")
@@ -241,7 +242,7 @@ def main():
             "hbm": {"achieved": n * w["bytes"] / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": n * w["bytes"] / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "bytes_per_unit": w["bytes"]},
         }
-        if wl == "varbase":
+        if wl == "varbase" and not a.no_extras:
             # the other half of BASELINE.json's metric, measured in the same process (outside the timed region above)
             fs = scalars if log2n >= 22 else torch.randint(0, 256, (1 << 22, 32), dtype=torch.uint8, device=dev, generator=g)
             eng.fixedbase_mul(table, fs)
