@@ -44,6 +44,13 @@ while time.time() < t_end:
     wbits = [0, 8, 10, 12][rnd % 4]
     tab = eng.fixedbase_table(bp, wbits)
     assert (eng.fixedbase_mul(tab, S) == O.fixedbase_mul(S, bp)).all(), ("fixedbase", rnd, wbits)
+    if rnd % 2 == 0:                                          # sums over two fixed bases; one scalar with many bases
+        bp2 = P[int(rng.integers(0, n))]
+        tab2 = eng.fixedbase_table(bp2, [0, 12][rnd % 4 // 2])
+        want2 = O.point_op("add", O.fixedbase_mul(S, bp), O.fixedbase_mul(K, bp2))
+        assert (eng.fixedbase_multi_mul([tab, tab2], np.stack([S, K])) == want2).all(), ("multi-base", rnd)
+        tab2.close()
+        assert (eng.varbase_mul_scalar(S[0], P) == O.varbase_mul(np.repeat(S[:1], n, axis=0), P)).all(), ("shared scalar", rnd)
     tab.close()
     m = n
     want_msm = O.msm(S[:m], P[:m])
