@@ -242,6 +242,11 @@ def main():
             "hbm": {"achieved": n * w["bytes"] / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": n * w["bytes"] / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "bytes_per_unit": w["bytes"]},
         }
+        if wl == "varbase" and log2n == 20:
+            # not collected live (PMC needs rocprofv3): the committed counter passes of this same launch
+            res["roofline"]["traffic_profiled"] = {"bytes_per_launch": 11.39e9 + 3.08e9, "fetch_bytes": 11.39e9, "write_bytes": 3.08e9,
+                                                   "source": "profiles/r1_varbase_pmc.txt (FETCH_SIZE x2 per the gfx950 note, WRITE_SIZE; separate --pmc passes)",
+                                                   "note": "per-lane window tables; algorithmic I/O is 160 B per unit"}
         if wl == "varbase" and not a.no_extras:
             # the other half of BASELINE.json's metric, measured in the same process (outside the timed region above)
             fs = scalars if log2n >= 22 else torch.randint(0, 256, (1 << 22, 32), dtype=torch.uint8, device=dev, generator=g)
