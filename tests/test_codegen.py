@@ -42,10 +42,15 @@ def resources(asm, needle):
 
 @pytest.mark.parametrize("needle", ["k_varbaseEm", "k_fixedbaseILb1", "k_fixedbase_gather", "k_varbase_quadILb0"])
 def test_products_are_pinned(asm, needle):
-    ops = collections.Counter(l.split()[0] for l in kernel_body(asm, needle).splitlines() if re.match(r"^\s+[vs]_", l))
-    mads, merges = ops["v_mad_u64_u32"], ops["v_lshl_add_u64"]
-    assert mads > 1000
-    assert merges * 16 < mads, "column carries are re-joined with 64-bit adds again (%d for %d multiply-adds)" % (merges, mads)
+    # the basic block with the most multiply-adds is the ladder body; 64-bit adds elsewhere are address arithmetic
+    best = None
+    for blk in re.split(r"\n(?=\.LBB\d+_\d+:)", kernel_body(asm, needle)):
+        ops = collections.Counter(l.split()[0] for l in blk.splitlines() if re.match(r"^\s+[vs]_", l))
+        if best is None or ops["v_mad_u64_u32"] > best["v_mad_u64_u32"]:
+            best = ops
+    mads, merges = best["v_mad_u64_u32"], best["v_lshl_add_u64"]
+    assert mads > 600
+    assert merges * 40 < mads, "column carries are re-joined with 64-bit adds again (%d for %d multiply-adds)" % (merges, mads)
 
 
 @pytest.mark.parametrize("needle", ["k_varbaseEm", "k_fixedbaseILb1", "k_fixedbase_gather", "k_msm_accumulateEm", "k_msm_accumulate_seg",
