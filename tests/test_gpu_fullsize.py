@@ -153,6 +153,27 @@ def test_subgroup_check_2p20(env, monkeypatch):
     assert bool((ok.bool() == want).all()) and bool((out[want] == P[want]).all()) and bool((out[~want] == 0).all())
 
 
+def test_msm_2p25_two_passes_and_decompress_2p26(env):
+    """Beyond one Pippenger pass (2^24 terms) and at BASELINE config 5's whole size on a single GPU."""
+    eng, dev, g, base, table = env
+    n = 1 << 25
+    S = rand_scalars(dev, g, n)
+    P = eng.fixedbase_mul(table, rand_scalars(dev, g, n))
+    full = eng.msm(S, P)
+    q = 3 * (n // 8)                                               # uneven split: passes of different sizes
+    parts = torch.stack([eng.msm(S[:q], P[:q]), eng.msm(S[q:], P[q:])])
+    assert bool((eng.point_sum(parts) == full).all())
+    del S
+    enc = eng.compress(P)
+    enc = torch.cat([enc, enc])                                    # 2^26 encodings
+    out, ok = eng.decompress(enc, 1 | 4 | 8)
+    assert bool(ok.all()) and bool((out[:n] == out[n:]).all())
+    idx = torch.arange(0, n, 8191, device=dev)
+    assert bool((out[idx] == eng.mul_by_cofactor(P[idx])).all())
+    eo, ek = O.decompress(enc[idx[:256]].cpu().numpy(), 1 | 4 | 8)
+    assert (out[idx[:256]].cpu().numpy() == eo).all() and (ok[idx[:256]].cpu().numpy() == ek).all()
+
+
 @pytest.mark.parametrize("fname,which,p", [("fq", O.FQ, J.Q), ("fr", O.FR, J.R_MOD)])
 def test_field_ops_2p20_vs_oracle(env, fname, which, p):
     """2^20 random pairs plus structured operands (2^k, 2^k - 1, p - 2^k, saturated 29-bit limb patterns) through
