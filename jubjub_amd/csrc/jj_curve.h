@@ -1,33 +1,33 @@
 // Jubjub twisted-Edwards group law on CDNA4 — device code, one point per lane, all coordinates in registers.
 //
-// Formulas are the reference's (same completed-point structure, so projective coordinates agree with the
-// Rust code up to the field representation):
+// Formulas are the reference's (same completed-point structure, so the projective point agrees with the Rust code):
 //   double        : reference ExtendedPoint::double           src/lib.rs:739-828  (4S + 3M)
 //   add ExtNiels  : reference Add<&ExtendedNielsPoint>        src/lib.rs:883-920  (8M)
 //   add AffNiels  : reference Add<&AffineNielsPoint>          src/lib.rs:944-968  (7M)
 //   into_extended : reference CompletedPoint::into_extended   src/lib.rs:1052-1060
-// Lazy-reduction bounds of every intermediate are verified by tools/bounds_check.py.
+// written for the signed lazy limbs of jj_field.h: subtraction is a limb-wise v_sub, a carry step is inserted only
+// where the next product's 64-bit column bound needs it.  Lazy-reduction bounds of every intermediate are verified by
+// tools/bounds_check.py (static intervals) and tests/test_emu_field.py (host emulation with a 128-bit shadow).
 #pragma once
 #include "jj_field.h"
 
 namespace jj {
 
 struct Affine { Fe u, v; };                 // reference AffinePoint          src/lib.rs:80-84
-struct Ext { Fe u, v, z, t1, t2; };         // reference ExtendedPoint        src/lib.rs:138-145 ; t1 is kept lazy (limbs < 2^31)
+struct Ext { Fe u, v, z, t1, t2; };         // reference ExtendedPoint        src/lib.rs:138-145 ; u, v, z are products ("N"), t1 and t2 stay lazy
 struct ANiels { Fe vpu, vmu, t2d; };        // reference AffineNielsPoint     src/lib.rs:254-259
-struct ENiels { Fe vpu, vmu, z, t2d; };     // reference ExtendedNielsPoint   src/lib.rs:326-332
+struct ENiels { Fe vpu, vmu, z2, t2d; };    // reference ExtendedNielsPoint   src/lib.rs:326-332 ; z2 = 2Z (the addition only ever uses 2*Z1*Z2)
 
-// FT: the field flavour (Field<FqP, PIN>); Curve = CurveT<Fq> everywhere except register-bound kernels.
 template <class FT>
 struct CurveT {
   typedef FT F;
 
   static JJ_DEV Ext identity() { Ext p; p.u = F::zero(); p.v = F::one(); p.z = F::one(); p.t1 = F::zero(); p.t2 = F::zero(); return p; }  // lib.rs:680-688
   static JJ_DEV ANiels aniels_identity() { ANiels n; n.vpu = F::one(); n.vmu = F::one(); n.t2d = F::zero(); return n; }                      // lib.rs:263-269
-  static JJ_DEV ENiels eniels_identity() { ENiels n; n.vpu = F::one(); n.vmu = F::one(); n.z = F::one(); n.t2d = F::zero(); return n; }       // lib.rs:347-354
+  static JJ_DEV ENiels eniels_identity() { ENiels n; n.vpu = F::one(); n.vmu = F::one(); n.z2 = F::add(F::one(), F::one()); n.t2d = F::zero(); return n; }   // lib.rs:347-354
   static JJ_DEV Ext from_affine(const Affine& a) { Ext p; p.u = a.u; p.v = a.v; p.z = F::one(); p.t1 = a.u; p.t2 = a.v; return p; }           // lib.rs:640-648
 
-  // completed point (u:z, v:t) -> extended; lib.rs:1052-1060.  cu,ct,cz N-like; cv L.
+  // completed point (u:z, v:t) -> extended; lib.rs:1052-1060.
   static JJ_DEV Ext into_extended(const Fe& cu, const Fe& cv, const Fe& cz, const Fe& ct) {
     Ext p;
     p.u = F::mul(cu, ct);
@@ -38,75 +38,83 @@ struct CurveT {
     return p;
   }
 
-  // lib.rs:739-828
+  // lib.rs:739-828.  2UV is taken from (U-V)^2 rather than (U+V)^2: the difference of two N's has limbs in
+  // (-2^29, 2^29), so its square needs no carry step; 2Z^2 comes out of one product (sqr2).
   static JJ_DEV Ext dbl(const Ext& p) {
     const Fe uu = F::sqr(p.u);
     const Fe vv = F::sqr(p.v);
-    const Fe zz = F::sqr(p.z);
-    const Fe uv2 = F::sqr(F::add(p.u, p.v));
-    const Fe vpu = F::add(vv, uu);            // VV + UU   (L)
-    const Fe vmu = F::sub(vv, uu);            // VV - UU   (N, +3p)
-    const Fe cu = F::sub_lazy(uv2, vpu);      // (U+V)^2 - (VV+UU)   (lazy: meets the carried ct, and is T1)
-    const Fe ct = F::dbl_sub_wide(zz, vmu);   // 2Z^2 - (VV-UU)
+    const Fe zz2 = F::sqr2(p.z);
+    const Fe s = F::sqr(F::sub(p.u, p.v));   // UU + VV - 2UV
+    const Fe vpu = F::add(vv, uu);            // VV + UU
+    const Fe vmu = F::sub(vv, uu);            // VV - UU
+    const Fe cu = F::sub(vpu, s);             // 2UV   (= T1, lazy)
+    const Fe ct = F::carry(F::sub(zz2, vmu)); // 2Z^2 - (VV-UU)
     return into_extended(cu, vpu, vmu, ct);
   }
 
+  // shared tail of the four additions: a, b, c, d (d = 2 Z1 Z2, product or lazy 2 Z1) -> extended
+  static JJ_DEV Ext add_tail(const Fe& a, const Fe& b, const Fe& c, const Fe& d) {
+    return into_extended(F::sub(b, a), F::add(b, a), F::carry(F::add(d, c)), F::sub(d, c));
+  }
+  // T1*T2 of an accumulator: after a doubling t1 = 2UV-class (limbs up to 2^30) needs one carry step before it meets
+  // the lazy t2; after an addition (T1_SMALL) t1 = b - a has limbs in (-2^29, 2^29) and goes in as it is.
+  template <bool T1_SMALL>
+  static JJ_DEV Fe tt(const Ext& p) { if constexpr (T1_SMALL) return F::mul(p.t1, p.t2); else return F::mul(F::carry(p.t1), p.t2); }
+
   // lib.rs:883-920
+  template <bool T1_SMALL = false>
   static JJ_DEV Ext add(const Ext& p, const ENiels& n) {
     const Fe a = F::mul(F::sub(p.v, p.u), n.vmu);
     const Fe b = F::mul(F::add(p.v, p.u), n.vpu);
-    const Fe c = F::mul(F::mul(F::carry(p.t1), p.t2), n.t2d);
-    const Fe zz = F::mul(p.z, n.z);
-    const Fe d = F::add(zz, zz);
-    return into_extended(F::sub_lazy(b, a), F::add(b, a), F::carry(F::add(d, c)), F::sub(d, c));
+    const Fe c = F::mul(tt<T1_SMALL>(p), n.t2d);
+    const Fe d = F::mul(p.z, n.z2);
+    return add_tail(a, b, c, d);
   }
   // lib.rs:922-940
+  template <bool T1_SMALL = false>
   static JJ_DEV Ext sub(const Ext& p, const ENiels& n) {
     const Fe a = F::mul(F::sub(p.v, p.u), n.vpu);
     const Fe b = F::mul(F::add(p.v, p.u), n.vmu);
-    const Fe c = F::mul(F::mul(F::carry(p.t1), p.t2), n.t2d);
-    const Fe zz = F::mul(p.z, n.z);
-    const Fe d = F::add(zz, zz);
-    return into_extended(F::sub_lazy(b, a), F::add(b, a), F::sub(d, c), F::carry(F::add(d, c)));
+    const Fe c = F::neg(F::mul(tt<T1_SMALL>(p), n.t2d));
+    const Fe d = F::mul(p.z, n.z2);
+    return add_tail(a, b, c, d);
   }
   // lib.rs:944-968
+  template <bool T1_SMALL = false>
   static JJ_DEV Ext add(const Ext& p, const ANiels& n) {
     const Fe a = F::mul(F::sub(p.v, p.u), n.vmu);
     const Fe b = F::mul(F::add(p.v, p.u), n.vpu);
-    const Fe c = F::mul(F::mul(F::carry(p.t1), p.t2), n.t2d);
-    const Fe d = F::add(p.z, p.z);
-    return into_extended(F::sub_lazy(b, a), F::add(b, a), F::carry(F::add(d, c)), F::sub(d, c));
+    const Fe c = F::mul(tt<T1_SMALL>(p), n.t2d);
+    return add_tail(a, b, c, F::add(p.z, p.z));
   }
   // lib.rs:970-988
+  template <bool T1_SMALL = false>
   static JJ_DEV Ext sub(const Ext& p, const ANiels& n) {
     const Fe a = F::mul(F::sub(p.v, p.u), n.vpu);
     const Fe b = F::mul(F::add(p.v, p.u), n.vmu);
-    const Fe c = F::mul(F::mul(F::carry(p.t1), p.t2), n.t2d);
-    const Fe d = F::add(p.z, p.z);
-    return into_extended(F::sub_lazy(b, a), F::add(b, a), F::sub(d, c), F::carry(F::add(d, c)));
+    const Fe c = F::neg(F::mul(tt<T1_SMALL>(p), n.t2d));
+    return add_tail(a, b, c, F::add(p.z, p.z));
   }
 
   // p + n (negmask = 0) or p - n (negmask = ~0) without negating the operand: the subtraction formulas (lib.rs:922-940,
-  // 970-988) swap v+u / v-u and d+c / d-c, so four selects replace a field negation and three selects.
+  // 970-988) swap v+u / v-u (two selects) and flip the sign of c (a conditional negation, two VOP2 per limb).
+  template <bool T1_SMALL = false>
   static JJ_DEV Ext add_signed(const Ext& p, const ENiels& n, u32 negmask) {
     const Fe a = F::mul(F::sub(p.v, p.u), F::select(n.vmu, n.vpu, negmask));
     const Fe b = F::mul(F::add(p.v, p.u), F::select(n.vpu, n.vmu, negmask));
-    const Fe c = F::mul(F::mul(F::carry(p.t1), p.t2), n.t2d);
-    const Fe zz = F::mul(p.z, n.z);
-    const Fe d = F::add(zz, zz);
-    const Fe plus = F::carry(F::add(d, c)), minus = F::sub(d, c);
-    return into_extended(F::sub_lazy(b, a), F::add(b, a), F::select(plus, minus, negmask), F::select(minus, plus, negmask));
+    const Fe c = F::cneg(F::mul(tt<T1_SMALL>(p), n.t2d), negmask);
+    const Fe d = F::mul(p.z, n.z2);
+    return add_tail(a, b, c, d);
   }
+  template <bool T1_SMALL = false>
   static JJ_DEV Ext add_signed(const Ext& p, const ANiels& n, u32 negmask) {
     const Fe a = F::mul(F::sub(p.v, p.u), F::select(n.vmu, n.vpu, negmask));
     const Fe b = F::mul(F::add(p.v, p.u), F::select(n.vpu, n.vmu, negmask));
-    const Fe c = F::mul(F::mul(F::carry(p.t1), p.t2), n.t2d);
-    const Fe d = F::add(p.z, p.z);
-    const Fe plus = F::carry(F::add(d, c)), minus = F::sub(d, c);
-    return into_extended(F::sub_lazy(b, a), F::add(b, a), F::select(plus, minus, negmask), F::select(minus, plus, negmask));
+    const Fe c = F::cneg(F::mul(tt<T1_SMALL>(p), n.t2d), negmask);
+    return add_tail(a, b, c, F::add(p.z, p.z));
   }
 
-  // lib.rs:652-658 : (v+u, v-u, u*v*2d), all N
+  // lib.rs:652-658 : (v+u, v-u, u*v*2d); vpu carried so that it can meet the lazy (V+U) of an accumulator
   static JJ_DEV ANiels to_niels(const Affine& a) {
     ANiels n;
     n.vpu = F::carry(F::add(a.v, a.u));
@@ -119,19 +127,19 @@ struct CurveT {
     ENiels n;
     n.vpu = F::carry(F::add(p.v, p.u));
     n.vmu = F::sub(p.v, p.u);
-    n.z = p.z;
+    n.z2 = F::add(p.z, p.z);
     n.t2d = F::mul(F::mul(F::carry(p.t1), p.t2), F::konst(FqP::D2));
     return n;
   }
   // -(vpu, vmu, t2d) = (vmu, vpu, -t2d)   (negation of the underlying point, lib.rs:92-104)
-  static JJ_DEV ENiels neg(const ENiels& n) { ENiels r; r.vpu = n.vmu; r.vmu = n.vpu; r.z = n.z; r.t2d = F::neg(n.t2d); return r; }
-  static JJ_DEV ANiels neg(const ANiels& n) { ANiels r; r.vpu = n.vmu; r.vmu = n.vpu; r.t2d = F::neg(n.t2d); return r; }
+  static JJ_DEV ENiels neg(const ENiels& n) { ENiels r; r.vpu = F::carry(n.vmu); r.vmu = n.vpu; r.z2 = n.z2; r.t2d = F::neg(n.t2d); return r; }
+  static JJ_DEV ANiels neg(const ANiels& n) { ANiels r; r.vpu = F::carry(n.vmu); r.vmu = n.vpu; r.t2d = F::neg(n.t2d); return r; }
   // lib.rs:195-211
-  static JJ_DEV Ext neg(const Ext& p) { Ext r; r.u = F::neg(p.u); r.v = p.v; r.z = p.z; r.t1 = F::neg(F::carry(p.t1)); r.t2 = p.t2; return r; }
+  static JJ_DEV Ext neg(const Ext& p) { Ext r; r.u = F::neg(p.u); r.v = p.v; r.z = p.z; r.t1 = F::neg(p.t1); r.t2 = p.t2; return r; }
 
   // masked select: mask all-ones -> b
   static JJ_DEV ENiels select(const ENiels& a, const ENiels& b, u32 mask) {
-    ENiels r; r.vpu = F::select(a.vpu, b.vpu, mask); r.vmu = F::select(a.vmu, b.vmu, mask); r.z = F::select(a.z, b.z, mask); r.t2d = F::select(a.t2d, b.t2d, mask); return r;
+    ENiels r; r.vpu = F::select(a.vpu, b.vpu, mask); r.vmu = F::select(a.vmu, b.vmu, mask); r.z2 = F::select(a.z2, b.z2, mask); r.t2d = F::select(a.t2d, b.t2d, mask); return r;
   }
   static JJ_DEV ANiels select(const ANiels& a, const ANiels& b, u32 mask) {
     ANiels r; r.vpu = F::select(a.vpu, b.vpu, mask); r.vmu = F::select(a.vmu, b.vmu, mask); r.t2d = F::select(a.t2d, b.t2d, mask); return r;
@@ -153,7 +161,7 @@ struct CurveT {
     if (F::is_zero(a.u) && F::eq(a.v, F::one())) return true;
     const Fe pp = F::add(F::one(), a.v), mm = F::sub(F::one(), a.v);
     const Fe l1 = F::sub(pp, F::mul(a.u, F::add(F::mul(F::konst(FqP::TP_A1), a.v), F::konst(FqP::TP_B1))));
-    const Fe l2 = F::sub(pp, F::mul(a.u, F::add(F::mul(F::konst(FqP::TP_A2), a.v), F::konst(FqP::TP_B2))));
+    const Fe l2 = F::carry(F::sub(pp, F::mul(a.u, F::add(F::mul(F::konst(FqP::TP_A2), a.v), F::konst(FqP::TP_B2)))));
     const Fe g = F::mul(l1, F::mul(a.u, a.v));
     const Fe g4 = F::sqr(F::sqr(g));
     const Fe k = F::mul(F::sqr(a.u), F::mul(pp, mm));
@@ -177,6 +185,5 @@ struct CurveT {
 
 };
 typedef CurveT<Fq> Curve;
-typedef CurveT<Field<FqP, 0>> CurveNP;   // products without association pins (see JJ_MUL_PIN in jj_field.h)
 
 }  // namespace jj

@@ -57,10 +57,10 @@ static JJ_DEV Fe fr_sqrt(const Fe& a, bool& ok) {
 // ---- Fq square root: the value ff::helpers::sqrt_tonelli_shanks returns (bls12_381 0.8.0 Scalar::sqrt, S = 32,
 // ROOT_OF_UNITY = 7^t; call sites reference src/lib.rs:515,610,1253), computed by a 4 x 8-bit Pohlig-Hellman discrete
 // log in the 2^32-torsion instead of Tonelli-Shanks' ~500 data-dependent squarings.  With g = ROOT_OF_UNITY, b = a^t = g^e; the digits e_i come from a 64 KiB direct table
-// keyed by 16 low bits of canon(b_i^(2^(24-8i))); Tonelli-Shanks' answer is x = a^((t+1)/2) * g^s with
+// keyed by the 16 low bits of the canonical integer b_i^(2^(24-8i)); Tonelli-Shanks' answer is x = a^((t+1)/2) * g^s with
 // s = ((2^32 - e) mod 2^32) / 2, i.e. x for e = 0 and -(x * g^(-e/2)) otherwise.
 struct SqrtTables {
-  const uint8_t* dlog;   // [65536]  key16 -> k   with key16 = low 16 bits of limb 0 of canon((g^(2^24))^k)
+  const uint8_t* dlog;   // [65536]  key16 -> k   with key16 = low 16 bits of the canonical integer (g^(2^24))^k
   const u32* npow;       // [4][256][NL]  g^(-k * 2^(8i))
 };
 static JJ_DEV Fe sqrt_tab(const SqrtTables& T, int i, u32 k) {
@@ -82,10 +82,10 @@ static JJ_DEV Fe fq_sqrt_fast(const Fe& a, bool& ok, const SqrtTables& T) {
   Fe c3 = c2;
   #pragma unroll 1
   for (int s = 0; s < 8; s++) c3 = Fq::sqr(c3);
-  const u32 e0 = T.dlog[Fq::canon(c3).l[0] & 0xffffu];
-  const u32 e1 = T.dlog[Fq::canon(Fq::mul(c2, sqrt_tab(T, 2, e0))).l[0] & 0xffffu];
-  const u32 e2 = T.dlog[Fq::canon(Fq::mul(Fq::mul(c1, sqrt_tab(T, 1, e0)), sqrt_tab(T, 2, e1))).l[0] & 0xffffu];
-  const u32 e3 = T.dlog[Fq::canon(Fq::mul(Fq::mul(b, sqrt_tab(T, 0, e0)), Fq::mul(sqrt_tab(T, 1, e1), sqrt_tab(T, 2, e2)))).l[0] & 0xffffu];
+  const u32 e0 = T.dlog[Fq::to_plain(c3).l[0] & 0xffffu];
+  const u32 e1 = T.dlog[Fq::to_plain(Fq::mul(c2, sqrt_tab(T, 2, e0))).l[0] & 0xffffu];
+  const u32 e2 = T.dlog[Fq::to_plain(Fq::mul(Fq::mul(c1, sqrt_tab(T, 1, e0)), sqrt_tab(T, 2, e1))).l[0] & 0xffffu];
+  const u32 e3 = T.dlog[Fq::to_plain(Fq::mul(Fq::mul(b, sqrt_tab(T, 0, e0)), Fq::mul(sqrt_tab(T, 1, e1), sqrt_tab(T, 2, e2)))).l[0] & 0xffffu];
   const u32 e = e0 | (e1 << 8) | (e2 << 16) | (e3 << 24);
   const u32 h = e >> 1;
   Fe z = Fq::mul(sqrt_tab(T, 0, h & 255u), sqrt_tab(T, 1, (h >> 8) & 255u));
@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(256) k_sqrt_tables_init(uint8_t* dlog, u32* np
     Fe gam = Fq::konst(FqP::ROOT_POW2[24]);              // g^(2^24), order 256
     Fe p = Fq::one();
     for (int j = 0; j < tid; j++) p = Fq::mul(p, gam);
-    dlog[Fq::canon(p).l[0] & 0xffffu] = (uint8_t)tid;
+    dlog[Fq::to_plain(p).l[0] & 0xffffu] = (uint8_t)tid;
   } else if (tid < 256 + 1024) {
     const int i = (tid - 256) >> 8, k = (tid - 256) & 255;
     Fe base = Fq::konst(FqP::ROOT_OF_UNITY_INV);
@@ -218,8 +218,7 @@ __global__ void __launch_bounds__(256) k_small_order_cofactor(size_t n, const vo
 // batch_normalize (reference src/lib.rs:1084-1107, ff::BatchInverter): each lane owns CHUNK elements
 // (element j of lane t is index t + j*T, so every access is coalesced), multiplies their Z's through, inverts
 // once, and walks back.  Zero Z's are skipped like ff's BatchInverter (cannot occur for valid points).
-// mode 0: write affine 64 B; mode 1: write compressed 32 B (AffinePoint::to_bytes, src/lib.rs:455-464);
-// mode 2: write `ok`-style byte is_identity (U == 0 && V == Z) without inversion.
+// mode 0: write affine 64 B; any other mode: write compressed 32 B (AffinePoint::to_bytes, src/lib.rs:455-464).
 template <int CHUNK>
 __global__ void __launch_bounds__(256) k_normalize(size_t n, size_t T, SoA ext, SoA scratch, void* out, int mode) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -301,7 +300,7 @@ constexpr int ENIELS_WORDS = 4 * NL;   // 36 words = 144 B
 
 static JJ_DEV void store_eniels(u32* slot, const ENiels& n) {
   uint4* p = reinterpret_cast<uint4*>(slot);
-  const Fe* c[4] = {&n.vpu, &n.vmu, &n.z, &n.t2d};
+  const Fe* c[4] = {&n.vpu, &n.vmu, &n.z2, &n.t2d};
   u32 w[ENIELS_WORDS];
   _Pragma("unroll") for (int k = 0; k < 4; k++) _Pragma("unroll") for (int l = 0; l < NL; l++) w[k * NL + l] = c[k]->l[l];
   _Pragma("unroll") for (int v = 0; v < ENIELS_WORDS / 4; v++) p[v] = make_uint4(w[4 * v], w[4 * v + 1], w[4 * v + 2], w[4 * v + 3]);
@@ -311,7 +310,7 @@ static JJ_DEV ENiels load_eniels(const u32* slot) {
   u32 w[ENIELS_WORDS];
   _Pragma("unroll") for (int v = 0; v < ENIELS_WORDS / 4; v++) { const uint4 x = p[v]; w[4 * v] = x.x; w[4 * v + 1] = x.y; w[4 * v + 2] = x.z; w[4 * v + 3] = x.w; }
   ENiels n;
-  _Pragma("unroll") for (int l = 0; l < NL; l++) { n.vpu.l[l] = w[l]; n.vmu.l[l] = w[NL + l]; n.z.l[l] = w[2 * NL + l]; n.t2d.l[l] = w[3 * NL + l]; }
+  _Pragma("unroll") for (int l = 0; l < NL; l++) { n.vpu.l[l] = w[l]; n.vmu.l[l] = w[NL + l]; n.z2.l[l] = w[2 * NL + l]; n.t2d.l[l] = w[3 * NL + l]; }
   return n;
 }
 // recode: k' = (k & (2^252-1)) + sum_{i < NWIN-1} 2^(w i + w - 1); digit_i = window_i(k') - 2^(w-1), top window unsigned
@@ -345,7 +344,7 @@ static JJ_DEV Ext varbase_windowed(const Affine& P, u32 (&k)[8], u32* slot) {
   store_eniels(slot, Curve::to_niels(cur));
   #pragma unroll 1
   for (int j = 1; j < VB_TABLE; j++) {
-    cur = Curve::add(cur, pn);
+    cur = Curve::add<true>(cur, pn);
     store_eniels(slot + j * ENIELS_WORDS, Curve::to_niels(cur));
   }
   recode_signed(k);
@@ -474,7 +473,7 @@ __global__ void __launch_bounds__(512) k_fixedbase(size_t n, const void* scalars
     const ANiels idn = Curve::aniels_identity();
     Ext acc = Curve::identity();
     if ((chain & 1) && live) acc = soa_ext(ext, idx);
-    acc = Curve::add(acc, Curve::select(idn, lds_aniels(lds + (size_t)(FB_NWIN * FB_ENT) * ANIELS_WORDS), 0u - top));
+    acc = Curve::add<true>(acc, Curve::select(idn, lds_aniels(lds + (size_t)(FB_NWIN * FB_ENT) * ANIELS_WORDS), 0u - top));
     #pragma unroll 1
     for (int i = FB_NWIN - 1; i >= 0; i--) {
       const u32 nb = window6(k, i);                          // d + 32
@@ -493,7 +492,7 @@ __global__ void __launch_bounds__(512) k_fixedbase(size_t n, const void* scalars
       } else {
         e = lds_aniels(lds + ((size_t)i * FB_ENT + j) * ANIELS_WORDS);
       }
-      acc = Curve::add_signed(acc, Curve::select(e, idn, a == 0 ? ~0u : 0u), d < 0 ? ~0u : 0u);
+      acc = Curve::add_signed<true>(acc, Curve::select(e, idn, a == 0 ? ~0u : 0u), d < 0 ? ~0u : 0u);
     }
     if (live) {
       ext.put(0, idx, acc.u); ext.put(1, idx, acc.v); ext.put(2, idx, acc.z);
@@ -542,7 +541,7 @@ __global__ void __launch_bounds__(256) k_fixedbase_gather(size_t n, const void* 
         neg = d < 0; a = (u32)(d < 0 ? -d : d);
         e = lds_aniels(table + ((size_t)(i - 1) * fp.E + (a ? a - 1 : 0)) * GNIELS_WORDS);
       }
-      acc = Curve::add_signed(acc, s, smask);
+      acc = Curve::add_signed<true>(acc, s, smask);
     }
     ext.put(0, idx, acc.u); ext.put(1, idx, acc.v); ext.put(2, idx, acc.z);
     if (chain & 2) { ext.put(3, idx, Fq::carry(acc.t1)); ext.put(4, idx, Fq::carry(acc.t2)); }
@@ -554,8 +553,8 @@ __global__ void __launch_bounds__(256) k_affine_to_table(size_t n, const void* p
   if (i >= n) return;
   const ANiels t = Curve::to_niels(load_affine(pts, i));
   u32* e = table + i * (size_t)stride;
-  // canonical Montgomery limbs so the table is a deterministic function of the base point
-  const Fe a = Fq::canon(t.vpu), b = Fq::canon(t.vmu), c = Fq::canon(t.t2d);
+  // a deterministic function of the base point: v+u carried, v-u with signed limbs, t2d a product
+  const Fe a = t.vpu, b = t.vmu, c = t.t2d;
   _Pragma("unroll") for (int l = 0; l < NL; l++) { e[l] = a.l[l]; e[NL + l] = b.l[l]; e[2 * NL + l] = c.l[l]; }
   for (int l = 27; l < stride; l++) e[l] = 0;
 }
@@ -572,7 +571,7 @@ __global__ void __launch_bounds__(256) k_sum_pass(size_t n, size_t T, SoA in, So
     const size_t i = t + (size_t)j * T;
     if (i >= n) break;
     Ext e; e.u = in.get(0, i); e.v = in.get(1, i); e.z = in.get(2, i); e.t1 = in.get(3, i); e.t2 = in.get(4, i);
-    acc = Curve::add(acc, Curve::to_niels(e));
+    acc = Curve::add<true>(acc, Curve::to_niels(e));
   }
   out.put(0, t, acc.u); out.put(1, t, acc.v); out.put(2, t, acc.z); out.put(3, t, Fq::carry(acc.t1)); out.put(4, t, Fq::carry(acc.t2));
 }
@@ -879,18 +878,18 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(size_t nb, u32 chunk, co
   u32 nxt = offset[b + 1];
   while (nxt <= start) { b++; nxt = offset[b + 1]; }     // skip empty buckets that share the offset
   bool inherited = offset[b] < start;                       // first run continues a bucket begun in an earlier chunk
-  Ext acc = CurveNP::identity();
+  Ext acc = Curve::identity();
   bool any = false;
   #pragma unroll 1
   for (size_t pos = start; pos < end; pos++) {
     if (pos >= nxt) {
       if (inherited) { aos_put_ext(head, t, acc); inherited = false; } else if (any) aos_put_ext(buckets, b, acc);
-      acc = CurveNP::identity(); any = false;
+      acc = Curve::identity(); any = false;
       do { b++; nxt = offset[b + 1]; } while (nxt <= pos);
     }
     const u32 e = idx[pos];
     const ANiels p = lds_aniels(niels + (size_t)(e & 0x7fffffffu) * GNIELS_WORDS);
-    acc = CurveNP::add_signed(acc, p, (e >> 31) ? ~0u : 0u);
+    acc = Curve::add_signed<true>(acc, p, (e >> 31) ? ~0u : 0u);
     any = true;
   }
   if (inherited) aos_put_ext(head, t, acc); else aos_put_ext(buckets, b, acc);
@@ -920,7 +919,7 @@ __global__ void __launch_bounds__(256) k_msm_fixup(size_t nb, u32 chunk, const u
   acc = aos_ext(buckets, b);
   #pragma unroll 1
   for (size_t t = t_first; t <= t_last; t++) {
-    acc = Curve::add(acc, Curve::to_niels(aos_ext(head, t)));
+    acc = Curve::add<true>(acc, Curve::to_niels(aos_ext(head, t)));
   }
   aos_put_ext(buckets, b, acc);
 }
@@ -1002,13 +1001,13 @@ __global__ void __launch_bounds__(256) k_msm_accumulate_seg(const u32* nseg_tota
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= *nseg_total) return;
   const Seg sg = seg[t];
-  Ext acc = CurveNP::identity();
+  Ext acc = Curve::identity();
   const u32* ip = idx + sg.start;
   #pragma unroll 1
   for (u32 k = 0; k < sg.len; k++) {
     const u32 e = ip[k];
     const ANiels p = lds_aniels(niels + (size_t)(e & 0x7fffffffu) * GNIELS_WORDS);
-    acc = CurveNP::add_signed(acc, p, (e >> 31) ? ~0u : 0u);
+    acc = Curve::add_signed<true>(acc, p, (e >> 31) ? ~0u : 0u);
   }
   if (sg.dst >> 31) aos_put_ext(head, sg.dst & 0x7fffffffu, acc); else aos_put_ext(buckets, sg.dst, acc);
 }
@@ -1019,7 +1018,7 @@ __global__ void __launch_bounds__(256) k_msm_merge(const u32* counters, const Me
   const MergeItem it = merge[m];
   Ext acc = aos_ext(buckets, it.bucket);
   #pragma unroll 1
-  for (u32 j = 0; j < it.k; j++) acc = Curve::add(acc, Curve::to_niels(aos_ext(head, (size_t)it.h0 + j)));
+  for (u32 j = 0; j < it.k; j++) acc = Curve::add<true>(acc, Curve::to_niels(aos_ext(head, (size_t)it.h0 + j)));
   aos_put_ext(buckets, it.bucket, acc);
 }
 static JJ_DEV Ext soa_ext(const SoA& s, size_t i) { Ext e; e.u = s.get(0, i); e.v = s.get(1, i); e.z = s.get(2, i); e.t1 = s.get(3, i); e.t2 = s.get(4, i); return e; }
@@ -1027,7 +1026,7 @@ static JJ_DEV void soa_put_ext(const SoA& s, size_t i, const Ext& e) {
   s.put(0, i, e.u); s.put(1, i, e.v); s.put(2, i, e.z); s.put(3, i, Fq::carry(e.t1)); s.put(4, i, Fq::carry(e.t2));
 }
 // Latency-bound tails (bucket reduce, folds, big-bucket fix-up) are serial chains of point operations, and a lone
-// wave issues only one VALU instruction per ~9 cycles, so each point operation is spread over the four lanes of a quad: lane r squares {U, V, Z, U+V}[r], the four
+// wave issues only one VALU instruction per ~9 cycles, so each point operation is spread over the four lanes of a quad: lane r squares {U, V, Z, U-V}[r], the four
 // squares are broadcast inside the quad with DPP quad_perm moves, every lane forms the completed point, and lane r
 // multiplies one of (cu*ct, cv*cz, cz*ct).  Same formulas as Curve::dbl (reference src/lib.rs:739-828), ~2.4x fewer
 // instructions on the critical path.
@@ -1042,17 +1041,20 @@ static JJ_DEV Fe role_select4(const Fe& a0, const Fe& a1, const Fe& a2, const Fe
   r = Fq::select(r, a2, role == 2 ? ~0u : 0u);
   return Fq::select(r, a3, role == 3 ? ~0u : 0u);
 }
+// the doubling's completed point from the four squares UU, VV, ZZ, (U-V)^2 (same steps as Curve::dbl)
+static JJ_DEV void quad_dbl_completed(const Fe& sq, Fe& cu, Fe& vpu, Fe& vmu, Fe& ct) {
+  const Fe uu = quad_bcast<0>(sq), vv = quad_bcast<1>(sq), zz = quad_bcast<2>(sq), s = quad_bcast<3>(sq);
+  vpu = Fq::add(vv, uu);
+  vmu = Fq::sub(vv, uu);
+  cu = Fq::sub(vpu, s);                                   // 2UV
+  ct = Fq::carry(Fq::sub(Fq::add(zz, zz), vmu));          // 2Z^2 - (VV-UU)
+}
 static JJ_DEV Ext quad_dbl(const Ext& p, u32 role) {
-  const Fe sq = Fq::sqr(role_select4(p.u, p.v, p.z, Fq::add(p.u, p.v), role));
-  const Fe uu = quad_bcast<0>(sq), vv = quad_bcast<1>(sq), zz = quad_bcast<2>(sq), uv2 = quad_bcast<3>(sq);
-  const Fe vpu = Fq::add(vv, uu);
-  const Fe vmu = Fq::sub(vv, uu);
-  const Fe cu = Fq::sub_lazy(uv2, vpu);
-  const Fe ct = Fq::dbl_sub_wide(zz, vmu);
+  const Fe sq = Fq::sqr(role_select4(p.u, p.v, p.z, Fq::sub(p.u, p.v), role));
+  Fe cu, vpu, vmu, ct;
+  quad_dbl_completed(sq, cu, vpu, vmu, ct);
   // lane 0: cu*ct   lane 1: cv*cz   lane 2,3: cz*ct
-  const Fe a = role_select4(cu, vpu, vmu, vmu, role);
-  const Fe b = role_select4(ct, vmu, ct, ct, role);
-  const Fe pr = Fq::mul(a, b);
+  const Fe pr = Fq::mul(role_select4(cu, vpu, vmu, vmu, role), role_select4(ct, vmu, ct, ct, role));
   Ext r;
   r.u = quad_bcast<0>(pr); r.v = quad_bcast<1>(pr); r.z = quad_bcast<2>(pr); r.t1 = cu; r.t2 = vpu;
   return r;
@@ -1070,7 +1072,7 @@ static JJ_DEV Ext quad_add_ext(const Ext& p, const Ext& q, u32 role) {
   // round 3: c = 2d * ttp * ttq  (every lane)
   const Fe c = Fq::mul(tpq, Fq::konst(FqP::D2));
   const Fe d = Fq::add(zz, zz);
-  const Fe cu = Fq::sub_lazy(b, a), cv = Fq::add(b, a), cz = Fq::carry(Fq::add(d, c)), ct = Fq::sub(d, c);
+  const Fe cu = Fq::sub(b, a), cv = Fq::add(b, a), cz = Fq::carry(Fq::add(d, c)), ct = Fq::sub(d, c);
   // round 4: lane0 cu*ct, lane1 cv*cz, lane2/3 cz*ct
   const Fe r4 = Fq::mul(role_select4(cu, cv, cz, cz, role), role_select4(ct, cz, ct, ct, role));
   Ext r;
@@ -1080,45 +1082,38 @@ static JJ_DEV Ext quad_add_ext(const Ext& p, const Ext& q, u32 role) {
 // ---- quad variants that keep T = t1*t2 alongside the point, for adding table entries in two rounds
 // doubling; lane 3 multiplies carry(cu)*cv so the caller also gets T of the result
 static JJ_DEV Ext quad_dbl_t(const Ext& p, u32 role, Fe& T) {
-  const Fe sq = Fq::sqr(role_select4(p.u, p.v, p.z, Fq::add(p.u, p.v), role));
-  const Fe uu = quad_bcast<0>(sq), vv = quad_bcast<1>(sq), zz = quad_bcast<2>(sq), uv2 = quad_bcast<3>(sq);
-  const Fe vpu = Fq::add(vv, uu);
-  const Fe vmu = Fq::sub(vv, uu);
-  const Fe cu = Fq::sub_lazy(uv2, vpu);
-  const Fe ct = Fq::dbl_sub_wide(zz, vmu);
+  const Fe sq = Fq::sqr(role_select4(p.u, p.v, p.z, Fq::sub(p.u, p.v), role));
+  Fe cu, vpu, vmu, ct;
+  quad_dbl_completed(sq, cu, vpu, vmu, ct);
   const Fe pr = Fq::mul(role_select4(cu, vpu, vmu, Fq::carry(cu), role), role_select4(ct, vmu, ct, vpu, role));
   Ext r;
   r.u = quad_bcast<0>(pr); r.v = quad_bcast<1>(pr); r.z = quad_bcast<2>(pr); r.t1 = cu; r.t2 = vpu;
   T = quad_bcast<3>(pr);
   return r;
 }
-// p (+/-) n for an extended-Niels operand, given T = p.t1*p.t2 (reference src/lib.rs:883-940): round 1 a, b, c = T*t2d,
-// zz on the four lanes; round 2 U, V, Z, T.  neg selects the subtraction formula (swap v+u / v-u, swap d+c / d-c).
-static JJ_DEV Ext quad_add_eniels(const Ext& p, const Fe& T, const ENiels& n, u32 neg, u32 role, Fe& Tout) {
-  const u32 nm = neg ? ~0u : 0u;
-  const Fe fa = Fq::select(n.vmu, n.vpu, nm), fb = Fq::select(n.vpu, n.vmu, nm);
-  const Fe r1 = Fq::mul(role_select4(Fq::sub(p.v, p.u), Fq::add(p.v, p.u), T, p.z, role), role_select4(fa, fb, n.t2d, n.z, role));
-  const Fe a = quad_bcast<0>(r1), b = quad_bcast<1>(r1), c = quad_bcast<2>(r1), zz = quad_bcast<3>(r1);
-  const Fe d = Fq::add(zz, zz);
-  const Fe plus = Fq::carry(Fq::add(d, c)), minus = Fq::sub(d, c);
-  const Fe cu = Fq::sub_lazy(b, a), cv = Fq::add(b, a), cz = Fq::select(plus, minus, nm), ct = Fq::select(minus, plus, nm);
-  const Fe r2 = Fq::mul(role_select4(cu, cv, cz, Fq::carry(cu), role), role_select4(ct, cz, ct, cv, role));
+// shared second half of the quad additions: a, b, c, d -> result and its T (lane 3: cu*cv; cu = b - a is small)
+static JJ_DEV Ext quad_add_finish(const Fe& a, const Fe& b, const Fe& c, const Fe& d, u32 role, Fe& Tout) {
+  const Fe cu = Fq::sub(b, a), cv = Fq::add(b, a), cz = Fq::carry(Fq::add(d, c)), ct = Fq::sub(d, c);
+  const Fe r2 = Fq::mul(role_select4(cu, cv, cz, cu, role), role_select4(ct, cz, ct, cv, role));
   Ext r;
   r.u = quad_bcast<0>(r2); r.v = quad_bcast<1>(r2); r.z = quad_bcast<2>(r2); r.t1 = cu; r.t2 = cv;
   Tout = quad_bcast<3>(r2);
   return r;
 }
+// p (+/-) n for an extended-Niels operand, given T = p.t1*p.t2 (reference src/lib.rs:883-940): round 1 a, b, c = T*t2d,
+// d = Z*2Z' on the four lanes; round 2 U, V, Z, T.  neg selects the subtraction formula (swap v+u / v-u, negate c).
+static JJ_DEV Ext quad_add_eniels(const Ext& p, const Fe& T, const ENiels& n, u32 neg, u32 role, Fe& Tout) {
+  const u32 nm = neg ? ~0u : 0u;
+  const Fe fa = Fq::select(n.vmu, n.vpu, nm), fb = Fq::select(n.vpu, n.vmu, nm);
+  const Fe r1 = Fq::mul(role_select4(Fq::sub(p.v, p.u), Fq::add(p.v, p.u), T, p.z, role), role_select4(fa, fb, n.t2d, n.z2, role));
+  const Fe a = quad_bcast<0>(r1), b = quad_bcast<1>(r1), c = Fq::cneg(quad_bcast<2>(r1), nm), d = quad_bcast<3>(r1);
+  return quad_add_finish(a, b, c, d, role, Tout);
+}
 // p + n for an affine-Niels operand (Z2 = 1: d = 2 Z1; reference src/lib.rs:944-968)
 static JJ_DEV Ext quad_add_aniels(const Ext& p, const Fe& T, const ANiels& n, u32 role, Fe& Tout) {
   const Fe r1 = Fq::mul(role_select4(Fq::sub(p.v, p.u), Fq::add(p.v, p.u), T, T, role), role_select4(n.vmu, n.vpu, n.t2d, n.t2d, role));
   const Fe a = quad_bcast<0>(r1), b = quad_bcast<1>(r1), c = quad_bcast<2>(r1);
-  const Fe d = Fq::add(p.z, p.z);
-  const Fe cu = Fq::sub_lazy(b, a), cv = Fq::add(b, a), cz = Fq::carry(Fq::add(d, c)), ct = Fq::sub(d, c);
-  const Fe r2 = Fq::mul(role_select4(cu, cv, cz, Fq::carry(cu), role), role_select4(ct, cz, ct, cv, role));
-  Ext r;
-  r.u = quad_bcast<0>(r2); r.v = quad_bcast<1>(r2); r.z = quad_bcast<2>(r2); r.t1 = cu; r.t2 = cv;
-  Tout = quad_bcast<3>(r2);
-  return r;
+  return quad_add_finish(a, b, c, Fq::add(p.z, p.z), role, Tout);
 }
 // Extended + Extended with both T = t1*t2 known: round 1 a, b, T1*T2, Z1*Z2; round 2 c = 2d*T1*T2 (lane 0 used; lane 1
 // does a side product sa*sb for the caller, typically T of the NEXT operand); round 3 U, V, Z, T.  Three rounds
@@ -1131,13 +1126,7 @@ static JJ_DEV Ext quad_add_ext_t(const Ext& p, const Fe& Tp, const Ext& q, const
   const Fe r2 = Fq::mul(role_select4(tt, sa, tt, tt, role), role_select4(Fq::konst(FqP::D2), sb, Fq::konst(FqP::D2), Fq::konst(FqP::D2), role));
   const Fe c = quad_bcast<0>(r2);
   sout = quad_bcast<1>(r2);
-  const Fe d = Fq::add(zz, zz);
-  const Fe cu = Fq::sub_lazy(b, a), cv = Fq::add(b, a), cz = Fq::carry(Fq::add(d, c)), ct = Fq::sub(d, c);
-  const Fe r3 = Fq::mul(role_select4(cu, cv, cz, Fq::carry(cu), role), role_select4(ct, cz, ct, cv, role));
-  Ext r;
-  r.u = quad_bcast<0>(r3); r.v = quad_bcast<1>(r3); r.z = quad_bcast<2>(r3); r.t1 = cu; r.t2 = cv;
-  Tout = quad_bcast<3>(r3);
-  return r;
+  return quad_add_finish(a, b, c, Fq::add(zz, zz), role, Tout);
 }
 // Small batches: one scalar multiplication per quad of lanes.  Same signed-window ladder and table as
 // varbase_windowed, but every point operation is two multiplication rounds on four lanes (12 rounds per 5-bit window
@@ -1148,12 +1137,12 @@ static JJ_DEV Ext varbase_windowed_quad(const Affine& P, u32 (&k)[8], u32* slot,
   Ext cur = Curve::from_affine(P);
   Fe T = Fq::mul(P.u, P.v);
   ENiels en;
-  en.vpu = pn.vpu; en.vmu = pn.vmu; en.z = Fq::one(); en.t2d = pn.t2d;
+  en.vpu = pn.vpu; en.vmu = pn.vmu; en.z2 = Fq::add(Fq::one(), Fq::one()); en.t2d = pn.t2d;
   store_eniels(slot, en);
   #pragma unroll 1
   for (int j = 1; j < VB_TABLE; j++) {
     cur = quad_add_aniels(cur, T, pn, role, T);
-    en.vpu = Fq::carry(Fq::add(cur.v, cur.u)); en.vmu = Fq::sub(cur.v, cur.u); en.z = cur.z;
+    en.vpu = Fq::carry(Fq::add(cur.v, cur.u)); en.vmu = Fq::sub(cur.v, cur.u); en.z2 = Fq::add(cur.z, cur.z);
     en.t2d = Fq::mul(T, Fq::konst(FqP::D2));
     store_eniels(slot + j * ENIELS_WORDS, en);
   }

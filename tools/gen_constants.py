@@ -26,6 +26,17 @@ def arr(name, vals, ty="u32"):
     return "  static constexpr %s %s[%d] = {%s};\n" % (ty, name, len(vals), body)
 
 
+def signed_digits(x):
+    """x (any sign) as 9 digits: limbs 0..7 in [0, 2^29), top limb signed (two's complement u32)."""
+    out = []
+    for _ in range(NL - 1):
+        out.append(x & MASK)
+        x >>= LB          # floor (arithmetic) shift
+    assert -(1 << 31) <= x < (1 << 31)
+    out.append(x & 0xFFFFFFFF)
+    return out
+
+
 def bias(p, K, s):
     """K*p written with limbs 0..7 in [2^s, 2^s + 2^29) (borrowing 2^(s-29) from the next limb):
     same VALUE K*p, but every low limb is >= 2^s so that a + bias - b never underflows limb-wise
@@ -58,10 +69,7 @@ def field_block(name, p, extra=""):
     s += arr("ONE", limbs(MONT % p))  # R mod p  (Montgomery 1)
     s += arr("R2", limbs((MONT * MONT) % p))  # to-Montgomery multiplier
     s += arr("R2_256", limbs(((1 << 256) * MONT * MONT) % p))  # converts hi half of a 512-bit value: x*2^256 -> Montgomery
-    # biases: K*p with lifted limbs (see bias()); SUB_N: subtrahend limbs < 2^29+2^6 value < 2.x p ; SUB_L: limbs < 2^30+2^7, value < 4.x p
-    s += arr("BIAS_N", bias(p, 3, 30))   # low limbs >= 2^30  (covers subtrahend limbs up to 2^30)
-    s += arr("BIAS_L", bias(p, 5, 31))   # low limbs >= 2^31  (covers subtrahend limbs up to 2^31)
-    s += "  static constexpr int BIAS_N_K = 3, BIAS_L_K = 5;\n"
+    s += arr("NEGP_DIGITS", signed_digits(-p))   # -p as the digits a Montgomery product emits (limbs 0..7 in [0, 2^29), signed top limb)
     s += arr("PM2", words32(p - 2, 8))  # exponent for inversion
     s += "  static constexpr int PBITS = %d;\n" % p.bit_length()
     s += extra
