@@ -38,7 +38,7 @@ struct jj_ctx {
   int cus = 0, clock_khz = 0, wave = 64;
   std::string err;
   // staging for host-pointer arguments (inputs 0..3, outputs 0..1) and kernel workspaces
-  DevBuf in[4], out[2], okb, ws_ext, msm_seg, ws_scratch, ws_tables, ws_tmp[4], msm[8], sqrt_tabs;
+  DevBuf in[4], out[2], okb, ws_ext, msm_seg, ws_scratch, ws_tables, ws_tmp[4], msm[8], sqrt_tabs, cursor;
   SqrtTables sqrt_tables{nullptr, nullptr};
   int msm_window = 0;            // 0 = choose from n (JJ_MSM_WINDOW overrides; 8..16)
   int msm_segments = -1;         // bucket accumulation: 1 = length-sorted segments, 0 = fixed chunks + fix-up, -1 = segments from 2^19 terms
@@ -63,7 +63,7 @@ struct jj_ctx {
   bool fb_const_time = true;     // fixed-base window select: true = lane-staged + ds_bpermute shuffle, false = per-lane LDS gather
   int vb_quad_max = 32768;       // batches up to this size run one scalar-mul per quad of lanes (JJ_VB_QUAD_MAX; 0 = never)
   int fb_gather_blocks_per_cu = 3;   // wide-window fixed-base kernel: resident blocks of 256 per CU (JJ_FB_GATHER_BLOCKS_PER_CU)
-  int vb_blocks_per_cu = 3;      // var-base ladder: 3 resident blocks of 256 per CU (156 VGPRs); measured 2 % faster than 2 with the pinned products
+  int vb_blocks_per_cu = 2;      // var-base ladder: resident blocks of 256 per CU (the ladder holds ~190 VGPRs: 2 waves per SIMD); JJ_VB_BLOCKS_PER_CU
   bool profile = false;
   struct Rec { hipEvent_t e0, e1, e2; };
   std::vector<Rec> recs;
@@ -310,7 +310,7 @@ JJ_API int jj_ctx_destroy(jj_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   DevBuf* all[] = {&c->in[0], &c->in[1], &c->in[2], &c->in[3], &c->out[0], &c->out[1], &c->okb, &c->ws_ext, &c->msm_seg, &c->ws_scratch, &c->ws_tables,
                    &c->ws_tmp[0], &c->ws_tmp[1], &c->ws_tmp[2], &c->ws_tmp[3], &c->msm[0], &c->msm[1], &c->msm[2], &c->msm[3],
-                   &c->msm[4], &c->msm[5], &c->msm[6], &c->msm[7], &c->sqrt_tabs};
+                   &c->msm[4], &c->msm[5], &c->msm[6], &c->msm[7], &c->sqrt_tabs, &c->cursor};
   for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
   if (c->tail_host) (void)hipHostFree(c->tail_host);
   if (c->pipe.ready) {
@@ -509,8 +509,10 @@ static int varbase_to_ext(jj_ctx* c, size_t n, const void* ds, const void* dp, S
   unsigned blocks; size_t threads;
   varbase_geometry(c, n, &blocks, &threads);
   int rc = ensure(c, c->ws_tables, threads * (size_t)(VB_TABLE * ENIELS_WORDS) * 4); if (rc) return rc;
-  if (five) hipLaunchKernelGGL(k_varbase5, dim3(blocks), dim3(256), 0, c->stream, n, ds, dp, (u32*)c->ws_tables.p, ext);
-  else hipLaunchKernelGGL(k_varbase, dim3(blocks), dim3(256), 0, c->stream, n, ds, dp, (u32*)c->ws_tables.p, ext);
+  if ((rc = ensure(c, c->cursor, 64))) return rc;
+  HIPCHK(c, hipMemsetAsync(c->cursor.p, 0, 8, c->stream));          // the waves' work cursor
+  if (five) hipLaunchKernelGGL(k_varbase<true>, dim3(blocks), dim3(256), 0, c->stream, n, ds, dp, (u32*)c->ws_tables.p, ext, (unsigned long long*)c->cursor.p);
+  else hipLaunchKernelGGL(k_varbase<false>, dim3(blocks), dim3(256), 0, c->stream, n, ds, dp, (u32*)c->ws_tables.p, ext, (unsigned long long*)c->cursor.p);
   return JJ_OK;
 }
 static int varbase_api(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out, int mode) {

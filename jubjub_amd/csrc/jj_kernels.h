@@ -57,10 +57,13 @@ static JJ_DEV Fe fr_sqrt(const Fe& a, bool& ok) {
 // ---- Fq square root: the value ff::helpers::sqrt_tonelli_shanks returns (bls12_381 0.8.0 Scalar::sqrt, S = 32,
 // ROOT_OF_UNITY = 7^t; call sites reference src/lib.rs:515,610,1253), computed by a 4 x 8-bit Pohlig-Hellman discrete
 // log in the 2^32-torsion instead of Tonelli-Shanks' ~500 data-dependent squarings.  With g = ROOT_OF_UNITY, b = a^t = g^e; the digits e_i come from a 64 KiB direct table
-// keyed by the 16 low bits of the canonical integer b_i^(2^(24-8i)); Tonelli-Shanks' answer is x = a^((t+1)/2) * g^s with
+// keyed by 16 bits (limb SQRT_KEY_LIMB) of the canonical integer b_i^(2^(24-8i)); Tonelli-Shanks' answer is x = a^((t+1)/2) * g^s with
 // s = ((2^32 - e) mod 2^32) / 2, i.e. x for e = 0 and -(x * g^(-e/2)) otherwise.
+// the 256 values (g^(2^24))^k are told apart by 16 bits of their canonical integer: bits [0, 16) of limb 3 (bits 87..102) are
+// collision-free (limb 0 is not: 254 distinct keys); tests/test_bounds.py::test_sqrt_dlog_key_is_collision_free
+constexpr int SQRT_KEY_LIMB = 3;
 struct SqrtTables {
-  const uint8_t* dlog;   // [65536]  key16 -> k   with key16 = low 16 bits of the canonical integer (g^(2^24))^k
+  const uint8_t* dlog;   // [65536]  key16 -> k   with key16 = 16 bits (limb SQRT_KEY_LIMB) of the canonical integer (g^(2^24))^k
   const u32* npow;       // [4][256][NL]  g^(-k * 2^(8i))
 };
 static JJ_DEV Fe sqrt_tab(const SqrtTables& T, int i, u32 k) {
@@ -82,10 +85,10 @@ static JJ_DEV Fe fq_sqrt_fast(const Fe& a, bool& ok, const SqrtTables& T) {
   Fe c3 = c2;
   #pragma unroll 1
   for (int s = 0; s < 8; s++) c3 = Fq::sqr(c3);
-  const u32 e0 = T.dlog[Fq::to_plain(c3).l[0] & 0xffffu];
-  const u32 e1 = T.dlog[Fq::to_plain(Fq::mul(c2, sqrt_tab(T, 2, e0))).l[0] & 0xffffu];
-  const u32 e2 = T.dlog[Fq::to_plain(Fq::mul(Fq::mul(c1, sqrt_tab(T, 1, e0)), sqrt_tab(T, 2, e1))).l[0] & 0xffffu];
-  const u32 e3 = T.dlog[Fq::to_plain(Fq::mul(Fq::mul(b, sqrt_tab(T, 0, e0)), Fq::mul(sqrt_tab(T, 1, e1), sqrt_tab(T, 2, e2)))).l[0] & 0xffffu];
+  const u32 e0 = T.dlog[Fq::to_plain(c3).l[SQRT_KEY_LIMB] & 0xffffu];
+  const u32 e1 = T.dlog[Fq::to_plain(Fq::mul(c2, sqrt_tab(T, 2, e0))).l[SQRT_KEY_LIMB] & 0xffffu];
+  const u32 e2 = T.dlog[Fq::to_plain(Fq::mul(Fq::mul(c1, sqrt_tab(T, 1, e0)), sqrt_tab(T, 2, e1))).l[SQRT_KEY_LIMB] & 0xffffu];
+  const u32 e3 = T.dlog[Fq::to_plain(Fq::mul(Fq::mul(b, sqrt_tab(T, 0, e0)), Fq::mul(sqrt_tab(T, 1, e1), sqrt_tab(T, 2, e2)))).l[SQRT_KEY_LIMB] & 0xffffu];
   const u32 e = e0 | (e1 << 8) | (e2 << 16) | (e3 << 24);
   const u32 h = e >> 1;
   Fe z = Fq::mul(sqrt_tab(T, 0, h & 255u), sqrt_tab(T, 1, (h >> 8) & 255u));
@@ -101,7 +104,7 @@ __global__ void __launch_bounds__(256) k_sqrt_tables_init(uint8_t* dlog, u32* np
     Fe gam = Fq::konst(FqP::ROOT_POW2[24]);              // g^(2^24), order 256
     Fe p = Fq::one();
     for (int j = 0; j < tid; j++) p = Fq::mul(p, gam);
-    dlog[Fq::to_plain(p).l[0] & 0xffffu] = (uint8_t)tid;
+    dlog[Fq::to_plain(p).l[SQRT_KEY_LIMB] & 0xffffu] = (uint8_t)tid;
   } else if (tid < 256 + 1024) {
     const int i = (tid - 256) >> 8, k = (tid - 256) & 255;
     Fe base = Fq::konst(FqP::ROOT_OF_UNITY_INV);
@@ -370,18 +373,31 @@ static JJ_DEV Ext varbase_windowed(const Affine& P, u32 (&k)[8], u32* slot) {
   return acc;
 }
 
-// grid-stride over scalars; each thread owns one table slot
-__global__ void __launch_bounds__(256, JJ_VB_MINWAVES) k_varbase(size_t n, const void* scalars, const void* points, u32* tables, SoA ext) {
+// Persistent grid, each thread owns one table slot; waves draw their next 64 units from a global cursor (one atomic per
+// wave and ladder), so the batch needs no particular relation to the grid size (a static grid-stride split of 2^20 units
+// over 196 608 lanes leaves a third of them with 6 ladders and the rest with 5).
+static JJ_DEV bool next_wave_units(unsigned long long* cursor, size_t n, size_t& i) {
+  unsigned long long base = 0;
+  if ((threadIdx.x & 63u) == 0) base = atomicAdd(cursor, 64ull);
+  const u32 lo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)base), hi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(base >> 32));
+  base = ((unsigned long long)hi << 32) | lo;
+  i = (size_t)base + (threadIdx.x & 63u);
+  return base < n;
+}
+template <bool FIVE>
+__global__ void __launch_bounds__(256, JJ_VB_MINWAVES) k_varbase(size_t n, const void* scalars, const void* points, u32* tables, SoA ext, unsigned long long* cursor) {
   const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t T = (size_t)gridDim.x * blockDim.x;
   u32* slot = tables + gtid * (size_t)(VB_TABLE * ENIELS_WORDS);
+  size_t i;
   #pragma unroll 1
-  for (size_t i = gtid; i < n; i += T) {
+  while (next_wave_units(cursor, n, i)) {
+    if (i >= n) continue;                                     // ragged last wave: idle lanes wait for their neighbours
     u32 k[8];
     load8(k, scalars, i);
     const Affine P = load_affine(points, i);
     const Ext r = varbase_windowed(P, k, slot);
     ext.put(0, i, r.u); ext.put(1, i, r.v); ext.put(2, i, r.z);
+    if constexpr (FIVE) { ext.put(3, i, Fq::carry(r.t1)); ext.put(4, i, Fq::carry(r.t2)); }
   }
 }
 // the reference's exact ladder; writes all five projective coordinates canonically (160 B)
@@ -581,21 +597,6 @@ __global__ void __launch_bounds__(256) k_affine_to_soa5(size_t n, const void* pt
   const Affine a = load_affine(pts, i);
   ext.put(0, i, a.u); ext.put(1, i, a.v); ext.put(2, i, Fq::one()); ext.put(3, i, a.u); ext.put(4, i, a.v);
 }
-// varbase writing all five coordinates (MSM terms)
-__global__ void __launch_bounds__(256) k_varbase5(size_t n, const void* scalars, const void* points, u32* tables, SoA ext) {
-  const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t T = (size_t)gridDim.x * blockDim.x;
-  u32* slot = tables + gtid * (size_t)(VB_TABLE * ENIELS_WORDS);
-  #pragma unroll 1
-  for (size_t i = gtid; i < n; i += T) {
-    u32 k[8];
-    load8(k, scalars, i);
-    const Affine P = load_affine(points, i);
-    const Ext r = varbase_windowed(P, k, slot);
-    ext.put(0, i, r.u); ext.put(1, i, r.v); ext.put(2, i, r.z); ext.put(3, i, Fq::carry(r.t1)); ext.put(4, i, Fq::carry(r.t2));
-  }
-}
-
 // ------------------------------------------------------------------------------------------------ K6: decompress
 // AffinePoint::from_bytes_inner / batch_from_bytes (reference src/lib.rs:492-534, 541-627): u^2 = (v^2-1)/(1+d v^2).
 // Like batch_from_bytes the denominators share one inversion: each lane owns CHUNK strided encodings, multiplies

@@ -189,6 +189,7 @@ def main():
     out += field_block("FrP", R, fr_extra)
     out += "// r (scalar field modulus) as 32 little-endian bytes = FR_MODULUS_BYTES (reference src/lib.rs:73-76)\n"
     out += "constexpr uint8_t FR_MODULUS_BYTES[32] = {" + ", ".join(str(b) for b in R.to_bytes(32, "little")) + "};\n"
+    out += "constexpr u32 FR_MODULUS_W[8] = {" + ", ".join("0x%08xu" % v for v in words32(R, 8)) + "};\n"
     out += "// generator (reference src/lib.rs:1380-1396), canonical 32-bit words\n"
     out += "constexpr u32 GEN_U_W[8] = {" + ", ".join("0x%08xu" % v for v in words32(gen_u, 8)) + "};\n"
     out += "constexpr u32 GEN_V_W[8] = {11u, 0, 0, 0, 0, 0, 0, 0};\n"
