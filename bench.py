@@ -2,27 +2,43 @@
 """
 bench.py — headline benchmark of the MI355X Jubjub engine (BASELINE.json metric: Jubjub scalar-muls/sec).
 
-  python bench.py --gpus N --steps K --warmup W [--workload varbase|fixedbase|msm|decompress] [--log2n L]
+  python bench.py --gpus N --steps K --warmup W [--workload varbase|fixedbase|msm|decompress] [--log2n L] [--scaling weak|strong]
 
-One "step" = one pass of the hot path over one batch of synthetic inputs already resident in HBM.
-N = 1 default workload: BASELINE.json configs[1] — 2^20 variable-base scalar-muls (random 252-bit scalars x random
-curve points).  N > 1: one process per GPU (launched by torch.distributed.run), every rank runs the same batch
-size on its own shard (weak scaling, no data-path collective for the independent-batch workloads; the MSM
-workload all-gathers one 64-byte partial point per rank over RCCL).  Rank 0 prints ONE JSON line.
+One "step" = PASSES back-to-back passes of the hot path over one batch of synthetic inputs already resident in HBM (the
+pass count per workload is fixed below and reported in `config`, it only makes the timed region long enough for the
+clocks to settle; `value` is units per second either way).
+N = 1 default workload: BASELINE.json configs[1] — 2^20 variable-base scalar-muls (random Fr x random curve points).
+N > 1: one process per GPU.  When this script is started WITHOUT a launcher (no WORLD_SIZE in the environment) it spawns
+the N ranks itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT) and relays rank 0's single JSON
+line; under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` it uses the ranks it is given.
+--scaling weak   : every rank runs 2^log2n units (independent shards, no data-path collective; the MSM workload all-gathers
+                   one 64-byte partial point per rank over RCCL and folds them on every rank).
+--scaling strong : 2^log2n units IN TOTAL, cut into contiguous shards (BASELINE configs[3]: 2^20-term MSM over 8 GPUs;
+                   configs[4]: 2^26 encodings over 8 GPUs with --log2n 26).
+Rank 0 prints ONE JSON line.
+
+Inputs come from the library's counter-based generators (jj_synth_scalars / jj_random_points: Group::random semantics,
+reference src/lib.rs:1244-1267, over splitmix64 streams indexed by the GLOBAL unit index), so any rank — and the host-side
+checker — can reproduce any unit without moving data.
 
 The JSON carries:
-  roofline     integer-VALU roofline of the dominant kernel (this path is carry-free integer multiply-add work,
-               not HBM- or MFMA-bound): achieved = algorithmic IMAD32/s with the SURVEY §8(d) convention
-               (field mul = 128, square = 100 IMAD32) for the algorithm the kernel actually runs, divided by the
-               kernel's HIP-event duration; peak = v_mad_u64_u32 rate measured live on this device
-               (jj_peak_imad32).  `hbm` gives the algorithmic HBM bytes/s beside the 8 TB/s peak to show the
-               kernel is not memory-limited.
-  cpu_baseline the oracle's C port of the reference algorithm (exact 252-step ladder, 4x64 Montgomery limbs)
-               timed with OpenMP on this box's host cores on a bounded sample.
+  roofline     integer-VALU roofline of the dominant kernel (this path is carry-free integer multiply-add work, not HBM- or
+               MFMA-bound): achieved = algorithmic IMAD32/s with the SURVEY §8(d) convention (field mul = 128, square = 100
+               IMAD32) for the field operations THAT KERNEL runs, divided by that kernel's HIP-event duration; peak =
+               v_mad_u64_u32 rate measured live on this device (jj_peak_imad32).  `hbm` gives the algorithmic HBM bytes/s
+               beside the 8 TB/s peak; `traffic` the PMC-measured fabric bytes per launch from profiles/traffic.json when
+               that file was collected for exactly this build of the kernels (source hash), else null.
+  verified     a strided sample of the LAST timed output (every 2^10-th unit of rank 0's shard, plus the injected edge
+               encodings for the decoder) recomputed by the oracle from the unit indices: true / false.
+  cpu_baseline the oracle's C port of the reference algorithm (exact 252-step ladder, 4x64 Montgomery limbs) timed on this
+               box's host cores on a bounded sample: one thread and all cores, CPU model stated (N = 1 only).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,31 +46,39 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+SEED = 0x4A55424A5542
+POINT_SEED = SEED ^ 0x9E3779B97F4A7C15
+RAW_SEED = SEED ^ 0x5DEECE66D
 
-# Field-operation counts of the algorithms the kernels actually run, per unit.
+# Field-operation counts of the algorithms the kernels actually run, per unit, split into the dominant
+# kernel ("main": what roofline.kernel_ms times) and the normalisation tail that follows it.
 # IMAD32 convention: M = 128, S = 100.
 WORK = {
-    # signed 5-bit windows: table {1..16}P 139M (15 mixed adds + 17 to_niels); 51 adds x 8M; 250 dbl x (4S+3M); load 2M;
-    # normalise 7M + (255S+78M)/32 inversion share
-    "varbase": {"S": 250 * 4 + 8, "M": 139 + 51 * 8 + 250 * 3 + 2 + 7 + 3, "bytes": 32 + 64 + 64},
-    # 43 mixed adds x 7M ; normalise as above
-    "fixedbase": {"S": 8, "M": 43 * 7 + 7 + 3, "bytes": 32 + 64},
+    # k_varbase: 2 from_words + to_niels(P) 2M; table {1..16}P: to_niels 2M + 15 x (mixed add 7M + to_niels 2M);
+    # 51 additions x 8M; 250 doublings x (4S + 3M).   tail k_normalize<32>: ~9M + (255S + 75M)/32 per unit
+    "varbase": {"S": 1000, "M": 2 + 2 + 2 + 15 * 9 + 51 * 8 + 250 * 3, "tail_S": 8, "tail_M": 11, "bytes": 32 + 64 + 64},
+    # k_fixedbase: 43 mixed additions x 7M
+    "fixedbase": {"S": 0, "M": 43 * 7, "tail_S": 8, "tail_M": 11, "bytes": 32 + 64},
     # Pippenger, c = 16: per term 2M load + 2M to_niels + 16 windows x 7M mixed add; bucket reduce 2 x 10M per bucket
     # (16 x 2^15 buckets / 2^20 terms -> +10M); the 240-doubling Horner tail is per MSM (on the host), not per term
-    "msm": {"S": 0, "M": 2 + 2 + 16 * 7 + 10, "bytes": 32 + 64},
-    # decode kernel only (roofline.kernel_ms is k_decompress; the flag kernels run after it and show up in tail_ms):
-    # two decode passes (2 x (1M + 1S + 1M)), shared inversion (3M + (253S+61M)/32), u^2 1M,
-    # sqrt = a^((t-1)/2) (220S + 52M, sliding windows) + 2M + 24S + 6M digit extraction + 4 canon + 4M table multiplies
-    # + verify (1S + 2M), 3 to_words
-    "decompress": {"S": 2 + 8 + 220 + 24 + 1, "M": 4 + 3 + 2 + 1 + 52 + 2 + 6 + 4 + 4 + 2 + 3, "bytes": 32 + 65},
+    "msm": {"S": 0, "M": 2 + 2 + 16 * 7 + 10, "tail_S": 0, "tail_M": 0, "bytes": 32 + 64},
+    # k_decompress (the flag kernels run after it and show up in tail_ms): two decode passes (2 x (1M + 1S + 1M)), shared
+    # inversion (3M + (253S+61M)/32), u^2 1M, sqrt = a^((t-1)/2) (220S + 52M, sliding windows) + 2M + 24S + 6M digit
+    # extraction + 4 canonical forms + 4M table multiplies + verify (1S + 2M), 3 to_words
+    "decompress": {"S": 2 + 8 + 220 + 24 + 1, "M": 4 + 3 + 2 + 1 + 52 + 2 + 6 + 4 + 4 + 2 + 3, "tail_S": 0, "tail_M": 0, "bytes": 32 + 65},
 }
-# the reference's own algorithm for comparison in the JSON
+REFERENCE_WORK = {"varbase": {"S": 1008, "M": 2774}, "fixedbase": {"S": 1008, "M": 2520}}   # the reference's own ladders
+PASSES = {"varbase": 4, "fixedbase": 2, "msm": 32, "decompress": 4}       # passes per step: >= ~50 ms of kernels per step
+DEFAULT_LOG2N = {"varbase": 20, "fixedbase": 24, "msm": 20, "decompress": 23}
+UNIT = {"varbase": "scalar-muls/s", "fixedbase": "scalar-muls/s", "msm": "terms/s", "decompress": "points/s"}
 GEN_U = 0x62EDCBB8BF3787C88B0F03DDD60A8187CAF55D1B29BF81AFE4B3D35DF1A7ADFE   # generator (u, 11), reference src/lib.rs:1380-1396
-REFERENCE_WORK = {"varbase": {"S": 1008, "M": 2774}, "fixedbase": {"S": 1008, "M": 2520}}
+SAMPLE_STRIDE = 1 << 10
+# edge encodings injected into the decoder's input at fixed global indices: (index, kind)
+INJECT_FIRST, INJECT_STEP = 1000, 4096
 
 
-def imad32(w):
-    return 100 * w["S"] + 128 * w["M"]
+def imad32(s, m):
+    return 100 * s + 128 * m
 
 
 def parse():
@@ -63,32 +87,159 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="varbase", choices=sorted(WORK))
-    ap.add_argument("--log2n", type=int, default=None, help="log2 of the per-GPU batch (default: 20 varbase/msm, 24 fixedbase, 23 decompress = 2^26 over 8 GPUs)")
+    ap.add_argument("--log2n", type=int, default=None, help="log2 of the batch: per GPU (weak) or in total (strong); default 20 varbase/msm, 24 fixedbase, 23 decompress")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--passes", type=int, default=0, help="passes per step (default: per workload, see PASSES)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="varbase workload: skip the fixed-base side measurements (clean per-kernel profiles)")
-    ap.add_argument("--fb-window", type=int, default=0, help="fixed-base window bits: 0/6 = LDS-staged constant-time table (default), 8..12 = L2-resident table")
+    ap.add_argument("--fb-window", type=int, default=0, help="fixed-base window bits: 0/6 = LDS-staged constant-time table (default), 8..16 = table gathered from L2 / Infinity Cache")
     ap.add_argument("--decompress-flags", type=int, default=13,
                     help="jj_decompress flags: 1 ZIP-216 | 2 torsion-free (order-8 Tate pairing; JJ_TORSION_CHECK=ladder for the [r]P ladder) | 4 reject small order | 8 clear cofactor (default 13 = BASELINE config 5: decode + small-order check + mul_by_cofactor)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for plumbing tests)")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target wall time of the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target wall time of each CPU baseline sample")
     return ap.parse_args()
 
 
-def cpu_baseline(workload, target_s):
-    """Times the oracle's C port of the reference algorithm on the host cores (reported baseline, not a target)."""
+# ------------------------------------------------------------------------------------------------ self-launch
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) and relay rank 0's line."""
+    import torch
+
+    ndev = torch.cuda.device_count()
+    if ndev < a.gpus and "JJ_BENCH_FORCE_DEVICE" not in os.environ:
+        print("bench.py: --gpus %d but only %d device(s) visible; refusing to report a smaller run as n_gpus=%d "
+              "(set JJ_BENCH_FORCE_DEVICE=0 to stack the ranks on one GPU for a plumbing check)" % (a.gpus, ndev, a.gpus), file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+# ------------------------------------------------------------------------------------------------ traffic (PMC) record
+def build_id():
+    """hash of the kernel sources: profiles/traffic.json is only valid for the build it was collected on"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "jubjub_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def traffic_record(workload, log2n):
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        rec = json.load(open(path))
+    except Exception:
+        return None, "profiles/traffic.json not present"
+    if rec.get("build_id") != build_id():
+        return None, "profiles/traffic.json was collected on build %s, this is %s: refused (re-run tools/collect_traffic.py)" % (rec.get("build_id"), build_id())
+    e = rec.get("workloads", {}).get("%s:%d" % (workload, log2n))
+    if not e:
+        return None, "profiles/traffic.json has no entry for %s at 2^%d" % (workload, log2n)
+    return e, None
+
+
+# ------------------------------------------------------------------------------------------------ oracle leg (checker + CPU baseline)
+def injected_encodings():
+    """the 2 ZIP-216 non-canonical encodings (reference src/lib.rs:1894-1907) and the 8 small-order encodings, as bytes"""
+    from oracle import jubjub_ref as J
+
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_vectors.json")))
+    enc = [bytes(e) for e in g["zip216_noncanonical"]["encodings"]]
+    for p in g["EIGHT_TORSION_raw"]["points"]:
+        pt = (sum(int(h, 16) << (64 * i) for i, h in enumerate(p["u"])) % J.Q, sum(int(h, 16) << (64 * i) for i, h in enumerate(p["v"])) % J.Q)
+        enc.append(J.affine_to_bytes(pt))
+    return enc
+
+
+def decoder_input_for(i, inj):
+    from oracle import jubjub_ref as J
+
+    if i >= INJECT_FIRST and (i - INJECT_FIRST) % INJECT_STEP == 0 and (i - INJECT_FIRST) // INJECT_STEP < len(inj):
+        return inj[(i - INJECT_FIRST) // INJECT_STEP]
+    if i % 16 == 15:
+        return J.synth_bytes32(i, RAW_SEED)
+    return J.affine_to_bytes(J.synth_point(i, POINT_SEED)[0])
+
+
+def verify_sample(wl, a, lo, n, out, ok, msm_inputs):
+    """Recomputes every SAMPLE_STRIDE-th unit of rank 0's shard with the oracle, from the unit indices alone."""
     import numpy as np
 
     from oracle import c_oracle as O
     from oracle import jubjub_ref as J
 
-    cores = os.cpu_count() or 1
-    try:
-        import ctypes
+    b32 = lambda k: np.frombuffer(int(k).to_bytes(32, "little"), dtype=np.uint8)
+    pt64 = lambda p: np.concatenate([b32(p[0]), b32(p[1])])
+    idx = list(range(0, n, SAMPLE_STRIDE))
+    if wl == "decompress":
+        inj = injected_encodings()
+        idx = sorted(set(idx) | {i - lo for i in range(INJECT_FIRST, INJECT_FIRST + INJECT_STEP * len(inj), INJECT_STEP) if lo <= i < lo + n})
+        enc = np.stack([np.frombuffer(decoder_input_for(lo + i, inj), dtype=np.uint8) for i in idx])
+        eo, ek = O.decompress(enc, a.decompress_flags)
+        got_o, got_k = out[idx].cpu().numpy(), ok[idx].cpu().numpy()
+        return bool((got_k == ek).all() and (got_o == eo).all()), len(idx)
+    if wl == "msm":
+        # the whole shard: the oracle's OpenMP MSM over the terms rank 0 reduced (inputs copied back once, outside the timed region)
+        s, p = msm_inputs
+        want = O.msm(s.cpu().numpy(), p.cpu().numpy())
+        return bool((out.cpu().numpy().reshape(64) == want.reshape(64)).all()), int(s.shape[0])
+    scal = np.stack([b32(J.synth_scalar(lo + i, SEED)) for i in idx])
+    if wl == "fixedbase":
+        want = O.fixedbase_mul(scal, pt64((GEN_U, 11)))
+    else:
+        pts = np.stack([pt64(J.synth_point(lo + i, POINT_SEED)[0]) for i in idx])
+        want = O.varbase_mul(scal, pts)
+    return bool((out[idx].cpu().numpy() == want).all()), len(idx)
 
-        omp = ctypes.CDLL("libgomp.so.1")
-        cores = int(omp.omp_get_max_threads())
+
+def cpu_info():
+    model, n_logical = "unknown", os.cpu_count() or 1
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
     except Exception:
         pass
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except Exception:
+        affinity = n_logical
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    return {"model": model, "logical_cpus": n_logical, "affinity": affinity, "cgroup_cpu_quota": quota}
+
+
+def cpu_baseline(workload, target_s):
+    """Times the oracle's C port of the reference algorithm on the host cores: one thread and all cores."""
+    import ctypes
+
+    import numpy as np
+
+    from oracle import c_oracle as O
+    from oracle import jubjub_ref as J
+
+    omp = ctypes.CDLL("libgomp.so.1")
+    omp.omp_get_max_threads.restype = ctypes.c_int
+    all_threads = int(omp.omp_get_max_threads())
     base = np.frombuffer(J.GENERATOR[0].to_bytes(32, "little") + J.GENERATOR[1].to_bytes(32, "little"), dtype=np.uint8)
     rng = np.random.default_rng(2024)
 
@@ -105,64 +256,94 @@ def cpu_baseline(workload, target_s):
             t0 = time.perf_counter(); O.msm(s, pts); return time.perf_counter() - t0
         t0 = time.perf_counter(); O.varbase_mul(s, pts); return time.perf_counter() - t0
 
-    probe = max(64, 16 * cores)
-    t = run(probe)                                                  # warm-up + first calibration
-    n = int(max(probe, min(1 << 18, probe * 1.0 / max(t, 1e-6))))   # ~1 s sample for a stable rate estimate
-    t = run(n)
-    n = int(max(probe, min(1 << 22, n * target_s / max(t, 1e-6))))  # the reported sample: ~target_s of wall time
-    t = run(n)
-    unit = {"varbase": "scalar-muls/s", "fixedbase": "scalar-muls/s", "msm": "terms/s", "decompress": "points/s"}[workload]
-    return {"value": n / t, "unit": unit, "cores": cores, "kind": "port",
-            "sample": "%d units of the same synthetic workload, reference algorithm (exact 252-step ladder / per-point decode), "
-                      "oracle/jubjub_oracle.c -O3 + OpenMP, %.1f s wall" % (n, t)}
+    def measure(threads, seconds):
+        omp.omp_set_num_threads(threads)
+        probe = max(32, 16 * threads)
+        t = run(probe)
+        n = int(max(probe, min(1 << 22, probe * seconds / max(t, 1e-6))))
+        t = run(n)
+        return n / t, n, t
+
+    one, n1, t1 = measure(1, min(target_s, 4.0))
+    allc, na, ta = measure(all_threads, target_s)
+    omp.omp_set_num_threads(all_threads)
+    info = cpu_info()
+    return {"value": allc, "unit": UNIT[workload], "cores": all_threads, "kind": "port",
+            "single_thread": {"value": one, "sample_units": n1, "seconds": t1},
+            "all_cores": {"value": allc, "threads": all_threads, "sample_units": na, "seconds": ta, "speedup_over_one_thread": allc / one},
+            "cpu": info,
+            "sample": "%d units (all cores) / %d units (one thread) of the same synthetic workload, reference algorithm (exact 252-step ladder / "
+                      "per-point decode), oracle/jubjub_oracle.c -O3 + OpenMP" % (na, n1),
+            "note": "OpenMP threads = omp_get_max_threads(); the speed-up over one thread is bounded by the physical cores / the container's CPU "
+                    "quota behind the logical CPUs listed in `cpu`"}
 
 
-def main():
-    a = parse()
+# ------------------------------------------------------------------------------------------------ one rank
+def run(a):
     import numpy as np
     import torch
     import torch.distributed as dist
 
     from jubjub_amd import Engine
+    from jubjub_amd.dist import shard_bounds
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1 or os.environ.get("JJ_BENCH_FORCE_DIST") == "1"   # the latter: 1-rank RCCL plumbing check
-    if distributed:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if a.backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend=a.backend)
-    n_gpus = world if distributed else 1
-    if a.gpus != n_gpus and rank == 0:
-        print("note: --gpus %d but WORLD_SIZE=%d; using %d" % (a.gpus, world, n_gpus), file=sys.stderr)
-    dev_index = int(os.environ.get("JJ_BENCH_FORCE_DEVICE", local_rank))   # plumbing tests: several ranks on one GPU
+    dev_index = int(os.environ.get("JJ_BENCH_FORCE_DEVICE", local_rank))      # plumbing tests: several ranks on one GPU
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if a.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=a.backend)
+    n_gpus = world
+    if a.gpus != n_gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but the launcher started %d rank(s); refusing to mislabel the run" % (a.gpus, world), file=sys.stderr)
+        return 2
     eng = Engine(dev_index)
 
     wl = a.workload
-    log2n = a.log2n if a.log2n is not None else {"varbase": 20, "fixedbase": 24, "msm": 20, "decompress": 23}[wl]
-    n = 1 << log2n
+    log2n = a.log2n if a.log2n is not None else DEFAULT_LOG2N[wl]
+    total = (1 << log2n) * (n_gpus if a.scaling == "weak" else 1)
+    lo, hi = shard_bounds(total, rank, n_gpus)
+    n = hi - lo
+    passes = a.passes or PASSES[wl]
 
-    # ---- synthetic inputs, generated on the device, resident in HBM before the timed region
-    g = torch.Generator(device=dev)
-    g.manual_seed(0x4A55424A5542 + rank)
-    scalars = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
-    scalars[:, 31] &= 0x0F                                          # uniform below 2^252 (reference ladder width)
+    # ---- synthetic inputs, generated on the device from the global unit indices, resident in HBM before the timed region
+    scalars = eng.synth_scalars(n, SEED, lo, device=dev)
     base = torch.from_numpy(np.frombuffer(GEN_U.to_bytes(32, "little") + (11).to_bytes(32, "little"), dtype=np.uint8).copy()).to(dev)
     table = eng.fixedbase_table(base, a.fb_window)
-    points = None
+    points = enc = None
     if wl in ("varbase", "msm", "decompress"):
-        ks = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
-        points = eng.fixedbase_mul(table, ks)                       # random points of the full group (order 8r), on-curve by construction
+        points = eng.random_points(n, POINT_SEED, lo, subgroup=False, device=dev)   # Group::random: points of the full group (order 8r)
         assert bool(eng.predicate("is_on_curve", points[:4096]).all())
-    enc = eng.compress(points) if wl == "decompress" else None
+    if wl == "decompress":
+        # 15/16 valid encodings, 1/16 raw PRNG bytes (off-curve, >= q, sign noise), edge encodings injected at fixed indices
+        enc = eng.compress(points)
+        raw = eng.synth_bytes32(n, RAW_SEED, lo, device=dev)
+        gi = torch.arange(lo, hi, device=dev)
+        m = (gi % 16) == 15
+        enc[m] = raw[m]
+        if True:
+            g = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_vectors.json")))
+            zip216 = [bytes(e) for e in g["zip216_noncanonical"]["encodings"]]
+            tors = np.array([[b for b in (sum(int(h, 16) << (64 * i) for i, h in enumerate(p[c])) % (1 << 256)).to_bytes(32, "little")]
+                             for p in g["EIGHT_TORSION_raw"]["points"] for c in ("u", "v")], dtype=np.uint8).reshape(8, 64)
+            tors_enc = eng.compress(torch.from_numpy(tors).to(dev))
+            inj = torch.cat([torch.tensor([list(z) for z in zip216], dtype=torch.uint8, device=dev), tors_enc])
+            for k in range(inj.shape[0]):
+                gidx = INJECT_FIRST + INJECT_STEP * k
+                if lo <= gidx < hi:
+                    enc[gidx - lo] = inj[k]
+        points = None
 
-    def step():
+    def one_pass():
         if wl == "varbase":
             return eng.varbase_mul(scalars, points)
         if wl == "fixedbase":
@@ -173,13 +354,19 @@ def main():
         if distributed:
             if a.backend == "nccl":
                 parts = [torch.empty_like(part) for _ in range(world)]
-                dist.all_gather(parts, part)                        # 64 B per rank over RCCL/xGMI; EC add is not a reduce op
+                dist.all_gather(parts, part)                        # 64 B per rank over RCCL/xGMI; EC addition is not a reduce op
                 part = eng.point_sum(torch.stack(parts))
             else:
                 parts = [torch.empty(64, dtype=torch.uint8) for _ in range(world)]
                 dist.all_gather(parts, part.cpu())
                 part = eng.point_sum(torch.stack(parts).to(dev))
         return part
+
+    def step():
+        o = None
+        for _ in range(passes):
+            o = one_pass()
+        return o
 
     def barrier():
         if distributed:
@@ -202,85 +389,116 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    units_per_step = n * n_gpus
+    units_per_step = total * passes
     value = units_per_step * a.steps / dt
     res = {
         "metric": "Jubjub scalar-muls/sec (%s)" % wl if wl in ("varbase", "fixedbase") else "Jubjub %s units/sec" % wl,
-        "value": value,
-        "unit": {"varbase": "scalar-muls/s", "fixedbase": "scalar-muls/s", "msm": "terms/s", "decompress": "points/s"}[wl],
+        "value": value, "unit": UNIT[wl],
         "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u32x9 (29-bit limbs, v_mad_u64_u32 integer multiply-add)",
+        "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
+        "dtype": "i32x9 (signed 29-bit limbs, v_mad_i64_i32 integer multiply-add)",
         "data": "synthetic",
-        "config": {"workload": "%s, 2^%d units per GPU per step (BASELINE.json configs[%d])" % (
-            wl, log2n, {"varbase": 1, "fixedbase": 2, "msm": 3, "decompress": 4}[wl]),
-            "scalars": "uniform 252-bit", "points": "random points of the full group (order 8r), affine 64 B",
-            "parallelism": "independent shards, one process per GPU" + ("; all_gather of 64 B partial points" if wl == "msm" else "")},
+        "config": {"workload": "%s, 2^%d units %s, %d passes per step (BASELINE.json configs[%d])" % (
+            wl, log2n, "per GPU" if a.scaling == "weak" else "in total over %d GPU(s)" % n_gpus, passes, {"varbase": 1, "fixedbase": 2, "msm": 3, "decompress": 4}[wl]),
+            "units_per_step": units_per_step, "passes_per_step": passes, "ms_per_pass": dt / a.steps / passes * 1e3,
+            "scalars": "jj_synth_scalars: canonical Fr from splitmix64(seed + 4 i + j)", "points": "jj_random_points: Group::random rejection sampling (full group, order 8r), affine 64 B",
+            "parallelism": "contiguous shards, one process per GPU" + ("; all_gather of 64 B partial points (%s)" % a.backend if wl == "msm" else "; no data-path collective")},
     }
+    rc = 0
     if rank == 0:
         w = dict(WORK[wl])
         if wl == "fixedbase" and a.fb_window >= 8:
-            w["M"] = -(-253 // a.fb_window) * 7 + 10          # ceil(253/w) mixed additions + normalise
+            w["M"] = -(-253 // a.fb_window) * 7              # ceil(253/w) mixed additions
         if main_ms:
             kern_ms = sum(main_ms) / len(main_ms)
             tail = sum(tail_ms) / len(tail_ms)
-        else:                                                       # workloads without the event hooks: whole step
-            kern_ms, tail = dt / a.steps * 1e3, 0.0
+        else:                                                       # workloads without the event hooks: whole pass
+            kern_ms, tail = dt / a.steps / passes * 1e3, 0.0
         peak = eng.peak_imad32()
-        achieved = n * imad32(w) / (kern_ms * 1e-3)
+        work_main = imad32(w["S"], w["M"])
+        achieved = n * work_main / (kern_ms * 1e-3)
+        traffic, traffic_note = traffic_record(wl, log2n)
         res["roofline"] = {
             "bound": "valu_int32", "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TIMAD32/s",
             "frac": achieved / peak,
-            # multiply-adds actually issued by the 9x29-bit representation (162 per mul, 126 per square) / measured peak
-            "mad_issue_frac": n * (162 * w["M"] + 126 * w["S"]) / (kern_ms * 1e-3) / peak,
-            "traffic": None,
-            "kernel": {"varbase": "k_varbase", "fixedbase": "k_fixedbase" if a.fb_window < 8 else "k_fixedbase_gather(w=%d)" % a.fb_window, "msm": "k_msm_accumulate (+sort/fix-up/reduce; Horner on the host)", "decompress": "k_decompress"}[wl],
-            "kernel_ms": kern_ms, "tail_ms": tail,
-            "work_per_unit": {"field_squares": w["S"], "field_muls": w["M"], "imad32": imad32(w), "convention": "M=128,S=100 (SURVEY 8d)"},
-            "reference_algorithm_imad32": imad32(REFERENCE_WORK[wl]) if wl in REFERENCE_WORK else None,
+            # multiply-adds actually issued by the signed 9x29-bit representation (153 per mul, 117 per square) / measured peak
+            "mad_issue_frac": n * (153 * w["M"] + 117 * w["S"]) / (kern_ms * 1e-3) / peak,
+            "traffic": traffic["bytes_per_launch"] if traffic else None,
+            "traffic_detail": traffic if traffic else traffic_note,
+            "kernel": {"varbase": "k_varbase", "fixedbase": "k_fixedbase" if a.fb_window < 8 else "k_fixedbase_gather(w=%d)" % a.fb_window, "msm": "whole MSM: k_msm_accumulate(_seg) + sort / fix-up / reduce; Horner on the host", "decompress": "k_decompress"}[wl],
+            "kernel_ms": kern_ms, "tail_ms": tail, "units_per_launch": n,
+            "work_per_unit": {"field_squares": w["S"], "field_muls": w["M"], "imad32": work_main, "convention": "M=128,S=100 (SURVEY 8d); the kernel named above only",
+                              "tail_kernel": {"field_squares": w["tail_S"], "field_muls": w["tail_M"], "imad32": imad32(w["tail_S"], w["tail_M"])}},
+            "whole_pass_frac": n * (work_main + imad32(w["tail_S"], w["tail_M"])) / ((kern_ms + tail) * 1e-3) / peak,
+            "reference_algorithm_imad32": imad32(**REFERENCE_WORK[wl]) if wl in REFERENCE_WORK else None,
             "hbm": {"achieved": n * w["bytes"] / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": n * w["bytes"] / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "bytes_per_unit": w["bytes"]},
+            "build_id": build_id(),
         }
-        if wl == "varbase" and log2n == 20:
-            # not collected live (PMC needs rocprofv3): the committed counter passes of this same launch
-            res["roofline"]["traffic_profiled"] = {"bytes_per_launch": 11.39e9 + 3.08e9, "fetch_bytes": 11.39e9, "write_bytes": 3.08e9,
-                                                   "source": "profiles/r1_varbase_pmc.txt (FETCH_SIZE x2 per the gfx950 note, WRITE_SIZE; separate --pmc passes)",
-                                                   "note": "per-lane window tables; algorithmic I/O is 160 B per unit"}
-        if wl == "varbase" and not a.no_extras:
-            # the other half of BASELINE.json's metric, measured in the same process (outside the timed region above)
-            fs = scalars if log2n >= 22 else torch.randint(0, 256, (1 << 22, 32), dtype=torch.uint8, device=dev, generator=g)
-            eng.fixedbase_mul(table, fs)
+        if wl == "msm":
+            res["msm_result"] = bytes(out.cpu().numpy().reshape(64).tolist()).hex()     # the point every rank ends up with
+        if not a.no_verify:
+            o, k = (out if isinstance(out, tuple) else (out, None))
+            if wl == "msm" and n_gpus > 1:
+                # the timed output is the all-rank fold; rank 0's own shard is re-reduced and compared with the oracle here,
+                # the folded point of a whole multi-rank run is compared in tests/test_gpu_dist.py
+                o = eng.msm(scalars, points)
+                res["verified_note"] = "rank 0's shard vs the oracle (the all-rank fold is checked by tests/test_gpu_dist.py)"
+            okv, cnt = verify_sample(wl, a, lo, n, o, k, (scalars, points))
+            res["verified"], res["verified_units"] = okv, cnt
+            if not okv:
+                rc = 3
+        if wl == "varbase" and not a.no_extras and n_gpus == 1:
+            # the other half of BASELINE.json's metric at ITS config (2^24 fixed-base scalar-muls), same process, outside the timed region above
+            fn = 1 << 24
+            fs = eng.synth_scalars(fn, SEED, 0, device=dev)
+            fo = eng.fixedbase_mul(table, fs)
             torch.cuda.synchronize(dev)
             eng.profile(True)
             t1 = time.perf_counter()
-            for _ in range(5):
-                eng.fixedbase_mul(table, fs)
+            for _ in range(4):
+                fo = eng.fixedbase_mul(table, fs)
             torch.cuda.synchronize(dev)
-            fdt = (time.perf_counter() - t1) / 5
+            fdt = (time.perf_counter() - t1) / 4
             fm, _ft = eng.profile_read()
             eng.profile(False)
             fw = WORK["fixedbase"]
-            res["fixed_base"] = {"value": fs.shape[0] / fdt, "unit": "scalar-muls/s per GPU", "units_per_step": int(fs.shape[0]),
-                                 "ms_per_step": fdt * 1e3, "kernel_ms": sum(fm) / max(len(fm), 1),
-                                 "roofline_frac": fs.shape[0] * imad32(fw) / (sum(fm) / max(len(fm), 1) * 1e-3) / peak,
+            fkm = sum(fm) / max(len(fm), 1)
+            res["fixed_base"] = {"value": fn / fdt, "unit": "scalar-muls/s per GPU", "units_per_pass": fn, "ms_per_pass": fdt * 1e3, "kernel_ms": fkm,
+                                 "roofline_frac": fn * imad32(fw["S"], fw["M"]) / (fkm * 1e-3) / peak,
                                  "window_select": "LDS-staged table, ds_bpermute constant-time select"}
+            if not a.no_verify:
+                res["fixed_base"]["verified"], _ = verify_sample("fixedbase", a, 0, fn, fo, None, None)
             wt = eng.fixedbase_table(base, 16)                      # wide-window alternative (64 MB table in the Infinity Cache, per-lane gather)
-            eng.fixedbase_mul(wt, fs)
+            fo = eng.fixedbase_mul(wt, fs)
             torch.cuda.synchronize(dev)
             t1 = time.perf_counter()
-            for _ in range(5):
-                eng.fixedbase_mul(wt, fs)
+            for _ in range(4):
+                fo = eng.fixedbase_mul(wt, fs)
             torch.cuda.synchronize(dev)
-            res["fixed_base_wide_window"] = {"value": fs.shape[0] * 5 / (time.perf_counter() - t1), "unit": "scalar-muls/s per GPU",
+            res["fixed_base_wide_window"] = {"value": fn * 4 / (time.perf_counter() - t1), "unit": "scalar-muls/s per GPU", "units_per_pass": fn,
                                               "window_bits": 16, "table": "64 MB (one 128-byte line per entry), Infinity-Cache resident, variable-time gather: 16 additions per scalar"}
+            if not a.no_verify:
+                res["fixed_base_wide_window"]["verified"], _ = verify_sample("fixedbase", a, 0, fn, fo, None, None)
             wt.close()
+            del fs, fo
         if not a.no_cpu_baseline and n_gpus == 1:
             res["cpu_baseline"] = cpu_baseline(wl, a.cpu_seconds)
         print(json.dumps(res))
+        sys.stdout.flush()
     table.close()
     if distributed:
+        dist.barrier()
         dist.destroy_process_group()
+    return rc
+
+
+def main():
+    a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a))
+    sys.exit(run(a))
 
 
 if __name__ == "__main__":

@@ -18,7 +18,9 @@
  * Pointers may be host or device pointers (detected per pointer with hipPointerGetAttributes); host data is
  * staged through the context's buffers.  With device pointers the call is asynchronous on the context's
  * stream; with any host pointer it returns after the results are in host memory.  A context belongs to one
- * device (one process per GPU is the intended deployment); calls on one context must not overlap.
+ * device; its entry points may be called from several host threads (they serialise on a per-context lock), and a
+ * change of launch stream is ordered after the work queued on the previous stream (the context's workspaces are shared).
+ * jj_multi_* below drives several devices of one node from one process.
  *
  * Every function returns 0 on success or a negative jj_status.
  */
@@ -95,6 +97,11 @@ int jj_fq_from_bytes(jj_ctx*, size_t n, const void* in32, void* out, uint8_t* ok
 int jj_fr_from_bytes(jj_ctx*, size_t n, const void* in32, void* out, uint8_t* ok);
 int jj_fq_from_bytes_wide(jj_ctx*, size_t n, const void* in64, void* out);
 int jj_fr_from_bytes_wide(jj_ctx*, size_t n, const void* in64, void* out);
+/* PrimeFieldBits::to_le_bits (src/fr.rs:746-773): the canonical integer as 256 bytes of 0/1, bit 0 first;
+ * char_le_bits (src/fr.rs:775-785): the modulus r in the same layout (host only, no context). */
+int jj_fq_to_le_bits(jj_ctx*, size_t n, const void* a, void* out256);
+int jj_fr_to_le_bits(jj_ctx*, size_t n, const void* a, void* out256);
+int jj_fr_char_le_bits(uint8_t out256[256]);
 
 /* ---- elementwise point operations (affine in, affine out; extended coordinates inside) ----------------- */
 /* double src/lib.rs:739-828; add/sub = Ext +/- Affine src/lib.rs:1012-1028; neg 92-104; mul_by_cofactor 722-724 */
@@ -151,7 +158,7 @@ int jj_fixedbase_multi_mul(jj_ctx*, const jj_table* const* tables, int nbases, s
 /* Multi-scalar multiplication: out = to_affine(sum_i points[i] * scalars[i])  (semantics: iterator Sum of
  * `p * k`, src/lib.rs:183-193 + 873-879; the reference has no MSM algorithm).  n = 0 gives the identity.
  * Pippenger on the device; the last step (Horner over the 16-17 window sums and one inversion, a chain of ~250
- * dependent doublings) runs on the calling host thread, so for n >= 512 this call synchronises the stream even when
+ * dependent doublings) runs on the calling host thread, so for every n > 0 this call synchronises the stream even when
  * all pointers are device pointers (the 64-byte result is then copied back to out64 asynchronously). */
 int jj_msm(jj_ctx*, size_t n, const void* scalars32, const void* points64, void* out64);
 
@@ -166,6 +173,42 @@ int jj_decompress(jj_ctx*, size_t n, const void* in32, unsigned flags, void* out
 int jj_compress(jj_ctx*, size_t n, const void* points64, void* out32);
 /* batch_normalize src/lib.rs:1084-1107: n x 160 bytes (U,V,Z,T1,T2 canonical LE) -> n x 64 bytes affine */
 int jj_batch_normalize(jj_ctx*, size_t n, const void* ext160, void* out64);
+
+
+/* ---- synthetic inputs (Group::random semantics; counter-based, reproducible on any device or on the host) ---- */
+/* scalars[i] = four splitmix64 words of the stream seed + (first_index + i) * 4 + j, top 4 bits cleared, minus r if >= r:
+ * canonical Fr elements (the input side of Field::random, src/fr.rs:684-688, with a counter-based generator). */
+int jj_synth_scalars(jj_ctx*, size_t n, uint64_t seed, uint64_t first_index, void* out32);
+/* the same four words per unit as they come (arbitrary 256-bit patterns: values >= q, sign-bit noise for the decoder) */
+int jj_synth_bytes32(jj_ctx*, size_t n, uint64_t seed, uint64_t first_index, void* out32);
+/* ExtendedPoint::random (src/lib.rs:1244-1267): v = Fq::random (64 PRNG bytes through from_bytes_wide), flip = next_u32 % 2,
+ * u = sqrt((v^2 - 1) / (1 + d v^2)) or draw again, (flip ? -u : u, v), draw again if it is the identity.  subgroup != 0:
+ * SubgroupPoint::random (src/lib.rs:1290-1298), i.e. [8]P, drawn again if that is the identity.  Unit i reads the
+ * splitmix64 stream seed + ((first_index + i) << 16) + 16 * attempt + {0..7: v, 8: flip}.  attempts (optional): draws used. */
+int jj_random_points(jj_ctx*, size_t n, uint64_t seed, uint64_t first_index, int subgroup, void* out64, uint32_t* attempts);
+
+
+/* ---- several devices of one node ---------------------------------------------------------- */
+/* One context per listed device, one host thread + stream per device, contiguous shards [g*n/G, (g+1)*n/G); no data-path
+ * collective for the independent-batch workloads (north_star: "shard embarrassingly across the 8 GPUs of one node").
+ * jj_multi_msm: every device reduces its own terms to one point; the G partial points (64 bytes each) are added on the
+ * calling host thread.  Array arguments are HOST pointers (a device pointer is JJ_ERR_INVALID).  A device may be listed
+ * more than once.  Processes that keep their batches resident in HBM run one process per GPU instead and exchange the MSM
+ * partial points with RCCL all_gather (jubjub_amd/dist.py).  A jj_ctx may be used from several host threads: its entry
+ * points serialise on a per-context lock. */
+typedef struct jj_multi jj_multi;
+typedef struct jj_mtable jj_mtable;
+int jj_multi_create(const int* devices, int ndev, jj_multi** out);
+int jj_multi_destroy(jj_multi* m);
+int jj_multi_device_count(jj_multi* m);
+jj_ctx* jj_multi_ctx(jj_multi* m, int index);            /* the per-device context, for the single-device entry points */
+const char* jj_multi_last_error(jj_multi* m);
+int jj_multi_varbase_mul(jj_multi* m, size_t n, const void* scalars32, const void* points64, void* out64);
+int jj_multi_fixedbase_table_create(jj_multi* m, const void* base64, int window_bits, jj_mtable** out);   /* replicated per device */
+int jj_multi_fixedbase_table_destroy(jj_multi* m, jj_mtable* t);
+int jj_multi_fixedbase_mul(jj_multi* m, const jj_mtable* t, size_t n, const void* scalars32, void* out64);
+int jj_multi_decompress(jj_multi* m, size_t n, const void* in32, unsigned flags, void* out64, uint8_t* ok);
+int jj_multi_msm(jj_multi* m, size_t n, const void* scalars32, const void* points64, void* out64);
 
 #ifdef __cplusplus
 }

@@ -5,8 +5,8 @@ The product is the C-ABI library jubjub_amd/lib/libjubjub_hip.so (sources in jub
 include/jubjub_hip.h).  This package is the Python host side: `Engine` (typed wrapper over the C ABI) and
 `group` (batch mirrors of the reference crate's public types and method names).
 """
-from .engine import (Engine, FixedBaseTable, JubjubError, FLAG_ZIP216, FLAG_TORSION_FREE, FLAG_NOT_SMALL_ORDER,
+from .engine import (Engine, MultiEngine, FixedBaseTable, JubjubError, FLAG_ZIP216, FLAG_TORSION_FREE, FLAG_NOT_SMALL_ORDER,
                      FLAG_CLEAR_COFACTOR)
 
-__all__ = ["Engine", "FixedBaseTable", "JubjubError", "FLAG_ZIP216", "FLAG_TORSION_FREE", "FLAG_NOT_SMALL_ORDER",
+__all__ = ["Engine", "MultiEngine", "FixedBaseTable", "JubjubError", "FLAG_ZIP216", "FLAG_TORSION_FREE", "FLAG_NOT_SMALL_ORDER",
            "FLAG_CLEAR_COFACTOR"]

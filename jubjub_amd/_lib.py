@@ -45,10 +45,24 @@ _SIGS.update({
     "jj_ctx_profile": [C.c_int],
     "jj_ctx_profile_read": [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)],
     "jj_peak_imad32": [C.POINTER(C.c_double)],
+    "jj_fq_to_le_bits": [_sz, _vp, _vp],
+    "jj_fr_to_le_bits": [_sz, _vp, _vp],
+    "jj_synth_scalars": [_sz, C.c_uint64, C.c_uint64, _vp],
+    "jj_synth_bytes32": [_sz, C.c_uint64, C.c_uint64, _vp],
+    "jj_random_points": [_sz, C.c_uint64, C.c_uint64, C.c_int, _vp, _vp],
+    # several devices of one node: the first argument is a jj_multi*
+    "jj_multi_destroy": [],
+    "jj_multi_device_count": [],
+    "jj_multi_varbase_mul": [_sz, _vp, _vp, _vp],
+    "jj_multi_fixedbase_table_create": [_vp, C.c_int, C.POINTER(_vp)],
+    "jj_multi_fixedbase_table_destroy": [_vp],
+    "jj_multi_fixedbase_mul": [_vp, _sz, _vp, _vp],
+    "jj_multi_decompress": [_sz, _vp, C.c_uint, _vp, _u8p],
+    "jj_multi_msm": [_sz, _vp, _vp, _vp],
 })
 
 EXPORTS = sorted(list(_SIGS) + ["jj_ctx_create", "jj_ctx_destroy", "jj_last_error", "jj_version", "jj_device_info", "jj_recommended_wnaf_for_num_scalars",
-                                "jj_fixedbase_table_create"])
+                                "jj_fixedbase_table_create", "jj_fr_char_le_bits", "jj_multi_create", "jj_multi_ctx", "jj_multi_last_error"])
 
 _lib = None
 
@@ -100,6 +114,14 @@ def load():
     lib.jj_version.argtypes = []
     lib.jj_recommended_wnaf_for_num_scalars.restype = C.c_int
     lib.jj_recommended_wnaf_for_num_scalars.argtypes = [C.c_size_t]
+    lib.jj_multi_create.restype = C.c_int
+    lib.jj_multi_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(_vp)]
+    lib.jj_multi_ctx.restype = _vp
+    lib.jj_multi_ctx.argtypes = [_vp, C.c_int]
+    lib.jj_multi_last_error.restype = C.c_char_p
+    lib.jj_multi_last_error.argtypes = [_vp]
+    lib.jj_fr_char_le_bits.restype = C.c_int
+    lib.jj_fr_char_le_bits.argtypes = [C.POINTER(C.c_uint8)]
     lib.jj_device_info.restype = C.c_int
     lib.jj_device_info.argtypes = [_vp, C.POINTER(C.c_int64)]
     lib.jj_fixedbase_table_create.restype = C.c_int

@@ -10,6 +10,8 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <mutex>
+#include <thread>
 
 #include "../../include/jubjub_hip.h"
 #include "jj_kernels.h"
@@ -32,9 +34,11 @@ struct jj_table {
 };
 
 struct jj_ctx {
+  std::recursive_mutex mu;       // every entry point locks its context: calls from several host threads are serialised
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
+  hipEvent_t order_ev = nullptr;   // orders a newly selected launch stream after the work queued on the previous one
   int cus = 0, clock_khz = 0, wave = 64;
   std::string err;
   // staging for host-pointer arguments (inputs 0..3, outputs 0..1) and kernel workspaces
@@ -96,6 +100,10 @@ static void prof_mark(jj_ctx* c, int which) {
     }                                                                                       \
   } while (0)
 
+// entry of every API function: serialise the host threads that share this context, select its device
+#define JJ_ENTER(ctx) std::lock_guard<std::recursive_mutex> jj_lock_((ctx)->mu); HIPCHK(ctx, hipSetDevice((ctx)->device))
+
+static int switch_stream(jj_ctx* c, hipStream_t s);
 static int ensure(jj_ctx* c, DevBuf& b, size_t bytes) {
   if (bytes <= b.cap) return JJ_OK;
   if (b.p) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
@@ -202,7 +210,7 @@ static int run_pipelined(jj_ctx* c, size_t n, const HostIn (&in)[NIN], const Hos
   clock_gettime(CLOCK_MONOTONIC, &ts1);
   jj_ctx::Pipe& P = c->pipe;
   hipStream_t saved = c->stream;
-  c->stream = c->own_stream;
+  if ((rc = switch_stream(c, c->own_stream))) { unlock(); return rc; }
   const size_t nchunks = (n + CH - 1) / CH;
   rc = JJ_OK;
   #define PIPE_CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { c->err = std::string(#call) + " failed: " + hipGetErrorString(e_); rc = JJ_ERR_HIP; goto done; } } while (0)
@@ -242,7 +250,7 @@ static int run_pipelined(jj_ctx* c, size_t n, const HostIn (&in)[NIN], const Hos
 done:
   #undef PIPE_CHK
   if (rc != JJ_OK) { (void)hipStreamSynchronize(P.h2d); (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(P.d2h); }
-  c->stream = saved;
+  { const int rc2 = switch_stream(c, saved); if (rc == JJ_OK) rc = rc2; }
   unlock();
   return rc;
 }
@@ -272,6 +280,7 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
   c->clock_khz = prop.clockRate;
   c->wave = prop.warpSize;
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return JJ_ERR_HIP; }
+  if (hipEventCreateWithFlags(&c->order_ev, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(c->own_stream); delete c; return JJ_ERR_HIP; }
   c->stream = c->own_stream;
   if (const char* e = getenv("JJ_PIPE_CHUNK_LOG2")) { int v = atoi(e); if (v >= 8 && v <= 24) c->pipe_chunk = (size_t)1 << v; }
   if (const char* e = getenv("JJ_MSM_WINDOW")) c->msm_window = atoi(e);
@@ -286,11 +295,16 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
   if (const char* e = getenv("JJ_FB_GATHER_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) c->fb_gather_blocks_per_cu = v; }
   if (const char* e = getenv("JJ_VB_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) c->vb_blocks_per_cu = v; }
   // the fixed-base kernel needs the full 160 KiB LDS carve-out
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fixedbase<true>), hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS_BYTES);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fixedbase<false>), hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS_BYTES);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_hist), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_seg_plan), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4);
+  {
+    const struct { const void* fn; int bytes; } lds_needs[] = {
+      {reinterpret_cast<const void*>(k_fixedbase<true>), FB_LDS_BYTES}, {reinterpret_cast<const void*>(k_fixedbase<false>), FB_LDS_BYTES},
+      {reinterpret_cast<const void*>(k_msm_hist), 32768 * 4}, {reinterpret_cast<const void*>(k_seg_plan), 80 * 1024},
+      {reinterpret_cast<const void*>(k_msm_scatter), 32768 * 4}};
+    for (const auto& a : lds_needs)
+      if (hipFuncSetAttribute(a.fn, hipFuncAttributeMaxDynamicSharedMemorySize, a.bytes) != hipSuccess) {
+        (void)hipEventDestroy(c->order_ev); (void)hipStreamDestroy(c->own_stream); delete c; return JJ_ERR_HIP;   // the kernels could not launch later
+      }
+  }
   if (const char* e = getenv("JJ_TORSION_CHECK")) c->torsion_ladder = strcmp(e, "ladder") == 0;
   if (const char* e = getenv("JJ_FIXEDBASE_SELECT")) c->fb_const_time = strcmp(e, "gather") != 0;
   // square-root tables (64 KiB dlog + 36 KiB powers), built on the device
@@ -322,22 +336,33 @@ JJ_API int jj_ctx_destroy(jj_ctx* c) {
     (void)hipStreamDestroy(c->pipe.h2d); (void)hipStreamDestroy(c->pipe.d2h);
   }
   for (auto& r : c->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); (void)hipEventDestroy(r.e2); }
+  if (c->order_ev) (void)hipEventDestroy(c->order_ev);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
   return JJ_OK;
 }
+// Every call reuses the context's workspaces (window tables, extended SoA, staging buffers), so work queued on the
+// previous launch stream must finish before work on a new one may touch them: the new stream waits on an event recorded
+// on the old one (device-side ordering, no host synchronisation).
+static int switch_stream(jj_ctx* c, hipStream_t s) {
+  if (s == c->stream) return JJ_OK;
+  JJ_ENTER(c);
+  HIPCHK(c, hipEventRecord(c->order_ev, c->stream));
+  HIPCHK(c, hipStreamWaitEvent(s, c->order_ev, 0));
+  c->stream = s;
+  return JJ_OK;
+}
 JJ_API int jj_ctx_set_stream(jj_ctx* c, void* s) {
   if (!c) return JJ_ERR_INVALID;
-  c->stream = (hipStream_t)s;            // NULL is HIP's default (null) stream — e.g. torch's default stream
-  return JJ_OK;
+  return switch_stream(c, (hipStream_t)s);            // NULL is HIP's default (null) stream — e.g. torch's default stream
 }
 JJ_API int jj_ctx_use_own_stream(jj_ctx* c) {
   if (!c) return JJ_ERR_INVALID;
-  c->stream = c->own_stream;
-  return JJ_OK;
+  return switch_stream(c, c->own_stream);
 }
 JJ_API int jj_ctx_sync(jj_ctx* c) {
   if (!c) return JJ_ERR_INVALID;
+  JJ_ENTER(c);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return JJ_OK;
 }
@@ -350,6 +375,7 @@ JJ_API int jj_device_info(jj_ctx* c, int64_t out[4]) {
 
 JJ_API int jj_ctx_profile(jj_ctx* c, int enable) {
   if (!c) return JJ_ERR_INVALID;
+  JJ_ENTER(c);
   c->profile = enable != 0;
   c->rec_used = 0;
   return JJ_OK;
@@ -357,6 +383,7 @@ JJ_API int jj_ctx_profile(jj_ctx* c, int enable) {
 // Returns up to `max` (main_ms, tail_ms) pairs recorded since jj_ctx_profile(ctx, 1) and resets the log.
 JJ_API int jj_ctx_profile_read(jj_ctx* c, int max, float* main_ms, float* tail_ms, int* count) {
   if (!c || !count) return JJ_ERR_INVALID;
+  JJ_ENTER(c);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   int k = 0;
   for (size_t i = 0; i < c->rec_used && k < max; i++, k++) {
@@ -373,7 +400,7 @@ JJ_API int jj_ctx_profile_read(jj_ctx* c, int max, float* main_ms, float* tail_m
 // Measured integer-VALU roofline denominator: sustained v_mad_u64_u32 lane-operations per second on this device.
 JJ_API int jj_peak_imad32(jj_ctx* c, double* out_per_sec) {
   if (!c || !out_per_sec) return JJ_ERR_INVALID;
-  HIPCHK(c, hipSetDevice(c->device));
+  JJ_ENTER(c);
   int rc = ensure(c, c->ws_tmp[0], (size_t)c->cus * 8 * 256 * 4); if (rc) return rc;
   const int iters = 4000, blocks = c->cus * 8;
   hipEvent_t e0, e1;
@@ -399,7 +426,7 @@ JJ_API int jj_peak_imad32(jj_ctx* c, double* out_per_sec) {
 template <class P, int OP>
 static int field_op(jj_ctx* c, size_t n, const void* a, const void* b, void* out, uint8_t* ok, bool want_ok) {
   if (!c) return JJ_ERR_INVALID;
-  HIPCHK(c, hipSetDevice(c->device));
+  JJ_ENTER(c);
   const size_t in_bytes = (OP == OP_FROM_WIDE ? 64 : 32) * n;
   const void *da = nullptr, *db = nullptr;
   int rc;
@@ -417,7 +444,7 @@ static int field_op(jj_ctx* c, size_t n, const void* a, const void* b, void* out
 }
 #define FIELD_BIN(name, P, OP) JJ_API int name(jj_ctx* c, size_t n, const void* a, const void* b, void* out) { return field_op<P, OP>(c, n, a, b, out, nullptr, false); }
 #define FIELD_UN(name, P, OP) JJ_API int name(jj_ctx* c, size_t n, const void* a, void* out) { return field_op<P, OP>(c, n, a, nullptr, out, nullptr, false); }
-#define FIELD_UN_OK(name, P, OP) JJ_API int name(jj_ctx* c, size_t n, const void* a, void* out, uint8_t* ok) { if (!ok) return JJ_ERR_INVALID; return field_op<P, OP>(c, n, a, nullptr, out, ok, true); }
+#define FIELD_UN_OK(name, P, OP) JJ_API int name(jj_ctx* c, size_t n, const void* a, void* out, uint8_t* ok) { if (!ok && n) return JJ_ERR_INVALID; return field_op<P, OP>(c, n, a, nullptr, out, ok, true); }
 FIELD_BIN(jj_fq_add, FqP, OP_ADD) FIELD_BIN(jj_fq_sub, FqP, OP_SUB) FIELD_BIN(jj_fq_mul, FqP, OP_MUL)
 FIELD_UN(jj_fq_neg, FqP, OP_NEG) FIELD_UN(jj_fq_square, FqP, OP_SQUARE) FIELD_UN(jj_fq_double, FqP, OP_DOUBLE)
 FIELD_UN_OK(jj_fq_invert, FqP, OP_INVERT) FIELD_UN_OK(jj_fq_sqrt, FqP, OP_SQRT) FIELD_UN_OK(jj_fq_from_bytes, FqP, OP_FROM_BYTES)
@@ -430,7 +457,7 @@ FIELD_UN(jj_fr_from_bytes_wide, FrP, OP_FROM_WIDE)
 template <class P>
 static int field_pow(jj_ctx* c, size_t n, const void* a, const void* e, void* out) {
   if (!c) return JJ_ERR_INVALID;
-  HIPCHK(c, hipSetDevice(c->device));
+  JJ_ENTER(c);
   const void *da, *de; int rc; OutRef o;
   if ((rc = stage_in(c, 0, a, 32 * n, &da))) return rc;
   if ((rc = stage_in(c, 1, e, 32 * n, &de))) return rc;
@@ -442,6 +469,27 @@ static int field_pow(jj_ctx* c, size_t n, const void* a, const void* e, void* ou
 }
 JJ_API int jj_fq_pow(jj_ctx* c, size_t n, const void* a, const void* exp32, void* out) { return field_pow<FqP>(c, n, a, exp32, out); }
 JJ_API int jj_fr_pow(jj_ctx* c, size_t n, const void* a, const void* exp32, void* out) { return field_pow<FrP>(c, n, a, exp32, out); }
+
+template <class P>
+static int field_to_bits(jj_ctx* c, size_t n, const void* a, void* out256) {
+  if (!c) return JJ_ERR_INVALID;
+  JJ_ENTER(c);
+  const void* da; int rc; OutRef o;
+  if ((rc = stage_in(c, 0, a, 32 * n, &da))) return rc;
+  if ((rc = stage_out(c, c->out[0], out256, 256 * n, &o))) return rc;
+  if (n) hipLaunchKernelGGL((k_field_to_bits<P>), dim3(blocks_for(n)), dim3(256), 0, c->stream, n, da, o.dev);
+  bool sync = false;
+  if ((rc = finish_out(c, o, &sync))) return rc;
+  return finish(c, sync);
+}
+JJ_API int jj_fq_to_le_bits(jj_ctx* c, size_t n, const void* a, void* out256) { return field_to_bits<FqP>(c, n, a, out256); }
+JJ_API int jj_fr_to_le_bits(jj_ctx* c, size_t n, const void* a, void* out256) { return field_to_bits<FrP>(c, n, a, out256); }
+// PrimeFieldBits::char_le_bits (reference src/fr.rs:775-785): the modulus, same layout; host-only
+JJ_API int jj_fr_char_le_bits(uint8_t out256[256]) {
+  if (!out256) return JJ_ERR_INVALID;
+  for (int b = 0; b < 256; b++) out256[b] = (FR_MODULUS_BYTES[b >> 3] >> (b & 7)) & 1;
+  return JJ_OK;
+}
 
 // ---------------------------------------------------------------------------------------------------- normalisation
 static SoA soa_of(DevBuf& b, size_t n) { SoA s; s.base = (u32*)b.p; s.n = n; return s; }
@@ -464,7 +512,7 @@ static int normalize_launch(jj_ctx* c, size_t n, SoA ext, void* dout, int mode) 
 template <int OP>
 static int point_op(jj_ctx* c, size_t n, const void* p, const void* q, void* out, size_t out_elem) {
   if (!c) return JJ_ERR_INVALID;
-  HIPCHK(c, hipSetDevice(c->device));
+  JJ_ENTER(c);
   const void *dp = nullptr, *dq = nullptr;
   int rc;
   if ((rc = stage_in(c, 0, p, 64 * n, &dp))) return rc;
@@ -517,7 +565,7 @@ static int varbase_to_ext(jj_ctx* c, size_t n, const void* ds, const void* dp, S
 }
 static int varbase_api(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out, int mode) {
   if (!c) return JJ_ERR_INVALID;
-  HIPCHK(c, hipSetDevice(c->device));
+  JJ_ENTER(c);
   if (n >= 2 * c->pipe_chunk && all_host({scalars, points, out})) {
     const HostIn in[2] = {{scalars, 32}, {points, 64}};
     const HostOut ho[1] = {{out, (size_t)(mode ? 32 : 64)}};
@@ -552,7 +600,7 @@ JJ_API int jj_varbase_mul_compressed(jj_ctx* c, size_t n, const void* scalars, c
 // one scalar, many bases (group::Wnaf's `scalar(..).base(..)` reuse pattern): the scalar is broadcast on the device
 JJ_API int jj_varbase_mul_scalar(jj_ctx* c, size_t n, const void* scalar32, const void* points, void* out) {
   if (!c || !scalar32) return JJ_ERR_INVALID;
-  HIPCHK(c, hipSetDevice(c->device));
+  JJ_ENTER(c);
   const void* dp; int rc; OutRef o;
   if ((rc = stage_in(c, 1, points, 64 * n, &dp))) return rc;
   if ((rc = stage_out(c, c->out[0], out, 64 * n, &o))) return rc;
@@ -572,7 +620,7 @@ JJ_API int jj_varbase_mul_scalar(jj_ctx* c, size_t n, const void* scalar32, cons
 }
 JJ_API int jj_varbase_mul_exact(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out160) {
   if (!c) return JJ_ERR_INVALID;
-  HIPCHK(c, hipSetDevice(c->device));
+  JJ_ENTER(c);
   const void *ds, *dp; int rc; OutRef o;
   if ((rc = stage_in(c, 0, scalars, 32 * n, &ds))) return rc;
   if ((rc = stage_in(c, 1, points, 64 * n, &dp))) return rc;
@@ -603,7 +651,7 @@ static int torsion_free_dev(jj_ctx* c, size_t n, const void* dpts, uint8_t* dok,
 }
 static int torsion_pred(jj_ctx* c, size_t n, const void* p, uint8_t* out, bool prime_order) {
   if (!c) return JJ_ERR_INVALID;
-  HIPCHK(c, hipSetDevice(c->device));
+  JJ_ENTER(c);
   const void* dp; int rc; OutRef o;
   if ((rc = stage_in(c, 0, p, 64 * n, &dp))) return rc;
   if ((rc = stage_out(c, c->okb, out, n, &o))) return rc;
@@ -662,8 +710,8 @@ static int build_window_table(jj_ctx* c, const uint8_t base[64], int w, int W, u
 JJ_API int jj_fixedbase_table_create(jj_ctx* c, const void* base64, int window_bits, jj_table** out) {
   if (!c || !out || !base64) return JJ_ERR_INVALID;
   if (window_bits == 0) window_bits = FB_W;
-  if (window_bits != FB_W && (window_bits < 8 || window_bits > 16)) { c->err = "window_bits must be 0/6 (LDS table) or 8..16 (L2/MALL-resident table)"; return JJ_ERR_INVALID; }
-  HIPCHK(c, hipSetDevice(c->device));
+  if (window_bits != FB_W && (window_bits < 8 || window_bits > 16)) { c->err = "window_bits must be 0 or 6 (LDS-staged table) or 8..16 (table gathered from L2 / Infinity Cache)"; return JJ_ERR_INVALID; }
+  JJ_ENTER(c);
   uint8_t base[64];
   if (is_device_ptr(base64)) { HIPCHK(c, hipMemcpy(base, base64, 64, hipMemcpyDeviceToHost)); } else memcpy(base, base64, 64);
   jj_table* t = new jj_table();
@@ -685,6 +733,7 @@ JJ_API int jj_fixedbase_table_create(jj_ctx* c, const void* base64, int window_b
 }
 JJ_API int jj_fixedbase_table_destroy(jj_ctx* c, jj_table* t) {
   if (!c || !t) return JJ_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   if (t->dev) (void)hipFree(t->dev);
@@ -702,7 +751,7 @@ static int fixedbase_launch(jj_ctx* c, const jj_table* t, size_t n, const void* 
 }
 static int fixedbase_api(jj_ctx* c, const jj_table* t, size_t n, const void* scalars, void* out, int mode) {
   if (!c || !t) return JJ_ERR_INVALID;
-  HIPCHK(c, hipSetDevice(c->device));
+  JJ_ENTER(c);
   if (n >= 2 * c->pipe_chunk && all_host({scalars, out})) {
     const HostIn in[1] = {{scalars, 32}};
     const HostOut ho[1] = {{out, (size_t)(mode ? 32 : 64)}};
@@ -737,7 +786,7 @@ JJ_API int jj_fixedbase_mul(jj_ctx* c, const jj_table* t, size_t n, const void* 
 JJ_API int jj_fixedbase_multi_mul(jj_ctx* c, const jj_table* const* tables, int nbases, size_t n, const void* scalars, void* out64) {
   if (!c || !tables || nbases < 1) return JJ_ERR_INVALID;
   for (int j = 0; j < nbases; j++) if (!tables[j]) return JJ_ERR_INVALID;
-  HIPCHK(c, hipSetDevice(c->device));
+  JJ_ENTER(c);
   const void* ds; int rc; OutRef o;
   if ((rc = stage_in(c, 0, scalars, 32 * n * (size_t)nbases, &ds))) return rc;
   if ((rc = stage_out(c, c->out[0], out64, 64 * n, &o))) return rc;
@@ -782,7 +831,7 @@ static int write_identity(jj_ctx* c, const OutRef& o) {
 }
 JJ_API int jj_point_sum(jj_ctx* c, size_t n, const void* p, void* out64) {
   if (!c) return JJ_ERR_INVALID;
-  HIPCHK(c, hipSetDevice(c->device));
+  JJ_ENTER(c);
   int rc; OutRef o;
   if ((rc = stage_out(c, c->out[0], out64, 64, &o))) return rc;
   if (n == 0) { if ((rc = write_identity(c, o))) return rc; }
@@ -812,7 +861,8 @@ static int msm_pippenger(jj_ctx* c, size_t n, const void* ds, const void* dp, jj
   memset(mp.recode, 0, sizeof mp.recode);
   for (int w = 0; w < mp.W - 1; w++) { const int bit = mp.c * w + mp.c - 1; mp.recode[bit >> 5] |= 1u << (bit & 31); }
   const size_t nb = (size_t)mp.W * mp.B;
-  const u32 L = c->msm_reduce_chunk;                  // buckets per reduce chunk (serial depth 2L + ~2c; JJ_MSM_REDUCE_CHUNK)
+  const u32 L = std::min<u32>((u32)c->msm_reduce_chunk, mp.B);   // buckets per reduce chunk (serial depth 2L + ~2c; JJ_MSM_REDUCE_CHUNK), never more than one window
+  if (mp.B % L || (L & (L - 1)) || (c->msm_fold & (c->msm_fold - 1))) { c->err = "inconsistent MSM tuning overrides (JJ_MSM_REDUCE_CHUNK / JJ_MSM_FOLD must be powers of two dividing the bucket count)"; return JJ_ERR_INVALID; }
   const size_t nchunks = nb / L;
   int rc;
   DevBuf &kprime = c->msm[0], &niels = c->msm[1], &cnt = c->msm[2], &idx = c->msm[3], &buckets = c->msm[4], &ra = c->msm[5], &rb = c->msm[6], &tcnt = c->msm[7];
@@ -895,7 +945,7 @@ static int msm_pippenger(jj_ctx* c, size_t n, const void* ds, const void* dp, jj
 }
 JJ_API int jj_msm(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out64) {
   if (!c) return JJ_ERR_INVALID;
-  HIPCHK(c, hipSetDevice(c->device));
+  JJ_ENTER(c);
   int rc; OutRef o;
   if ((rc = stage_out(c, c->out[0], out64, 64, &o))) return rc;
   if (n == 0) { if ((rc = write_identity(c, o))) return rc; }
@@ -932,10 +982,37 @@ JJ_API int jj_msm(jj_ctx* c, size_t n, const void* scalars, const void* points, 
   return finish(c, sync);
 }
 
+// ---------------------------------------------------------------------------------------------------- synthetic inputs
+static int synth32(jj_ctx* c, size_t n, uint64_t seed, uint64_t first_index, int raw, void* out32);
+JJ_API int jj_synth_scalars(jj_ctx* c, size_t n, uint64_t seed, uint64_t first_index, void* out32) { return synth32(c, n, seed, first_index, 0, out32); }
+JJ_API int jj_synth_bytes32(jj_ctx* c, size_t n, uint64_t seed, uint64_t first_index, void* out32) { return synth32(c, n, seed, first_index, 1, out32); }
+static int synth32(jj_ctx* c, size_t n, uint64_t seed, uint64_t first_index, int raw, void* out32) {
+  if (!c) return JJ_ERR_INVALID;
+  JJ_ENTER(c);
+  int rc; OutRef o;
+  if ((rc = stage_out(c, c->out[0], out32, 32 * n, &o))) return rc;
+  if (n) hipLaunchKernelGGL(k_synth_scalars, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, (u64)seed, (u64)first_index, raw, o.dev);
+  bool sync = false;
+  if ((rc = finish_out(c, o, &sync))) return rc;
+  return finish(c, sync);
+}
+JJ_API int jj_random_points(jj_ctx* c, size_t n, uint64_t seed, uint64_t first_index, int subgroup, void* out64, uint32_t* attempts) {
+  if (!c) return JJ_ERR_INVALID;
+  JJ_ENTER(c);
+  int rc; OutRef o, ao; ao.host = false; ao.dev = nullptr;
+  if ((rc = stage_out(c, c->out[0], out64, 64 * n, &o))) return rc;
+  if (attempts && (rc = stage_out(c, c->out[1], attempts, 4 * n, &ao))) return rc;
+  if (n) hipLaunchKernelGGL(k_random_points, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, (u64)seed, (u64)first_index, subgroup ? 1 : 0, c->sqrt_tables, o.dev, (u32*)ao.dev);
+  bool sync = false;
+  if ((rc = finish_out(c, o, &sync))) return rc;
+  if (attempts && (rc = finish_out(c, ao, &sync))) return rc;
+  return finish(c, sync);
+}
+
 // ---------------------------------------------------------------------------------------------------- encodings
 JJ_API int jj_compress(jj_ctx* c, size_t n, const void* points, void* out32) {
   if (!c) return JJ_ERR_INVALID;
-  HIPCHK(c, hipSetDevice(c->device));
+  JJ_ENTER(c);
   const void* dp; int rc; OutRef o;
   if ((rc = stage_in(c, 0, points, 64 * n, &dp))) return rc;
   if ((rc = stage_out(c, c->out[0], out32, 32 * n, &o))) return rc;
@@ -945,8 +1022,8 @@ JJ_API int jj_compress(jj_ctx* c, size_t n, const void* points, void* out32) {
   return finish(c, sync);
 }
 JJ_API int jj_decompress(jj_ctx* c, size_t n, const void* in32, unsigned flags, void* out64, uint8_t* ok) {
-  if (!c || !ok) return JJ_ERR_INVALID;
-  HIPCHK(c, hipSetDevice(c->device));
+  if (!c || (!ok && n)) return JJ_ERR_INVALID;
+  JJ_ENTER(c);
   const void* di; int rc; OutRef o, ko;
   if ((rc = stage_in(c, 0, in32, 32 * n, &di))) return rc;
   if ((rc = stage_out(c, c->out[0], out64, 64 * n, &o))) return rc;
@@ -979,7 +1056,7 @@ JJ_API int jj_decompress(jj_ctx* c, size_t n, const void* in32, unsigned flags, 
 }
 JJ_API int jj_batch_normalize(jj_ctx* c, size_t n, const void* ext160, void* out64) {
   if (!c) return JJ_ERR_INVALID;
-  HIPCHK(c, hipSetDevice(c->device));
+  JJ_ENTER(c);
   const void* de; int rc; OutRef o;
   if ((rc = stage_in(c, 0, ext160, 160 * n, &de))) return rc;
   if ((rc = stage_out(c, c->out[0], out64, 64 * n, &o))) return rc;
@@ -992,4 +1069,112 @@ JJ_API int jj_batch_normalize(jj_ctx* c, size_t n, const void* ext160, void* out
   bool sync = false;
   if ((rc = finish_out(c, o, &sync))) return rc;
   return finish(c, sync);
+}
+
+// ---------------------------------------------------------------------------------------------------- several devices
+// one context per device, one host thread + stream per device, contiguous shards [g*n/G, (g+1)*n/G), no
+// data-path collective for the independent-batch workloads; the MSM's partial points (64 bytes per device) are folded on
+// the calling host thread, where the Horner tail of every device's Pippenger already ran.  Array arguments are HOST
+// pointers here (the batch lives in host memory and is cut across the devices; each shard goes through the single-device
+// entry point, i.e. page-locked in place and pipelined over copy streams when it is large).  The same device may be listed
+// more than once (several contexts on one GPU: used by the tests, and a way to overlap copies and kernels).
+// Processes that keep their batches in HBM scale as one process per GPU instead (jubjub_amd/dist.py, bench.py).
+struct jj_multi {
+  std::vector<jj_ctx*> ctx;
+  std::mutex mu;
+  std::string err;
+};
+struct jj_mtable { std::vector<jj_table*> t; };
+
+JJ_API int jj_multi_create(const int* devices, int ndev, jj_multi** out) {
+  if (!out) return JJ_ERR_INVALID;
+  *out = nullptr;
+  if (!devices || ndev < 1 || ndev > 64) return JJ_ERR_INVALID;
+  jj_multi* m = new jj_multi();
+  for (int g = 0; g < ndev; g++) {
+    jj_ctx* c = nullptr;
+    const int rc = jj_ctx_create(devices[g], &c);
+    if (rc) { for (jj_ctx* x : m->ctx) (void)jj_ctx_destroy(x); delete m; return rc; }
+    m->ctx.push_back(c);
+  }
+  *out = m;
+  return JJ_OK;
+}
+JJ_API int jj_multi_destroy(jj_multi* m) {
+  if (!m) return JJ_ERR_INVALID;
+  for (jj_ctx* c : m->ctx) (void)jj_ctx_destroy(c);
+  delete m;
+  return JJ_OK;
+}
+JJ_API int jj_multi_device_count(jj_multi* m) { return m ? (int)m->ctx.size() : JJ_ERR_INVALID; }
+JJ_API jj_ctx* jj_multi_ctx(jj_multi* m, int g) { return (m && g >= 0 && g < (int)m->ctx.size()) ? m->ctx[g] : nullptr; }
+JJ_API const char* jj_multi_last_error(jj_multi* m) { return m ? m->err.c_str() : "null context"; }
+
+static inline void shard_of(size_t n, int g, int G, size_t* lo, size_t* hi) {
+  const size_t base = n / G, rem = n % G;
+  *lo = (size_t)g * base + std::min<size_t>((size_t)g, rem);
+  *hi = *lo + base + ((size_t)g < rem ? 1 : 0);
+}
+// body(ctx, g, lo, hi) on one host thread per device; the first failing status (lowest device index) is returned
+template <class Body>
+static int multi_run(jj_multi* m, size_t n, Body body) {
+  const int G = (int)m->ctx.size();
+  std::vector<int> rc(G, JJ_OK);
+  std::vector<std::thread> th;
+  for (int g = 0; g < G; g++) th.emplace_back([&, g]() { size_t lo, hi; shard_of(n, g, G, &lo, &hi); rc[g] = body(m->ctx[g], g, lo, hi); });
+  for (auto& t : th) t.join();
+  for (int g = 0; g < G; g++) if (rc[g]) { std::lock_guard<std::mutex> lk(m->mu); m->err = "device shard " + std::to_string(g) + ": " + jj_last_error(m->ctx[g]); return rc[g]; }
+  return JJ_OK;
+}
+static bool host_args(jj_multi* m, std::initializer_list<const void*> ptrs, size_t n) {
+  if (n == 0) return true;
+  for (const void* p : ptrs) if (!p || is_device_ptr(p)) { std::lock_guard<std::mutex> lk(m->mu); m->err = "multi-device entry points take host pointers"; return false; }
+  return true;
+}
+#define U8(p) ((const uint8_t*)(p))
+#define U8W(p) ((uint8_t*)(p))
+JJ_API int jj_multi_varbase_mul(jj_multi* m, size_t n, const void* scalars, const void* points, void* out64) {
+  if (!m || !host_args(m, {scalars, points, out64}, n)) return JJ_ERR_INVALID;
+  return multi_run(m, n, [&](jj_ctx* c, int, size_t lo, size_t hi) { return jj_varbase_mul(c, hi - lo, U8(scalars) + 32 * lo, U8(points) + 64 * lo, U8W(out64) + 64 * lo); });
+}
+JJ_API int jj_multi_fixedbase_table_create(jj_multi* m, const void* base64, int window_bits, jj_mtable** out) {
+  if (!m || !out || !base64) return JJ_ERR_INVALID;
+  *out = nullptr;
+  jj_mtable* mt = new jj_mtable();
+  mt->t.assign(m->ctx.size(), nullptr);
+  const int rc = multi_run(m, m->ctx.size(), [&](jj_ctx* c, int g, size_t, size_t) { return jj_fixedbase_table_create(c, base64, window_bits, &mt->t[g]); });
+  if (rc) { for (size_t g = 0; g < mt->t.size(); g++) if (mt->t[g]) (void)jj_fixedbase_table_destroy(m->ctx[g], mt->t[g]); delete mt; return rc; }
+  *out = mt;
+  return JJ_OK;
+}
+JJ_API int jj_multi_fixedbase_table_destroy(jj_multi* m, jj_mtable* mt) {
+  if (!m || !mt || mt->t.size() != m->ctx.size()) return JJ_ERR_INVALID;
+  for (size_t g = 0; g < mt->t.size(); g++) if (mt->t[g]) (void)jj_fixedbase_table_destroy(m->ctx[g], mt->t[g]);
+  delete mt;
+  return JJ_OK;
+}
+JJ_API int jj_multi_fixedbase_mul(jj_multi* m, const jj_mtable* mt, size_t n, const void* scalars, void* out64) {
+  if (!m || !mt || mt->t.size() != m->ctx.size() || !host_args(m, {scalars, out64}, n)) return JJ_ERR_INVALID;
+  return multi_run(m, n, [&](jj_ctx* c, int g, size_t lo, size_t hi) { return jj_fixedbase_mul(c, mt->t[g], hi - lo, U8(scalars) + 32 * lo, U8W(out64) + 64 * lo); });
+}
+JJ_API int jj_multi_decompress(jj_multi* m, size_t n, const void* in32, unsigned flags, void* out64, uint8_t* ok) {
+  if (!m || !host_args(m, {in32, out64, ok}, n)) return JJ_ERR_INVALID;
+  return multi_run(m, n, [&](jj_ctx* c, int, size_t lo, size_t hi) { return jj_decompress(c, hi - lo, U8(in32) + 32 * lo, flags, U8W(out64) + 64 * lo, ok + lo); });
+}
+// sum over ALL terms: every device reduces its shard to one affine point, the partial points are added on the host
+JJ_API int jj_multi_msm(jj_multi* m, size_t n, const void* scalars, const void* points, void* out64) {
+  if (!m || !out64 || is_device_ptr(out64) || !host_args(m, {scalars, points}, n)) return JJ_ERR_INVALID;
+  const int G = (int)m->ctx.size();
+  std::vector<uint8_t> part((size_t)G * 64);
+  const int rc = multi_run(m, n, [&](jj_ctx* c, int g, size_t lo, size_t hi) { return jj_msm(c, hi - lo, U8(scalars) + 32 * lo, U8(points) + 64 * lo, &part[(size_t)g * 64]); });
+  if (rc) return rc;
+  jjhost::Ext total = jjhost::identity();
+  for (int g = 0; g < G; g++) {
+    jjhost::Ext p;
+    p.u = jjhost::from_canon(&part[(size_t)g * 64]); p.v = jjhost::from_canon(&part[(size_t)g * 64 + 32]);
+    p.z = jjhost::consts().one; p.t1 = p.u; p.t2 = p.v;
+    total = jjhost::point_add(total, p);
+  }
+  jjhost::to_affine64((uint8_t*)out64, total);
+  return JJ_OK;
 }

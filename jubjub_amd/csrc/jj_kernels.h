@@ -177,6 +177,24 @@ __global__ void __launch_bounds__(256) k_field_pow(size_t n, const void* a, cons
   store8(out, i, wo);
 }
 
+// PrimeFieldBits::to_le_bits (reference src/fr.rs:746-785): the canonical integer, one byte (0/1) per bit, little-endian
+template <class P>
+__global__ void __launch_bounds__(256) k_field_to_bits(size_t n, const void* a, void* out256) {
+  typedef Field<P> F;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 wa[8], w[8];
+  load8(wa, a, i);
+  F::to_words(w, F::from_words(wa));
+  uint4* o = reinterpret_cast<uint4*>(static_cast<uint8_t*>(out256) + i * 256);
+  _Pragma("unroll") for (int v = 0; v < 16; v++) {            // 16 bits -> four words of four 0/1 bytes
+    const u32 h = (w[v >> 1] >> (16 * (v & 1))) & 0xffffu;
+    u32 q[4];
+    _Pragma("unroll") for (int k = 0; k < 4; k++) { const u32 nib = (h >> (4 * k)) & 15u; q[k] = (nib & 1u) | ((nib & 2u) << 7) | ((nib & 4u) << 14) | ((nib & 8u) << 21); }
+    o[v] = make_uint4(q[0], q[1], q[2], q[3]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ K2: point ops
 enum PointOp { PT_DOUBLE = 0, PT_ADD, PT_SUB, PT_NEG, PT_COFACTOR, PT_TO_NIELS,
                PT_IS_IDENTITY, PT_IS_SMALL_ORDER, PT_IS_ON_CURVE };
@@ -1280,6 +1298,76 @@ __global__ void __launch_bounds__(256) k_sum_groups(size_t n, size_t T, int fold
     q = nx; Tq = Tn;
   }
   if (role == 0) soa_put_ext(out, t, acc);
+}
+
+// ------------------------------------------------------------------------------------------------ synthetic inputs
+// Counter-based generator of SURVEY 8(d): word j of unit i is splitmix64(seed + i * stride + j), so any index can be
+// produced on any GPU or on the host (oracle/jubjub_ref.py synth_scalar / synth_point restate the same streams).
+static JJ_DEV u64 splitmix64(u64 x) {
+  x += 0x9E3779B97F4A7C15ull;
+  u64 z = x;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+// scalar_i = four PRNG words, top 4 bits cleared, minus r if >= r (uniform-ish in [0, r)); raw != 0: the 32 PRNG bytes
+// as they are (arbitrary bit patterns: inputs >= q, sign-bit noise for the decoder)
+__global__ void __launch_bounds__(256) k_synth_scalars(size_t n, u64 seed, u64 first, int raw, void* out32) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 w[8];
+  _Pragma("unroll") for (int j = 0; j < 4; j++) { const u64 x = splitmix64(seed + (first + i) * 4 + j); w[2 * j] = (u32)x; w[2 * j + 1] = (u32)(x >> 32); }
+  if (!raw) {
+    w[7] &= 0x0fffffffu;
+    u32 d[8]; int64_t borrow = 0;
+    _Pragma("unroll") for (int j = 0; j < 8; j++) { const int64_t t = (int64_t)w[j] - (int64_t)FR_MODULUS_W[j] + borrow; d[j] = (u32)t; borrow = t >> 32; }
+    if (borrow == 0) { _Pragma("unroll") for (int j = 0; j < 8; j++) w[j] = d[j]; }
+  }
+  store8(out32, i, w);
+}
+// Group::random (reference src/lib.rs:1244-1267; SubgroupPoint::random 1290-1298 with `subgroup`): rejection sampling
+//   loop { v = Fq::random (64 PRNG bytes, from_bytes_wide); flip = next_u32 % 2; u = sqrt((v^2-1)/(1+d v^2)) or retry;
+//          p = (flip ? -u : u, v); retry if identity; [subgroup: p = [8]p; retry if identity] }
+// The reference draws from one sequential RNG; here every unit owns the counter range [(first+i) << 16, ...) and attempt t
+// reads words 16 t .. 16 t + 8 of it (8 for v, 1 for the flip), so the result is a pure function of (seed, index).
+constexpr int RANDOM_POINT_STRIDE_LOG2 = 16;
+__global__ void __launch_bounds__(256) k_random_points(size_t n, u64 seed, u64 first, int subgroup, SqrtTables tabs, void* out64, u32* attempts) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u64 base = seed + ((first + i) << RANDOM_POINT_STRIDE_LOG2);
+  u32 t = 0;
+  bool done = false;
+  #pragma unroll 1
+  while (!done) {                                              // divergent: lanes leave as their sample is accepted
+    u32 lo[8], hi[8];
+    _Pragma("unroll") for (int j = 0; j < 4; j++) {
+      const u64 a = splitmix64(base + 16ull * t + j), b = splitmix64(base + 16ull * t + 4 + j);
+      lo[2 * j] = (u32)a; lo[2 * j + 1] = (u32)(a >> 32); hi[2 * j] = (u32)b; hi[2 * j + 1] = (u32)(b >> 32);
+    }
+    const u32 flip = (u32)splitmix64(base + 16ull * t + 8) & 1u;
+    t++;
+    const Fe v = Fq::mul(Fq::from_words_wide(lo, hi), Fq::one());          // one carried representative of the 512-bit value mod q
+    const Fe v2 = Fq::sqr(v);
+    const Fe den = Fq::carry(Fq::add(Fq::one(), Fq::mul(Fq::konst(FqP::D), v2)));
+    const Fe u2 = Fq::mul(Fq::sub(v2, Fq::one()), Fq::invert(den));       // invert(0) = 0, as unwrap_or(zero)
+    bool ok;
+    Fe u = fq_sqrt_fast(u2, ok, tabs);
+    if (!ok) continue;
+    u = Fq::cneg(u, flip ? ~0u : 0u);
+    Affine a; a.u = Fq::mul(u, Fq::one()); a.v = v;
+    Ext e = Curve::from_affine(a);
+    if (Curve::is_identity(e)) continue;
+    if (subgroup) {
+      e = Curve::mul_by_cofactor(e);
+      if (Curve::is_identity(e)) continue;
+      const Fe zi = Fq::invert(e.z);
+      store_affine(out64, i, Fq::mul(e.u, zi), Fq::mul(e.v, zi));
+    } else {
+      store_affine(out64, i, a.u, a.v);
+    }
+    done = true;
+  }
+  if (attempts) attempts[i] = t;
 }
 
 // ------------------------------------------------------------------------------------------------ roofline probe

@@ -6,6 +6,8 @@ tensors (device; zero-copy, asynchronous on torch's current stream).  Results co
 Shapes: scalars / field elements (n, 32); affine points (n, 64); compressed points (n, 32).
 """
 import ctypes as C
+import functools
+import threading
 
 import numpy as np
 
@@ -72,6 +74,7 @@ class FixedBaseTable:
 
 class Engine:
     def __init__(self, device=0):
+        self._mu = threading.RLock()      # stream selection + call form one critical section per Engine (see _locked below)
         self._lib = _lib.load()
         ctx = C.c_void_p()
         rc = self._lib.jj_ctx_create(int(device), C.byref(ctx))
@@ -268,3 +271,136 @@ class Engine:
 
     def batch_normalize(self, ext160):
         return self._call("jj_batch_normalize", [ext160], [160], [64])
+
+    # -------------------------------------------------------------- bit decomposition (reference src/fr.rs:746-785)
+    def to_le_bits(self, field, a):
+        return self._call("jj_%s_to_le_bits" % field, [a], [32], [256])
+
+    def char_le_bits(self):
+        out = (C.c_uint8 * 256)()
+        self._check(self._lib.jj_fr_char_le_bits(out))
+        return np.frombuffer(bytes(out), dtype=np.uint8)
+
+    # -------------------------------------------------------------- synthetic inputs (reference Group::random, src/lib.rs:1244-1298)
+    def _generate(self, name, n, width, device, extra):
+        """device: None -> numpy result, else a torch device -> CUDA tensor on torch's current stream"""
+        if device is None:
+            out = np.empty((n, width), dtype=np.uint8)
+            ptr = out.ctypes.data if n else None
+            self._lib.jj_ctx_use_own_stream(self._ctx)
+        else:
+            import torch
+
+            out = torch.empty((n, width), dtype=torch.uint8, device=device)
+            ptr = out.data_ptr()
+            self._lib.jj_ctx_set_stream(self._ctx, C.c_void_p(torch.cuda.current_stream(device).cuda_stream))
+        self._check(getattr(self._lib, name)(self._ctx, C.c_size_t(n), *extra(ptr)))
+        return out
+
+    def synth_scalars(self, n, seed, first_index=0, device=None):
+        return self._generate("jj_synth_scalars", n, 32, device, lambda p: (C.c_uint64(seed), C.c_uint64(first_index), p))
+
+    def synth_bytes32(self, n, seed, first_index=0, device=None):
+        return self._generate("jj_synth_bytes32", n, 32, device, lambda p: (C.c_uint64(seed), C.c_uint64(first_index), p))
+
+    def random_points(self, n, seed, first_index=0, subgroup=False, device=None):
+        return self._generate("jj_random_points", n, 64, device,
+                              lambda p: (C.c_uint64(seed), C.c_uint64(first_index), C.c_int(1 if subgroup else 0), p, None))
+
+
+
+def _locked(fn):
+    @functools.wraps(fn)
+    def wrapper(self, *a, **k):
+        with self._mu:
+            return fn(self, *a, **k)
+    return wrapper
+
+
+# Engine methods select the launch stream and then call the library: two host threads sharing an Engine must not
+# interleave those two steps (the C entry points themselves serialise on the context lock).
+for _name, _fn in list(vars(Engine).items()):
+    if callable(_fn) and not _name.startswith("__"):
+        setattr(Engine, _name, _locked(_fn))
+
+
+class MultiEngine:
+    """Several devices of one node driven from one process (include/jubjub_hip.h jj_multi_*): one context, host thread and
+    stream per listed device, contiguous shards, host (numpy) arrays in and out; the MSM's per-device partial points are
+    added on the host.  A device may be listed more than once."""
+
+    def __init__(self, devices):
+        self._lib = _lib.load()
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        h = C.c_void_p()
+        rc = self._lib.jj_multi_create(devs, C.c_int(len(devices)), C.byref(h))
+        self._h = None
+        if rc != 0:
+            raise JubjubError("jj_multi_create(%r) failed with %d" % (list(devices), rc))
+        self._h = h
+        self._tables = []
+
+    def close(self):
+        if self._h is not None:
+            for t in self._tables:
+                self._lib.jj_multi_fixedbase_table_destroy(self._h, t)
+            self._tables = []
+            self._lib.jj_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise JubjubError("rc=%d: %s" % (rc, (self._lib.jj_multi_last_error(self._h) or b"").decode()))
+
+    @property
+    def device_count(self):
+        return self._lib.jj_multi_device_count(self._h)
+
+    @staticmethod
+    def _np(x, width):
+        a = np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, width)
+        return a, (a.ctypes.data if a.size else None)
+
+    def varbase_mul(self, scalars, points):
+        s, sp = self._np(scalars, 32)
+        p, pp = self._np(points, 64)
+        if len(s) != len(p):
+            raise ValueError("length mismatch")
+        out = np.empty((len(s), 64), np.uint8)
+        self._check(self._lib.jj_multi_varbase_mul(self._h, C.c_size_t(len(s)), sp, pp, out.ctypes.data if len(s) else None))
+        return out
+
+    def fixedbase_table(self, base, window_bits=0):
+        b, bp = self._np(base, 64)
+        t = C.c_void_p()
+        self._check(self._lib.jj_multi_fixedbase_table_create(self._h, bp, C.c_int(window_bits), C.byref(t)))
+        self._tables.append(t)
+        return t
+
+    def fixedbase_mul(self, table, scalars):
+        s, sp = self._np(scalars, 32)
+        out = np.empty((len(s), 64), np.uint8)
+        self._check(self._lib.jj_multi_fixedbase_mul(self._h, table, C.c_size_t(len(s)), sp, out.ctypes.data if len(s) else None))
+        return out
+
+    def decompress(self, enc, flags=FLAG_ZIP216):
+        e, ep = self._np(enc, 32)
+        out, ok = np.empty((len(e), 64), np.uint8), np.empty((len(e),), np.uint8)
+        self._check(self._lib.jj_multi_decompress(self._h, C.c_size_t(len(e)), ep, C.c_uint(flags), out.ctypes.data if len(e) else None,
+                                                  ok.ctypes.data if len(e) else None))
+        return out, ok
+
+    def msm(self, scalars, points):
+        s, sp = self._np(scalars, 32)
+        p, pp = self._np(points, 64)
+        if len(s) != len(p):
+            raise ValueError("length mismatch")
+        out = np.empty((64,), np.uint8)
+        self._check(self._lib.jj_multi_msm(self._h, C.c_size_t(len(s)), sp, pp, out.ctypes.data))
+        return out

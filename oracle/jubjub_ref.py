@@ -526,3 +526,42 @@ def synth_scalar(i, seed=SEED):
     if k >= R_MOD:
         k -= R_MOD
     return k
+
+
+def synth_bytes32(i, seed=SEED):
+    """the four PRNG words of unit i as 32 raw little-endian bytes (jj_synth_bytes32)"""
+    k = 0
+    for j in range(4):
+        k |= splitmix64((seed + i * 4 + j) & _M64) << (64 * j)
+    return k.to_bytes(32, "little")
+
+
+def synth_point(i, seed=SEED, subgroup=False):
+    """ExtendedPoint::random / SubgroupPoint::random (src/lib.rs:1244-1267, 1290-1298) over the counter-based stream of
+    unit i: attempt t reads splitmix64(seed + (i << 16) + 16 t + j), j = 0..7 for the 64 bytes of Fq::random
+    (from_bytes_wide, src/fr.rs:684-688 pattern), j = 8 for `next_u32() % 2`.  Returns (affine point, attempts)."""
+    base = (seed + (i << 16)) & _M64
+    t = 0
+    while True:
+        wide = 0
+        for j in range(8):
+            wide |= splitmix64((base + 16 * t + j) & _M64) << (64 * j)
+        flip = splitmix64((base + 16 * t + 8) & _M64) & 1
+        t += 1
+        v = wide % Q
+        v2 = v * v % Q
+        den = (1 + EDWARDS_D * v2) % Q
+        u2 = (v2 - 1) * (pow(den, -1, Q) if den else 0) % Q
+        u, ok = fq_sqrt(u2)
+        if not ok:
+            continue
+        if flip:
+            u = -u % Q
+        if (u, v) == AFFINE_IDENTITY:
+            continue
+        if subgroup:
+            e = ext_mul_by_cofactor(affine_to_extended((u, v)))
+            if ext_is_identity(e):
+                continue
+            return ext_to_affine(e), t
+        return (u, v), t

@@ -1,0 +1,82 @@
+"""
+Multi-rank path of bench.py on real hardware (one GPU is enough): the ranks bench.py spawns itself, the torch.distributed
+exchange of the MSM's 64-byte partial points (gloo with two ranks stacked on one GPU; RCCL with one rank), strong and weak
+scaling shards built from the global unit indices, and the folded point against the oracle.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle as O
+from oracle import jubjub_ref as J
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def run_bench(args, env_extra, timeout=900):
+    env = dict(os.environ, **env_extra)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, BENCH] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:] + r.stdout[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def oracle_msm(total):
+    import bench
+
+    b32 = lambda k: np.frombuffer(int(k).to_bytes(32, "little"), dtype=np.uint8)
+    s = np.stack([b32(J.synth_scalar(i, bench.SEED)) for i in range(total)])
+    p = np.stack([np.concatenate([b32(c) for c in J.synth_point(i, bench.POINT_SEED)[0]]) for i in range(total)])
+    return bytes(O.msm(s, p).tolist()).hex()
+
+
+def test_self_spawned_two_ranks_msm_strong_scaling_over_gloo():
+    """`python bench.py --gpus 2` (no launcher): two ranks stacked on GPU 0, BASELINE config 4 shape (terms cut across the
+    ranks, one all_gather of the partial points), the folded point equals the oracle's MSM over ALL terms"""
+    res = run_bench(["--gpus", "2", "--workload", "msm", "--scaling", "strong", "--log2n", "12", "--steps", "2", "--warmup", "1",
+                     "--passes", "2", "--backend", "gloo", "--no-cpu-baseline"], {"JJ_BENCH_FORCE_DEVICE": "0"})
+    assert res["n_gpus"] == 2 and res["scaling"] == "strong" and res["verified"] is True
+    assert res["config"]["units_per_step"] == 2 * (1 << 12)
+    assert res["msm_result"] == oracle_msm(1 << 12)
+
+
+def test_self_spawned_two_ranks_weak_scaling_independent_shards():
+    res = run_bench(["--gpus", "2", "--workload", "varbase", "--log2n", "12", "--steps", "2", "--warmup", "1", "--backend", "gloo",
+                     "--no-cpu-baseline", "--no-extras"], {"JJ_BENCH_FORCE_DEVICE": "0"})
+    assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["verified"] is True
+    assert res["config"]["units_per_step"] == 2 * (1 << 12) * res["config"]["passes_per_step"]
+    res = run_bench(["--gpus", "2", "--workload", "decompress", "--scaling", "strong", "--log2n", "16", "--steps", "2", "--warmup", "1",
+                     "--backend", "gloo", "--no-cpu-baseline"], {"JJ_BENCH_FORCE_DEVICE": "0"})
+    assert res["n_gpus"] == 2 and res["verified"] is True and res["verified_units"] > 32
+
+
+def test_one_rank_rccl_all_gather_leg():
+    """the RCCL (backend nccl) exchange itself, with the one rank a 1-GPU box can hold"""
+    res = run_bench(["--gpus", "1", "--workload", "msm", "--log2n", "12", "--steps", "2", "--warmup", "1", "--passes", "2", "--no-cpu-baseline"],
+                    {"JJ_BENCH_FORCE_DIST": "1", "MASTER_PORT": "29611"})
+    assert res["n_gpus"] == 1 and res["verified"] is True
+    assert res["msm_result"] == oracle_msm(1 << 12)
+    assert "all_gather" in res["config"]["parallelism"]
+
+
+def test_too_many_gpus_is_refused_not_mislabelled():
+    """--gpus 8 on a box with fewer devices must fail loudly instead of reporting a 1-GPU run"""
+    import torch
+
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("8 devices present")
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "JJ_BENCH_FORCE_DEVICE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -454,3 +454,122 @@ def test_host_buffer_pipeline_default_chunks(eng):
     assert (got == dev).all()
     idx = np.arange(0, n, 257)
     assert (got[idx] == O.varbase_mul(S[idx], P[idx])).all()
+
+
+def test_synthetic_input_generators(eng):
+    """jj_synth_scalars / jj_random_points (Group::random semantics, reference src/lib.rs:1244-1267, 1290-1298) against the
+    oracle's restatement of the same counter-based streams; any index is reproducible on any device."""
+    n, first = 300, 12345
+    s = eng.synth_scalars(n, J.SEED, first)
+    assert (s == arr32([J.synth_scalar(first + i) for i in range(n)])).all()
+    assert all(to_int(r) < R for r in s)
+    pts = eng.random_points(n, J.SEED, first)
+    want = [J.synth_point(first + i) for i in range(n)]
+    assert (pts == arr64([p for p, _ in want])).all()
+    assert max(t for _, t in want) >= 5                      # the rejection loop is exercised well past the first draw
+    assert eng.predicate("is_on_curve", pts).all() and not eng.predicate("is_identity", pts).any()
+    sub = eng.random_points(64, J.SEED ^ 0x55, 7, subgroup=True)
+    assert (sub == arr64([J.synth_point(7 + i, seed=J.SEED ^ 0x55, subgroup=True)[0] for i in range(64)])).all()
+    assert eng.predicate("is_prime_order", sub).all()
+    # a later window of the same stream, produced independently, equals the corresponding slice
+    assert (eng.random_points(50, J.SEED, first + 100) == pts[100:150]).all()
+    assert eng.synth_scalars(0, 1).shape == (0, 32) and eng.random_points(0, 1).shape == (0, 64)
+    raw = eng.synth_bytes32(n, 99, first)
+    assert raw.tobytes() == b"".join(J.synth_bytes32(first + i, 99) for i in range(n))
+    import torch
+
+    dev = torch.device("cuda", 0)
+    assert (eng.random_points(n, J.SEED, first, device=dev).cpu().numpy() == pts).all()
+    assert (eng.synth_scalars(n, J.SEED, first, device=dev).cpu().numpy() == s).all()
+
+
+@pytest.mark.parametrize("fname,p", [("fq", Q), ("fr", R)])
+def test_to_le_bits(eng, fname, p):
+    """PrimeFieldBits::to_le_bits / char_le_bits (reference src/fr.rs:746-785): bits of the canonical integer, LSB first"""
+    a, _ = field_inputs(p, 91, n=200)
+    bits = eng.to_le_bits(fname, a)
+    assert bits.shape == (len(a), 256)
+    want = np.array([[(to_int(x) % p >> b) & 1 for b in range(256)] for x in a], dtype=np.uint8)
+    assert (bits == want).all()
+    assert eng.to_le_bits(fname, a[:0]).shape == (0, 256)
+    assert (eng.char_le_bits() == np.array([(R >> b) & 1 for b in range(256)], dtype=np.uint8)).all()
+
+
+def test_empty_batches_with_validity_outputs(eng):
+    """n = 0 is accepted by the entry points that also return a validity array"""
+    e32 = np.zeros((0, 32), np.uint8)
+    out, ok = eng.decompress(e32, 1)
+    assert out.shape == (0, 64) and ok.shape == (0,)
+    for f in ("fq", "fr"):
+        for op in ("invert", "sqrt", "from_bytes"):
+            o, k = eng.field_unary_ok(f, op, e32)
+            assert o.shape == (0, 32) and k.shape == (0,)
+
+
+@pytest.mark.parametrize("wbits", [13, 14, 16])
+def test_fixedbase_wide_windows(eng, wbits):
+    """the wide-window tables behind the published fixed_base_wide_window figure (16-bit: 64 MB table)"""
+    s = np.concatenate([arr32(EDGE_SCALARS), rand_scalars(300 + wbits, 2000), rand_scalars(400 + wbits, 48, full_width=True)])
+    base = pt64(J.GENERATOR)
+    tab = eng.fixedbase_table(base, wbits)
+    assert (eng.fixedbase_mul(tab, s) == O.fixedbase_mul(s, base)).all()
+    tab.close()
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
+def test_multi_device_c_abi(devices):
+    """jj_multi_*: one context + host thread per listed device (here the same GPU listed several times), contiguous shards,
+    MSM partial points folded on the host -- against the oracle and against ragged / empty / fewer-units-than-devices batches"""
+    from jubjub_amd import MultiEngine
+
+    me = MultiEngine(devices)
+    assert me.device_count == len(devices)
+    base = pt64(J.GENERATOR)
+    tab = me.fixedbase_table(base)
+    for n in (0, 1, 2, 1001):
+        s, p = rand_scalars(50 + n, n), rand_points(60 + n, n)
+        assert (me.varbase_mul(s, p) == O.varbase_mul(s, p)).all()
+        assert (me.fixedbase_mul(tab, s) == O.fixedbase_mul(s, base)).all()
+        assert (me.msm(s, p) == O.msm(s, p)).all()
+        enc = O.compress(p) if n else np.zeros((0, 32), np.uint8)
+        if n:
+            enc[::5] ^= 0x40
+        out, ok = me.decompress(enc, 1 | 4 | 8)
+        eo, ek = O.decompress(enc, 1 | 4 | 8)
+        assert (ok == ek).all() and (out == eo).all()
+    import torch
+
+    with pytest.raises(Exception):                       # device pointers are refused: the batch is cut on the host
+        me._check(me._lib.jj_multi_varbase_mul(me._h, 4, torch.zeros(128, dtype=torch.uint8, device="cuda").data_ptr(), None, None))
+    me.close()
+
+
+def test_context_is_thread_safe_and_stream_switches_are_ordered(eng):
+    """two host threads share one context (entry points serialise on the context lock); an asynchronous call on a torch
+    stream followed by a call on the context's own stream must not corrupt the first one's workspaces"""
+    import threading
+
+    import torch
+
+    s, p = rand_scalars(71, 20000), rand_points(72, 20000)
+    want = O.varbase_mul(s, p)
+    res = [None, None]
+
+    def work(k):
+        res[k] = eng.varbase_mul(s, p) if k == 0 else eng.fixedbase_mul(tab, s)
+
+    tab = eng.fixedbase_table(pt64(J.GENERATOR))
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert (res[0] == want).all() and (res[1] == O.fixedbase_mul(s, pt64(J.GENERATOR))).all()
+    dev = torch.device("cuda", 0)
+    st, pt = torch.from_numpy(s).to(dev), torch.from_numpy(p).to(dev)
+    side = torch.cuda.Stream(dev)
+    for _ in range(3):
+        with torch.cuda.stream(side):
+            a = eng.varbase_mul(st, pt)                    # asynchronous on `side`
+        b = eng.varbase_mul(s[:3000], p[:3000])            # numpy: the context's own stream, same workspaces
+        side.synchronize()
+        assert (a.cpu().numpy() == want).all() and (b == want[:3000]).all()
+    tab.close()
