@@ -297,6 +297,8 @@ def run(a):
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         if a.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
@@ -431,7 +433,7 @@ def run(a):
             "work_per_unit": {"field_squares": w["S"], "field_muls": w["M"], "imad32": work_main, "convention": "M=128,S=100 (SURVEY 8d); the kernel named above only",
                               "tail_kernel": {"field_squares": w["tail_S"], "field_muls": w["tail_M"], "imad32": imad32(w["tail_S"], w["tail_M"])}},
             "whole_pass_frac": n * (work_main + imad32(w["tail_S"], w["tail_M"])) / ((kern_ms + tail) * 1e-3) / peak,
-            "reference_algorithm_imad32": imad32(**REFERENCE_WORK[wl]) if wl in REFERENCE_WORK else None,
+            "reference_algorithm_imad32": imad32(REFERENCE_WORK[wl]["S"], REFERENCE_WORK[wl]["M"]) if wl in REFERENCE_WORK else None,
             "hbm": {"achieved": n * w["bytes"] / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": n * w["bytes"] / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "bytes_per_unit": w["bytes"]},
             "build_id": build_id(),

@@ -1022,11 +1022,17 @@ __global__ void __launch_bounds__(256) k_msm_accumulate_seg(const u32* nseg_tota
   const Seg sg = seg[t];
   Ext acc = Curve::identity();
   const u32* ip = idx + sg.start;
+  // software pipeline: the entry of term k+1 (a dependent 4-byte index load, then a random 128-byte gather) is in flight
+  // while term k is added
+  u32 e = ip[0];
+  ANiels p = lds_aniels(niels + (size_t)(e & 0x7fffffffu) * GNIELS_WORDS);
+  u32 e_next = sg.len > 1 ? ip[1] : e;
   #pragma unroll 1
   for (u32 k = 0; k < sg.len; k++) {
-    const u32 e = ip[k];
-    const ANiels p = lds_aniels(niels + (size_t)(e & 0x7fffffffu) * GNIELS_WORDS);
+    const ANiels p_next = lds_aniels(niels + (size_t)(e_next & 0x7fffffffu) * GNIELS_WORDS);
+    const u32 e_next2 = k + 2 < sg.len ? ip[k + 2] : e_next;
     acc = Curve::add_signed<true>(acc, p, (e >> 31) ? ~0u : 0u);
+    e = e_next; p = p_next; e_next = e_next2;
   }
   if (sg.dst >> 31) aos_put_ext(head, sg.dst & 0x7fffffffu, acc); else aos_put_ext(buckets, sg.dst, acc);
 }
