@@ -55,8 +55,8 @@ RAW_SEED = SEED ^ 0x5DEECE66D
 # IMAD32 convention: M = 128, S = 100.
 WORK = {
     # k_varbase: 2 from_words + to_niels(P) 2M; table {1..16}P: to_niels 2M + 15 x (mixed add 7M + to_niels 2M);
-    # 51 additions x 8M; 250 doublings x (4S + 3M).   tail k_normalize<32>: ~9M + (255S + 75M)/32 per unit
-    "varbase": {"S": 1000, "M": 2 + 2 + 2 + 15 * 9 + 51 * 8 + 250 * 3, "tail_S": 8, "tail_M": 11, "bytes": 32 + 64 + 64},
+    # 51 additions x 8M; 250 doublings x (3S + 4M: 2UV is a product here, jj_curve.h).   tail k_normalize<32>: ~9M + (255S + 75M)/32 per unit
+    "varbase": {"S": 250 * 3, "M": 2 + 2 + 2 + 15 * 9 + 51 * 8 + 250 * 4, "tail_S": 8, "tail_M": 11, "bytes": 32 + 64 + 64},
     # k_fixedbase: 43 mixed additions x 7M
     "fixedbase": {"S": 0, "M": 43 * 7, "tail_S": 8, "tail_M": 11, "bytes": 32 + 64},
     # Pippenger, c = 16: per term 2M load + 2M to_niels + 16 windows x 7M mixed add; bucket reduce 2 x 10M per bucket

@@ -549,14 +549,14 @@ static void varbase_geometry(jj_ctx* c, size_t n, unsigned* blocks, size_t* thre
 }
 static int varbase_to_ext(jj_ctx* c, size_t n, const void* ds, const void* dp, SoA ext, bool five) {
   if (n <= (size_t)c->vb_quad_max) {      // small batch: one scalar multiplication per quad of lanes (3x lower latency)
-    int rc = ensure(c, c->ws_tables, n * (size_t)(VB_TABLE * ENIELS_WORDS) * 4); if (rc) return rc;
+    int rc = ensure(c, c->ws_tables, n * (size_t)(VB_SLOTS * ENIELS_WORDS) * 4); if (rc) return rc;
     if (five) hipLaunchKernelGGL(k_varbase_quad<true>, dim3(blocks_for(4 * n)), dim3(256), 0, c->stream, n, ds, dp, (u32*)c->ws_tables.p, ext);
     else hipLaunchKernelGGL(k_varbase_quad<false>, dim3(blocks_for(4 * n)), dim3(256), 0, c->stream, n, ds, dp, (u32*)c->ws_tables.p, ext);
     return JJ_OK;
   }
   unsigned blocks; size_t threads;
   varbase_geometry(c, n, &blocks, &threads);
-  int rc = ensure(c, c->ws_tables, threads * (size_t)(VB_TABLE * ENIELS_WORDS) * 4); if (rc) return rc;
+  int rc = ensure(c, c->ws_tables, threads * (size_t)(VB_SLOTS * ENIELS_WORDS) * 4); if (rc) return rc;
   if ((rc = ensure(c, c->cursor, 64))) return rc;
   HIPCHK(c, hipMemsetAsync(c->cursor.p, 0, 8, c->stream));          // the waves' work cursor
   if (five) hipLaunchKernelGGL(k_varbase<true>, dim3(blocks), dim3(256), 0, c->stream, n, ds, dp, (u32*)c->ws_tables.p, ext, (unsigned long long*)c->cursor.p);

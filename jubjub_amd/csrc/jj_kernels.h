@@ -208,8 +208,8 @@ __global__ void __launch_bounds__(256) k_point_op(size_t n, const void* p, const
   const Affine a = load_affine(p, i);
   Ext e = Curve::from_affine(a), r;
   if constexpr (OP == PT_DOUBLE) r = Curve::dbl(e);
-  if constexpr (OP == PT_ADD) r = Curve::add(e, Curve::to_niels(load_affine(q, i)));
-  if constexpr (OP == PT_SUB) r = Curve::sub(e, Curve::to_niels(load_affine(q, i)));
+  if constexpr (OP == PT_ADD) r = Curve::add<true>(e, Curve::to_niels(load_affine(q, i)));
+  if constexpr (OP == PT_SUB) r = Curve::sub<true>(e, Curve::to_niels(load_affine(q, i)));
   if constexpr (OP == PT_NEG) r = Curve::neg(e);
   if constexpr (OP == PT_COFACTOR) r = Curve::mul_by_cofactor(e);
   if constexpr (OP <= PT_COFACTOR) { ext.put(0, i, r.u); ext.put(1, i, r.v); ext.put(2, i, r.z); }
@@ -353,39 +353,42 @@ static JJ_DEV u32 vb_window(const u32 (&k)[8], int i) {
   const u64 both = ((u64)hi << 32) | lo;
   return (u32)(both >> sh) & ((1u << VB_W) - 1u);
 }
-// zero digit -> identity entry (the sign is applied inside Curve::add_signed)
-static JJ_DEV ENiels zeroed_entry(const ENiels& e, u32 zero) {
-  return Curve::select(e, Curve::eniels_identity(), zero ? ~0u : 0u);
-}
+// The lane's table holds VB_SLOTS entries: slot[0] = the identity entry (digit 0), slot[j] = j P for j = 1 .. 2^(w-1): a zero
+// digit is a plain table read instead of a 36-instruction select (the sign is applied inside Curve::add_signed).
+constexpr int VB_SLOTS = VB_TABLE + 1;
 
 static JJ_DEV Ext varbase_windowed(const Affine& P, u32 (&k)[8], u32* slot) {
-  // table: slot[j] = (j+1) P
   const ANiels pn = Curve::to_niels(P);
   Ext cur = Curve::from_affine(P);
-  store_eniels(slot, Curve::to_niels(cur));
+  store_eniels(slot, Curve::eniels_identity());
+  store_eniels(slot + ENIELS_WORDS, Curve::to_niels<true>(cur));
   #pragma unroll 1
-  for (int j = 1; j < VB_TABLE; j++) {
+  for (int j = 2; j <= VB_TABLE; j++) {
     cur = Curve::add<true>(cur, pn);
-    store_eniels(slot + j * ENIELS_WORDS, Curve::to_niels(cur));
+    store_eniels(slot + j * ENIELS_WORDS, Curve::to_niels<true>(cur));
   }
   recode_signed(k);
   // top window: unsigned digit (0 .. 2^(253 - w (NWIN-1)))
   u32 a = vb_window(k, VB_NWIN - 1), neg = 0;
-  ENiels e = load_eniels(slot + (a ? a - 1 : 0) * ENIELS_WORDS);
+  ENiels e = load_eniels(slot + a * ENIELS_WORDS);
   Ext acc = Curve::identity();
   #pragma unroll 1
   for (int i = VB_NWIN - 1; i >= 0; i--) {
-    const ENiels s = zeroed_entry(e, a == 0);
+    const ENiels s = e;
     const u32 smask = neg ? ~0u : 0u;
     if (i > 0) {                                             // fetch the next window's entry before the doublings
       const int d = (int)vb_window(k, i - 1) - VB_TABLE;
       neg = d < 0; a = (u32)(d < 0 ? -d : d);
-      e = load_eniels(slot + (a ? a - 1 : 0) * ENIELS_WORDS);
+      e = load_eniels(slot + a * ENIELS_WORDS);
     }
-    acc = Curve::add_signed(acc, s, smask);
+    acc = Curve::add_signed<true>(acc, s, smask);
     if (i > 0) {
+      // two doublings per trip so that the results can alternate between two register sets (a rolled loop copies 36
+      // registers back per doubling); VB_W - 1 is even for the default 5-bit windows
+      static_assert((VB_W - 1) % 2 == 0, "the doubling loop is unrolled by two");
       #pragma unroll 1
-      for (int d = 0; d < VB_W; d++) acc = Curve::dbl(acc);
+      for (int d = 0; d < (VB_W - 1) / 2; d++) acc = Curve::dbl(Curve::dbl(acc));
+      acc = Curve::dbl(acc);
     }
   }
   return acc;
@@ -405,7 +408,7 @@ static JJ_DEV bool next_wave_units(unsigned long long* cursor, size_t n, size_t&
 template <bool FIVE>
 __global__ void __launch_bounds__(256, JJ_VB_MINWAVES) k_varbase(size_t n, const void* scalars, const void* points, u32* tables, SoA ext, unsigned long long* cursor) {
   const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  u32* slot = tables + gtid * (size_t)(VB_TABLE * ENIELS_WORDS);
+  u32* slot = tables + gtid * (size_t)(VB_SLOTS * ENIELS_WORDS);
   size_t i;
   #pragma unroll 1
   while (next_wave_units(cursor, n, i)) {
@@ -425,7 +428,7 @@ __global__ void __launch_bounds__(256) k_varbase_exact(size_t n, const void* sca
   u32 k[8];
   load8(k, scalars, i);
   const Affine P = load_affine(points, i);
-  const ENiels pn = Curve::to_niels(Curve::from_affine(P));
+  const ENiels pn = Curve::to_niels<true>(Curve::from_affine(P));
   const ENiels zero = Curve::eniels_identity();
   Ext acc = Curve::identity();
   #pragma unroll 1
@@ -434,7 +437,7 @@ __global__ void __launch_bounds__(256) k_varbase_exact(size_t n, const void* sca
     _Pragma("unroll") for (int w = 1; w < 8; w++) word = ((i2 >> 5) == w) ? k[w] : word;
     const u32 bit = (word >> (i2 & 31)) & 1u;
     acc = Curve::dbl(acc);
-    acc = Curve::add(acc, Curve::select(zero, pn, 0u - bit));
+    acc = Curve::add<true>(acc, Curve::select(zero, pn, 0u - bit));
   }
   u32 w[8];
   Fq::to_words(w, acc.u); store8(out160, 5 * i, w);
@@ -605,7 +608,7 @@ __global__ void __launch_bounds__(256) k_sum_pass(size_t n, size_t T, SoA in, So
     const size_t i = t + (size_t)j * T;
     if (i >= n) break;
     Ext e; e.u = in.get(0, i); e.v = in.get(1, i); e.z = in.get(2, i); e.t1 = in.get(3, i); e.t2 = in.get(4, i);
-    acc = Curve::add<true>(acc, Curve::to_niels(e));
+    acc = Curve::add<true>(acc, Curve::to_niels<true>(e));
   }
   out.put(0, t, acc.u); out.put(1, t, acc.v); out.put(2, t, acc.z); out.put(3, t, Fq::carry(acc.t1)); out.put(4, t, Fq::carry(acc.t2));
 }
@@ -938,7 +941,7 @@ __global__ void __launch_bounds__(256) k_msm_fixup(size_t nb, u32 chunk, const u
   acc = aos_ext(buckets, b);
   #pragma unroll 1
   for (size_t t = t_first; t <= t_last; t++) {
-    acc = Curve::add<true>(acc, Curve::to_niels(aos_ext(head, t)));
+    acc = Curve::add<true>(acc, Curve::to_niels<true>(aos_ext(head, t)));
   }
   aos_put_ext(buckets, b, acc);
 }
@@ -1043,7 +1046,7 @@ __global__ void __launch_bounds__(256) k_msm_merge(const u32* counters, const Me
   const MergeItem it = merge[m];
   Ext acc = aos_ext(buckets, it.bucket);
   #pragma unroll 1
-  for (u32 j = 0; j < it.k; j++) acc = Curve::add<true>(acc, Curve::to_niels(aos_ext(head, (size_t)it.h0 + j)));
+  for (u32 j = 0; j < it.k; j++) acc = Curve::add<true>(acc, Curve::to_niels<true>(aos_ext(head, (size_t)it.h0 + j)));
   aos_put_ext(buckets, it.bucket, acc);
 }
 static JJ_DEV Ext soa_ext(const SoA& s, size_t i) { Ext e; e.u = s.get(0, i); e.v = s.get(1, i); e.z = s.get(2, i); e.t1 = s.get(3, i); e.t2 = s.get(4, i); return e; }
@@ -1163,9 +1166,10 @@ static JJ_DEV Ext varbase_windowed_quad(const Affine& P, u32 (&k)[8], u32* slot,
   Fe T = Fq::mul(P.u, P.v);
   ENiels en;
   en.vpu = pn.vpu; en.vmu = pn.vmu; en.z2 = Fq::add(Fq::one(), Fq::one()); en.t2d = pn.t2d;
-  store_eniels(slot, en);
+  store_eniels(slot, Curve::eniels_identity());
+  store_eniels(slot + ENIELS_WORDS, en);
   #pragma unroll 1
-  for (int j = 1; j < VB_TABLE; j++) {
+  for (int j = 2; j <= VB_TABLE; j++) {
     cur = quad_add_aniels(cur, T, pn, role, T);
     en.vpu = Fq::carry(Fq::add(cur.v, cur.u)); en.vmu = Fq::sub(cur.v, cur.u); en.z2 = Fq::add(cur.z, cur.z);
     en.t2d = Fq::mul(T, Fq::konst(FqP::D2));
@@ -1173,17 +1177,17 @@ static JJ_DEV Ext varbase_windowed_quad(const Affine& P, u32 (&k)[8], u32* slot,
   }
   recode_signed(k);
   u32 a = vb_window(k, VB_NWIN - 1), neg = 0;
-  ENiels e = load_eniels(slot + (a ? a - 1 : 0) * ENIELS_WORDS);
+  ENiels e = load_eniels(slot + a * ENIELS_WORDS);
   Ext acc = Curve::identity();
   T = Fq::zero();
   #pragma unroll 1
   for (int i = VB_NWIN - 1; i >= 0; i--) {
-    const ENiels s = Curve::select(e, Curve::eniels_identity(), a == 0 ? ~0u : 0u);
+    const ENiels s = e;
     const u32 sneg = neg;
     if (i > 0) {
       const int d = (int)vb_window(k, i - 1) - VB_TABLE;
       neg = d < 0; a = (u32)(d < 0 ? -d : d);
-      e = load_eniels(slot + (a ? a - 1 : 0) * ENIELS_WORDS);
+      e = load_eniels(slot + a * ENIELS_WORDS);
     }
     acc = quad_add_eniels(acc, T, s, sneg, role, T);
     if (i > 0) {
@@ -1202,7 +1206,7 @@ __global__ void __launch_bounds__(256) k_varbase_quad(size_t n, const void* scal
   u32 k[8];
   load8(k, scalars, q);
   const Affine P = load_affine(points, q);
-  const Ext r = varbase_windowed_quad(P, k, tables + q * (size_t)(VB_TABLE * ENIELS_WORDS), role);
+  const Ext r = varbase_windowed_quad(P, k, tables + q * (size_t)(VB_SLOTS * ENIELS_WORDS), role);
   if (role == 0) {
     ext.put(0, q, r.u); ext.put(1, q, r.v); ext.put(2, q, r.z);
     if constexpr (FIVE) { ext.put(3, q, Fq::carry(r.t1)); ext.put(4, q, Fq::carry(r.t2)); }

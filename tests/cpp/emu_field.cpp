@@ -76,8 +76,8 @@ extern "C" void emu_varbase(const uint8_t* scalar, const uint8_t* point, uint8_t
   const ANiels pn = Curve::to_niels(P);
   ENiels tab[TAB];
   Ext cur = Curve::from_affine(P);
-  tab[0] = Curve::to_niels(cur);
-  for (int j = 1; j < TAB; j++) { cur = Curve::add<true>(cur, pn); tab[j] = Curve::to_niels(cur); }
+  tab[0] = Curve::to_niels<true>(cur);
+  for (int j = 1; j < TAB; j++) { cur = Curve::add<true>(cur, pn); tab[j] = Curve::to_niels<true>(cur); }
   k[7] &= 0x0fffffffu;
   { uint64_t c = 0; for (int i = 0; i < 8; i++) { u32 rc = 0; for (int j = 0; j < NWIN - 1; j++) { const int bit = W * j + W - 1; if ((bit >> 5) == i) rc |= 1u << (bit & 31); } const uint64_t t = (uint64_t)k[i] + rc + c; k[i] = (u32)t; c = t >> 32; } }
   Ext acc = Curve::identity();
@@ -86,7 +86,7 @@ extern "C" void emu_varbase(const uint8_t* scalar, const uint8_t* point, uint8_t
     if (i != NWIN - 1) d -= TAB;
     const u32 neg = d < 0 ? ~0u : 0u, a = (u32)(d < 0 ? -d : d);
     const ENiels e = Curve::select(tab[a ? a - 1 : 0], Curve::eniels_identity(), a == 0 ? ~0u : 0u);
-    acc = Curve::add_signed<false>(acc, e, neg);
+    acc = Curve::add_signed<true>(acc, e, neg);
     if (i > 0) for (int s = 0; s < W; s++) acc = Curve::dbl(acc);
   }
   store_affine(out64, acc);
@@ -100,7 +100,7 @@ extern "C" void emu_varbase_exact(const uint8_t* scalar, const uint8_t* point, u
   for (int i = 251; i >= 0; i--) {
     const u32 bit = (k[i >> 5] >> (i & 31)) & 1u;
     acc = Curve::dbl(acc);
-    acc = Curve::add(acc, Curve::select(zero, pn, 0u - bit));
+    acc = Curve::add<true>(acc, Curve::select(zero, pn, 0u - bit));
   }
   u32 w[8];
   Fq::to_words(w, acc.u); st(out160, w); Fq::to_words(w, acc.v); st(out160 + 32, w); Fq::to_words(w, acc.z); st(out160 + 64, w);
@@ -112,7 +112,7 @@ extern "C" void emu_signed_sum(int n, const uint8_t* points, const uint8_t* sign
   for (int i = 0; i < n; i++) acc = Curve::add_signed<true>(acc, Curve::to_niels(load_affine(points + 64 * i)), signs[i] ? ~0u : 0u);
   for (int i = 0; i < doublings; i++) acc = Curve::dbl(acc);
   // fold with itself through the extended + extended path (to_niels(ext) + add<true>), then subtract it again
-  const ENiels en = Curve::to_niels(acc);
+  const ENiels en = Curve::to_niels<true>(acc);
   Ext twice = Curve::add<true>(Curve::add<true>(Curve::identity(), en), en);
   Ext back = Curve::sub<true>(twice, en);
   store_affine(out64, back);

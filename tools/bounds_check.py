@@ -157,10 +157,9 @@ def curve_ops(F):
 
     def dbl(p, w="dbl"):
         uu, vv, zz2 = F.sqr(p["u"], w + ".uu"), F.sqr(p["v"], w + ".vv"), F.sqr2(p["z"], w + ".zz2")
-        s = F.sqr(F.sub(p["u"], p["v"]), w + ".s")
+        cu = F.mul(p["u"], F.dbl(p["v"]), w + ".cu")
         vpu, vmu = F.add(vv, uu), F.sub(vv, uu)
-        cu = F.sub(vpu, s)
-        ct = F.carry(F.sub(zz2, vmu))
+        ct = F.sub(zz2, vmu)
         return into_extended(cu, vpu, vmu, ct, w)
 
     def dbl_quad(p, w="quad_dbl"):
@@ -221,18 +220,21 @@ def check_curve(verbose=True):
     acc = dict(u=ld, v=F.join(ld, ONE), z=F.join(ld, ONE), t1=F.join(ld, F.const(0)), t2=F.join(ld, F.const(0)))
     niels_aff = to_niels_aff(aff)
     idn = dict(vpu=ONE, vmu=ONE, z2=F.add(ONE, ONE), t2d=F.const(0))
-    # two inductive classes: `inv` = any accumulator, `inva` = an accumulator whose last operation was an addition (or
-    # that is freshly loaded / the identity): its t1 is small, so add<T1_SMALL> multiplies t1*t2 without a carry step
+    # two inductive classes: `inv` = any accumulator (including the quad-lane kernels' results, whose t1 = VV+UU-(U-V)^2 is
+    # lazy), `inva` = an accumulator produced by Curve::dbl / Curve::add* (or freshly loaded / the identity / reloaded from
+    # memory): its t1 is small, so add<T1_SMALL> and to_niels<T1_SMALL> multiply t1*t2 without a carry step
     inv, inva = acc, acc
     for it in range(80):
         tn = to_niels_ext(inv)
+        tns = {"t2d": F.mul(F.mul(inva["t1"], inva["t2"], "to_niels<small>.tt"), ops["D2"], "to_niels<small>.t2d")}
+        tn = dict(tn, t2d=F.join(tn["t2d"], tns["t2d"]))
         ne = {k: F.join(tn[k], idn[k]) for k in tn}                  # table entries built from accumulators, or the identity entry
         na = {k: F.join(niels_aff[k], idn[k]) for k in niels_aff}    # entries built from affine inputs
         adds = [add_signed(inv, ne, "addE"), add_signed(inv, na, "addA", affine=True),
                 add_signed(inva, ne, "addE.s", small=True), add_signed(inva, na, "addA.s", affine=True, small=True)]
         nxt, nxta = dict(inv), dict(inva)
         stored = dict(inv, t1=F.carry(inv["t1"]), t2=F.carry(inv["t2"]))      # accumulators reloaded from memory (t1, t2 are stored carried)
-        for cand in adds + [stored]:
+        for cand in adds + [stored, dbl(inva), dbl(inv)]:      # Curve::dbl's t1 is a product: small as well
             nxta = {k: F.join(nxta[k], cand[k]) for k in nxta}
         for cand in adds + [dbl(inv), ops["dbl_quad"](inv), ops["add_ext_quad"](inv, inv), nxta]:
             nxt = {k: F.join(nxt[k], cand[k]) for k in nxt}
