@@ -547,8 +547,8 @@ static void varbase_geometry(jj_ctx* c, size_t n, unsigned* blocks, size_t* thre
   if (t == 0) t = 256;
   *blocks = (unsigned)(t / 256); *threads = t;
 }
-static int varbase_to_ext(jj_ctx* c, size_t n, const void* ds, const void* dp, SoA ext, bool five) {
-  if (n <= (size_t)c->vb_quad_max) {      // small batch: one scalar multiplication per quad of lanes (3x lower latency)
+static int varbase_to_ext(jj_ctx* c, size_t n, const void* ds, const void* dp, SoA ext, bool five, bool shared_scalar = false) {
+  if (n <= (size_t)c->vb_quad_max && !shared_scalar) {      // small batch: one scalar multiplication per quad of lanes (3x lower latency)
     int rc = ensure(c, c->ws_tables, n * (size_t)(VB_SLOTS * ENIELS_WORDS) * 4); if (rc) return rc;
     if (five) hipLaunchKernelGGL(k_varbase_quad<true>, dim3(blocks_for(4 * n)), dim3(256), 0, c->stream, n, ds, dp, (u32*)c->ws_tables.p, ext);
     else hipLaunchKernelGGL(k_varbase_quad<false>, dim3(blocks_for(4 * n)), dim3(256), 0, c->stream, n, ds, dp, (u32*)c->ws_tables.p, ext);
@@ -559,8 +559,9 @@ static int varbase_to_ext(jj_ctx* c, size_t n, const void* ds, const void* dp, S
   int rc = ensure(c, c->ws_tables, threads * (size_t)(VB_SLOTS * ENIELS_WORDS) * 4); if (rc) return rc;
   if ((rc = ensure(c, c->cursor, 64))) return rc;
   HIPCHK(c, hipMemsetAsync(c->cursor.p, 0, 8, c->stream));          // the waves' work cursor
-  if (five) hipLaunchKernelGGL(k_varbase<true>, dim3(blocks), dim3(256), 0, c->stream, n, ds, dp, (u32*)c->ws_tables.p, ext, (unsigned long long*)c->cursor.p);
-  else hipLaunchKernelGGL(k_varbase<false>, dim3(blocks), dim3(256), 0, c->stream, n, ds, dp, (u32*)c->ws_tables.p, ext, (unsigned long long*)c->cursor.p);
+  if (shared_scalar) hipLaunchKernelGGL((k_varbase<false, true>), dim3(blocks), dim3(256), 0, c->stream, n, ds, dp, (u32*)c->ws_tables.p, ext, (unsigned long long*)c->cursor.p);
+  else if (five) hipLaunchKernelGGL((k_varbase<true, false>), dim3(blocks), dim3(256), 0, c->stream, n, ds, dp, (u32*)c->ws_tables.p, ext, (unsigned long long*)c->cursor.p);
+  else hipLaunchKernelGGL((k_varbase<false, false>), dim3(blocks), dim3(256), 0, c->stream, n, ds, dp, (u32*)c->ws_tables.p, ext, (unsigned long long*)c->cursor.p);
   return JJ_OK;
 }
 static int varbase_api(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out, int mode) {
@@ -597,21 +598,25 @@ static int varbase_api(jj_ctx* c, size_t n, const void* scalars, const void* poi
 }
 JJ_API int jj_varbase_mul(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out) { return varbase_api(c, n, scalars, points, out, 0); }
 JJ_API int jj_varbase_mul_compressed(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out32) { return varbase_api(c, n, scalars, points, out32, 1); }
-// one scalar, many bases (group::Wnaf's `scalar(..).base(..)` reuse pattern): the scalar is broadcast on the device
+// one scalar, many bases (group::Wnaf's `scalar(..).base(..)` reuse pattern): the ladder reads the one scalar through a
+// wave-uniform address (k_varbase<.., SHARED>): recoding and window digits are scalar-unit work, nothing is broadcast.
+// Small batches use the quad kernel on a broadcast copy (latency path).
 JJ_API int jj_varbase_mul_scalar(jj_ctx* c, size_t n, const void* scalar32, const void* points, void* out) {
   if (!c || !scalar32) return JJ_ERR_INVALID;
   JJ_ENTER(c);
   const void* dp; int rc; OutRef o;
   if ((rc = stage_in(c, 1, points, 64 * n, &dp))) return rc;
   if ((rc = stage_out(c, c->out[0], out, 64 * n, &o))) return rc;
-  if ((rc = ensure(c, c->ws_tmp[0], 32 * std::max(n, (size_t)1)))) return rc;
   if ((rc = ensure(c, c->ws_tmp[1], 32))) return rc;
   HIPCHK(c, hipMemcpyAsync(c->ws_tmp[1].p, scalar32, 32, is_device_ptr(scalar32) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
   if ((rc = ensure_ext(c, n, 3))) return rc;
   SoA ext = soa_of(c->ws_ext, n);
   if (n) {
-    hipLaunchKernelGGL(k_fill_scalar, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, c->ws_tmp[0].p, (const uint8_t*)c->ws_tmp[1].p);
-    if ((rc = varbase_to_ext(c, n, c->ws_tmp[0].p, dp, ext, false))) return rc;
+    if (n <= (size_t)c->vb_quad_max) {
+      if ((rc = ensure(c, c->ws_tmp[0], 32 * n))) return rc;
+      hipLaunchKernelGGL(k_fill_scalar, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, c->ws_tmp[0].p, (const uint8_t*)c->ws_tmp[1].p);
+      if ((rc = varbase_to_ext(c, n, c->ws_tmp[0].p, dp, ext, false))) return rc;
+    } else if ((rc = varbase_to_ext(c, n, c->ws_tmp[1].p, dp, ext, false, true))) return rc;
     if ((rc = normalize_launch(c, n, ext, o.dev, 0))) return rc;
   }
   bool sync = false;
@@ -672,7 +677,7 @@ JJ_API int jj_is_torsion_free(jj_ctx* c, size_t n, const void* p, uint8_t* out) 
 JJ_API int jj_is_prime_order(jj_ctx* c, size_t n, const void* p, uint8_t* out) { return torsion_pred(c, n, p, out, true); }
 
 // ---------------------------------------------------------------------------------------------------- fixed-base
-// entries (i, j) = (j+1) * 2^(w i) * B for i < W, j < E, built on the GPU in two var-base passes
+// entries (i, j) = j * 2^(w i) * B for i < W, j < E (j = 0: the identity), built on the GPU in two var-base passes
 // (Q_i = 2^(w i) B, then (j+1) Q_i) so that no scalar ever reaches bit 252, which the ladder ignores.
 static int build_window_table(jj_ctx* c, const uint8_t base[64], int w, int W, u32 E, size_t extra_top_entry, u32** out_dev, size_t* out_entries) {
   std::vector<uint8_t> s1((size_t)W * 32, 0), p1((size_t)W * 64), q((size_t)W * 64);
@@ -687,7 +692,7 @@ static int build_window_table(jj_ctx* c, const uint8_t base[64], int w, int W, u
   const size_t ne = (size_t)W * E + extra_top_entry;
   std::vector<uint8_t> s2(ne * 32, 0), p2(ne * 64), aff(ne * 64);
   for (size_t e = 0; e < (size_t)W * E; e++) {
-    const size_t i = e / E; const u32 mult = (u32)(e % E) + 1;
+    const size_t i = e / E; const u32 mult = (u32)(e % E);
     s2[e * 32] = (uint8_t)mult; s2[e * 32 + 1] = (uint8_t)(mult >> 8); s2[e * 32 + 2] = (uint8_t)(mult >> 16);
     memcpy(&p2[e * 64], &q[i * 64], 64);
   }
@@ -725,7 +730,7 @@ JJ_API int jj_fixedbase_table_create(jj_ctx* c, const void* base64, int window_b
     fp.w = window_bits; fp.W = (253 + window_bits - 1) / window_bits; fp.E = 1u << (window_bits - 1);
     memset(fp.recode, 0, sizeof fp.recode);
     for (int i = 0; i < fp.W - 1; i++) { const int bit = fp.w * i + fp.w - 1; fp.recode[bit >> 5] |= 1u << (bit & 31); }
-    rc = build_window_table(c, base, fp.w, fp.W, fp.E, 0, &t->dev, &ne);
+    rc = build_window_table(c, base, fp.w, fp.W, fp.E + 1, 0, &t->dev, &ne);
   }
   if (rc) { delete t; return rc; }
   *out = t;

@@ -405,7 +405,10 @@ static JJ_DEV bool next_wave_units(unsigned long long* cursor, size_t n, size_t&
   i = (size_t)base + (threadIdx.x & 63u);
   return base < n;
 }
-template <bool FIVE>
+// SHARED: `scalars` is ONE 32-byte scalar for the whole batch (group::Wnaf's `scalar(..)` then many `base(..)`, reference
+// src/lib.rs:1318-1336): it is read through a wave-uniform address, so the recoding and every window digit live in scalar
+// registers and cost no vector instruction, and no broadcast buffer is written.
+template <bool FIVE, bool SHARED>
 __global__ void __launch_bounds__(256, JJ_VB_MINWAVES) k_varbase(size_t n, const void* scalars, const void* points, u32* tables, SoA ext, unsigned long long* cursor) {
   const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   u32* slot = tables + gtid * (size_t)(VB_SLOTS * ENIELS_WORDS);
@@ -414,7 +417,7 @@ __global__ void __launch_bounds__(256, JJ_VB_MINWAVES) k_varbase(size_t n, const
   while (next_wave_units(cursor, n, i)) {
     if (i >= n) continue;                                     // ragged last wave: idle lanes wait for their neighbours
     u32 k[8];
-    load8(k, scalars, i);
+    load8(k, scalars, SHARED ? (size_t)0 : i);
     const Affine P = load_affine(points, i);
     const Ext r = varbase_windowed(P, k, slot);
     ext.put(0, i, r.u); ext.put(1, i, r.v); ext.put(2, i, r.z);
@@ -449,12 +452,12 @@ __global__ void __launch_bounds__(256) k_varbase_exact(size_t n, const void* sca
 
 // ------------------------------------------------------------------------------------------------ K4: fixed-base
 // Signed 6-bit windows: k = sum_{i<42} d_i 64^i + d_42 64^42, d_i in [-32,31], d_42 in {0,1} (k' = k + 0x820820..).
-// Table[i][j] = (j+1) * 64^i * B as AffineNiels (27 limbs + 1 pad = 112 B), i < 42, j < 32, plus one entry for the
-// top carry window.  The whole table (1345 entries, 147 KiB) is staged into LDS once per workgroup; every
-// scalar-mul is then 43 mixed additions and no doubling.
+// Table[i][j] = j * 64^i * B as AffineNiels (27 limbs + 1 pad = 112 B), i < 42, j <= 32 (j = 0: the identity entry, so
+// a zero digit is a plain table read), plus one entry for the top carry window.  The whole table (1387 entries,
+// 152 KiB) is staged into LDS once per workgroup; every scalar-mul is then 43 mixed additions and no doubling.
 constexpr int FB_W = 6;
 constexpr int FB_NWIN = 42;
-constexpr int FB_ENT = 32;
+constexpr int FB_ENT = 33;       // entries per window: multiples 0 .. 32
 constexpr int FB_ENTRIES = FB_NWIN * FB_ENT + 1;
 constexpr int ANIELS_WORDS = 28;   // 27 + 1 pad, 16-byte multiple: entry stride of the LDS table
 constexpr int GNIELS_WORDS = 32;   // entry stride of tables gathered from global memory: one 128-byte line per entry
@@ -477,10 +480,10 @@ static JJ_DEV u32 window6(const u32 (&k)[8], int i) {
   return (u32)(both >> sh) & 63u;
 }
 
-// CT = true: constant-time window select.  Lane L of every wave reads entry (L & 31) of the current window from
-// LDS (a fixed, conflict-free pattern), and each lane then pulls the entry it needs out of its neighbours'
-// registers with ds_bpermute_b32 (a crossbar shuffle: no address- or bank-dependent timing).  Sign and zero
-// digits are applied with bit masks.  CT = false reads the entry directly at a per-lane LDS address.
+// CT = true: constant-time window select.  Lane L of every wave reads entry L (L <= 32; the upper lanes re-read entries
+// 0..30) of the current window from LDS (a fixed pattern), and each lane then pulls the entry it needs out of its
+// neighbours' registers with ds_bpermute_b32 (a crossbar shuffle: no address- or bank-dependent timing).  The sign
+// is applied with bit masks.  CT = false reads the entry directly at a per-lane LDS address.
 static JJ_DEV Ext soa_ext(const SoA& s, size_t i);
 // chain: bit 0 = start from the point already in `ext` (sums over several fixed bases), bit 1 = also write t1, t2
 template <bool CT>
@@ -515,11 +518,10 @@ __global__ void __launch_bounds__(512) k_fixedbase(size_t n, const void* scalars
     for (int i = FB_NWIN - 1; i >= 0; i--) {
       const u32 nb = window6(k, i);                          // d + 32
       const int d = (int)nb - 32;
-      const u32 a = (u32)(d < 0 ? -d : d);
-      const u32 j = a ? a - 1 : 0;
+      const u32 j = (u32)(d < 0 ? -d : d);                    // table index = |digit| (0 = identity entry)
       ANiels e;
       if constexpr (CT) {
-        const ANiels mine = lds_aniels(lds + ((size_t)i * FB_ENT + (lane & 31u)) * ANIELS_WORDS);
+        const ANiels mine = lds_aniels(lds + ((size_t)i * FB_ENT + (lane < (u32)FB_ENT ? lane : lane - (u32)FB_ENT)) * ANIELS_WORDS);
         const int src = (int)(j << 2);                       // byte address of lane j
         _Pragma("unroll") for (int l = 0; l < NL; l++) {
           e.vpu.l[l] = (u32)__builtin_amdgcn_ds_bpermute(src, (int)mine.vpu.l[l]);
@@ -529,7 +531,7 @@ __global__ void __launch_bounds__(512) k_fixedbase(size_t n, const void* scalars
       } else {
         e = lds_aniels(lds + ((size_t)i * FB_ENT + j) * ANIELS_WORDS);
       }
-      acc = Curve::add_signed<true>(acc, Curve::select(e, idn, a == 0 ? ~0u : 0u), d < 0 ? ~0u : 0u);
+      acc = Curve::add_signed<true>(acc, e, d < 0 ? ~0u : 0u);
     }
     if (live) {
       ext.put(0, idx, acc.u); ext.put(1, idx, acc.v); ext.put(2, idx, acc.z);
@@ -542,7 +544,7 @@ __global__ void __launch_bounds__(512) k_fixedbase(size_t n, const void* scalars
 // kernel (w = 10: 26 instead of 43) at the price of a secret-dependent address (documented as variable-time).
 struct FbParams {
   int w, W;          // window bits, number of windows = ceil(253 / w)
-  u32 E;             // entries per window = 2^(w-1)
+  u32 E;             // largest multiple per window = 2^(w-1); a window holds E + 1 entries (multiples 0 .. E)
   u32 recode[8];     // sum_{i<W-1} 2^(w i + w - 1)
 };
 static JJ_DEV u32 fb_window(const u32 (&k)[8], int w, int i) {
@@ -568,15 +570,15 @@ __global__ void __launch_bounds__(256) k_fixedbase_gather(size_t n, const void* 
     if (chain & 1) acc = soa_ext(ext, idx);
     // top window: unsigned digit
     u32 a = fb_window(k, fp.w, fp.W - 1), neg = 0;
-    ANiels e = lds_aniels(table + ((size_t)(fp.W - 1) * fp.E + (a ? a - 1 : 0)) * GNIELS_WORDS);
+    ANiels e = lds_aniels(table + ((size_t)(fp.W - 1) * (fp.E + 1) + a) * GNIELS_WORDS);
     #pragma unroll 1
     for (int i = fp.W - 1; i >= 0; i--) {
-      const ANiels s = Curve::select(e, idn, a == 0 ? ~0u : 0u);
+      const ANiels s = e;
       const u32 smask = neg ? ~0u : 0u;
       if (i > 0) {                                           // fetch the next window's entry before this addition
         const int d = (int)fb_window(k, fp.w, i - 1) - (int)fp.E;
         neg = d < 0; a = (u32)(d < 0 ? -d : d);
-        e = lds_aniels(table + ((size_t)(i - 1) * fp.E + (a ? a - 1 : 0)) * GNIELS_WORDS);
+        e = lds_aniels(table + ((size_t)(i - 1) * (fp.E + 1) + a) * GNIELS_WORDS);
       }
       acc = Curve::add_signed<true>(acc, s, smask);
     }

@@ -53,7 +53,7 @@ def ladder_block(asm, needle):
     return best
 
 
-HOT = ["k_varbaseILb0", "k_fixedbaseILb1", "k_fixedbase_gather", "k_varbase_quadILb0", "k_msm_accumulate_seg", "k_decompressILi32"]
+HOT = ["k_varbaseILb0ELb0", "k_fixedbaseILb1", "k_fixedbase_gather", "k_varbase_quadILb0", "k_msm_accumulate_seg", "k_decompressILi32"]
 
 
 @pytest.mark.parametrize("needle", HOT)

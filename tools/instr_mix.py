@@ -15,7 +15,7 @@ SRC = os.path.join(ROOT, "jubjub_amd", "csrc", "jj_engine.hip")
 
 
 def main():
-    want = sys.argv[1:] or ["k_varbaseILb0", "k_fixedbaseILb1", "k_field_opINS_3FqPELi2", "k_field_opINS_3FqPELi4"]
+    want = sys.argv[1:] or ["k_varbaseILb0ELb0", "k_fixedbaseILb1", "k_field_opINS_3FqPELi2", "k_field_opINS_3FqPELi4"]
     with tempfile.TemporaryDirectory() as td:
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-save-temps", "-c", "-x", "hip", SRC,
                                "-I", os.path.dirname(SRC), "-o", os.path.join(td, "e.o")] + os.environ.get("JJ_CXXFLAGS", "").split(), cwd=td, stderr=subprocess.DEVNULL)

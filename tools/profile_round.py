@@ -30,7 +30,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (build_id, WORK)
 
-DOMINANT = {"varbase": "k_varbase", "fixedbase": "k_fixedbase", "msm": "k_msm_accumulate", "decompress": "k_decompress"}
+DOMINANT = {"varbase": "k_varbase<", "fixedbase": "k_fixedbase<", "msm": "k_msm_accumulate_seg", "decompress": "k_decompress<"}
 SQ_SET = "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES"
 
 
@@ -73,7 +73,8 @@ def kernel_stats(db_path):
 
 
 def pmc_pass(tag, wl, counters, scratch, bench_args):
-    """one rocprofv3 --pmc run (kernel-trace only, as gpurun requires); returns {counter: value of the longest dominant dispatch}"""
+    """one rocprofv3 --pmc run (kernel-trace only, as gpurun requires); returns {counter: value of the LAST dispatch of the dominant
+    kernel in the pass} (steady state: the first one pays the first touch of the workspaces) and that dispatch's duration"""
     d = os.path.join(scratch, "pmc_%s_%s" % (wl, counters.split()[0]))
     shutil.rmtree(d, ignore_errors=True)
     cmd = "rocprofv3 --kernel-trace --pmc %s --output-format csv -d %s -o pmc -- python bench.py %s" % (counters, d, bench_args)
@@ -85,11 +86,14 @@ def pmc_pass(tag, wl, counters, scratch, bench_args):
     for row in csv.DictReader(open(files[0])):
         if DOMINANT[wl] not in row["Kernel_Name"]:
             continue
-        dur = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
         key = row["Counter_Name"]
-        if key not in best or dur > best[key][0]:
-            best[key] = (dur, float(row["Counter_Value"]), int(row["Grid_Size"]))
-    return {k: v[1] for k, v in best.items()}, cmd
+        start = int(row["Start_Timestamp"])
+        if key not in best or start > best[key][0]:
+            best[key] = (start, float(row["Counter_Value"]), int(row["End_Timestamp"]) - start)
+    out = {k: v[1] for k, v in best.items()}
+    if best:
+        out["_dispatch_ns(%s)" % counters.split()[0]] = float(max(v[2] for v in best.values()))
+    return out, cmd
 
 
 def main():
@@ -103,7 +107,7 @@ def main():
     os.makedirs(scratch, exist_ok=True)
     traffic = {"build_id": bench.build_id(), "commit": commit(), "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate kernel-trace-only passes; "
                "FETCH_SIZE (KB) x 1024 x 2 (gfx950 counts 128-byte read requests as 64 B: MI355X_MICROARCH.md, HBM), WRITE_SIZE (KB) x 1024; "
-               "the longest dispatch of the dominant kernel in the pass", "workloads": {}}
+               "the last (steady-state) dispatch of the dominant kernel in the pass", "workloads": {}}
     for wl in a.workloads.split(","):
         log2n = bench.DEFAULT_LOG2N[wl]
         args = "--workload %s --steps 3 --warmup 1 --no-cpu-baseline --no-extras" % wl
@@ -132,19 +136,22 @@ def main():
         n = 1 << log2n
         with open(os.path.join(prof, "%s_%s_pmc.txt" % (a.tag, wl)), "w") as f:
             f.write(header(" ; ".join(cmds)))
-            f.write("# values of the longest %s dispatch of each pass (2^%d units per launch)\n" % (DOMINANT[wl], log2n))
+            f.write("# values of the last (steady-state) %s...> dispatch of each pass (2^%d units per launch); _dispatch_ns: its duration under the profiler\n" % (DOMINANT[wl], log2n))
             for k in sorted(vals):
                 f.write("%-28s %18.0f\n" % (k, vals[k]))
             f.write("\nderived:\n")
             if "GRBM_GUI_ACTIVE" in vals:
-                f.write("  GRBM_GUI_ACTIVE / 8 XCDs             = %.4g cycles per dispatch\n" % (vals["GRBM_GUI_ACTIVE"] / 8))
+                f.write("  GRBM_GUI_ACTIVE / 8 XCDs             = %.4g shader cycles per dispatch" % (vals["GRBM_GUI_ACTIVE"] / 8))
+                d = vals.get("_dispatch_ns(GRBM_GUI_ACTIVE)")
+                f.write("  (=> %.2f GHz over the %.3f ms the dispatch took under the profiler)\n" % (vals["GRBM_GUI_ACTIVE"] / 8 / d, d / 1e6) if d else "\n")
+            if "SQ_INSTS_VALU" in vals and "GRBM_GUI_ACTIVE" in vals:
+                f.write("  VALU wave-instructions per SIMD       = %.4g  => one every %.3f cycles (wave64 minimum: 4)\n" % (
+                    vals["SQ_INSTS_VALU"] / 1024, vals["GRBM_GUI_ACTIVE"] / 8 / (vals["SQ_INSTS_VALU"] / 1024)))
             if "SQ_INSTS_VALU" in vals:
                 f.write("  VALU lane-instructions per unit      = %.0f\n" % (vals["SQ_INSTS_VALU"] * 64 / n))
             if "SQ_ACTIVE_INST_VALU" in vals and "GRBM_GUI_ACTIVE" in vals:
-                f.write("  VALU busy = SQ_ACTIVE_INST_VALU (quad-cycles) / (1024 SIMDs x GUI cycles / 8 XCDs / 4) = %.3f\n" % (
+                f.write("  VALU issue utilisation = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GUI cycles / 8 XCDs) = %.3f\n" % (
                     vals["SQ_ACTIVE_INST_VALU"] / (1024 * vals["GRBM_GUI_ACTIVE"] / 8 / 4)))
-                if "SQ_INSTS_VALU" in vals:
-                    f.write("  cycles per VALU wave-instruction per SIMD = %.3f\n" % (4 * vals["SQ_ACTIVE_INST_VALU"] / vals["SQ_INSTS_VALU"]))
             if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
                 fb, wb = vals["FETCH_SIZE"] * 1024 * 2, vals["WRITE_SIZE"] * 1024
                 w = bench.WORK[wl]
