@@ -259,8 +259,10 @@ def cpu_baseline(workload, target_s):
     def measure(threads, seconds):
         omp.omp_set_num_threads(threads)
         probe = max(32, 16 * threads)
-        t = run(probe)
-        n = int(max(probe, min(1 << 22, probe * seconds / max(t, 1e-6))))
+        t = run(probe)                                                  # warm-up + first calibration
+        n = int(max(probe, min(1 << 18, probe * 1.0 / max(t, 1e-6))))   # ~1 s sample for a stable rate estimate
+        t = run(n)
+        n = int(max(probe, min(1 << 22, n * seconds / max(t, 1e-6))))   # the reported sample: ~`seconds` of wall time
         t = run(n)
         return n / t, n, t
 
