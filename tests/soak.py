@@ -41,7 +41,7 @@ while time.time() < t_end:
     assert (eng.varbase_mul(S, P) == want_vb).all(), ("varbase", rnd)
     assert (eng_alt.varbase_mul(S, P) == want_vb).all(), ("varbase per-lane", rnd)
     bp = P[int(rng.integers(0, n))]
-    wbits = [0, 8, 10, 12][rnd % 4]
+    wbits = [0, 8, 10, 12, 13, 14, 16, 0][rnd % 8]        # LDS table and every wide-window class (16 bits: the 64 MB table)
     tab = eng.fixedbase_table(bp, wbits)
     assert (eng.fixedbase_mul(tab, S) == O.fixedbase_mul(S, bp)).all(), ("fixedbase", rnd, wbits)
     if rnd % 2 == 0:                                          # sums over two fixed bases; one scalar with many bases
@@ -74,6 +74,12 @@ while time.time() < t_end:
             a1, b1 = eng.field_unary_ok(f, op, S[:q])
             a2, b2 = O.field_op(w, op, S[:q])
             assert (b1 == b2).all() and (a1 == a2).all(), (f, op, rnd)
+    q2 = min(n, 3000)                                         # generators, bit decomposition, several contexts on one device
+    canon = O.field_op(O.FR, "add", S[:q2], np.zeros((q2, 32), np.uint8))[0]          # S mod r, canonical bytes
+    assert (eng.to_le_bits("fr", S[:q2]) == np.unpackbits(canon, axis=1, bitorder="little")).all(), ("to_le_bits", rnd)
+    first = int(rng.integers(0, 1 << 40))
+    gp = eng.random_points(64, SEED0 + rnd, first, subgroup=bool(rnd & 1))
+    assert (gp == np.stack([pt64(J.synth_point(first + i, SEED0 + rnd, subgroup=bool(rnd & 1))[0]) for i in range(64)])).all(), ("random_points", rnd)
     Qp = O.fixedbase_mul(S, base)
     assert (eng.point_add(P, Qp) == O.point_op("add", P, Qp)).all() and (eng.point_sub(P, Qp) == O.point_op("sub", P, Qp)).all()
     assert (eng.point_double(P) == O.point_op("double", P)).all()
