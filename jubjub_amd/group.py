@@ -79,6 +79,18 @@ class _Field:
         out, ok = self.engine.field_unary_ok(self._name, "sqrt", self.data)
         return type(self)(self.engine, out), ok
 
+    def to_le_bits(self):                                   # PrimeFieldBits::to_le_bits (src/fr.rs:746-773): n x 256 bytes of 0/1
+        return self.engine.to_le_bits(self._name, self.data)
+
+    @classmethod
+    def random(cls, engine, n, seed, first_index=0):        # Field::random (src/fr.rs:684-688): 64 PRNG bytes -> from_bytes_wide
+        if cls._name == "fr":
+            return cls(engine, engine.synth_scalars(n, seed, first_index))
+        import numpy as np
+
+        wide = np.concatenate([engine.synth_bytes32(n, seed, first_index), engine.synth_bytes32(n, seed ^ 0xA5A5A5A5, first_index)], axis=1)
+        return cls(engine, engine.from_bytes_wide(cls._name, wide))
+
     def __eq__(self, o):
         return bool((self.data == o.data).all())
 
@@ -111,6 +123,10 @@ class Points:
     def generator(cls, engine, n=1):                        # src/lib.rs:1380-1396
         g = np.frombuffer(_GEN_U.to_bytes(32, "little") + (11).to_bytes(32, "little"), np.uint8)
         return cls(engine, np.tile(g, (n, 1)))
+
+    @classmethod
+    def random(cls, engine, n, seed, first_index=0, subgroup=False):   # Group::random (src/lib.rs:1244-1267; SubgroupPoint: 1290-1298)
+        return cls(engine, engine.random_points(n, seed, first_index, subgroup=subgroup))
 
     @classmethod
     def from_raw_unchecked(cls, engine, uv):                # src/lib.rs:662-664

@@ -573,3 +573,17 @@ def test_context_is_thread_safe_and_stream_switches_are_ordered(eng):
         side.synchronize()
         assert (a.cpu().numpy() == want).all() and (b == want[:3000]).all()
     tab.close()
+
+
+def test_group_mirror_random_and_bits(eng):
+    """jubjub_amd.group: Group::random / Field::random / to_le_bits under the crate's names"""
+    from jubjub_amd import group as G
+
+    k = G.Fr.random(eng, 40, 7, first_index=3)
+    assert (k.data == arr32([J.synth_scalar(3 + i, 7) for i in range(40)])).all()
+    bits = k.to_le_bits()
+    assert all(int("".join(str(b) for b in row[::-1]), 2) == to_int(x) for row, x in zip(bits, k.data))
+    p = G.Points.random(eng, 40, 9, subgroup=True)
+    assert p.is_prime_order().all() and p.is_on_curve().all()
+    q = G.Fq.random(eng, 8, 5)
+    assert all(to_int(x) < Q for x in q.data)
