@@ -514,24 +514,49 @@ __global__ void __launch_bounds__(512) k_fixedbase(size_t n, const void* scalars
     Ext acc = Curve::identity();
     if ((chain & 1) && live) acc = soa_ext(ext, idx);
     acc = Curve::add<true>(acc, Curve::select(idn, lds_aniels(lds + (size_t)(FB_NWIN * FB_ENT) * ANIELS_WORDS), 0u - top));
-    #pragma unroll 1
-    for (int i = FB_NWIN - 1; i >= 0; i--) {
-      const u32 nb = window6(k, i);                          // d + 32
-      const int d = (int)nb - 32;
-      const u32 j = (u32)(d < 0 ? -d : d);                    // table index = |digit| (0 = identity entry)
-      ANiels e;
+    // The 42 windows are consumed from the top: k' is kept left-aligned (bit 251 at bit 255) and shifted by 6 per window,
+    // so a digit is the top 6 bits of one register: no indexed access into k and no v_cndmask chains (a v_cndmask that
+    // re-reads an old VCC issues at ~22 cycles on gfx950).  The entry of window i-1 is fetched (LDS read + shuffles) before
+    // the addition of window i, so the LDS latency hides behind ~1500 multiply-adds.
+    u32 ks[8];
+    _Pragma("unroll") for (int q = 7; q >= 1; q--) ks[q] = (k[q] << 4) | (k[q - 1] >> 28);
+    ks[0] = k[0] << 4;
+    auto next_digit = [&](u32& j, u32& negmask) {
+      const int d = (int)(ks[7] >> 26) - 32;                 // window - 32 in [-32, 31]
+      _Pragma("unroll") for (int q = 7; q >= 1; q--) ks[q] = (ks[q] << 6) | (ks[q - 1] >> 26);
+      ks[0] <<= 6;
+      const u32 sgn = (u32)(d >> 31);                        // all-ones iff negative
+      j = ((u32)d ^ sgn) - sgn;                              // |d| = table index (0 = identity entry)
+      negmask = sgn;
+    };
+    auto fetch = [&](int i, u32 j) -> ANiels {
       if constexpr (CT) {
         const ANiels mine = lds_aniels(lds + ((size_t)i * FB_ENT + (lane < (u32)FB_ENT ? lane : lane - (u32)FB_ENT)) * ANIELS_WORDS);
         const int src = (int)(j << 2);                       // byte address of lane j
+        ANiels e;
         _Pragma("unroll") for (int l = 0; l < NL; l++) {
           e.vpu.l[l] = (u32)__builtin_amdgcn_ds_bpermute(src, (int)mine.vpu.l[l]);
           e.vmu.l[l] = (u32)__builtin_amdgcn_ds_bpermute(src, (int)mine.vmu.l[l]);
           e.t2d.l[l] = (u32)__builtin_amdgcn_ds_bpermute(src, (int)mine.t2d.l[l]);
         }
+        return e;
       } else {
-        e = lds_aniels(lds + ((size_t)i * FB_ENT + j) * ANIELS_WORDS);
+        return lds_aniels(lds + ((size_t)i * FB_ENT + j) * ANIELS_WORDS);
       }
-      acc = Curve::add_signed<true>(acc, e, d < 0 ? ~0u : 0u);
+    };
+    // two windows per trip with two entry registers sets (e0, e1), so that "the entry fetched last trip" needs no copy and
+    // the wait for the shuffles sits behind a whole addition
+    static_assert(FB_NWIN % 2 == 0, "the window loop is unrolled by two");
+    u32 j, neg0, neg1;
+    next_digit(j, neg0);
+    ANiels e0 = fetch(FB_NWIN - 1, j), e1;
+    #pragma unroll 1
+    for (int i = FB_NWIN - 1; i >= 1; i -= 2) {
+      next_digit(j, neg1);
+      e1 = fetch(i - 1, j);
+      acc = Curve::add_signed<true>(acc, e0, neg0);
+      if (i > 1) { next_digit(j, neg0); e0 = fetch(i - 2, j); }
+      acc = Curve::add_signed<true>(acc, e1, neg1);
     }
     if (live) {
       ext.put(0, idx, acc.u); ext.put(1, idx, acc.v); ext.put(2, idx, acc.z);
