@@ -384,10 +384,10 @@ static JJ_DEV Ext varbase_windowed(const Affine& P, u32 (&k)[8], u32* slot) {
     acc = Curve::add_signed<true>(acc, s, smask);
     if (i > 0) {
       // two doublings per trip so that the results can alternate between two register sets (a rolled loop copies 36
-      // registers back per doubling); VB_W - 1 is even for the default 5-bit windows
-      static_assert((VB_W - 1) % 2 == 0, "the doubling loop is unrolled by two");
+      // registers back per doubling)
       #pragma unroll 1
       for (int d = 0; d < (VB_W - 1) / 2; d++) acc = Curve::dbl(Curve::dbl(acc));
+      if constexpr ((VB_W - 1) % 2) acc = Curve::dbl(acc);
       acc = Curve::dbl(acc);
     }
   }
