@@ -93,6 +93,19 @@ class FieldBatch {
   }
   const std::vector<Bytes32>& to_bytes() const { return v_; }   // fr.rs:296-308 (already canonical)
   size_t len() const { return v_.size(); }
+  // PrimeFieldBits::to_le_bits (fr.rs:746-773): 256 bytes of 0/1 per element, bit 0 first
+  std::vector<std::array<uint8_t, 256>> to_le_bits() const {
+    std::vector<std::array<uint8_t, 256>> out(len());
+    c_->check((IS_FR ? jj_fr_to_le_bits : jj_fq_to_le_bits)(c_->raw(), len(), v_.data(), out.data()));
+    return out;
+  }
+  // Field::random (fr.rs:684-688) over the library's counter-based stream (Fr: canonical scalars of units first .. first+n)
+  static FieldBatch random(const Context& c, size_t n, uint64_t seed, uint64_t first_index = 0) {
+    static_assert(IS_FR, "jj_synth_scalars generates Fr elements");
+    FieldBatch r(c, std::vector<Bytes32>(n));
+    c.check(jj_synth_scalars(c.raw(), n, seed, first_index, r.v_.data()));
+    return r;
+  }
 
   FieldBatch operator+(const FieldBatch& o) const { return bin(IS_FR ? jj_fr_add : jj_fq_add, o); }
   FieldBatch operator-(const FieldBatch& o) const { return bin(IS_FR ? jj_fr_sub : jj_fq_sub, o); }
@@ -146,6 +159,12 @@ class AffineBatch {
     static const uint8_t U[32] = {0xfe, 0xad, 0xa7, 0xf1, 0x5d, 0xd3, 0xb3, 0xe4, 0xaf, 0x81, 0xbf, 0x29, 0x1b, 0x5d, 0xf5, 0xca,
                                   0x87, 0x81, 0x0a, 0xd6, 0xdd, 0x03, 0x0f, 0x8b, 0xc8, 0x87, 0x37, 0xbf, 0xb8, 0xcb, 0xed, 0x62};
     std::vector<Bytes64> p(n); for (auto& e : p) { e.fill(0); std::memcpy(e.data(), U, 32); e[32] = 11; } return AffineBatch(c, std::move(p));
+  }
+  // ExtendedPoint::random / SubgroupPoint::random (lib.rs:1244-1267, 1290-1298) over the library's counter-based stream
+  static AffineBatch random(const Context& c, size_t n, uint64_t seed, uint64_t first_index = 0, bool subgroup = false) {
+    std::vector<Bytes64> p(n);
+    c.check(jj_random_points(c.raw(), n, seed, first_index, subgroup ? 1 : 0, p.data(), nullptr));
+    return AffineBatch(c, std::move(p));
   }
   // AffinePoint::from_bytes / batch_from_bytes / from_bytes_pre_zip216_compatibility (lib.rs:469-627)
   static CtOptionBatch<AffineBatch> from_bytes(const Context& c, const std::vector<Bytes32>& enc, DecodeFlags f = DecodeFlags::zip216()) {

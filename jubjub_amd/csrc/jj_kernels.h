@@ -590,7 +590,6 @@ __global__ void __launch_bounds__(256) k_fixedbase_gather(size_t n, const void* 
       u64 c = 0;
       _Pragma("unroll") for (int i = 0; i < 8; i++) { const u64 t = (u64)k[i] + fp.recode[i] + c; k[i] = (u32)t; c = t >> 32; }
     }
-    const ANiels idn = Curve::aniels_identity();
     Ext acc = Curve::identity();
     if (chain & 1) acc = soa_ext(ext, idx);
     // top window: unsigned digit

@@ -183,6 +183,24 @@ int main(int argc, char** argv) {
     test_fr_vectors(c);
     blackbox<FqBatch>(c, "fq");
     blackbox<FrBatch>(c, "fr");
+    // Group::random / Field::random / to_le_bits through the mirror (lib.rs:1244-1267, fr.rs:684-688, 746-773): sampled points are
+    // on the curve, in the prime-order subgroup when asked, never the identity; bits recompose the canonical bytes; and
+    // (k * P) over random inputs agrees between the ladder and the sum of its bit-decomposed doublings for k = 2^j.
+    {
+      std::puts("random / to_le_bits");
+      const AffineBatch p = AffineBatch::random(c, 300, 0x4a55, 5, true), q = AffineBatch::random(c, 300, 0x4a55, 5, false);
+      for (auto b : p.is_prime_order()) CHECK(b == 1);
+      for (auto b : q.is_on_curve()) CHECK(b == 1);
+      for (auto b : q.is_identity()) CHECK(b == 0);
+      const FrBatch k = FrBatch::random(c, 300, 0x4a55, 9);
+      const auto bits = k.to_le_bits();
+      for (size_t i = 0; i < k.len(); i++) {
+        Bytes32 re{}; for (int b = 0; b < 256; b++) re[b >> 3] |= (uint8_t)(bits[i][b] << (b & 7));
+        CHECK(re == k.to_bytes()[i]);
+      }
+      CHECK(FrBatch::from_bytes(c, k.to_bytes()).all_some());
+      CHECK(AffineBatch::random(c, 50, 0x4a55, 105, true) == AffineBatch(c, std::vector<Bytes64>(p.coords().begin() + 100, p.coords().begin() + 150)));
+    }
     // error behaviour: length mismatch is rejected like the assert at src/lib.rs:841
     bool threw = false;
     try { AffineBatch::generator(c, 2) * FrBatch::from_u64(c, {1}); } catch (const Error&) { threw = true; }
