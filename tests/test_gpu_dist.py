@@ -80,3 +80,19 @@ def test_too_many_gpus_is_refused_not_mislabelled():
         env.pop(k, None)
     r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_under_torch_distributed_run_launcher():
+    """the way the driver starts N > 1: `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
+    (ranks come from the launcher's environment, bench.py must not spawn again); two ranks stacked on GPU 0 over gloo"""
+    env = dict(os.environ, JJ_BENCH_FORCE_DEVICE="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29617", BENCH, "--gpus", "2", "--workload", "fixedbase", "--log2n", "14", "--steps", "2", "--warmup", "1",
+                        "--backend", "gloo", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                      # exactly one JSON line, from rank 0
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["verified"] is True and res["config"]["units_per_step"] == 2 * (1 << 14) * res["config"]["passes_per_step"]
