@@ -55,17 +55,17 @@ RAW_SEED = SEED ^ 0x5DEECE66D
 # IMAD32 convention: M = 128, S = 100.
 WORK = {
     # k_varbase: 2 from_words + to_niels(P) 2M; table {1..16}P: to_niels 2M + 15 x (mixed add 7M + to_niels 2M);
-    # 51 additions x 8M; 250 doublings x (3S + 4M: 2UV is a product here, jj_curve.h).   tail k_normalize<32>: ~9M + (255S + 75M)/32 per unit
-    "varbase": {"S": 250 * 3, "M": 2 + 2 + 2 + 15 * 9 + 51 * 8 + 250 * 4, "tail_S": 8, "tail_M": 11, "bytes": 32 + 64 + 64},
+    # 51 additions x 8M; 250 doublings x (3S + 4M: 2UV is a product here, jj_curve.h).   tail k_normalize<32>: 6M + (255S + 75M)/32 per unit
+    "varbase": {"S": 250 * 3, "M": 2 + 2 + 2 + 15 * 9 + 51 * 8 + 250 * 4, "tail_S": 8, "tail_M": 8, "bytes": 32 + 64 + 64},
     # k_fixedbase: 43 mixed additions x 7M
-    "fixedbase": {"S": 0, "M": 43 * 7, "tail_S": 8, "tail_M": 11, "bytes": 32 + 64},
+    "fixedbase": {"S": 0, "M": 43 * 7, "tail_S": 8, "tail_M": 8, "bytes": 32 + 64},
     # Pippenger, c = 16: per term 2M load + 2M to_niels + 16 windows x 7M mixed add; bucket reduce 2 x 10M per bucket
     # (16 x 2^15 buckets / 2^20 terms -> +10M); the 240-doubling Horner tail is per MSM (on the host), not per term
     "msm": {"S": 0, "M": 2 + 2 + 16 * 7 + 10, "tail_S": 0, "tail_M": 0, "bytes": 32 + 64},
     # k_decompress (the flag kernels run after it and show up in tail_ms): two decode passes (2 x (1M + 1S + 1M)), shared
     # inversion (3M + (253S+61M)/32), u^2 1M, sqrt = a^((t-1)/2) (220S + 52M, sliding windows) + 2M + 24S + 6M digit
-    # extraction + 4 canonical forms + 4M table multiplies + verify (1S + 2M), 3 to_words
-    "decompress": {"S": 2 + 8 + 220 + 24 + 1, "M": 4 + 3 + 2 + 1 + 52 + 2 + 6 + 4 + 4 + 2 + 3, "tail_S": 0, "tail_M": 0, "bytes": 32 + 65},
+    # extraction + 4 canonical forms + 4M table multiplies + verify (1S + 2M), 1 to_plain (v's bytes are the input's, -u = q - u)
+    "decompress": {"S": 2 + 8 + 220 + 24 + 1, "M": 4 + 3 + 2 + 1 + 52 + 2 + 6 + 4 + 4 + 2 + 1, "tail_S": 0, "tail_M": 0, "bytes": 32 + 65},
 }
 REFERENCE_WORK = {"varbase": {"S": 1008, "M": 2774}, "fixedbase": {"S": 1008, "M": 2520}}   # the reference's own ladders
 PASSES = {"varbase": 4, "fixedbase": 2, "msm": 32, "decompress": 4}       # passes per step: >= ~50 ms of kernels per step

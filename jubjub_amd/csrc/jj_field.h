@@ -237,6 +237,25 @@ static __device__ __forceinline__ u32 jj_opaque_asm(u32 x) { asm("" : "+v"(x)); 
     return o0 == 0 || o1 == 0;
   }
   static JJ_DEV bool eq(const Fe& a, const Fe& b) { return is_zero(sub(a, b)); }   // reference Fr::ct_eq src/fr.rs:48-55
+  // The same test without the product, for a value that is already in product form (a mul/sqr output or a canonical
+  // constant: limbs 0..7 in [0, 2^29), value in (-2p, p)): its digits are unique, so it is 0 mod p iff they are 0 or -p.
+  static JJ_DEV bool is_zero_product(const Fe& t) {
+    u32 o0 = 0, o1 = 0;
+    _Pragma("unroll") for (int i = 0; i < NL; i++) { o0 |= t.l[i]; o1 |= t.l[i] ^ P::NEGP_DIGITS[i]; }
+    return o0 == 0 || o1 == 0;
+  }
+  // canonical integer in [0, p) of a PLAIN (non-Montgomery) value held in product form, value in (-2p, p): two conditional
+  // additions of p (a product by a plain-form operand lands there directly, which saves the extra product of to_plain)
+  static JJ_DEV Fe canon_plain_product(const Fe& a) {
+    Fe w = a;
+    _Pragma("unroll") for (int rep = 0; rep < 2; rep++) {
+      const u32 negm = (u32)((i32)w.l[NL - 1] >> 31);
+      Fe s; _Pragma("unroll") for (int i = 0; i < NL; i++) s.l[i] = w.l[i] + (P::P[i] & negm);
+      w = carry_full(s);
+    }
+    return w;
+  }
+  static JJ_DEV Fe plain_one() { Fe r; _Pragma("unroll") for (int i = 0; i < NL; i++) r.l[i] = (i == 0); return r; }
   // Montgomery form -> the Montgomery-form representative in [0, p) with limbs in [0, 2^29) (table construction only)
   static JJ_DEV Fe canon(const Fe& a) {
     Fe w = mul(a, one());                                   // value in (-1.2p, 0.2p)

@@ -250,8 +250,8 @@ __global__ void __launch_bounds__(256) k_normalize(size_t n, size_t T, SoA ext, 
     const size_t i = t + (size_t)j * T;
     if (i >= n) break;
     scratch.put(0, i, acc);
-    const Fe z = ext.get(2, i);
-    const u32 zz = Fq::is_zero(z) ? ~0u : 0u;
+    const Fe z = ext.get(2, i);                            // Z coordinates in the SoA are products (or the constant one): unique digits
+    const u32 zz = Fq::is_zero_product(z) ? ~0u : 0u;
     acc = Fq::select(Fq::mul(acc, z), acc, zz);
   }
   Fe inv = Fq::invert(acc);
@@ -260,15 +260,19 @@ __global__ void __launch_bounds__(256) k_normalize(size_t n, size_t T, SoA ext, 
     const size_t i = t + (size_t)j * T;
     if (i >= n) continue;
     const Fe z = ext.get(2, i);
-    const u32 zz = Fq::is_zero(z) ? ~0u : 0u;
+    const u32 zz = Fq::is_zero_product(z) ? ~0u : 0u;
     const Fe zinv = Fq::select(Fq::mul(inv, scratch.get(0, i)), Fq::zero(), zz);
     inv = Fq::select(Fq::mul(inv, z), inv, zz);
-    const Fe u = Fq::mul(ext.get(0, i), zinv), v = Fq::mul(ext.get(1, i), zinv);
+    // U/Z and V/Z straight to plain integers: multiply by the PLAIN form of 1/Z (one product for both coordinates instead
+    // of one per coordinate in to_words), then two conditional additions of q
+    const Fe zp = Fq::mul(zinv, Fq::plain_one());
+    u32 wu[8], wv[8];
+    Fq::pack(wu, Fq::canon_plain_product(Fq::mul(ext.get(0, i), zp)));
+    Fq::pack(wv, Fq::canon_plain_product(Fq::mul(ext.get(1, i), zp)));
     if (mode == 0) {
-      store_affine(out, i, u, v);
+      store8(out, 2 * i, wu);
+      store8(out, 2 * i + 1, wv);
     } else {
-      u32 wu[8], wv[8];
-      Fq::to_words(wu, u); Fq::to_words(wv, v);
       wv[7] |= (wu[0] & 1u) << 31;
       store8(out, i, wv);
     }
@@ -650,8 +654,7 @@ __global__ void __launch_bounds__(256) k_affine_to_soa5(size_t n, const void* pt
 // their (never-zero) denominators through, inverts once and walks back, recomputing v, v^2 on the way (cheaper
 // than storing them).  The square root is fq_sqrt_fast; the sign bit picks the root (lib.rs:518-520) and the
 // ZIP-216 rule rejects u = 0 with the sign bit set (lib.rs:522-531).
-static JJ_DEV void decode_v(const void* in32, size_t i, Fe& v, Fe& v2, Fe& den, u32& sign, bool& ok) {
-  u32 w[8];
+static JJ_DEV void decode_v(const void* in32, size_t i, Fe& v, Fe& v2, Fe& den, u32& sign, bool& ok, u32 (&w)[8]) {
   load8(w, in32, i);
   sign = w[7] >> 31;
   w[7] &= 0x7fffffffu;
@@ -669,8 +672,8 @@ __global__ void __launch_bounds__(256) k_decompress(size_t n, size_t T, const vo
   for (int j = 0; j < CHUNK; j++) {
     const size_t i = t + (size_t)j * T;
     if (i >= n) break;
-    Fe v, v2, den; u32 sign; bool ok;
-    decode_v(in32, i, v, v2, den, sign, ok);
+    Fe v, v2, den; u32 sign, wv[8]; bool ok;
+    decode_v(in32, i, v, v2, den, sign, ok, wv);
     scratch.put(0, i, acc);
     acc = Fq::mul(acc, den);
   }
@@ -679,22 +682,23 @@ __global__ void __launch_bounds__(256) k_decompress(size_t n, size_t T, const vo
   for (int j = CHUNK - 1; j >= 0; j--) {
     const size_t i = t + (size_t)j * T;
     if (i >= n) continue;
-    Fe v, v2, den; u32 sign; bool ok;
-    decode_v(in32, i, v, v2, den, sign, ok);
+    Fe v, v2, den; u32 sign, wv[8]; bool ok;
+    decode_v(in32, i, v, v2, den, sign, ok, wv);         // wv: the encoding without its sign bit = the canonical bytes of v when ok
     const Fe deninv = Fq::mul(inv, scratch.get(0, i));
     inv = Fq::mul(inv, den);
     const Fe u2 = Fq::mul(Fq::sub(v2, Fq::one()), deninv);
     bool sq_ok;
     const Fe u = fq_sqrt_fast(u2, sq_ok, tabs);
     ok = ok && sq_ok;
-    u32 wu[8], wn[8], wv[8];
-    Fq::to_words(wu, u);
-    const u32 flip = (wu[0] ^ sign) & 1u;
-    u32 nz = 0; _Pragma("unroll") for (int k = 0; k < 8; k++) nz |= wu[k];
-    if ((flags & 1u) && nz == 0 && flip) ok = false;
-    Fq::to_words(wn, Fq::neg(u));
-    Fq::to_words(wv, v);
-    _Pragma("unroll") for (int k = 0; k < 8; k++) { wu[k] = flip ? wn[k] : wu[k]; if (!ok) { wu[k] = 0; wv[k] = 0; } }
+    // canonical u once; -u is q - u on the plain limbs (no second conversion product)
+    const Fe up = Fq::to_plain(u);
+    u32 nzl = 0; _Pragma("unroll") for (int k = 0; k < NL; k++) nzl |= up.l[k];
+    const u32 flip = (up.l[0] ^ sign) & 1u;
+    if ((flags & 1u) && nzl == 0 && flip) ok = false;
+    Fe un; _Pragma("unroll") for (int k = 0; k < NL; k++) un.l[k] = (nzl ? FqP::P[k] : 0u) - up.l[k];
+    u32 wu[8];
+    Fq::pack(wu, Fq::select(up, Fq::carry_full(un), flip ? ~0u : 0u));
+    _Pragma("unroll") for (int k = 0; k < 8; k++) { if (!ok) { wu[k] = 0; wv[k] = 0; } }
     store8(out64, 2 * i, wu);
     store8(out64, 2 * i + 1, wv);
     okp[i] = ok ? 1 : 0;

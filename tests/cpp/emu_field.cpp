@@ -117,6 +117,21 @@ extern "C" void emu_signed_sum(int n, const uint8_t* points, const uint8_t* sign
   Ext back = Curve::sub<true>(twice, en);
   store_affine(out64, back);
 }
+// the arithmetic of k_normalize (jj_kernels.h) for one element: (U, V, Z) = (u s, v s, s) -> affine through the plain-form
+// inverse and canon_plain_product; also exercises is_zero_product on Z
+extern "C" int emu_normalize(const uint8_t* point, const uint8_t* scale32, uint8_t* out64) {
+  const Affine a = load_affine(point);
+  u32 ws[8]; ld(ws, scale32);
+  const Fe sc = Fq::from_words(ws);
+  const Fe U = Fq::mul(a.u, sc), V = Fq::mul(a.v, sc), Z = Fq::mul(Fq::one(), sc);
+  const bool zz = Fq::is_zero_product(Z);
+  const Fe zinv = Fq::select(Fq::invert(Z), Fq::zero(), zz ? ~0u : 0u);
+  const Fe zp = Fq::mul(zinv, Fq::plain_one());
+  u32 w[8];
+  Fq::pack(w, Fq::canon_plain_product(Fq::mul(U, zp))); st(out64, w);
+  Fq::pack(w, Fq::canon_plain_product(Fq::mul(V, zp))); st(out64 + 32, w);
+  return (zz ? 1 : 0) | (Fq::is_zero_product(Fq::one()) ? 2 : 0) | (Fq::is_zero_product(Fq::mul(Fq::zero(), sc)) ? 0 : 4) | (Fq::is_zero(Z) != zz ? 8 : 0);
+}
 extern "C" int emu_predicates(const uint8_t* point) {
   const Affine a = load_affine(point);
   const Ext e = Curve::from_affine(a);

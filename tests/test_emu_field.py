@@ -140,3 +140,17 @@ def test_predicates_emulated(emu, golden):
                (8 if J.ext_is_identity(e) else 0) | (16 if J.ext_is_identity(J.ext_mul_by_cofactor(e)) else 0)
         assert emu.emu_predicates(_in(pt64(P))) == want, P
     assert emu.emu_predicates(_in(pt64((5, 7)))) & 1 == 0          # off the curve
+
+
+def test_normalise_tail_emulated(emu):
+    """k_normalize's per-element arithmetic: plain-form inverse, canon_plain_product, is_zero_product"""
+    rng = random.Random(17)
+    out = _buf(64)
+    pts = _points(5, 31) + [(0, 1), (0, Q - 1)]
+    for P in pts:
+        for sc in (1, 2, Q - 1, rng.randrange(1, Q), rng.getrandbits(256)):
+            flags = emu.emu_normalize(_in(pt64(P)), _in(b32(sc)), out)
+            assert flags == (1 if sc % Q == 0 else 0)
+            assert to_pt(np.frombuffer(bytes(out), dtype=np.uint8)) == ((P[0] % Q, P[1] % Q) if sc % Q else (0, 0))
+        flags = emu.emu_normalize(_in(pt64(P)), _in(b32(Q)), out)          # Z = 0 is skipped like ff's BatchInverter: output zeroed
+        assert flags == 1 and to_pt(np.frombuffer(bytes(out), dtype=np.uint8)) == (0, 0)

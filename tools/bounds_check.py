@@ -265,7 +265,10 @@ def check_kernel_formulas(verbose=True):
     z = inv["z"]
     accp = F.mul(N, z, "norm.acc")
     zinv = F.mul(N, N, "norm.zinv")
-    F.mul(inv["u"], zinv, "norm.u")
+    zp = F.mul(F.join(zinv, F.const(0)), V([1] + [0] * (NL - 1), [1] + [0] * (NL - 1), 1, 1), "norm.zp")      # plain form of 1/Z
+    for k in ("u", "v"):
+        o = F.mul(inv[k], zp, "norm." + k)
+        assert -2 * Q < o.vlo and o.vhi < Q, "canon_plain_product needs a value in (-2q, q)"
     # ---- is_on_curve
     u2, v2 = F.sqr(ld, "oc.u2"), F.sqr(ld, "oc.v2")
     F.canon_ok(F.sub(F.sub(v2, u2), F.add(ONE, F.mul(kc, F.mul(u2, v2, "oc.uv"), "oc.d"))), "oc.eq")
