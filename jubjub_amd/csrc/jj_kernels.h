@@ -784,19 +784,23 @@ __global__ void __launch_bounds__(256) k_msm_convert(size_t n, const void* scala
 //   k_msm_scatter    : LDS cursors start at the tile bases; every term takes the next slot of its bucket
 // No global atomics, and the global traffic is coalesced except the final 4-byte index writes.
 constexpr int MSM_SORT_THREADS = 1024;
+#ifndef JJ_MSM_SORT_UNROLL
+#define JJ_MSM_SORT_UNROLL 4
+#endif
+constexpr int MSM_SORT_UNROLL = JJ_MSM_SORT_UNROLL;   // terms per thread and trip: that many loads / LDS atomics / stores in flight
 __global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_hist(size_t n, size_t tile, MsmParams mp, const u32* kp, u32* tcount) {
   extern __shared__ u32 msm_lds[];
   const int w = blockIdx.y;
   for (u32 b = threadIdx.x; b < mp.B; b += MSM_SORT_THREADS) msm_lds[b] = 0;
   __syncthreads();
   const size_t lo = (size_t)blockIdx.x * tile, hi = lo + tile < n ? lo + tile : n;
-  for (size_t i0 = lo + threadIdx.x; i0 < hi; i0 += 4 * MSM_SORT_THREADS) {
-    u32 a[4];
-    _Pragma("unroll") for (int q = 0; q < 4; q++) {
+  for (size_t i0 = lo + threadIdx.x; i0 < hi; i0 += MSM_SORT_UNROLL * MSM_SORT_THREADS) {
+    u32 a[MSM_SORT_UNROLL];
+    _Pragma("unroll") for (int q = 0; q < MSM_SORT_UNROLL; q++) {
       const size_t i = i0 + (size_t)q * MSM_SORT_THREADS;
       u32 neg; a[q] = i < hi ? msm_digit_wm(kp, n, i, mp, w, neg) : 0u;
     }
-    _Pragma("unroll") for (int q = 0; q < 4; q++) if (a[q]) atomicAdd(&msm_lds[a[q] - 1], 1u);
+    _Pragma("unroll") for (int q = 0; q < MSM_SORT_UNROLL; q++) if (a[q]) atomicAdd(&msm_lds[a[q] - 1], 1u);
   }
   __syncthreads();
   u32* out = tcount + ((size_t)w * gridDim.x + blockIdx.x) * mp.B;
@@ -831,17 +835,17 @@ __global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_scatter(size_t n, size
   for (u32 b = threadIdx.x; b < mp.B; b += MSM_SORT_THREADS) msm_lds[b] = base[b];
   __syncthreads();
   const size_t lo = (size_t)tile_id * tile, hi = lo + tile < n ? lo + tile : n;
-  // four terms per trip: the digit loads, then the LDS cursor updates, then the stores (more memory operations in flight)
-  for (size_t i0 = lo + threadIdx.x; i0 < hi; i0 += 4 * MSM_SORT_THREADS) {
-    u32 a[4], neg[4];
-    _Pragma("unroll") for (int q = 0; q < 4; q++) {
+  // MSM_SORT_UNROLL terms per trip: the digit loads, then the LDS cursor updates, then the stores (more memory operations in flight)
+  for (size_t i0 = lo + threadIdx.x; i0 < hi; i0 += MSM_SORT_UNROLL * MSM_SORT_THREADS) {
+    u32 a[MSM_SORT_UNROLL], neg[MSM_SORT_UNROLL];
+    _Pragma("unroll") for (int q = 0; q < MSM_SORT_UNROLL; q++) {
       const size_t i = i0 + (size_t)q * MSM_SORT_THREADS;
       a[q] = 0; neg[q] = 0;
       if (i < hi) a[q] = msm_digit_wm(kp, n, i, mp, w, neg[q]);
     }
-    u32 slot[4];
-    _Pragma("unroll") for (int q = 0; q < 4; q++) slot[q] = a[q] ? atomicAdd(&msm_lds[a[q] - 1], 1u) : 0u;
-    _Pragma("unroll") for (int q = 0; q < 4; q++) if (a[q]) idx[slot[q]] = (u32)(i0 + (size_t)q * MSM_SORT_THREADS) | (neg[q] << 31);
+    u32 slot[MSM_SORT_UNROLL];
+    _Pragma("unroll") for (int q = 0; q < MSM_SORT_UNROLL; q++) slot[q] = a[q] ? atomicAdd(&msm_lds[a[q] - 1], 1u) : 0u;
+    _Pragma("unroll") for (int q = 0; q < MSM_SORT_UNROLL; q++) if (a[q]) idx[slot[q]] = (u32)(i0 + (size_t)q * MSM_SORT_THREADS) | (neg[q] << 31);
   }
 }
 // exclusive scan of `count` (m entries) into `offset` (m+1 entries), three small passes:

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Prints the numbers DESIGN.md §6 quotes, straight from the committed bench lines and PMC summaries in profiles/
+(python tools/design_numbers.py [tag]).  Nothing is typed by hand in that table."""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
+
+
+def line(name):
+    p = os.path.join(ROOT, "profiles", "%s_%s.json" % (tag, name))
+    return json.load(open(p)) if os.path.exists(p) else None
+
+
+def pmc(wl):
+    p = os.path.join(ROOT, "profiles", "%s_%s_pmc.txt" % (tag, wl))
+    if not os.path.exists(p):
+        return {}
+    t = open(p).read()
+    g = lambda pat: (re.search(pat, t) or [None, "?"])[1]
+    return {"instr": g(r"VALU lane-instructions per unit\s+=\s+(\d+)"), "interval": g(r"one every ([\d.]+) cycles"), "ghz": g(r"=> ([\d.]+) GHz"),
+            "bytes": g(r"=>\s+(\d+) B per unit")}
+
+
+for name in ("varbase_bench", "fixedbase_bench", "msm_bench", "decompress_bench", "bench_default", "bench_dec1", "bench_dec3", "bench_msm17", "bench_msm22", "bench_fb16"):
+    d = line(name)
+    if not d:
+        continue
+    r = d["roofline"]
+    print("%-18s %8.1f M %-13s ms/pass %7.3f  kernel %7.3f ms  tail %6.3f  frac %.3f  whole-pass %.3f  verified %s  build %s" % (
+        name, d["value"] / 1e6, d["unit"], d["config"]["ms_per_pass"], r["kernel_ms"], r["tail_ms"], r["frac"], r["whole_pass_frac"], d.get("verified"), r["build_id"]))
+d = line("bench_default")
+if d:
+    fb, fw, cb = d.get("fixed_base"), d.get("fixed_base_wide_window"), d.get("cpu_baseline")
+    if fb:
+        print("default.fixed_base      %.1f M/s  kernel %.3f ms  frac %.3f  verified %s" % (fb["value"] / 1e6, fb["kernel_ms"], fb["roofline_frac"], fb.get("verified")))
+    if fw:
+        print("default.wide_window     %.1f M/s  verified %s" % (fw["value"] / 1e6, fw.get("verified")))
+    if cb:
+        print("cpu_baseline            one thread %.0f /s, %d threads %.0f /s (x%.1f); %s, logical %d, cgroup quota %s" % (
+            cb["single_thread"]["value"], cb["all_cores"]["threads"], cb["all_cores"]["value"], cb["all_cores"]["speedup_over_one_thread"],
+            cb["cpu"]["model"], cb["cpu"]["logical_cpus"], cb["cpu"]["cgroup_cpu_quota"]))
+for wl in ("varbase", "fixedbase", "msm", "decompress"):
+    print("pmc %-11s %s" % (wl, pmc(wl)))
