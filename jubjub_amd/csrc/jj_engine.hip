@@ -49,7 +49,7 @@ struct jj_ctx {
                                  // (2-4 % faster there, slower below: more launches) (JJ_MSM_ACCUM=segments|chunks)
   int msm_seg_len = 0;           // segment length override (JJ_MSM_SEG_LEN; 0 = n / 2^14 clamped to [32, 1024])
   int msm_chunk = 0;             // accumulation chunk override (JJ_MSM_CHUNK; 0 = scale with n)
-  int msm_reduce_chunk = 32, msm_fold = 4;   // bucket-reduce chunk length / fan-in of the chunk folds (powers of two)
+  int msm_reduce_chunk = 0, msm_fold = 4;    // bucket-reduce chunk length (0 = from the bucket count, see msm_pippenger) / fan-in of the chunk folds (powers of two)
   int msm_pass_log2 = 24;        // terms per Pippenger pass (JJ_MSM_PASS_LOG2 overrides; for tests)
   int msm_min_pippenger = 1;     // below this many terms the MSM is var-base ladders + fold (JJ_MSM_NAIVE_BELOW; Pippenger is faster at every size, measured)
   // optional per-call kernel timing (HIP events on the launch stream): e0 | main kernel | e1 | normalise tail | e2
@@ -866,7 +866,12 @@ static int msm_pippenger(jj_ctx* c, size_t n, const void* ds, const void* dp, jj
   memset(mp.recode, 0, sizeof mp.recode);
   for (int w = 0; w < mp.W - 1; w++) { const int bit = mp.c * w + mp.c - 1; mp.recode[bit >> 5] |= 1u << (bit & 31); }
   const size_t nb = (size_t)mp.W * mp.B;
-  const u32 L = std::min<u32>((u32)c->msm_reduce_chunk, mp.B);   // buckets per reduce chunk (serial depth 2L + ~2c; JJ_MSM_REDUCE_CHUNK), never more than one window
+  // buckets per reduce chunk (serial depth 2L + ~2c): the reduce is latency-bound, so short chunks (more quads in flight) win
+  // as long as the per-chunk double-and-add by the chunk's first index stays small against the 2L additions -- measured:
+  // 32 for the 2^19 buckets of 16-bit windows, 4-8 for the 11- and 8-bit windows of small inputs (-14 % at 2^17 terms,
+  // -23 % at 2^14).  JJ_MSM_REDUCE_CHUNK overrides; never more than one window.
+  const u32 L_auto = nb >= ((size_t)1 << 18) ? 32u : (nb >= ((size_t)1 << 16) ? 8u : 4u);
+  const u32 L = std::min<u32>(c->msm_reduce_chunk ? (u32)c->msm_reduce_chunk : L_auto, mp.B);
   if (mp.B % L || (L & (L - 1)) || (c->msm_fold & (c->msm_fold - 1))) { c->err = "inconsistent MSM tuning overrides (JJ_MSM_REDUCE_CHUNK / JJ_MSM_FOLD must be powers of two dividing the bucket count)"; return JJ_ERR_INVALID; }
   const size_t nchunks = nb / L;
   int rc;
@@ -874,6 +879,7 @@ static int msm_pippenger(jj_ctx* c, size_t n, const void* ds, const void* dp, jj
   const size_t nscan = (nb + SCAN_TILE - 1) / SCAN_TILE;
   u32 chunk = MSM_CHUNK_MIN;                           // 16 entries per lane up to 2^19 terms, 32 at 2^20, then proportional to n (measured)
   while (chunk < 256 && ((size_t)chunk << 15) < n) chunk <<= 1;
+  if (n <= ((size_t)1 << 15)) chunk = 8;              // small inputs: more lanes, shorter chains (-8 % at 2^14 terms)
   if (c->msm_chunk) chunk = (u32)c->msm_chunk;
   const size_t max_chunks = (n * (size_t)mp.W + chunk - 1) / chunk;
   if ((rc = ensure(c, kprime, n * 32))) return rc;
