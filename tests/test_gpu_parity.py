@@ -193,6 +193,25 @@ def test_varbase_shared_scalar(eng, golden):
     assert eng.varbase_mul_scalar(b32(5), pts[:0]).shape == (0, 64)
 
 
+def test_varbase_shared_scalar_kernel_large_ragged_batch(eng, golden, monkeypatch):
+    """above JJ_VB_QUAD_MAX the shared-scalar kernel runs (k_varbase<.., SHARED>: the scalar is read through a wave-uniform
+    address, its digits live in scalar registers); ragged batch sizes exercise the waves' work cursor"""
+    from jubjub_amd import Engine
+
+    monkeypatch.setenv("JJ_VB_QUAD_MAX", "0")                # every size through the per-lane kernels
+    e2 = Engine(0)
+    pts = np.concatenate([rand_points(93, 40001 - 10), torsion_points(golden), arr64([J.GENERATOR, J.AFFINE_IDENTITY])])
+    for k in (to_int(rand_scalars(94, 1, full_width=True)[0]), R - 1):
+        S = np.repeat(b32(k)[None, :], len(pts), axis=0)
+        want = O.varbase_mul(S, pts)
+        assert (e2.varbase_mul_scalar(b32(k), pts) == want).all()
+        for m in (1, 63, 65, 4099):
+            assert (e2.varbase_mul_scalar(b32(k), pts[:m]) == want[:m]).all(), m
+    Sr = rand_scalars(95, len(pts), full_width=True)
+    assert (e2.varbase_mul(Sr, pts) == O.varbase_mul(Sr, pts)).all()      # per-unit scalars, same ragged size
+    e2.close()
+
+
 def test_varbase_exact_projective(eng):
     n = 200
     S = np.concatenate([arr32(EDGE_SCALARS), rand_scalars(7, n)])
