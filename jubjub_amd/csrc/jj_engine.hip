@@ -61,7 +61,14 @@ struct jj_ctx {
     bool ready = false;
   } pipe;
   size_t pipe_chunk = (size_t)1 << 18;   // elements per pipeline chunk (JJ_PIPE_CHUNK_LOG2)
-  uint8_t* tail_host = nullptr;  // pinned staging for the MSM window sums (host-side Horner)
+  uint8_t* tail_host = nullptr;  // pinned staging for the MSM window sums (host-side Horner) + the two input pointers of the MSM graph
+  // The ~25 launches of one Pippenger pass are captured once per shape into a hipGraph and replayed (JJ_MSM_GRAPH=0: plain
+  // launches).  A graph is valid for one (n, window, chunking) shape and one generation of the workspaces it points into.
+  struct MsmGraph { hipGraphExec_t exec = nullptr; size_t n = 0; int cbits = 0, seg = 0; u32 L = 0, chunk = 0, P = 0; uint64_t gen = 0, used = 0; };
+  MsmGraph msm_graphs[4];
+  uint64_t alloc_gen = 0, graph_clock = 0;
+  bool msm_graph = true;
+  DevBuf msm_io;
   uint8_t host_out[64];
   bool torsion_ladder = false;   // subgroup test: false = Tate pairing (k_torsion_free), true = multiply by r (reference definition)
   bool fb_const_time = true;     // fixed-base window select: true = lane-staged + ds_bpermute shuffle, false = per-lane LDS gather
@@ -111,6 +118,7 @@ static int ensure(jj_ctx* c, DevBuf& b, size_t bytes) {
   hipError_t e = hipMalloc(&b.p, want);
   if (e != hipSuccess) { c->err = std::string("hipMalloc failed: ") + hipGetErrorString(e); b.p = nullptr; return JJ_ERR_NOMEM; }
   b.cap = want;
+  c->alloc_gen++;                  // captured graphs point into the workspaces: a (re)allocation invalidates them
   return JJ_OK;
 }
 
@@ -291,6 +299,7 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
   if (const char* e = getenv("JJ_MSM_FOLD")) { int v = atoi(e); if (v >= 2 && v <= 64 && (v & (v - 1)) == 0) c->msm_fold = v; }
   if (const char* e = getenv("JJ_MSM_PASS_LOG2")) { int v = atoi(e); if (v >= 10 && v <= 24) c->msm_pass_log2 = v; }
   if (const char* e = getenv("JJ_MSM_NAIVE_BELOW")) { int v = atoi(e); if (v >= 0) c->msm_min_pippenger = v; }
+  if (const char* e = getenv("JJ_MSM_GRAPH")) c->msm_graph = atoi(e) != 0;
   if (const char* e = getenv("JJ_VB_QUAD_MAX")) { int v = atoi(e); if (v >= 0 && v <= (1 << 20)) c->vb_quad_max = v; }
   if (const char* e = getenv("JJ_FB_GATHER_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) c->fb_gather_blocks_per_cu = v; }
   if (const char* e = getenv("JJ_VB_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) c->vb_blocks_per_cu = v; }
@@ -324,7 +333,8 @@ JJ_API int jj_ctx_destroy(jj_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   DevBuf* all[] = {&c->in[0], &c->in[1], &c->in[2], &c->in[3], &c->out[0], &c->out[1], &c->okb, &c->ws_ext, &c->msm_seg, &c->ws_scratch, &c->ws_tables,
                    &c->ws_tmp[0], &c->ws_tmp[1], &c->ws_tmp[2], &c->ws_tmp[3], &c->msm[0], &c->msm[1], &c->msm[2], &c->msm[3],
-                   &c->msm[4], &c->msm[5], &c->msm[6], &c->msm[7], &c->sqrt_tabs, &c->cursor};
+                   &c->msm[4], &c->msm[5], &c->msm[6], &c->msm[7], &c->sqrt_tabs, &c->cursor, &c->msm_io};
+  for (auto& g : c->msm_graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
   for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
   if (c->tail_host) (void)hipHostFree(c->tail_host);
   if (c->pipe.ready) {
@@ -896,61 +906,107 @@ static int msm_pippenger(jj_ctx* c, size_t n, const void* ds, const void* dp, jj
   if ((rc = ensure(c, ra, (size_t)EXT_AOS_WORDS * 4 * std::max(nchunks, std::max(max_chunks, (n * (size_t)mp.W) / 8 + 1))))) return rc;   // first the chunk heads, later the fold ping-pong
   if ((rc = ensure(c, rb, (size_t)5 * NL * 4 * nchunks))) return rc;
   u32* count = (u32*)cnt.p; u32* offset = count + nb; u32* bsum = offset + nb + 1;
-  hipLaunchKernelGGL(k_msm_convert, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, ds, dp, mp, (u32*)kprime.p, (u32*)niels.p);
-  hipLaunchKernelGGL(k_msm_hist, dim3(ntiles, mp.W), dim3(MSM_SORT_THREADS), mp.B * 4, c->stream, n, tile, mp, (const u32*)kprime.p, (u32*)tcnt.p);
-  hipLaunchKernelGGL(k_msm_tile_totals, dim3(blocks_for(nb)), dim3(256), 0, c->stream, nb, mp.B, ntiles, (const u32*)tcnt.p, count);
-  hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)nscan), dim3(256), 0, c->stream, nb, (const u32*)count, bsum);
-  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, c->stream, nscan, bsum, offset + nb);
-  hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nscan), dim3(256), 0, c->stream, nb, (const u32*)count, (const u32*)bsum, offset);
-  hipLaunchKernelGGL(k_msm_tile_bases, dim3(blocks_for(nb)), dim3(256), 0, c->stream, nb, mp.B, ntiles, (const u32*)offset, (u32*)tcnt.p);
-  hipLaunchKernelGGL(k_msm_scatter, dim3(ntiles * 8 * ((mp.W + 7) / 8)), dim3(MSM_SORT_THREADS), mp.B * 4, c->stream, n, tile, ntiles, mp, (const u32*)kprime.p, (const u32*)tcnt.p, (u32*)idx.p);
-  {
-    const ExtAoS head{(u32*)ra.p}, bk{(u32*)buckets.p};
-    u32* counters = (u32*)c->ws_tmp[1].p;                   // [0] heads, [1] merge items, [2] big buckets (work list follows at +64)
-    u32* big_count = counters + 2; BigBucket* big = (BigBucket*)((uint8_t*)c->ws_tmp[1].p + 64);
-    SoA partial = soa_of(c->ws_tmp[0], (size_t)FIXUP_BIG_MAX * FIXUP_BIG_QUADS);
-    HIPCHK(c, hipMemsetAsync(counters, 0, 16, c->stream));
-    if (c->msm_segments == 1 || (c->msm_segments < 0 && n >= ((size_t)1 << 19))) {
-      // segments of at most P entries, sorted by length; P bounds the serial depth of one lane (~ n / 2^14 additions)
-      u32 P = (u32)std::min<size_t>(SEG_PMAX, std::max<size_t>(32, n >> 14));
-      if (c->msm_seg_len >= 8 && c->msm_seg_len <= SEG_PMAX) P = (u32)c->msm_seg_len;
-      const u32 stiles = (u32)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(256, 15000 / (P + 1)), (nb + 255) / 256));   // the plan kernel keeps the tiles x (P+1) matrix in LDS
-      const u32 per_tile = (u32)((nb + stiles - 1) / stiles);
-      const size_t max_segs = nb + (n * (size_t)mp.W) / P + 1;
-      DevBuf& sb = c->msm_seg;                                // bh [stiles][P+1] | count [P+1] | offset [P+2] | block sums | merge list | segments
-      const size_t bh_words = (size_t)stiles * (P + 1), hdr_words = bh_words + 2 * (P + 2) + 16;
-      if ((rc = ensure(c, sb, hdr_words * 4 + 16 + nb * sizeof(MergeItem) + max_segs * sizeof(Seg)))) return rc;
-      u32* bh = (u32*)sb.p; u32* soff = bh + bh_words + (P + 1);
-      MergeItem* merge = (MergeItem*)(((uintptr_t)(bh + hdr_words) + 15) & ~(uintptr_t)15);
-      Seg* seg = (Seg*)(merge + nb);
-      hipLaunchKernelGGL(k_seg_hist, dim3(stiles), dim3(256), 0, c->stream, nb, per_tile, P, (const u32*)offset, bk, bh);
-      hipLaunchKernelGGL(k_seg_plan, dim3(1), dim3(1024), (bh_words + P + 2) * 4, c->stream, stiles, P, bh, soff + (P + 1));
-      hipLaunchKernelGGL(k_seg_scatter, dim3(stiles), dim3(256), 0, c->stream, nb, per_tile, P, (const u32*)offset, (const u32*)bh, seg, counters, merge, big);
-      hipLaunchKernelGGL(k_msm_accumulate_seg, dim3(blocks_for(max_segs)), dim3(256), 0, c->stream, (const u32*)(soff + (P + 1)), (const Seg*)seg, (const u32*)idx.p, (const u32*)niels.p, bk, head);
-      hipLaunchKernelGGL(k_msm_merge, dim3(blocks_for(std::min(nb, max_segs))), dim3(256), 0, c->stream, (const u32*)counters, (const MergeItem*)merge, bk, head);
-    } else {
-      hipLaunchKernelGGL(k_msm_accumulate, dim3(blocks_for(max_chunks)), dim3(256), 0, c->stream, nb, chunk, (const u32*)offset, (const u32*)idx.p, (const u32*)niels.p, bk, head);
-      hipLaunchKernelGGL(k_msm_fixup, dim3(blocks_for(nb)), dim3(256), 0, c->stream, nb, chunk, (const u32*)offset, bk, head, big_count, big);
-    }
-    hipLaunchKernelGGL(k_msm_fixup_big, dim3(256), dim3(256), 0, c->stream, (const u32*)big_count, (const BigBucket*)big, bk, head, partial, 0);
-    hipLaunchKernelGGL(k_msm_fixup_big, dim3(256), dim3(256), 0, c->stream, (const u32*)big_count, (const BigBucket*)big, bk, head, partial, 1);
-  }
-  hipLaunchKernelGGL(k_msm_bucket_reduce, dim3(blocks_for(nchunks * 4)), dim3(256), 0, c->stream, nchunks, L, mp.B, mp.c - 1, ExtAoS{(u32*)buckets.p}, soa_of(ra, nchunks));
-  // fold the chunks of each window: per-window count B/L -> 1
-  size_t per_window = mp.B / L, m = nchunks;
-  DevBuf* cur = &ra; DevBuf* nxt = &rb;
-  while (per_window > 1) {
-    const int fold = (int)std::min<size_t>(per_window, (size_t)c->msm_fold);
-    const size_t T = m / fold;
-    hipLaunchKernelGGL(k_sum_groups, dim3(blocks_for(T * 4)), dim3(256), 0, c->stream, m, T, fold, soa_of(*cur, m), soa_of(*nxt, T));
-    std::swap(cur, nxt); m = T; per_window /= fold;
-  }
-  // m == W window sums; Horner combine on the host
-  if (!c->tail_host) HIPCHK(c, hipHostMalloc((void**)&c->tail_host, 160 * 64, hipHostMallocDefault));
+  const bool use_segments = c->msm_segments == 1 || (c->msm_segments < 0 && n >= ((size_t)1 << 19));
+  // segments of at most P entries, sorted by length; P bounds the serial depth of one lane (~ n / 2^14 additions)
+  u32 P = (u32)std::min<size_t>(SEG_PMAX, std::max<size_t>(32, n >> 14));
+  if (c->msm_seg_len >= 8 && c->msm_seg_len <= SEG_PMAX) P = (u32)c->msm_seg_len;
+  const u32 stiles = (u32)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(256, 15000 / (P + 1)), (nb + 255) / 256));   // the plan kernel keeps the tiles x (P+1) matrix in LDS
+  const u32 per_tile = (u32)((nb + stiles - 1) / stiles);
+  const size_t max_segs = nb + (n * (size_t)mp.W) / P + 1;
+  const size_t bh_words = (size_t)stiles * (P + 1), hdr_words = bh_words + 2 * (P + 2) + 16;
+  if (use_segments && (rc = ensure(c, c->msm_seg, hdr_words * 4 + 16 + nb * sizeof(MergeItem) + max_segs * sizeof(Seg)))) return rc;   // bh [stiles][P+1] | count [P+1] | offset [P+2] | block sums | merge list | segments
+  if (!c->tail_host) HIPCHK(c, hipHostMalloc((void**)&c->tail_host, 160 * 64 + 64, hipHostMallocDefault));
   if ((rc = ensure(c, c->ws_tmp[3], 160 * 64))) return rc;
-  hipLaunchKernelGGL(k_soa_to_ext160, dim3(1), dim3(64), 0, c->stream, (size_t)mp.W, soa_of(*cur, m), c->ws_tmp[3].p);
-  HIPCHK(c, hipMemcpyAsync(c->tail_host, c->ws_tmp[3].p, (size_t)160 * mp.W, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if ((rc = ensure(c, c->msm_io, 64))) return rc;
+  // everything from here to the copy of the window sums is launches only (no allocation, no synchronisation): it can run
+  // directly on a stream or be recorded into a graph
+  auto enqueue = [&](hipStream_t st) -> int {
+    hipLaunchKernelGGL(k_msm_convert, dim3(blocks_for(n)), dim3(256), 0, st, n, (const void* const*)c->msm_io.p, mp, (u32*)kprime.p, (u32*)niels.p);
+    hipLaunchKernelGGL(k_msm_hist, dim3(ntiles, mp.W), dim3(MSM_SORT_THREADS), mp.B * 4, st, n, tile, mp, (const u32*)kprime.p, (u32*)tcnt.p);
+    hipLaunchKernelGGL(k_msm_tile_totals, dim3(blocks_for(nb)), dim3(256), 0, st, nb, mp.B, ntiles, (const u32*)tcnt.p, count);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)nscan), dim3(256), 0, st, nb, (const u32*)count, bsum);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, nscan, bsum, offset + nb);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nscan), dim3(256), 0, st, nb, (const u32*)count, (const u32*)bsum, offset);
+    hipLaunchKernelGGL(k_msm_tile_bases, dim3(blocks_for(nb)), dim3(256), 0, st, nb, mp.B, ntiles, (const u32*)offset, (u32*)tcnt.p);
+    hipLaunchKernelGGL(k_msm_scatter, dim3(ntiles * 8 * ((mp.W + 7) / 8)), dim3(MSM_SORT_THREADS), mp.B * 4, st, n, tile, ntiles, mp, (const u32*)kprime.p, (const u32*)tcnt.p, (u32*)idx.p);
+    {
+      const ExtAoS head{(u32*)ra.p}, bk{(u32*)buckets.p};
+      u32* counters = (u32*)c->ws_tmp[1].p;                   // [0] heads, [1] merge items, [2] big buckets (work list follows at +64)
+      u32* big_count = counters + 2; BigBucket* big = (BigBucket*)((uint8_t*)c->ws_tmp[1].p + 64);
+      SoA partial = soa_of(c->ws_tmp[0], (size_t)FIXUP_BIG_MAX * FIXUP_BIG_QUADS);
+      HIPCHK(c, hipMemsetAsync(counters, 0, 16, st));
+      if (use_segments) {
+        u32* bh = (u32*)c->msm_seg.p; u32* soff = bh + bh_words + (P + 1);
+        MergeItem* merge = (MergeItem*)(((uintptr_t)(bh + hdr_words) + 15) & ~(uintptr_t)15);
+        Seg* seg = (Seg*)(merge + nb);
+        hipLaunchKernelGGL(k_seg_hist, dim3(stiles), dim3(256), 0, st, nb, per_tile, P, (const u32*)offset, bk, bh);
+        hipLaunchKernelGGL(k_seg_plan, dim3(1), dim3(1024), (bh_words + P + 2) * 4, st, stiles, P, bh, soff + (P + 1));
+        hipLaunchKernelGGL(k_seg_scatter, dim3(stiles), dim3(256), 0, st, nb, per_tile, P, (const u32*)offset, (const u32*)bh, seg, counters, merge, big);
+        hipLaunchKernelGGL(k_msm_accumulate_seg, dim3(blocks_for(max_segs)), dim3(256), 0, st, (const u32*)(soff + (P + 1)), (const Seg*)seg, (const u32*)idx.p, (const u32*)niels.p, bk, head);
+        hipLaunchKernelGGL(k_msm_merge, dim3(blocks_for(std::min(nb, max_segs))), dim3(256), 0, st, (const u32*)counters, (const MergeItem*)merge, bk, head);
+      } else {
+        hipLaunchKernelGGL(k_msm_accumulate, dim3(blocks_for(max_chunks)), dim3(256), 0, st, nb, chunk, (const u32*)offset, (const u32*)idx.p, (const u32*)niels.p, bk, head);
+        hipLaunchKernelGGL(k_msm_fixup, dim3(blocks_for(nb)), dim3(256), 0, st, nb, chunk, (const u32*)offset, bk, head, big_count, big);
+      }
+      hipLaunchKernelGGL(k_msm_fixup_big, dim3(256), dim3(256), 0, st, (const u32*)big_count, (const BigBucket*)big, bk, head, partial, 0);
+      hipLaunchKernelGGL(k_msm_fixup_big, dim3(256), dim3(256), 0, st, (const u32*)big_count, (const BigBucket*)big, bk, head, partial, 1);
+    }
+    hipLaunchKernelGGL(k_msm_bucket_reduce, dim3(blocks_for(nchunks * 4)), dim3(256), 0, st, nchunks, L, mp.B, mp.c - 1, ExtAoS{(u32*)buckets.p}, soa_of(ra, nchunks));
+    // fold the chunks of each window: per-window count B/L -> 1
+    size_t per_window = mp.B / L, m = nchunks;
+    DevBuf* cur = &ra; DevBuf* nxt = &rb;
+    while (per_window > 1) {
+      const int fold = (int)std::min<size_t>(per_window, (size_t)c->msm_fold);
+      const size_t T = m / fold;
+      hipLaunchKernelGGL(k_sum_groups, dim3(blocks_for(T * 4)), dim3(256), 0, st, m, T, fold, soa_of(*cur, m), soa_of(*nxt, T));
+      std::swap(cur, nxt); m = T; per_window /= fold;
+    }
+    // m == W window sums, copied back for the Horner combine on the host
+    hipLaunchKernelGGL(k_soa_to_ext160, dim3(1), dim3(64), 0, st, (size_t)mp.W, soa_of(*cur, m), c->ws_tmp[3].p);
+    HIPCHK(c, hipMemcpyAsync(c->tail_host, c->ws_tmp[3].p, (size_t)160 * mp.W, hipMemcpyDeviceToHost, st));
+    return JJ_OK;
+  };
+  // the caller's two pointers, through pinned memory (asynchronous 16-byte copy)
+  const void** io_host = (const void**)(c->tail_host + 160 * 64);
+  io_host[0] = ds; io_host[1] = dp;
+  HIPCHK(c, hipMemcpyAsync(c->msm_io.p, io_host, 16, hipMemcpyHostToDevice, c->stream));
+  bool done = false;
+  if (c->msm_graph) {
+    // The graph runs on the context's own stream (the legacy null stream, which a caller may have selected, cannot be
+    // captured), ordered after what is queued on the launch stream; this call synchronises anyway for the host tail.
+    jj_ctx::MsmGraph* slot = nullptr;
+    for (auto& g : c->msm_graphs)
+      if (g.exec && g.n == n && g.cbits == mp.c && g.seg == (int)use_segments && g.L == L && g.chunk == chunk && g.P == P && g.gen == c->alloc_gen) slot = &g;
+    if (!slot) {
+      slot = &c->msm_graphs[0];
+      for (auto& g : c->msm_graphs) if (g.used < slot->used) slot = &g;       // least recently used
+      if (slot->exec) { (void)hipGraphExecDestroy(slot->exec); slot->exec = nullptr; }
+      hipGraph_t graph = nullptr;
+      bool ok = hipStreamBeginCapture(c->own_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+      if (ok) {
+        const int erc = enqueue(c->own_stream);
+        ok = hipStreamEndCapture(c->own_stream, &graph) == hipSuccess && erc == JJ_OK && graph;
+      }
+      if (ok) ok = hipGraphInstantiate(&slot->exec, graph, nullptr, nullptr, 0) == hipSuccess;
+      if (graph) (void)hipGraphDestroy(graph);
+      if (ok) { slot->n = n; slot->cbits = mp.c; slot->seg = (int)use_segments; slot->L = L; slot->chunk = chunk; slot->P = P; slot->gen = c->alloc_gen; }
+      else { (void)hipGetLastError(); slot->exec = nullptr; slot = nullptr; c->msm_graph = false; }   // fall back to plain launches for good
+    }
+    if (slot) {
+      slot->used = ++c->graph_clock;
+      if (c->stream != c->own_stream) {
+        HIPCHK(c, hipEventRecord(c->order_ev, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->own_stream, c->order_ev, 0));
+      }
+      HIPCHK(c, hipGraphLaunch(slot->exec, c->own_stream));
+      HIPCHK(c, hipStreamSynchronize(c->own_stream));
+      done = true;
+    }
+  }
+  if (!done) {
+    if ((rc = enqueue(c->stream))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
   *res = jjhost::horner(c->tail_host, mp.W, mp.c);
   return JJ_OK;
 }

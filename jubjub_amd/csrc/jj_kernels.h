@@ -761,9 +761,13 @@ static JJ_DEV u32 msm_digit_wm(const u32* kp, size_t n, size_t i, const MsmParam
   return msm_digit_raw((u32)(both >> sh) & ((1u << mp.c) - 1u), mp, w, neg);
 }
 // recode scalars (k' = k + recode, word-major) and convert points to affine-Niels AoS (27 words in a 128-byte record)
-__global__ void __launch_bounds__(256) k_msm_convert(size_t n, const void* scalars, const void* points, MsmParams mp, u32* kprime, u32* niels) {
+// The two input pointers come through a two-entry device array (io[0] = scalars, io[1] = points) so that a captured graph of
+// the whole MSM does not depend on where the caller's batch lives.
+__global__ void __launch_bounds__(256) k_msm_convert(size_t n, const void* const* io, MsmParams mp, u32* kprime, u32* niels) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  const void* scalars = io[0];
+  const void* points = io[1];
   u32 k[8];
   load8(k, scalars, i);
   k[7] &= 0x0fffffffu;
@@ -1307,11 +1311,13 @@ __global__ void __launch_bounds__(256) k_msm_bucket_reduce(size_t nchunks, u32 L
     total = quad_add_ext_t(total, Tt, running, Tr, role, Tt, Tr, Tr, dummy);
     bk = nx; Tb = Tn;
   }
-  // total += j0 * running   (j0 < B = 2^jbits), double-and-add from the top bit
+  // total += j0 * running   (j0 < B = 2^jbits).  j0 is a multiple of the chunk length L = 2^lb: double-and-add over the
+  // jbits - lb significant bits, then lb plain doublings (no additions for bits that are zero by construction)
+  const int lb = __ffs((int)L) - 1;
   Ext m = Curve::identity();
   Fe Tm = Fq::zero();
   #pragma unroll 1
-  for (int bit = jbits - 1; bit >= 0; bit--) {
+  for (int bit = jbits - 1; bit >= lb; bit--) {
     m = quad_dbl_t(m, role, Tm);
     Ext sel = Curve::identity();
     const u32 mask = ((j0 >> bit) & 1u) ? ~0u : 0u;
@@ -1319,6 +1325,8 @@ __global__ void __launch_bounds__(256) k_msm_bucket_reduce(size_t nchunks, u32 L
     const Fe Ts = Fq::select(Fq::zero(), Tr, mask);
     m = quad_add_ext_t(m, Tm, sel, Ts, role, Tm, Tr, Tr, dummy);
   }
+  #pragma unroll 1
+  for (int bit = 0; bit < lb; bit++) m = quad_dbl_t(m, role, Tm);
   total = quad_add_ext_t(total, Tt, m, Tm, role, Tt, Tr, Tr, dummy);
   if (role == 0) soa_put_ext(out, t, total);
 }
