@@ -62,12 +62,15 @@ struct jj_ctx {
   } pipe;
   size_t pipe_chunk = (size_t)1 << 18;   // elements per pipeline chunk (JJ_PIPE_CHUNK_LOG2)
   uint8_t* tail_host = nullptr;  // pinned staging for the MSM window sums (host-side Horner) + the two input pointers of the MSM graph
-  // The ~25 launches of one Pippenger pass are captured once per shape into a hipGraph and replayed (JJ_MSM_GRAPH=0: plain
-  // launches).  A graph is valid for one (n, window, chunking) shape and one generation of the workspaces it points into.
+  // JJ_MSM_GRAPH=1: the ~25 launches of one Pippenger pass are captured once per shape into a hipGraph and replayed.  A graph
+  // is valid for one (n, window, chunking) shape and one generation of the workspaces it points into.  Off by default:
+  // measured on MI355X it does not pay (2^17 terms 0.514 ms with plain launches, 0.528 ms replayed; 2^20: 1.673 / 1.700 ms) --
+  // back-to-back launches on one stream are already pipelined by the runtime, the MSM's idle time is inside its
+  // latency-bound kernels, not between them.
   struct MsmGraph { hipGraphExec_t exec = nullptr; size_t n = 0; int cbits = 0, seg = 0; u32 L = 0, chunk = 0, P = 0; uint64_t gen = 0, used = 0; };
   MsmGraph msm_graphs[4];
   uint64_t alloc_gen = 0, graph_clock = 0;
-  bool msm_graph = true;
+  bool msm_graph = false;
   DevBuf msm_io;
   uint8_t host_out[64];
   bool torsion_ladder = false;   // subgroup test: false = Tate pairing (k_torsion_free), true = multiply by r (reference definition)

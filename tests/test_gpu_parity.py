@@ -606,3 +606,17 @@ def test_group_mirror_random_and_bits(eng):
     assert p.is_prime_order().all() and p.is_on_curve().all()
     q = G.Fq.random(eng, 8, 5)
     assert all(to_int(x) < Q for x in q.data)
+
+
+def test_msm_graph_replay(monkeypatch):
+    """JJ_MSM_GRAPH=1: one captured hipGraph per MSM shape, replayed with different inputs, sizes and workspace generations"""
+    from jubjub_amd import Engine
+
+    monkeypatch.setenv("JJ_MSM_GRAPH", "1")
+    e2 = Engine(0)
+    for n in (300, 300, 5000, 300, 70000, 5000):            # repeats hit the cache, new sizes grow the workspaces (new generation)
+        S, Pn = rand_scalars(1000 + n, n, full_width=True), rand_points(2000 + n, n)
+        assert (e2.msm(S, Pn) == O.msm(S, Pn)).all(), n
+        S2, P2 = rand_scalars(3000 + n, n), rand_points(4000 + n, n)      # same shape, other buffers
+        assert (e2.msm(S2, P2) == O.msm(S2, P2)).all(), n
+    e2.close()
