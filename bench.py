@@ -457,11 +457,15 @@ def run(a):
             # the other half of BASELINE.json's metric at ITS config (2^24 fixed-base scalar-muls), same process, outside the timed region above
             fn = 1 << 24
             fs = eng.synth_scalars(fn, SEED, 0, device=dev)
-            fo = eng.fixedbase_mul(table, fs)
+            fo = None
+            for _ in range(2):                                      # warm-up: the 1 GB output and the library's workspaces get allocated here
+                fo = None
+                fo = eng.fixedbase_mul(table, fs)
             torch.cuda.synchronize(dev)
             eng.profile(True)
             t1 = time.perf_counter()
             for _ in range(4):
+                fo = None                                           # release the previous 1 GB output to torch's caching allocator first
                 fo = eng.fixedbase_mul(table, fs)
             torch.cuda.synchronize(dev)
             fdt = (time.perf_counter() - t1) / 4
@@ -475,10 +479,13 @@ def run(a):
             if not a.no_verify:
                 res["fixed_base"]["verified"], _ = verify_sample("fixedbase", a, 0, fn, fo, None, None)
             wt = eng.fixedbase_table(base, 16)                      # wide-window alternative (64 MB table in the Infinity Cache, per-lane gather)
-            fo = eng.fixedbase_mul(wt, fs)
+            for _ in range(2):
+                fo = None
+                fo = eng.fixedbase_mul(wt, fs)
             torch.cuda.synchronize(dev)
             t1 = time.perf_counter()
             for _ in range(4):
+                fo = None
                 fo = eng.fixedbase_mul(wt, fs)
             torch.cuda.synchronize(dev)
             res["fixed_base_wide_window"] = {"value": fn * 4 / (time.perf_counter() - t1), "unit": "scalar-muls/s per GPU", "units_per_pass": fn,
