@@ -50,6 +50,7 @@ struct jj_ctx {
   int msm_seg_len = 0;           // segment length override (JJ_MSM_SEG_LEN; 0 = n / 2^14 clamped to [32, 1024])
   int msm_chunk = 0;             // accumulation chunk override (JJ_MSM_CHUNK; 0 = scale with n)
   int msm_reduce_chunk = 0, msm_fold = 4;    // bucket-reduce chunk length (0 = from the bucket count, see msm_pippenger) / fan-in of the chunk folds (powers of two)
+  int msm_two_pass = -1;         // counting sort in two passes (coarse bin, then low 8 bits): -1 = when the window has >= 13 bits; JJ_MSM_SORT=1pass|2pass
   int msm_pass_log2 = 24;        // terms per Pippenger pass (JJ_MSM_PASS_LOG2 overrides; for tests)
   int msm_min_pippenger = 1;     // below this many terms the MSM is var-base ladders + fold (JJ_MSM_NAIVE_BELOW; Pippenger is faster at every size, measured)
   // optional per-call kernel timing (HIP events on the launch stream): e0 | main kernel | e1 | normalise tail | e2
@@ -300,6 +301,7 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
   if (const char* e = getenv("JJ_MSM_CHUNK")) { int v = atoi(e); if (v >= 8 && v <= 1024) c->msm_chunk = v; }
   if (const char* e = getenv("JJ_MSM_REDUCE_CHUNK")) { int v = atoi(e); if (v >= 2 && v <= 256 && (v & (v - 1)) == 0) c->msm_reduce_chunk = v; }
   if (const char* e = getenv("JJ_MSM_FOLD")) { int v = atoi(e); if (v >= 2 && v <= 64 && (v & (v - 1)) == 0) c->msm_fold = v; }
+  if (const char* e = getenv("JJ_MSM_SORT")) c->msm_two_pass = !strcmp(e, "2pass") ? 1 : (!strcmp(e, "1pass") ? 0 : -1);
   if (const char* e = getenv("JJ_MSM_PASS_LOG2")) { int v = atoi(e); if (v >= 10 && v <= 24) c->msm_pass_log2 = v; }
   if (const char* e = getenv("JJ_MSM_NAIVE_BELOW")) { int v = atoi(e); if (v >= 0) c->msm_min_pippenger = v; }
   if (const char* e = getenv("JJ_MSM_GRAPH")) c->msm_graph = atoi(e) != 0;
@@ -904,7 +906,13 @@ static int msm_pippenger(jj_ctx* c, size_t n, const void* ds, const void* dp, jj
   // sort tiles: enough (tile, window) blocks to fill the GPU, each at least 4096 terms
   const u32 ntiles = (u32)std::max<size_t>(1, std::min<size_t>((size_t)(c->cus + mp.W - 1) / mp.W, (n + 4095) / 4096));
   const size_t tile = (n + ntiles - 1) / ntiles;
-  if ((rc = ensure(c, tcnt, (size_t)mp.W * ntiles * mp.B * 4))) return rc;
+  // wide windows: two-pass sort (k_msm_part_*); tiles of MSM_P1_TILE terms
+  const bool two_pass = mp.c >= 13 && c->msm_two_pass != 0;
+  const u32 HB = mp.B >> MSM_LO_BITS;
+  const u32 ptiles = (u32)((n + MSM_P1_TILE - 1) / MSM_P1_TILE);        // the first pass orders a whole tile in LDS
+  const size_t ptile = MSM_P1_TILE;
+  const size_t pcount = (size_t)mp.W * HB * ptiles;
+  if ((rc = ensure(c, tcnt, two_pass ? (2 * pcount + pcount / SCAN_TILE + 8) * 4 : (size_t)mp.W * ntiles * mp.B * 4))) return rc;
   if ((rc = ensure(c, buckets, (size_t)EXT_AOS_WORDS * 4 * nb))) return rc;
   if ((rc = ensure(c, ra, (size_t)EXT_AOS_WORDS * 4 * std::max(nchunks, std::max(max_chunks, (n * (size_t)mp.W) / 8 + 1))))) return rc;   // first the chunk heads, later the fold ping-pong
   if ((rc = ensure(c, rb, (size_t)5 * NL * 4 * nchunks))) return rc;
@@ -925,13 +933,26 @@ static int msm_pippenger(jj_ctx* c, size_t n, const void* ds, const void* dp, jj
   // directly on a stream or be recorded into a graph
   auto enqueue = [&](hipStream_t st) -> int {
     hipLaunchKernelGGL(k_msm_convert, dim3(blocks_for(n)), dim3(256), 0, st, n, (const void* const*)c->msm_io.p, mp, (u32*)kprime.p, (u32*)niels.p);
-    hipLaunchKernelGGL(k_msm_hist, dim3(ntiles, mp.W), dim3(MSM_SORT_THREADS), mp.B * 4, st, n, tile, mp, (const u32*)kprime.p, (u32*)tcnt.p);
-    hipLaunchKernelGGL(k_msm_tile_totals, dim3(blocks_for(nb)), dim3(256), 0, st, nb, mp.B, ntiles, (const u32*)tcnt.p, count);
-    hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)nscan), dim3(256), 0, st, nb, (const u32*)count, bsum);
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, nscan, bsum, offset + nb);
-    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nscan), dim3(256), 0, st, nb, (const u32*)count, (const u32*)bsum, offset);
-    hipLaunchKernelGGL(k_msm_tile_bases, dim3(blocks_for(nb)), dim3(256), 0, st, nb, mp.B, ntiles, (const u32*)offset, (u32*)tcnt.p);
-    hipLaunchKernelGGL(k_msm_scatter, dim3(ntiles * 8 * ((mp.W + 7) / 8)), dim3(MSM_SORT_THREADS), mp.B * 4, st, n, tile, ntiles, mp, (const u32*)kprime.p, (const u32*)tcnt.p, (u32*)idx.p);
+    if (two_pass) {
+      // tcnt: counts [pcount] | scanned [pcount + 1] | block sums
+      u32* tc = (u32*)tcnt.p; u32* tcs = tc + pcount; u32* tbs = tcs + pcount + 1;
+      const size_t pscan = (pcount + SCAN_TILE - 1) / SCAN_TILE;
+      u32* rec = (u32*)ra.p; uint8_t* lo8 = (uint8_t*)ra.p + n * (size_t)mp.W * 4;     // the chunk-head buffer is free until the accumulation
+      hipLaunchKernelGGL(k_msm_part_hist, dim3(ptiles, mp.W), dim3(MSM_SORT_THREADS), 0, st, n, ptile, mp, (const u32*)kprime.p, tc);
+      hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)pscan), dim3(256), 0, st, pcount, (const u32*)tc, tbs);
+      hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, pscan, tbs, tcs + pcount);
+      hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)pscan), dim3(256), 0, st, pcount, (const u32*)tc, (const u32*)tbs, tcs);
+      hipLaunchKernelGGL(k_msm_part_scatter, dim3(ptiles, mp.W), dim3(MSM_SORT_THREADS), 0, st, n, ptile, mp, (const u32*)kprime.p, (const u32*)tcs, rec, lo8);
+      hipLaunchKernelGGL(k_msm_part_sort, dim3(mp.W * HB), dim3(MSM_P2_THREADS), 0, st, mp, ptiles, (const u32*)tcs, (const u32*)rec, (const uint8_t*)lo8, (u32*)idx.p, offset);
+    } else {
+      hipLaunchKernelGGL(k_msm_hist, dim3(ntiles, mp.W), dim3(MSM_SORT_THREADS), mp.B * 4, st, n, tile, mp, (const u32*)kprime.p, (u32*)tcnt.p);
+      hipLaunchKernelGGL(k_msm_tile_totals, dim3(blocks_for(nb)), dim3(256), 0, st, nb, mp.B, ntiles, (const u32*)tcnt.p, count);
+      hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)nscan), dim3(256), 0, st, nb, (const u32*)count, bsum);
+      hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, nscan, bsum, offset + nb);
+      hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nscan), dim3(256), 0, st, nb, (const u32*)count, (const u32*)bsum, offset);
+      hipLaunchKernelGGL(k_msm_tile_bases, dim3(blocks_for(nb)), dim3(256), 0, st, nb, mp.B, ntiles, (const u32*)offset, (u32*)tcnt.p);
+      hipLaunchKernelGGL(k_msm_scatter, dim3(ntiles * 8 * ((mp.W + 7) / 8)), dim3(MSM_SORT_THREADS), mp.B * 4, st, n, tile, ntiles, mp, (const u32*)kprime.p, (const u32*)tcnt.p, (u32*)idx.p);
+    }
     {
       const ExtAoS head{(u32*)ra.p}, bk{(u32*)buckets.p};
       u32* counters = (u32*)c->ws_tmp[1].p;                   // [0] heads, [1] merge items, [2] big buckets (work list follows at +64)

@@ -852,6 +852,167 @@ __global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_scatter(size_t n, size
     _Pragma("unroll") for (int q = 0; q < MSM_SORT_UNROLL; q++) if (a[q]) idx[slot[q]] = (u32)(i0 + (size_t)q * MSM_SORT_THREADS) | (neg[q] << 31);
   }
 }
+// Two-pass sort for wide windows (c >= 13, i.e. >= 4096 buckets per window).  The single-pass scatter above ends in one 4-byte
+// store per entry into a 4 MB index segment shared by all tiles of the window: every store opens its own cache line and most
+// lines leave L2 partially written.  Here the bucket index is split into a coarse bin (bits 8 and up, <= 128 bins per window) and its
+// low 8 bits:
+//   k_msm_part_hist    : block (tile, window): entries per coarse bin -> tc[window][bin][tile]           (one small scan follows)
+//   k_msm_part_scatter : the same block writes (term | sign << 31) and the low 8 bits into its run of every bin: 128 open lines
+//                        per block, each filled front to back by one CU
+//   k_msm_part_sort    : block (window, bin): counts the 256 low values, writes the bucket offsets of its bin (the offsets of
+//                        the whole sort: no global scan over the buckets), orders the bin in LDS and copies it out coalesced
+// A bin larger than the LDS stage (skewed scalars) is scattered directly; its stores still stay within the one block.
+constexpr int MSM_LO_BITS = 8;
+// low bits of window w's bucket index: 8, except that the short top window (values <= 2^(252 - c (W-1)), recoding carry included)
+// is split so that it still spreads over the window's B / 256 coarse bins
+static JJ_DEV int msm_lo_bits(const MsmParams& mp, int w) {
+  if (w != mp.W - 1) return MSM_LO_BITS;
+  const int lo = (252 - mp.c * (mp.W - 1)) - (mp.c - 1 - MSM_LO_BITS);
+  return lo < 0 ? 0 : (lo > MSM_LO_BITS ? MSM_LO_BITS : lo);
+}
+#ifndef JJ_MSM_P2_THREADS
+#define JJ_MSM_P2_THREADS 512
+#endif
+constexpr int MSM_P2_THREADS = JJ_MSM_P2_THREADS;
+constexpr u32 MSM_P2_CAP = 12288;     // entries staged in LDS (48 KB): 1.5 x the mean bin of a 2^20-term, 16-bit-window pass
+__global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_part_hist(size_t n, size_t tile, MsmParams mp, const u32* kp, u32* tc) {
+  __shared__ u32 h[(MSM_SORT_THREADS / 64) * 128];          // one histogram per wave: fewer same-address collisions
+  const int w = blockIdx.y;
+  const u32 HB = mp.B >> MSM_LO_BITS, wave = threadIdx.x >> 6;
+  const int lo_w = msm_lo_bits(mp, w);
+  for (u32 b = threadIdx.x; b < (MSM_SORT_THREADS / 64) * HB; b += MSM_SORT_THREADS) h[b] = 0;
+  __syncthreads();
+  const size_t lo = (size_t)blockIdx.x * tile, hi = lo + tile < n ? lo + tile : n;
+  for (size_t i0 = lo + threadIdx.x; i0 < hi; i0 += MSM_SORT_UNROLL * MSM_SORT_THREADS) {
+    u32 a[MSM_SORT_UNROLL];
+    _Pragma("unroll") for (int q = 0; q < MSM_SORT_UNROLL; q++) {
+      const size_t i = i0 + (size_t)q * MSM_SORT_THREADS;
+      u32 neg; a[q] = i < hi ? msm_digit_wm(kp, n, i, mp, w, neg) : 0u;
+    }
+    _Pragma("unroll") for (int q = 0; q < MSM_SORT_UNROLL; q++) if (a[q]) atomicAdd(&h[wave * HB + ((a[q] - 1) >> lo_w)], 1u);
+  }
+  __syncthreads();
+  for (u32 b = threadIdx.x; b < HB; b += MSM_SORT_THREADS) {
+    u32 s = 0;
+    for (u32 v = 0; v < MSM_SORT_THREADS / 64; v++) s += h[v * HB + b];
+    tc[((size_t)w * HB + b) * gridDim.x + blockIdx.x] = s;
+  }
+}
+// tile of at most MSM_P1_TILE terms: ranks from one LDS atomic per entry, the tile ordered by bin in LDS, then copied out run by run
+// (consecutive stage slots of one bin are consecutive in rec / lo8: a wave's store touches a few lines instead of 64)
+constexpr u32 MSM_P1_TILE = 8192;
+constexpr int MSM_P1_PER = MSM_P1_TILE / MSM_SORT_THREADS;
+__global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_part_scatter(size_t n, size_t tile, MsmParams mp, const u32* kp, const u32* tc, u32* rec, uint8_t* lo8) {
+  __shared__ u32 cnt[128], delta[128], live_s;
+  __shared__ u32 st_rec[MSM_P1_TILE];
+  __shared__ uint8_t st_lo[MSM_P1_TILE], st_bin[MSM_P1_TILE];
+  const int w = blockIdx.y;
+  const u32 HB = mp.B >> MSM_LO_BITS, tid = threadIdx.x;
+  const int lo_w = msm_lo_bits(mp, w);
+  if (tid < 128) cnt[tid] = 0;
+  __syncthreads();
+  const size_t lo = (size_t)blockIdx.x * tile, hi = lo + tile < n ? lo + tile : n;
+  u32 a[MSM_P1_PER], neg[MSM_P1_PER], rank[MSM_P1_PER];
+  _Pragma("unroll") for (int q = 0; q < MSM_P1_PER; q++) {
+    const size_t i = lo + tid + (size_t)q * MSM_SORT_THREADS;
+    a[q] = 0; neg[q] = 0;
+    if (i < hi) a[q] = msm_digit_wm(kp, n, i, mp, w, neg[q]);
+  }
+  _Pragma("unroll") for (int q = 0; q < MSM_P1_PER; q++) rank[q] = a[q] ? atomicAdd(&cnt[(a[q] - 1) >> lo_w], 1u) : 0u;
+  __syncthreads();
+  if (tid < 64) {                        // exclusive scan of the (at most 128) bin counts: two per lane
+    const u32 v0 = cnt[2 * tid], v1 = cnt[2 * tid + 1], s = v0 + v1;
+    u32 inc = s;
+    _Pragma("unroll") for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, d, 64); if ((int)tid >= d) inc += o; }
+    const u32 l0 = inc - s, l1 = l0 + v0;
+    cnt[2 * tid] = l0; cnt[2 * tid + 1] = l1;
+    // first global slot of this tile's run of the bin, minus the run's first stage slot
+    delta[2 * tid] = (2 * tid < HB ? tc[((size_t)w * HB + 2 * tid) * gridDim.x + blockIdx.x] : 0u) - l0;
+    delta[2 * tid + 1] = (2 * tid + 1 < HB ? tc[((size_t)w * HB + 2 * tid + 1) * gridDim.x + blockIdx.x] : 0u) - l1;
+    if (tid == 63) live_s = inc;         // entries of the tile (terms with a nonzero digit)
+  }
+  __syncthreads();
+  _Pragma("unroll") for (int q = 0; q < MSM_P1_PER; q++) if (a[q]) {
+    const u32 bin = (a[q] - 1) >> lo_w, slot = cnt[bin] + rank[q];
+    st_rec[slot] = (u32)(lo + tid + (size_t)q * MSM_SORT_THREADS) | (neg[q] << 31);
+    st_lo[slot] = (uint8_t)((a[q] - 1) & ((1u << lo_w) - 1u));
+    st_bin[slot] = (uint8_t)bin;
+  }
+  __syncthreads();
+  const u32 live = live_s;
+  for (u32 j = tid; j < live; j += MSM_SORT_THREADS) {
+    const u32 g = j + delta[st_bin[j]];
+    rec[g] = st_rec[j];
+    lo8[g] = st_lo[j];
+  }
+}
+// tc holds the scanned counts: tc[bin * ntiles] is the first entry of bin (= window * HB + coarse bin), tc[nbins * ntiles] the entry count
+__global__ void __launch_bounds__(MSM_P2_THREADS) k_msm_part_sort(MsmParams mp, u32 ntiles, const u32* tc, const u32* rec, const uint8_t* lo8, u32* idx, u32* offset) {
+  constexpr u32 NLO = 1u << MSM_LO_BITS;
+  constexpr int PER = MSM_P2_CAP / MSM_P2_THREADS;
+  __shared__ u32 cnt[NLO];
+  __shared__ u32 stage[MSM_P2_CAP];
+  const u32 bin = blockIdx.x, nbins = gridDim.x, tid = threadIdx.x;
+  const u32 gb = tc[(size_t)bin * ntiles], ge = tc[(size_t)(bin + 1) * ntiles];
+  const bool staged = ge - gb <= MSM_P2_CAP;
+  const u32 HB = mp.B >> MSM_LO_BITS, w = bin / HB, coarse = bin % HB;
+  const int lo_w = msm_lo_bits(mp, (int)w);
+  const u32 nlo = 1u << lo_w;
+  const size_t wbase = (size_t)w * mp.B;
+  if (tid < NLO) cnt[tid] = 0;
+  __syncthreads();
+  // the usual bin fits the stage: every thread takes its PER entries in one round of loads, keeps them in registers and draws
+  // their ranks within the low value from the counting atomics (one LDS atomic per entry)
+  u32 r[PER], b[PER], rank[PER];
+  if (staged) {
+    _Pragma("unroll") for (int q = 0; q < PER; q++) {
+      const u32 i = gb + tid + (u32)q * MSM_P2_THREADS;
+      b[q] = i < ge ? (u32)lo8[i] : ~0u;
+      r[q] = i < ge ? rec[i] : 0u;
+    }
+    _Pragma("unroll") for (int q = 0; q < PER; q++) rank[q] = b[q] != ~0u ? atomicAdd(&cnt[b[q]], 1u) : 0u;
+  } else {
+    // oversized bin (the short top window, skewed scalars): the same rounds of PER loads per thread, stage by stage
+    for (u32 base = gb; base < ge; base += MSM_P2_CAP) {
+      _Pragma("unroll") for (int q = 0; q < PER; q++) { const u32 i = base + tid + (u32)q * MSM_P2_THREADS; b[q] = i < ge ? (u32)lo8[i] : ~0u; }
+      _Pragma("unroll") for (int q = 0; q < PER; q++) if (b[q] != ~0u) atomicAdd(&cnt[b[q]], 1u);
+    }
+  }
+  __syncthreads();
+  // exclusive scan of the 256 counters by the first wave: four per lane, then a shuffle scan over the lane sums
+  if (tid < 64) {
+    u32 v[NLO / 64], s = 0;
+    _Pragma("unroll") for (u32 j = 0; j < NLO / 64; j++) { v[j] = cnt[tid * (NLO / 64) + j]; s += v[j]; }
+    u32 inc = s;
+    _Pragma("unroll") for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, d, 64); if ((int)tid >= d) inc += o; }
+    u32 run = inc - s;
+    _Pragma("unroll") for (u32 j = 0; j < NLO / 64; j++) {
+      const u32 k = tid * (NLO / 64) + j;
+      cnt[k] = run;                                                    // first slot of the low value, relative to gb
+      if (k < nlo) offset[wbase + ((size_t)coarse << lo_w) + k] = gb + run;
+      run += v[j];
+    }
+    // buckets of a short top window above its coarse bins are empty
+    if (coarse + 1 == HB) for (u32 k = (HB << lo_w) + tid; k < mp.B; k += 64) offset[wbase + k] = ge;
+    if (bin + 1 == nbins && tid == 0) offset[(size_t)mp.W * mp.B] = ge;
+  }
+  __syncthreads();
+  if (staged) {
+    _Pragma("unroll") for (int q = 0; q < PER; q++) if (b[q] != ~0u) stage[cnt[b[q]] + rank[q]] = r[q];
+    __syncthreads();
+    for (u32 j = tid; j < ge - gb; j += MSM_P2_THREADS) idx[gb + j] = stage[j];
+  } else {
+    for (u32 base = gb; base < ge; base += MSM_P2_CAP) {
+      _Pragma("unroll") for (int q = 0; q < PER; q++) {
+        const u32 i = base + tid + (u32)q * MSM_P2_THREADS;
+        b[q] = i < ge ? (u32)lo8[i] : ~0u;
+        r[q] = i < ge ? rec[i] : 0u;
+      }
+      _Pragma("unroll") for (int q = 0; q < PER; q++) rank[q] = b[q] != ~0u ? atomicAdd(&cnt[b[q]], 1u) : 0u;
+      _Pragma("unroll") for (int q = 0; q < PER; q++) if (b[q] != ~0u) idx[gb + rank[q]] = r[q];
+    }
+  }
+}
 // exclusive scan of `count` (m entries) into `offset` (m+1 entries), three small passes:
 // (1) per-block sums of SCAN_TILE entries, (2) one block scans the block sums, (3) per-block local scan + base.
 constexpr int SCAN_TILE = 2048;   // entries per 256-thread block (8 per thread)

@@ -322,6 +322,33 @@ def test_msm_skewed_buckets(eng):
     assert to_pt(eng.msm(Z, P)) == J.AFFINE_IDENTITY
 
 
+@pytest.mark.parametrize("window", [13, 14, 15, 16])
+@pytest.mark.parametrize("sort", ["2pass", "1pass"])
+def test_msm_wide_windows_both_sorts(monkeypatch, window, sort):
+    """Windows of 13-16 bits (the default from 2^18 terms) forced on small inputs, with the two-pass sort (coarse bin, then the low
+    bits in LDS) and the single-pass one: ragged sizes, a bin far larger than the LDS stage (equal scalars), zero digits."""
+    from jubjub_amd import Engine
+
+    monkeypatch.setenv("JJ_MSM_WINDOW", str(window))
+    monkeypatch.setenv("JJ_MSM_SORT", sort)
+    e2 = Engine(0)
+    for n in (1, 2, 300, 8191, 8193, 30000):
+        S = rand_scalars(512 + n + window, n, full_width=True)
+        P = rand_points(513 + n, n, subgroup=(n % 2 == 0))
+        assert (e2.msm(S, P) == O.msm(S, P)).all(), (window, sort, n)
+    n = 20000
+    P = rand_points(61, n)
+    S = np.repeat(rand_scalars(62, 1, full_width=True), n, axis=0)      # one bucket per window holds every term
+    assert (e2.msm(S, P) == O.msm(S, P)).all()
+    S2 = rand_scalars(63, n)
+    S2[: n // 2] = S2[0]
+    S2[n // 2: n // 2 + 500] = 0
+    S2[-1] = 0xFF
+    S2[-1, 31] = 0x0F                                                     # 2^252 - 1: largest top-window digit after recoding
+    assert (e2.msm(S2, P) == O.msm(S2, P)).all()
+    e2.close()
+
+
 def test_msm_multipass(monkeypatch):
     """Inputs larger than one Pippenger pass are folded pass by pass (pass size shrunk here via the env knob)."""
     from jubjub_amd import Engine
