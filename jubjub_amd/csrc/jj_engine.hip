@@ -29,7 +29,8 @@ struct DevBuf {
 
 struct jj_table {
   u32* dev = nullptr;      // entries x ANIELS_WORDS
-  int window_bits = FB_W;  // 6: LDS-staged table (k_fixedbase); 8..12: L2-resident table (k_fixedbase_gather)
+  int window_bits = FB_W;  // 6: LDS-staged table (k_fixedbase); 8..16: table gathered from L2 / Infinity Cache (k_fixedbase_gather)
+  int device = -1;         // the table lives in this device's memory: only contexts of the same device may use it
   FbParams fp;
 };
 
@@ -45,7 +46,7 @@ struct jj_ctx {
   DevBuf in[4], out[2], okb, ws_ext, msm_seg, ws_scratch, ws_tables, ws_tmp[4], msm[8], sqrt_tabs, cursor;
   SqrtTables sqrt_tables{nullptr, nullptr};
   int msm_window = 0;            // 0 = choose from n (JJ_MSM_WINDOW overrides; 8..16)
-  int msm_segments = -1;         // bucket accumulation: 1 = length-sorted segments, 0 = fixed chunks + fix-up, -1 = segments from 2^19 terms
+  int msm_segments = -1;         // bucket accumulation: 1 = length-sorted segments, 0 = fixed chunks + fix-up, -1 = segments from 2^18 terms
                                  // (2-4 % faster there, slower below: more launches) (JJ_MSM_ACCUM=segments|chunks)
   int msm_seg_len = 0;           // segment length override (JJ_MSM_SEG_LEN; 0 = n / 2^14 clamped to [32, 1024])
   int msm_chunk = 0;             // accumulation chunk override (JJ_MSM_CHUNK; 0 = scale with n)
@@ -291,8 +292,17 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
   c->cus = prop.multiProcessorCount;
   c->clock_khz = prop.clockRate;
   c->wave = prop.warpSize;
-  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return JJ_ERR_HIP; }
-  if (hipEventCreateWithFlags(&c->order_ev, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(c->own_stream); delete c; return JJ_ERR_HIP; }
+  // every failure below releases what was created so far
+  auto fail = [&](int code) {
+    (void)hipGetLastError();
+    if (c->sqrt_tabs.p) (void)hipFree(c->sqrt_tabs.p);
+    if (c->order_ev) (void)hipEventDestroy(c->order_ev);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return code;
+  };
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(JJ_ERR_HIP);
+  if (hipEventCreateWithFlags(&c->order_ev, hipEventDisableTiming) != hipSuccess) return fail(JJ_ERR_HIP);
   c->stream = c->own_stream;
   if (const char* e = getenv("JJ_PIPE_CHUNK_LOG2")) { int v = atoi(e); if (v >= 8 && v <= 24) c->pipe_chunk = (size_t)1 << v; }
   if (const char* e = getenv("JJ_MSM_WINDOW")) c->msm_window = atoi(e);
@@ -315,20 +325,18 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
       {reinterpret_cast<const void*>(k_msm_hist), 32768 * 4}, {reinterpret_cast<const void*>(k_seg_plan), 80 * 1024},
       {reinterpret_cast<const void*>(k_msm_scatter), 32768 * 4}};
     for (const auto& a : lds_needs)
-      if (hipFuncSetAttribute(a.fn, hipFuncAttributeMaxDynamicSharedMemorySize, a.bytes) != hipSuccess) {
-        (void)hipEventDestroy(c->order_ev); (void)hipStreamDestroy(c->own_stream); delete c; return JJ_ERR_HIP;   // the kernels could not launch later
-      }
+      if (hipFuncSetAttribute(a.fn, hipFuncAttributeMaxDynamicSharedMemorySize, a.bytes) != hipSuccess) return fail(JJ_ERR_HIP);   // the kernels could not launch later
   }
   if (const char* e = getenv("JJ_TORSION_CHECK")) c->torsion_ladder = strcmp(e, "ladder") == 0;
   if (const char* e = getenv("JJ_FIXEDBASE_SELECT")) c->fb_const_time = strcmp(e, "gather") != 0;
   // square-root tables (64 KiB dlog + 36 KiB powers), built on the device
-  if (hipMalloc(&c->sqrt_tabs.p, 65536 + 4 * 256 * NL * 4) != hipSuccess) { (void)hipStreamDestroy(c->own_stream); delete c; return JJ_ERR_NOMEM; }
+  if (hipMalloc(&c->sqrt_tabs.p, 65536 + 4 * 256 * NL * 4) != hipSuccess) { c->sqrt_tabs.p = nullptr; return fail(JJ_ERR_NOMEM); }
   c->sqrt_tabs.cap = 65536 + 4 * 256 * NL * 4;
-  (void)hipMemsetAsync(c->sqrt_tabs.p, 0, c->sqrt_tabs.cap, c->stream);
+  if (hipMemsetAsync(c->sqrt_tabs.p, 0, c->sqrt_tabs.cap, c->stream) != hipSuccess) return fail(JJ_ERR_HIP);
   c->sqrt_tables.dlog = (const uint8_t*)c->sqrt_tabs.p;
   c->sqrt_tables.npow = (const u32*)((uint8_t*)c->sqrt_tabs.p + 65536);
   hipLaunchKernelGGL(k_sqrt_tables_init, dim3(5), dim3(256), 0, c->stream, (uint8_t*)c->sqrt_tabs.p, (u32*)((uint8_t*)c->sqrt_tabs.p + 65536));
-  if (hipStreamSynchronize(c->stream) != hipSuccess) { (void)hipFree(c->sqrt_tabs.p); (void)hipStreamDestroy(c->own_stream); delete c; return JJ_ERR_HIP; }
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(JJ_ERR_HIP);
   *out = c;
   return JJ_OK;
 }
@@ -736,6 +744,7 @@ JJ_API int jj_fixedbase_table_create(jj_ctx* c, const void* base64, int window_b
   if (is_device_ptr(base64)) { HIPCHK(c, hipMemcpy(base, base64, 64, hipMemcpyDeviceToHost)); } else memcpy(base, base64, 64);
   jj_table* t = new jj_table();
   t->window_bits = window_bits;
+  t->device = c->device;
   size_t ne = 0; int rc;
   if (window_bits == FB_W) {
     // 42 windows x 32 entries + the carry entry 2^252 B  (layout of k_fixedbase)
@@ -772,6 +781,7 @@ static int fixedbase_launch(jj_ctx* c, const jj_table* t, size_t n, const void* 
 static int fixedbase_api(jj_ctx* c, const jj_table* t, size_t n, const void* scalars, void* out, int mode) {
   if (!c || !t) return JJ_ERR_INVALID;
   JJ_ENTER(c);
+  if (t->device != c->device) { c->err = "fixed-base table belongs to another device"; return JJ_ERR_INVALID; }
   if (n >= 2 * c->pipe_chunk && all_host({scalars, out})) {
     const HostIn in[1] = {{scalars, 32}};
     const HostOut ho[1] = {{out, (size_t)(mode ? 32 : 64)}};
@@ -807,6 +817,7 @@ JJ_API int jj_fixedbase_multi_mul(jj_ctx* c, const jj_table* const* tables, int 
   if (!c || !tables || nbases < 1) return JJ_ERR_INVALID;
   for (int j = 0; j < nbases; j++) if (!tables[j]) return JJ_ERR_INVALID;
   JJ_ENTER(c);
+  for (int j = 0; j < nbases; j++) if (tables[j]->device != c->device) { c->err = "fixed-base table belongs to another device"; return JJ_ERR_INVALID; }
   const void* ds; int rc; OutRef o;
   if ((rc = stage_in(c, 0, scalars, 32 * n * (size_t)nbases, &ds))) return rc;
   if ((rc = stage_out(c, c->out[0], out64, 64 * n, &o))) return rc;
@@ -917,7 +928,7 @@ static int msm_pippenger(jj_ctx* c, size_t n, const void* ds, const void* dp, jj
   if ((rc = ensure(c, ra, (size_t)EXT_AOS_WORDS * 4 * std::max(nchunks, std::max(max_chunks, (n * (size_t)mp.W) / 8 + 1))))) return rc;   // first the chunk heads, later the fold ping-pong
   if ((rc = ensure(c, rb, (size_t)5 * NL * 4 * nchunks))) return rc;
   u32* count = (u32*)cnt.p; u32* offset = count + nb; u32* bsum = offset + nb + 1;
-  const bool use_segments = c->msm_segments == 1 || (c->msm_segments < 0 && n >= ((size_t)1 << 19));
+  const bool use_segments = c->msm_segments == 1 || (c->msm_segments < 0 && n >= ((size_t)1 << 18));   // measured: -5 % at 2^18 terms, +4 % at 2^17
   // segments of at most P entries, sorted by length; P bounds the serial depth of one lane (~ n / 2^14 additions)
   u32 P = (u32)std::min<size_t>(SEG_PMAX, std::max<size_t>(32, n >> 14));
   if (c->msm_seg_len >= 8 && c->msm_seg_len <= SEG_PMAX) P = (u32)c->msm_seg_len;
@@ -1027,11 +1038,21 @@ static int msm_pippenger(jj_ctx* c, size_t n, const void* ds, const void* dp, jj
       done = true;
     }
   }
+  static const bool timing = getenv("JJ_MSM_TIMING") != nullptr;      // stderr: enqueue / wait / host Horner, microseconds
+  timespec t0, t1, t2, t3;
+  if (timing) clock_gettime(CLOCK_MONOTONIC, &t0);
   if (!done) {
     if ((rc = enqueue(c->stream))) return rc;
+    if (timing) clock_gettime(CLOCK_MONOTONIC, &t1);
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
+  if (timing) clock_gettime(CLOCK_MONOTONIC, &t2);
   *res = jjhost::horner(c->tail_host, mp.W, mp.c);
+  if (timing) {
+    clock_gettime(CLOCK_MONOTONIC, &t3);
+    auto us = [](const timespec& a, const timespec& b) { return (b.tv_sec - a.tv_sec) * 1e6 + (b.tv_nsec - a.tv_nsec) * 1e-3; };
+    if (!done) fprintf(stderr, "[jj msm] n=%zu c=%d: enqueue %.1f us, wait %.1f us, host Horner %.1f us\n", n, mp.c, us(t0, t1), us(t1, t2), us(t2, t3));
+  }
   return JJ_OK;
 }
 JJ_API int jj_msm(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out64) {

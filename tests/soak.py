@@ -22,6 +22,11 @@ os.environ["JJ_MSM_ACCUM"] = "segments"      # second context: the large-input M
 os.environ["JJ_VB_QUAD_MAX"] = "0"           # ... and the per-lane var-base kernel instead of the per-quad one
 eng_alt = Engine(0)
 del os.environ["JJ_MSM_ACCUM"], os.environ["JJ_VB_QUAD_MAX"]
+eng_wide = []                                # wide MSM windows (the default only from 2^18 terms) and with them the two-pass sort
+for wbits_msm in (13, 16):
+    os.environ["JJ_MSM_WINDOW"] = str(wbits_msm)
+    eng_wide.append(Engine(0))
+del os.environ["JJ_MSM_WINDOW"]
 base = pt64(J.GENERATOR)
 G8 = J.scalar_mul_fast(J.GENERATOR, J.R_MOD)             # order-8 component of the generator
 TORS = np.stack([pt64(J.scalar_mul_fast(G8, j) if j else J.AFFINE_IDENTITY) for j in range(8)])
@@ -56,6 +61,7 @@ while time.time() < t_end:
     want_msm = O.msm(S[:m], P[:m])
     assert (eng.msm(S[:m], P[:m]) == want_msm).all(), ("msm", rnd)
     assert (eng_alt.msm(S[:m], P[:m]) == want_msm).all(), ("msm segments", rnd)
+    assert (eng_wide[rnd & 1].msm(S[:m], P[:m]) == want_msm).all(), ("msm wide windows", rnd)
     enc = O.compress(P)
     bad = rng.integers(0, n, size=max(1, n // 10))
     enc[bad] = rng.integers(0, 256, size=(len(bad), 32), dtype=np.uint8)
