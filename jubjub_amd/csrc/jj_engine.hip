@@ -50,7 +50,7 @@ struct jj_ctx {
                                  // (2-4 % faster there, slower below: more launches) (JJ_MSM_ACCUM=segments|chunks)
   int msm_seg_len = 0;           // segment length override (JJ_MSM_SEG_LEN; 0 = n / 2^14 clamped to [32, 1024])
   int msm_chunk = 0;             // accumulation chunk override (JJ_MSM_CHUNK; 0 = scale with n)
-  int msm_reduce_chunk = 0, msm_fold = 4;    // bucket-reduce chunk length (0 = from the bucket count, see msm_pippenger) / fan-in of the chunk folds (powers of two)
+  int msm_reduce_chunk = 0;      // bucket-reduce chunk length (0 = from the bucket count, see msm_pippenger; JJ_MSM_REDUCE_CHUNK, a power of two)
   int msm_two_pass = -1;         // counting sort in two passes (coarse bin, then low 8 bits): -1 = when the window has >= 13 bits; JJ_MSM_SORT=1pass|2pass
   int msm_pass_log2 = 24;        // terms per Pippenger pass (JJ_MSM_PASS_LOG2 overrides; for tests)
   int msm_min_pippenger = 1;     // below this many terms the MSM is var-base ladders + fold (JJ_MSM_NAIVE_BELOW; Pippenger is faster at every size, measured)
@@ -310,7 +310,6 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
   if (const char* e = getenv("JJ_MSM_SEG_LEN")) c->msm_seg_len = atoi(e);
   if (const char* e = getenv("JJ_MSM_CHUNK")) { int v = atoi(e); if (v >= 8 && v <= 1024) c->msm_chunk = v; }
   if (const char* e = getenv("JJ_MSM_REDUCE_CHUNK")) { int v = atoi(e); if (v >= 2 && v <= 256 && (v & (v - 1)) == 0) c->msm_reduce_chunk = v; }
-  if (const char* e = getenv("JJ_MSM_FOLD")) { int v = atoi(e); if (v >= 2 && v <= 64 && (v & (v - 1)) == 0) c->msm_fold = v; }
   if (const char* e = getenv("JJ_MSM_SORT")) c->msm_two_pass = !strcmp(e, "2pass") ? 1 : (!strcmp(e, "1pass") ? 0 : -1);
   if (const char* e = getenv("JJ_MSM_PASS_LOG2")) { int v = atoi(e); if (v >= 10 && v <= 24) c->msm_pass_log2 = v; }
   if (const char* e = getenv("JJ_MSM_NAIVE_BELOW")) { int v = atoi(e); if (v >= 0) c->msm_min_pippenger = v; }
@@ -898,10 +897,10 @@ static int msm_pippenger(jj_ctx* c, size_t n, const void* ds, const void* dp, jj
   // -23 % at 2^14).  JJ_MSM_REDUCE_CHUNK overrides; never more than one window.
   const u32 L_auto = nb >= ((size_t)1 << 18) ? 32u : (nb >= ((size_t)1 << 16) ? 8u : 4u);
   const u32 L = std::min<u32>(c->msm_reduce_chunk ? (u32)c->msm_reduce_chunk : L_auto, mp.B);
-  if (mp.B % L || (L & (L - 1)) || (c->msm_fold & (c->msm_fold - 1))) { c->err = "inconsistent MSM tuning overrides (JJ_MSM_REDUCE_CHUNK / JJ_MSM_FOLD must be powers of two dividing the bucket count)"; return JJ_ERR_INVALID; }
+  if (mp.B % L || (L & (L - 1))) { c->err = "inconsistent MSM tuning override (JJ_MSM_REDUCE_CHUNK must be a power of two dividing the bucket count)"; return JJ_ERR_INVALID; }
   const size_t nchunks = nb / L;
   int rc;
-  DevBuf &kprime = c->msm[0], &niels = c->msm[1], &cnt = c->msm[2], &idx = c->msm[3], &buckets = c->msm[4], &ra = c->msm[5], &rb = c->msm[6], &tcnt = c->msm[7];
+  DevBuf &kprime = c->msm[0], &niels = c->msm[1], &cnt = c->msm[2], &idx = c->msm[3], &buckets = c->msm[4], &ra = c->msm[5], &tcnt = c->msm[7];
   const size_t nscan = (nb + SCAN_TILE - 1) / SCAN_TILE;
   u32 chunk = MSM_CHUNK_MIN;                           // 16 entries per lane up to 2^19 terms, 32 at 2^20, then proportional to n (measured)
   while (chunk < 256 && ((size_t)chunk << 15) < n) chunk <<= 1;
@@ -925,8 +924,7 @@ static int msm_pippenger(jj_ctx* c, size_t n, const void* ds, const void* dp, jj
   const size_t pcount = (size_t)mp.W * HB * ptiles;
   if ((rc = ensure(c, tcnt, two_pass ? (2 * pcount + pcount / SCAN_TILE + 8) * 4 : (size_t)mp.W * ntiles * mp.B * 4))) return rc;
   if ((rc = ensure(c, buckets, (size_t)EXT_AOS_WORDS * 4 * nb))) return rc;
-  if ((rc = ensure(c, ra, (size_t)EXT_AOS_WORDS * 4 * std::max(nchunks, std::max(max_chunks, (n * (size_t)mp.W) / 8 + 1))))) return rc;   // first the chunk heads, later the fold ping-pong
-  if ((rc = ensure(c, rb, (size_t)5 * NL * 4 * nchunks))) return rc;
+  if ((rc = ensure(c, ra, (size_t)EXT_AOS_WORDS * 4 * std::max(nchunks, std::max(max_chunks, (n * (size_t)mp.W) / 8 + 1))))) return rc;   // first the sort's records, then the chunk heads, then the chunk results of the bucket reduce
   u32* count = (u32*)cnt.p; u32* offset = count + nb; u32* bsum = offset + nb + 1;
   const bool use_segments = c->msm_segments == 1 || (c->msm_segments < 0 && n >= ((size_t)1 << 18));   // measured: -5 % at 2^18 terms, +4 % at 2^17
   // segments of at most P entries, sorted by length; P bounds the serial depth of one lane (~ n / 2^14 additions)
@@ -978,26 +976,17 @@ static int msm_pippenger(jj_ctx* c, size_t n, const void* ds, const void* dp, jj
         hipLaunchKernelGGL(k_seg_plan, dim3(1), dim3(1024), (bh_words + P + 2) * 4, st, stiles, P, bh, soff + (P + 1));
         hipLaunchKernelGGL(k_seg_scatter, dim3(stiles), dim3(256), 0, st, nb, per_tile, P, (const u32*)offset, (const u32*)bh, seg, counters, merge, big);
         hipLaunchKernelGGL(k_msm_accumulate_seg, dim3(blocks_for(max_segs)), dim3(256), 0, st, (const u32*)(soff + (P + 1)), (const Seg*)seg, (const u32*)idx.p, (const u32*)niels.p, bk, head);
-        hipLaunchKernelGGL(k_msm_merge, dim3(blocks_for(std::min(nb, max_segs))), dim3(256), 0, st, (const u32*)counters, (const MergeItem*)merge, bk, head);
+        hipLaunchKernelGGL(k_msm_merge, dim3(blocks_for(4 * std::min(nb, max_segs))), dim3(256), 0, st, (const u32*)counters, (const MergeItem*)merge, bk, head);
       } else {
         hipLaunchKernelGGL(k_msm_accumulate, dim3(blocks_for(max_chunks)), dim3(256), 0, st, nb, chunk, (const u32*)offset, (const u32*)idx.p, (const u32*)niels.p, bk, head);
-        hipLaunchKernelGGL(k_msm_fixup, dim3(blocks_for(nb)), dim3(256), 0, st, nb, chunk, (const u32*)offset, bk, head, big_count, big);
+        hipLaunchKernelGGL(k_msm_fixup, dim3(blocks_for(4 * nb)), dim3(256), 0, st, nb, chunk, (const u32*)offset, bk, head, big_count, big);
       }
       hipLaunchKernelGGL(k_msm_fixup_big, dim3(256), dim3(256), 0, st, (const u32*)big_count, (const BigBucket*)big, bk, head, partial, 0);
       hipLaunchKernelGGL(k_msm_fixup_big, dim3(256), dim3(256), 0, st, (const u32*)big_count, (const BigBucket*)big, bk, head, partial, 1);
     }
     hipLaunchKernelGGL(k_msm_bucket_reduce, dim3(blocks_for(nchunks * 4)), dim3(256), 0, st, nchunks, L, mp.B, mp.c - 1, ExtAoS{(u32*)buckets.p}, soa_of(ra, nchunks));
-    // fold the chunks of each window: per-window count B/L -> 1
-    size_t per_window = mp.B / L, m = nchunks;
-    DevBuf* cur = &ra; DevBuf* nxt = &rb;
-    while (per_window > 1) {
-      const int fold = (int)std::min<size_t>(per_window, (size_t)c->msm_fold);
-      const size_t T = m / fold;
-      hipLaunchKernelGGL(k_sum_groups, dim3(blocks_for(T * 4)), dim3(256), 0, st, m, T, fold, soa_of(*cur, m), soa_of(*nxt, T));
-      std::swap(cur, nxt); m = T; per_window /= fold;
-    }
-    // m == W window sums, copied back for the Horner combine on the host
-    hipLaunchKernelGGL(k_soa_to_ext160, dim3(1), dim3(64), 0, st, (size_t)mp.W, soa_of(*cur, m), c->ws_tmp[3].p);
+    // fold the chunks of each window (B / L of them) to the window sum, copied back for the Horner combine on the host
+    hipLaunchKernelGGL(k_msm_window_fold, dim3(mp.W), dim3(1024), 0, st, (size_t)(mp.B / L), soa_of(ra, nchunks), c->ws_tmp[3].p);
     HIPCHK(c, hipMemcpyAsync(c->tail_host, c->ws_tmp[3].p, (size_t)160 * mp.W, hipMemcpyDeviceToHost, st));
     return JJ_OK;
   };

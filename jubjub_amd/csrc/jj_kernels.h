@@ -1125,24 +1125,27 @@ constexpr u32 FIXUP_BIG_QUADS = 64;       // quads (of 4 lanes) per big bucket
 struct BigBucket { u32 bucket, t_first, t_last, pad; };
 static JJ_DEV Ext soa_ext(const SoA& s, size_t i);
 static JJ_DEV Ext quad_add_ext(const Ext& p, const Ext& q, u32 role);
+// one quad of lanes per bucket (the chain of head additions is latency-bound: quad_add_ext is ~2.4x shorter than the per-lane addition)
 __global__ void __launch_bounds__(256) k_msm_fixup(size_t nb, u32 chunk, const u32* offset, ExtAoS buckets, ExtAoS head, u32* big_count, BigBucket* big) {
-  const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t b = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  const u32 role = threadIdx.x & 3u;
   if (b >= nb) return;
   const u32 lo = offset[b], hi = offset[b + 1];
-  if (lo == hi) { aos_put_ext(buckets, b, Curve::identity()); return; }
+  if (lo == hi) { if (role == 0) aos_put_ext(buckets, b, Curve::identity()); return; }
   const size_t t_first = lo / chunk + 1, t_last = (hi - 1) / chunk;
   if (t_first > t_last) return;
   if (t_last - t_first + 1 > FIXUP_SERIAL_MAX) {
-    const u32 slot = atomicAdd(big_count, 1u);
-    if (slot < FIXUP_BIG_MAX) { big[slot].bucket = (u32)b; big[slot].t_first = (u32)t_first; big[slot].t_last = (u32)t_last; big[slot].pad = 0; return; }
+    u32 slot = role == 0 ? atomicAdd(big_count, 1u) : 0u;
+    slot = (u32)__shfl((int)slot, (int)(threadIdx.x & 60u), 64);          // the quad leader's slot
+    if (slot < FIXUP_BIG_MAX) {
+      if (role == 0) { big[slot].bucket = (u32)b; big[slot].t_first = (u32)t_first; big[slot].t_last = (u32)t_last; big[slot].pad = 0; }
+      return;
+    }
   }
-  Ext acc;   // the bucket's own first run (written by the chunk that contains offset[b])
-  acc = aos_ext(buckets, b);
+  Ext acc = aos_ext(buckets, b);   // the bucket's own first run (written by the chunk that contains offset[b])
   #pragma unroll 1
-  for (size_t t = t_first; t <= t_last; t++) {
-    acc = Curve::add<true>(acc, Curve::to_niels<true>(aos_ext(head, t)));
-  }
-  aos_put_ext(buckets, b, acc);
+  for (size_t t = t_first; t <= t_last; t++) acc = quad_add_ext(acc, aos_ext(head, t), role);
+  if (role == 0) aos_put_ext(buckets, b, acc);
 }
 // ---- Segment-sorted accumulation (default).  Every non-empty bucket is cut into segments of at most P entries, the
 // segments are counting-sorted by length (longest first), and each lane adds up one segment: lanes of a wave run the
@@ -1238,15 +1241,16 @@ __global__ void __launch_bounds__(256) k_msm_accumulate_seg(const u32* nseg_tota
   }
   if (sg.dst >> 31) aos_put_ext(head, sg.dst & 0x7fffffffu, acc); else aos_put_ext(buckets, sg.dst, acc);
 }
-// buckets with a few extra segments: one lane folds them in
+// buckets with a few extra segments: one quad of lanes folds them in
 __global__ void __launch_bounds__(256) k_msm_merge(const u32* counters, const MergeItem* merge, ExtAoS buckets, ExtAoS head) {
-  const size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t m = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  const u32 role = threadIdx.x & 3u;
   if (m >= counters[1]) return;
   const MergeItem it = merge[m];
   Ext acc = aos_ext(buckets, it.bucket);
   #pragma unroll 1
-  for (u32 j = 0; j < it.k; j++) acc = Curve::add<true>(acc, Curve::to_niels<true>(aos_ext(head, (size_t)it.h0 + j)));
-  aos_put_ext(buckets, it.bucket, acc);
+  for (u32 j = 0; j < it.k; j++) acc = quad_add_ext(acc, aos_ext(head, (size_t)it.h0 + j), role);
+  if (role == 0) aos_put_ext(buckets, it.bucket, acc);
 }
 static JJ_DEV Ext soa_ext(const SoA& s, size_t i) { Ext e; e.u = s.get(0, i); e.v = s.get(1, i); e.z = s.get(2, i); e.t1 = s.get(3, i); e.t2 = s.get(4, i); return e; }
 static JJ_DEV void soa_put_ext(const SoA& s, size_t i, const Ext& e) {
@@ -1434,21 +1438,6 @@ __global__ void __launch_bounds__(256) k_msm_fixup_big(const u32* big_count, con
     }
   }
 }
-// window sums -> canonical 160-byte extended points for the host-side Horner (jj_host_tail.h)
-__global__ void __launch_bounds__(64) k_soa_to_ext160(size_t n, SoA src, void* out160) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const Ext e = soa_ext(src, i);
-  u32 w[8];
-  Fq::to_words(w, e.u); store8(out160, 5 * i, w);
-  Fq::to_words(w, e.v); store8(out160, 5 * i + 1, w);
-  Fq::to_words(w, e.z); store8(out160, 5 * i + 2, w);
-  Fq::to_words(w, Fq::carry(e.t1)); store8(out160, 5 * i + 3, w);
-  Fq::to_words(w, e.t2); store8(out160, 5 * i + 4, w);
-}
-__global__ void k_soa_copy5(SoA src, size_t i, SoA dst, size_t j) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) soa_put_ext(dst, j, soa_ext(src, i));
-}
 // The reduction kernels below are short and latency-bound (few independent chains), so each logical thread is a
 // quad of lanes running quad_dbl / quad_add_ext.
 // chunk of L consecutive buckets j0..j0+L-1 of one window (bucket j holds digit value j+1):
@@ -1491,26 +1480,35 @@ __global__ void __launch_bounds__(256) k_msm_bucket_reduce(size_t nchunks, u32 L
   total = quad_add_ext_t(total, Tt, m, Tm, role, Tt, Tr, Tr, dummy);
   if (role == 0) soa_put_ext(out, t, total);
 }
-// grouped fold: out[t] = sum_{j<fold} in[t*fold + j]  (contiguous groups keep the window-major order intact)
-__global__ void __launch_bounds__(256) k_sum_groups(size_t n, size_t T, int fold, SoA in, SoA out) {
-  const size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
-  const u32 role = threadIdx.x & 3u;
-  if (t >= T) return;
-  Ext acc = Curve::identity();
-  Fe Ta = Fq::zero();
-  const size_t i0 = t * (size_t)fold;
-  Ext q = soa_ext(in, i0 < n ? i0 : 0);
-  Fe Tq = Fq::mul(q.t1, q.t2);                          // stored t1, t2 are carried
+// Window sums: one workgroup per window folds the window's chunk results (per_window of them, contiguous in `in`) into one
+// point.  Each of the 256 quads first adds up its strided share, then a binary tree over the quads runs through LDS: depth
+// per_window / 256 + 8 additions in one launch (a fan-in-4 fold per launch took 4 additions and one launch per level).  The sum
+// leaves as a canonical 160-byte extended point for the host-side Horner (jj_host_tail.h).
+__global__ void __launch_bounds__(1024) k_msm_window_fold(size_t per_window, SoA in, void* out160) {
+  __shared__ u32 st[256 * EXT_AOS_WORDS];
+  const ExtAoS lds{st};
+  const u32 role = threadIdx.x & 3u, quad = threadIdx.x >> 2;
+  const size_t base = (size_t)blockIdx.x * per_window;
+  const u32 live = per_window < 256 ? (u32)per_window : 256u;          // quads that hold a partial sum
+  Ext acc = quad < live ? soa_ext(in, base + quad) : Curve::identity();
   #pragma unroll 1
-  for (int j = 0; j < fold; j++) {
-    const size_t i = i0 + j;
-    if (i >= n) break;
-    const Ext nx = soa_ext(in, i + 1 < n ? i + 1 : i);
-    Fe Tn;
-    acc = quad_add_ext_t(acc, Ta, q, Tq, role, Ta, nx.t1, nx.t2, Tn);
-    q = nx; Tq = Tn;
+  for (size_t j = (size_t)quad + 256; j < per_window; j += 256) acc = quad_add_ext(acc, soa_ext(in, base + j), role);
+  #pragma unroll 1
+  for (u32 s = 128; s > 0; s >>= 1) {
+    if (quad >= s && quad < 2 * s && quad < live && role == 0) aos_put_ext(lds, quad, acc);     // upper half hands over
+    __syncthreads();
+    if (quad < s && quad + s < live) acc = quad_add_ext(acc, aos_ext(lds, quad + s), role);
+    __syncthreads();
   }
-  if (role == 0) soa_put_ext(out, t, acc);
+  if (quad == 0 && role == 0) {
+    const size_t i = blockIdx.x;
+    u32 w[8];
+    Fq::to_words(w, acc.u); store8(out160, 5 * i, w);
+    Fq::to_words(w, acc.v); store8(out160, 5 * i + 1, w);
+    Fq::to_words(w, acc.z); store8(out160, 5 * i + 2, w);
+    Fq::to_words(w, Fq::carry(acc.t1)); store8(out160, 5 * i + 3, w);
+    Fq::to_words(w, Fq::carry(acc.t2)); store8(out160, 5 * i + 4, w);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ synthetic inputs
