@@ -1,4 +1,4 @@
-# scratch: A/B of MSM variants on the GPU box:  bash tools/_msm_ab.sh [log2n] [env assignments...]
+# per-kernel breakdown of one MSM on the GPU box:  bash experiments/misc/msm_breakdown.sh [log2n] [env assignments...]
 cd $GRAFT_REPO_ROOT
 LOG2N=${1:-20}; shift
 for kv in "$@"; do export "$kv"; done

@@ -14,4 +14,5 @@ python bench.py --workload msm --log2n 22 --no-cpu-baseline --no-verify > gpurun
 python bench.py --workload msm --log2n 17 --no-cpu-baseline > gpurun_out/${TAG}_bench_msm17.json 2>/dev/null
 python bench.py --workload fixedbase --fb-window 16 --no-cpu-baseline > gpurun_out/${TAG}_bench_fb16.json 2>/dev/null
 python tools/latency.py > gpurun_out/${TAG}_latency.txt 2>&1
+timeout 600 python tests/soak.py 240 2000 > gpurun_out/${TAG}_soak.txt 2>&1 || echo "SOAK FAILED" >> gpurun_out/${TAG}_soak.txt
 tail -1 gpurun_out/${TAG}_profile.log
