@@ -7,7 +7,7 @@ for f in gpurun_out/profiles_$TAG/*; do
   b=$(basename $f)
   case $b in ${TAG}_*_kernel_stats.txt|${TAG}_*_pmc.txt|${TAG}_*_bench.json|traffic.json|${TAG}_kernel_resources.txt|${TAG}_instr_mix.txt) cp $f profiles/;; esac
 done
-for f in default dec1 dec3 msm22 msm17 fb16; do cp gpurun_out/${TAG}_bench_$f.json profiles/${TAG}_bench_$f.json; done
+for f in default dec1 dec3 msm20 msm22 msm17 fb16; do cp gpurun_out/${TAG}_bench_$f.json profiles/${TAG}_bench_$f.json; done
 BID=$(python3 -c "import json; print(json.load(open('profiles/traffic.json'))['build_id'])")
 (echo "# commit $(cat profiles/BUILD_COMMIT) | build_id $BID | MI355X gfx950"; echo "# command: python tools/latency.py   (median wall time per C-ABI call, device-resident inputs)"; grep -v amdgpu gpurun_out/${TAG}_latency.txt) > profiles/${TAG}_latency.txt
 (echo "# commit $(cat profiles/BUILD_COMMIT) | build_id $BID | MI355X gfx950"; echo "# command: python tests/soak.py 240 2000   (randomised differential soak of every entry point against the C oracle; last rounds and verdict)"; grep -v amdgpu gpurun_out/${TAG}_soak.txt | tail -6) > profiles/${TAG}_soak.txt

@@ -25,7 +25,7 @@ def pmc(wl):
             "bytes": g(r"=>\s+(\d+) B per unit")}
 
 
-for name in ("varbase_bench", "fixedbase_bench", "msm_bench", "decompress_bench", "bench_default", "bench_dec1", "bench_dec3", "bench_msm17", "bench_msm22", "bench_fb16"):
+for name in ("varbase_bench", "fixedbase_bench", "msm_bench", "decompress_bench", "bench_default", "bench_dec1", "bench_dec3", "bench_msm20", "bench_msm17", "bench_msm22", "bench_fb16"):
     d = line(name)
     if not d:
         continue

@@ -11,6 +11,7 @@ python bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_benc
 python bench.py --workload decompress --decompress-flags 1 --no-cpu-baseline > gpurun_out/${TAG}_bench_dec1.json 2>/dev/null
 python bench.py --workload decompress --decompress-flags 3 --no-cpu-baseline > gpurun_out/${TAG}_bench_dec3.json 2>/dev/null
 python bench.py --workload msm --log2n 22 --no-cpu-baseline --no-verify > gpurun_out/${TAG}_bench_msm22.json 2>/dev/null
+python bench.py --workload msm --no-cpu-baseline > gpurun_out/${TAG}_bench_msm20.json 2>/dev/null      # without the profiler's per-dispatch overhead
 python bench.py --workload msm --log2n 17 --no-cpu-baseline > gpurun_out/${TAG}_bench_msm17.json 2>/dev/null
 python bench.py --workload fixedbase --fb-window 16 --no-cpu-baseline > gpurun_out/${TAG}_bench_fb16.json 2>/dev/null
 python tools/latency.py > gpurun_out/${TAG}_latency.txt 2>&1
