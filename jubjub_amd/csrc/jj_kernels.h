@@ -735,10 +735,17 @@ __global__ void __launch_bounds__(256) k_and_bytes(size_t n, uint8_t* a, const u
 
 // ------------------------------------------------------------------------------------------------ K7: Pippenger MSM
 // sum_i k_i P_i with signed c-bit windows (c <= 16): k' = k + sum_{w<W-1} 2^(cw+c-1); digit_w = window_w(k') - 2^(c-1)
-// (top window unsigned).  Terms are counting-sorted by (window, |digit|) with LDS histograms, then fixed-size chunks of the
-// sorted list are accumulated per lane (affine-Niels, 7M mixed addition), buckets are reduced per chunk with the running-sum trick,
-// chunks are folded, and the window sums are combined by Horner.  The group element equals the reference's
-// `sum of p * k` (src/lib.rs:183-193, 873-879); only +-P (exact on the whole curve) is used.
+// (top window unsigned).  Pipeline of one pass (host side: msm_pippenger in jj_engine.hip):
+//   k_msm_convert                      recoded scalars (word-major) + affine-Niels entries, one 128-byte line per term
+//   sort by (window, |digit|)          two passes for c >= 13 (k_msm_part_hist / _scatter / _sort), one pass below
+//                                      (k_msm_hist / _scatter with the whole window's histogram in LDS); no global atomics
+//   accumulate                         length-sorted segments, one per lane (k_seg_*, k_msm_accumulate_seg, k_msm_merge), or
+//                                      fixed chunks + fix-up for small inputs (k_msm_accumulate, k_msm_fixup); 7M mixed additions
+//   k_msm_bucket_reduce                running sums per chunk of buckets, on quads of lanes
+//   k_msm_window_fold                  one workgroup per window: tree over the chunk results -> W window sums (160 B each)
+//   host                               Horner over the window sums, one inversion (jj_host_tail.h)
+// The group element equals the reference's `sum of p * k` (src/lib.rs:183-193, 873-879); only +-P (exact on the whole
+// curve) is used.
 struct MsmParams {
   int c;            // window bits
   int W;            // number of windows
@@ -1152,6 +1159,9 @@ __global__ void __launch_bounds__(256) k_msm_fixup(size_t nb, u32 chunk, const u
 // same number of iterations, no lane ever switches buckets inside its loop, and a bucket with a single segment (the
 // common case) is finished by its lane.  Buckets with several segments (narrow top window, repeated scalars) get their
 // extra segments as `head` partials that k_msm_merge (few) or k_msm_fixup_big (many) folds in.
+#ifndef JJ_MSM_ACC_MINBLOCKS
+#define JJ_MSM_ACC_MINBLOCKS 1        // resident 256-thread blocks per CU the accumulate kernel is compiled for: 1 = no register cap (137 VGPRs,
+#endif                                // 3 waves per SIMD); capping at 128 (4 waves) changes nothing, 96 (5 waves) spills (profiles/r2_msm_acc_occupancy.txt)
 constexpr int SEG_PMAX = 1024;
 struct Seg { u32 start, len, dst, pad; };            // dst: bucket index, or 0x80000000 | head index
 struct MergeItem { u32 bucket, h0, k, pad; };         // buckets[bucket] += head[h0 .. h0 + k)
@@ -1221,7 +1231,7 @@ __global__ void __launch_bounds__(256) k_seg_scatter(size_t nb, u32 per_tile, u3
     }
   }
 }
-__global__ void __launch_bounds__(256) k_msm_accumulate_seg(const u32* nseg_total, const Seg* seg, const u32* idx, const u32* niels, ExtAoS buckets, ExtAoS head) {
+__global__ void __launch_bounds__(256, JJ_MSM_ACC_MINBLOCKS) k_msm_accumulate_seg(const u32* nseg_total, const Seg* seg, const u32* idx, const u32* niels, ExtAoS buckets, ExtAoS head) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= *nseg_total) return;
   const Seg sg = seg[t];
