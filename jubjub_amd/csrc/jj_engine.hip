@@ -38,6 +38,8 @@ struct jj_ctx {
   std::recursive_mutex mu;       // every entry point locks its context: calls from several host threads are serialised
   int device = 0;
   hipStream_t own_stream = nullptr;
+  hipStream_t aux_stream = nullptr;   // second stream of the MSM: the point conversion runs beside the sort
+  hipEvent_t fork_ev = nullptr, join_ev = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t order_ev = nullptr;   // orders a newly selected launch stream after the work queued on the previous one
   int cus = 0, clock_khz = 0, wave = 64;
@@ -297,12 +299,17 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
     (void)hipGetLastError();
     if (c->sqrt_tabs.p) (void)hipFree(c->sqrt_tabs.p);
     if (c->order_ev) (void)hipEventDestroy(c->order_ev);
+    if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
+    if (c->join_ev) (void)hipEventDestroy(c->join_ev);
+    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return code;
   };
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(JJ_ERR_HIP);
   if (hipEventCreateWithFlags(&c->order_ev, hipEventDisableTiming) != hipSuccess) return fail(JJ_ERR_HIP);
+  if (hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess) return fail(JJ_ERR_HIP);
+  if (hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming) != hipSuccess) return fail(JJ_ERR_HIP);
   c->stream = c->own_stream;
   if (const char* e = getenv("JJ_PIPE_CHUNK_LOG2")) { int v = atoi(e); if (v >= 8 && v <= 24) c->pipe_chunk = (size_t)1 << v; }
   if (const char* e = getenv("JJ_MSM_WINDOW")) c->msm_window = atoi(e);
@@ -359,6 +366,9 @@ JJ_API int jj_ctx_destroy(jj_ctx* c) {
   }
   for (auto& r : c->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); (void)hipEventDestroy(r.e2); }
   if (c->order_ev) (void)hipEventDestroy(c->order_ev);
+  if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
+  if (c->join_ev) (void)hipEventDestroy(c->join_ev);
+  if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
   return JJ_OK;
@@ -940,8 +950,21 @@ static int msm_pippenger(jj_ctx* c, size_t n, const void* ds, const void* dp, jj
   if ((rc = ensure(c, c->msm_io, 64))) return rc;
   // everything from here to the copy of the window sums is launches only (no allocation, no synchronisation): it can run
   // directly on a stream or be recorded into a graph
-  auto enqueue = [&](hipStream_t st) -> int {
-    hipLaunchKernelGGL(k_msm_convert, dim3(blocks_for(n)), dim3(256), 0, st, n, (const void* const*)c->msm_io.p, mp, (u32*)kprime.p, (u32*)niels.p);
+  auto enqueue = [&](hipStream_t st, bool allow_fork) -> int {
+    // Large inputs: the point half of the conversion (bandwidth- and multiplier-bound, 55 us at 2^20 terms) runs on the second
+    // stream beside the sort (LDS-bound) and is joined before the accumulation: -45 us at 2^20 terms; the two extra events cost
+    // ~10 us, more than the overlap returns below 2^18 terms.  Not inside a graph capture (JJ_MSM_GRAPH).  JJ_MSM_FORK=0/1 overrides.
+    static const int fork_env = getenv("JJ_MSM_FORK") ? atoi(getenv("JJ_MSM_FORK")) : -1;
+    const bool fork = allow_fork && (fork_env < 0 ? n >= ((size_t)1 << 18) : fork_env != 0);
+    if (fork) {
+      HIPCHK(c, hipEventRecord(c->fork_ev, st));
+      HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->fork_ev, 0));
+      hipLaunchKernelGGL(k_msm_convert, dim3(blocks_for(n)), dim3(256), 0, c->aux_stream, n, (const void* const*)c->msm_io.p, mp, (u32*)kprime.p, (u32*)niels.p, 2);
+      HIPCHK(c, hipEventRecord(c->join_ev, c->aux_stream));
+      hipLaunchKernelGGL(k_msm_convert, dim3(blocks_for(n)), dim3(256), 0, st, n, (const void* const*)c->msm_io.p, mp, (u32*)kprime.p, (u32*)niels.p, 1);
+    } else {
+      hipLaunchKernelGGL(k_msm_convert, dim3(blocks_for(n)), dim3(256), 0, st, n, (const void* const*)c->msm_io.p, mp, (u32*)kprime.p, (u32*)niels.p, 3);
+    }
     if (two_pass) {
       // tcnt: counts [pcount] | scanned [pcount + 1] | block sums
       u32* tc = (u32*)tcnt.p; u32* tcs = tc + pcount; u32* tbs = tcs + pcount + 1;
@@ -975,9 +998,11 @@ static int msm_pippenger(jj_ctx* c, size_t n, const void* ds, const void* dp, jj
         hipLaunchKernelGGL(k_seg_hist, dim3(stiles), dim3(256), 0, st, nb, per_tile, P, (const u32*)offset, bk, bh);
         hipLaunchKernelGGL(k_seg_plan, dim3(1), dim3(1024), (bh_words + P + 2) * 4, st, stiles, P, bh, soff + (P + 1));
         hipLaunchKernelGGL(k_seg_scatter, dim3(stiles), dim3(256), 0, st, nb, per_tile, P, (const u32*)offset, (const u32*)bh, seg, counters, merge, big);
+        if (fork) HIPCHK(c, hipStreamWaitEvent(st, c->join_ev, 0));
         hipLaunchKernelGGL(k_msm_accumulate_seg, dim3(blocks_for(max_segs)), dim3(256), 0, st, (const u32*)(soff + (P + 1)), (const Seg*)seg, (const u32*)idx.p, (const u32*)niels.p, bk, head);
         hipLaunchKernelGGL(k_msm_merge, dim3(blocks_for(4 * std::min(nb, max_segs))), dim3(256), 0, st, (const u32*)counters, (const MergeItem*)merge, bk, head);
       } else {
+        if (fork) HIPCHK(c, hipStreamWaitEvent(st, c->join_ev, 0));
         hipLaunchKernelGGL(k_msm_accumulate, dim3(blocks_for(max_chunks)), dim3(256), 0, st, nb, chunk, (const u32*)offset, (const u32*)idx.p, (const u32*)niels.p, bk, head);
         hipLaunchKernelGGL(k_msm_fixup, dim3(blocks_for(4 * nb)), dim3(256), 0, st, nb, chunk, (const u32*)offset, bk, head, big_count, big);
       }
@@ -1008,7 +1033,7 @@ static int msm_pippenger(jj_ctx* c, size_t n, const void* ds, const void* dp, jj
       hipGraph_t graph = nullptr;
       bool ok = hipStreamBeginCapture(c->own_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
       if (ok) {
-        const int erc = enqueue(c->own_stream);
+        const int erc = enqueue(c->own_stream, false);
         ok = hipStreamEndCapture(c->own_stream, &graph) == hipSuccess && erc == JJ_OK && graph;
       }
       if (ok) ok = hipGraphInstantiate(&slot->exec, graph, nullptr, nullptr, 0) == hipSuccess;
@@ -1031,7 +1056,7 @@ static int msm_pippenger(jj_ctx* c, size_t n, const void* ds, const void* dp, jj
   timespec t0, t1, t2, t3;
   if (timing) clock_gettime(CLOCK_MONOTONIC, &t0);
   if (!done) {
-    if ((rc = enqueue(c->stream))) return rc;
+    if ((rc = enqueue(c->stream, true))) return rc;
     if (timing) clock_gettime(CLOCK_MONOTONIC, &t1);
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }

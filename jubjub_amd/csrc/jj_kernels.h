@@ -770,16 +770,21 @@ static JJ_DEV u32 msm_digit_wm(const u32* kp, size_t n, size_t i, const MsmParam
 // recode scalars (k' = k + recode, word-major) and convert points to affine-Niels AoS (27 words in a 128-byte record)
 // The two input pointers come through a two-entry device array (io[0] = scalars, io[1] = points) so that a captured graph of
 // the whole MSM does not depend on where the caller's batch lives.
-__global__ void __launch_bounds__(256) k_msm_convert(size_t n, const void* const* io, MsmParams mp, u32* kprime, u32* niels) {
+// what: 1 = scalars, 2 = points, 3 = both (the two halves are independent: the sort needs only the scalars, so the host may run
+// the point half on a second stream beside it)
+__global__ void __launch_bounds__(256) k_msm_convert(size_t n, const void* const* io, MsmParams mp, u32* kprime, u32* niels, int what) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const void* scalars = io[0];
   const void* points = io[1];
-  u32 k[8];
-  load8(k, scalars, i);
-  k[7] &= 0x0fffffffu;
-  u64 cy = 0;
-  _Pragma("unroll") for (int j = 0; j < 8; j++) { const u64 t = (u64)k[j] + mp.recode[j] + cy; kprime[(size_t)j * n + i] = (u32)t; cy = t >> 32; }
+  if (what & 1) {
+    u32 k[8];
+    load8(k, scalars, i);
+    k[7] &= 0x0fffffffu;
+    u64 cy = 0;
+    _Pragma("unroll") for (int j = 0; j < 8; j++) { const u64 t = (u64)k[j] + mp.recode[j] + cy; kprime[(size_t)j * n + i] = (u32)t; cy = t >> 32; }
+  }
+  if (!(what & 2)) return;
   const ANiels t = Curve::to_niels(load_affine(points, i));
   u32 wv[ANIELS_WORDS];
   _Pragma("unroll") for (int l = 0; l < NL; l++) { wv[l] = t.vpu.l[l]; wv[NL + l] = t.vmu.l[l]; wv[2 * NL + l] = t.t2d.l[l]; }

@@ -349,6 +349,21 @@ def test_msm_wide_windows_both_sorts(monkeypatch, window, sort):
     e2.close()
 
 
+@pytest.mark.parametrize("fork", ["1", "0"])
+def test_msm_point_conversion_on_second_stream(monkeypatch, fork):
+    """JJ_MSM_FORK: the point half of the MSM's conversion kernel on the context's second stream beside the sort (default from 2^18
+    terms), forced on / off for small inputs; back-to-back calls reuse the workspaces the forked kernel writes."""
+    from jubjub_amd import Engine
+
+    monkeypatch.setenv("JJ_MSM_FORK", fork)
+    e2 = Engine(0)
+    for n in (1, 300, 5000, 40000, 2000, 40001):
+        S = rand_scalars(712 + n, n, full_width=True)
+        P = rand_points(713 + n, n)
+        assert (e2.msm(S, P) == O.msm(S, P)).all(), (fork, n)
+    e2.close()
+
+
 def test_msm_multipass(monkeypatch):
     """Inputs larger than one Pippenger pass are folded pass by pass (pass size shrunk here via the env knob)."""
     from jubjub_amd import Engine
