@@ -55,18 +55,30 @@ RAW_SEED = SEED ^ 0x5DEECE66D
 # IMAD32 convention: M = 128, S = 100.
 WORK = {
     # k_varbase: 2 from_words + to_niels(P) 2M; table {1..16}P: to_niels 2M + 15 x (mixed add 7M + to_niels 2M);
-    # 51 additions x 8M; 250 doublings x (3S + 4M: 2UV is a product here, jj_curve.h).   tail k_normalize<32>: 6M + (255S + 75M)/32 per unit
-    "varbase": {"S": 250 * 3, "M": 2 + 2 + 2 + 15 * 9 + 51 * 8 + 250 * 4, "tail_S": 8, "tail_M": 8, "bytes": 32 + 64 + 64},
+    # 51 additions x 8M; 250 doublings x (3S + 4M: 2UV is a product here, jj_curve.h).   normalisation tail: tail_work() below
+    "varbase": {"S": 250 * 3, "M": 2 + 2 + 2 + 15 * 9 + 51 * 8 + 250 * 4, "bytes": 32 + 64 + 64},
     # k_fixedbase: 43 mixed additions x 7M
-    "fixedbase": {"S": 0, "M": 43 * 7, "tail_S": 8, "tail_M": 8, "bytes": 32 + 64},
+    "fixedbase": {"S": 0, "M": 43 * 7, "bytes": 32 + 64},
     # Pippenger, c = 16: per term 2M load + 2M to_niels + 16 windows x 7M mixed add; bucket reduce 2 x 10M per bucket
     # (16 x 2^15 buckets / 2^20 terms -> +10M); the 240-doubling Horner tail is per MSM (on the host), not per term
-    "msm": {"S": 0, "M": 2 + 2 + 16 * 7 + 10, "tail_S": 0, "tail_M": 0, "bytes": 32 + 64},
+    "msm": {"S": 0, "M": 2 + 2 + 16 * 7 + 10, "bytes": 32 + 64},
     # k_decompress (the flag kernels run after it and show up in tail_ms): two decode passes (2 x (1M + 1S + 1M)), shared
     # inversion (3M + (253S+61M)/32), u^2 1M, sqrt = a^((t-1)/2) (220S + 52M, sliding windows) + 2M + 24S + 6M digit
     # extraction + 4 canonical forms + 4M table multiplies + verify (1S + 2M), 1 to_plain (v's bytes are the input's, -u = q - u)
-    "decompress": {"S": 2 + 8 + 220 + 24 + 1, "M": 4 + 3 + 2 + 1 + 52 + 2 + 6 + 4 + 4 + 2 + 1, "tail_S": 0, "tail_M": 0, "bytes": 32 + 65},
+    "decompress": {"S": 2 + 8 + 220 + 24 + 1, "M": 4 + 3 + 2 + 1 + 52 + 2 + 6 + 4 + 4 + 2 + 1, "bytes": 32 + 65},
 }
+
+
+def tail_work(wl, n, cus=256):
+    """field operations per unit of the normalisation that follows the ladder kernels: 6M per point + one inversion (255S + 75M) per
+    chunk; the chunk length is the one normalize_launch (jj_engine.hip) picks for n units"""
+    if wl not in ("varbase", "fixedbase"):
+        return 0, 0
+    lanes = cus * 64 * 8
+    chunk = 64 if n >= lanes * 128 else (32 if n >= lanes * 32 else (16 if n >= lanes * 4 else 4))
+    return -(-255 // chunk), 6 + -(-75 // chunk)
+
+
 REFERENCE_WORK = {"varbase": {"S": 1008, "M": 2774}, "fixedbase": {"S": 1008, "M": 2520}}   # the reference's own ladders (SURVEY §3)
 PASSES = {"varbase": 4, "fixedbase": 2, "msm": 32, "decompress": 4}       # passes per step: >= ~50 ms of kernels per step
 DEFAULT_LOG2N = {"varbase": 20, "fixedbase": 24, "msm": 20, "decompress": 23}
@@ -423,6 +435,7 @@ def run(a):
         work_main = imad32(w["S"], w["M"])
         achieved = n * work_main / (kern_ms * 1e-3)
         traffic, traffic_note = traffic_record(wl, log2n)
+        tail_s, tail_m = tail_work(wl, n)
         res["roofline"] = {
             "bound": "valu_int32", "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TIMAD32/s",
             "frac": achieved / peak,
@@ -433,8 +446,8 @@ def run(a):
             "kernel": {"varbase": "k_varbase", "fixedbase": "k_fixedbase" if a.fb_window < 8 else "k_fixedbase_gather(w=%d)" % a.fb_window, "msm": "whole MSM: k_msm_accumulate(_seg) + sort / fix-up / reduce; Horner on the host", "decompress": "k_decompress"}[wl],
             "kernel_ms": kern_ms, "tail_ms": tail, "units_per_launch": n,
             "work_per_unit": {"field_squares": w["S"], "field_muls": w["M"], "imad32": work_main, "convention": "M=128,S=100 (SURVEY 8d); the kernel named above only",
-                              "tail_kernel": {"field_squares": w["tail_S"], "field_muls": w["tail_M"], "imad32": imad32(w["tail_S"], w["tail_M"])}},
-            "whole_pass_frac": n * (work_main + imad32(w["tail_S"], w["tail_M"])) / ((kern_ms + tail) * 1e-3) / peak,
+                              "tail_kernel": {"field_squares": tail_s, "field_muls": tail_m, "imad32": imad32(tail_s, tail_m)}},
+            "whole_pass_frac": n * (work_main + imad32(tail_s, tail_m)) / ((kern_ms + tail) * 1e-3) / peak,
             "reference_algorithm_imad32": imad32(REFERENCE_WORK[wl]["S"], REFERENCE_WORK[wl]["M"]) if wl in REFERENCE_WORK else None,
             "hbm": {"achieved": n * w["bytes"] / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": n * w["bytes"] / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "bytes_per_unit": w["bytes"]},
