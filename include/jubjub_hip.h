@@ -144,7 +144,9 @@ int jj_varbase_mul_exact(jj_ctx*, size_t n, const void* scalars32, const void* p
  *   window_bits 0 or 6 : 147 KiB table staged in LDS, window entry selected with a ds_bpermute shuffle
  *                        (constant-time: no secret-dependent address) — 43 mixed additions per scalar;
  *   window_bits 8..16  : wider windows (0.6 MB .. 64 MB table, one 128-byte line per entry) kept in L2 / Infinity Cache and gathered per lane
- *                        (variable-time addressing) — ceil(253/w) additions per scalar. */
+ *                        (variable-time addressing) — ceil(253/w) additions per scalar.
+ * A table lives in the memory of the device of the context that built it and serves every context of that device; a context of
+ * another device gets JJ_ERR_INVALID (jj_multi_fixedbase_table_create replicates a table per device). */
 int jj_fixedbase_table_create(jj_ctx*, const void* base64, int window_bits /* 0 = default */, jj_table** out);
 int jj_fixedbase_table_destroy(jj_ctx*, jj_table* t);
 int jj_fixedbase_mul(jj_ctx*, const jj_table* t, size_t n, const void* scalars32, void* out64);
