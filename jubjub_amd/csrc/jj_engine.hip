@@ -54,6 +54,8 @@ struct jj_ctx {
   int msm_chunk = 0;             // accumulation chunk override (JJ_MSM_CHUNK; 0 = scale with n)
   int msm_reduce_chunk = 0;      // bucket-reduce chunk length (0 = from the bucket count, see msm_pippenger; JJ_MSM_REDUCE_CHUNK, a power of two)
   int msm_two_pass = -1;         // counting sort in two passes (coarse bin, then low 8 bits): -1 = when the window has >= 13 bits; JJ_MSM_SORT=1pass|2pass
+  int msm_fork = -1;             // point half of the MSM conversion on the second stream: -1 = from 2^18 terms, 0 / 1 = never / always (JJ_MSM_FORK)
+  bool msm_timing = false;       // JJ_MSM_TIMING: host-side breakdown of every Pippenger pass on stderr
   int msm_pass_log2 = 24;        // terms per Pippenger pass (JJ_MSM_PASS_LOG2 overrides; for tests)
   int msm_min_pippenger = 1;     // below this many terms the MSM is var-base ladders + fold (JJ_MSM_NAIVE_BELOW; Pippenger is faster at every size, measured)
   // optional per-call kernel timing (HIP events on the launch stream): e0 | main kernel | e1 | normalise tail | e2
@@ -318,6 +320,8 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
   if (const char* e = getenv("JJ_MSM_CHUNK")) { int v = atoi(e); if (v >= 8 && v <= 1024) c->msm_chunk = v; }
   if (const char* e = getenv("JJ_MSM_REDUCE_CHUNK")) { int v = atoi(e); if (v >= 2 && v <= 256 && (v & (v - 1)) == 0) c->msm_reduce_chunk = v; }
   if (const char* e = getenv("JJ_MSM_SORT")) c->msm_two_pass = !strcmp(e, "2pass") ? 1 : (!strcmp(e, "1pass") ? 0 : -1);
+  if (const char* e = getenv("JJ_MSM_FORK")) c->msm_fork = atoi(e) != 0 ? 1 : 0;
+  c->msm_timing = getenv("JJ_MSM_TIMING") != nullptr;
   if (const char* e = getenv("JJ_MSM_PASS_LOG2")) { int v = atoi(e); if (v >= 10 && v <= 24) c->msm_pass_log2 = v; }
   if (const char* e = getenv("JJ_MSM_NAIVE_BELOW")) { int v = atoi(e); if (v >= 0) c->msm_min_pippenger = v; }
   if (const char* e = getenv("JJ_MSM_GRAPH")) c->msm_graph = atoi(e) != 0;
@@ -956,8 +960,7 @@ static int msm_pippenger(jj_ctx* c, size_t n, const void* ds, const void* dp, jj
     // Large inputs: the point half of the conversion (bandwidth- and multiplier-bound, 55 us at 2^20 terms) runs on the second
     // stream beside the sort (LDS-bound) and is joined before the accumulation: -45 us at 2^20 terms; the two extra events cost
     // ~10 us, more than the overlap returns below 2^18 terms.  Not inside a graph capture (JJ_MSM_GRAPH).  JJ_MSM_FORK=0/1 overrides.
-    static const int fork_env = getenv("JJ_MSM_FORK") ? atoi(getenv("JJ_MSM_FORK")) : -1;
-    const bool fork = allow_fork && (fork_env < 0 ? n >= ((size_t)1 << 18) : fork_env != 0);
+    const bool fork = allow_fork && (c->msm_fork < 0 ? n >= ((size_t)1 << 18) : c->msm_fork != 0);
     if (fork) {
       HIPCHK(c, hipEventRecord(c->fork_ev, st));
       HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->fork_ev, 0));
@@ -1054,7 +1057,7 @@ static int msm_pippenger(jj_ctx* c, size_t n, const void* ds, const void* dp, jj
       done = true;
     }
   }
-  static const bool timing = getenv("JJ_MSM_TIMING") != nullptr;      // stderr: enqueue / wait / host Horner, microseconds
+  const bool timing = c->msm_timing;                                   // stderr: enqueue / wait / host Horner, microseconds
   timespec t0, t1, t2, t3;
   if (timing) clock_gettime(CLOCK_MONOTONIC, &t0);
   if (!done) {
