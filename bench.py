@@ -371,11 +371,11 @@ def run(a):
             if a.backend == "nccl":
                 parts = [torch.empty_like(part) for _ in range(world)]
                 dist.all_gather(parts, part)                        # 64 B per rank over RCCL/xGMI; EC addition is not a reduce op
-                part = eng.point_sum(torch.stack(parts))
+                part = eng.fold_partials(torch.stack(parts))        # world partial points -> one, on the host like the rest of the MSM's tail
             else:
                 parts = [torch.empty(64, dtype=torch.uint8) for _ in range(world)]
                 dist.all_gather(parts, part.cpu())
-                part = eng.point_sum(torch.stack(parts).to(dev))
+                part = eng.fold_partials(torch.stack(parts))
         return part
 
     def step():

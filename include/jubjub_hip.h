@@ -211,6 +211,11 @@ int jj_multi_fixedbase_table_destroy(jj_multi* m, jj_mtable* t);
 int jj_multi_fixedbase_mul(jj_multi* m, const jj_mtable* t, size_t n, const void* scalars32, void* out64);
 int jj_multi_decompress(jj_multi* m, size_t n, const void* in32, unsigned flags, void* out64, uint8_t* ok);
 int jj_multi_msm(jj_multi* m, size_t n, const void* scalars32, const void* points64, void* out64);
+/* Last step of an MSM cut across devices or processes (the reference's `Sum`, src/lib.rs:183-193, over the partial sums): adds
+ * `count` partial points (canonical affine, 64 bytes each) -> one affine point.  HOST pointers, no context: a short chain of
+ * dependent additions and one inversion, run on the calling thread with the arithmetic of the MSM's own host tail.
+ * jj_multi_msm ends with it; processes that all_gather their partial points (one process per GPU) call it on the gathered bytes. */
+int jj_msm_fold_partials(size_t count, const void* parts64_host, void* out64_host);
 
 #ifdef __cplusplus
 }

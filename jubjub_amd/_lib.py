@@ -62,7 +62,8 @@ _SIGS.update({
 })
 
 EXPORTS = sorted(list(_SIGS) + ["jj_ctx_create", "jj_ctx_destroy", "jj_last_error", "jj_version", "jj_device_info", "jj_recommended_wnaf_for_num_scalars",
-                                "jj_fixedbase_table_create", "jj_fr_char_le_bits", "jj_multi_create", "jj_multi_ctx", "jj_multi_last_error"])
+                                "jj_fixedbase_table_create", "jj_fr_char_le_bits", "jj_multi_create", "jj_multi_ctx", "jj_multi_last_error",
+                                "jj_msm_fold_partials"])
 
 _lib = None
 
@@ -120,6 +121,8 @@ def load():
     lib.jj_multi_ctx.argtypes = [_vp, C.c_int]
     lib.jj_multi_last_error.restype = C.c_char_p
     lib.jj_multi_last_error.argtypes = [_vp]
+    lib.jj_msm_fold_partials.restype = C.c_int
+    lib.jj_msm_fold_partials.argtypes = [C.c_size_t, _vp, _vp]
     lib.jj_fr_char_le_bits.restype = C.c_int
     lib.jj_fr_char_le_bits.argtypes = [C.POINTER(C.c_uint8)]
     lib.jj_device_info.restype = C.c_int

@@ -1292,6 +1292,23 @@ JJ_API int jj_multi_decompress(jj_multi* m, size_t n, const void* in32, unsigned
   if (!m || !host_args(m, {in32, out64, ok}, n)) return JJ_ERR_INVALID;
   return multi_run(m, n, [&](jj_ctx* c, int, size_t lo, size_t hi) { return jj_decompress(c, hi - lo, U8(in32) + 32 * lo, flags, U8W(out64) + 64 * lo, ok + lo); });
 }
+// Last step of an MSM that was cut across devices or processes: the sum of the `count` partial points (canonical
+// affine, 64 bytes each, HOST memory: what jj_msm wrote on every device / what the ranks' all_gather delivered) -> one affine
+// point.  Runs on the calling host thread with the arithmetic of the MSM's own host tail (jj_host_tail.h): a chain of `count`
+// dependent additions and one inversion takes a few microseconds there and ~180 us as GPU launches (jj_point_sum).
+JJ_API int jj_msm_fold_partials(size_t count, const void* parts64, void* out64) {
+  if (!out64 || (count && !parts64) || is_device_ptr(out64) || (count && is_device_ptr(parts64))) return JJ_ERR_INVALID;
+  jjhost::Ext total = jjhost::identity();
+  for (size_t g = 0; g < count; g++) {
+    const uint8_t* src = U8(parts64) + 64 * g;
+    jjhost::Ext p;
+    p.u = jjhost::from_canon(src); p.v = jjhost::from_canon(src + 32);
+    p.z = jjhost::consts().one; p.t1 = p.u; p.t2 = p.v;
+    total = jjhost::point_add(total, p);
+  }
+  jjhost::to_affine64((uint8_t*)out64, total);
+  return JJ_OK;
+}
 // sum over ALL terms: every device reduces its shard to one affine point, the partial points are added on the host
 JJ_API int jj_multi_msm(jj_multi* m, size_t n, const void* scalars, const void* points, void* out64) {
   if (!m || !out64 || is_device_ptr(out64) || !host_args(m, {scalars, points}, n)) return JJ_ERR_INVALID;
@@ -1299,13 +1316,5 @@ JJ_API int jj_multi_msm(jj_multi* m, size_t n, const void* scalars, const void* 
   std::vector<uint8_t> part((size_t)G * 64);
   const int rc = multi_run(m, n, [&](jj_ctx* c, int g, size_t lo, size_t hi) { return jj_msm(c, hi - lo, U8(scalars) + 32 * lo, U8(points) + 64 * lo, &part[(size_t)g * 64]); });
   if (rc) return rc;
-  jjhost::Ext total = jjhost::identity();
-  for (int g = 0; g < G; g++) {
-    jjhost::Ext p;
-    p.u = jjhost::from_canon(&part[(size_t)g * 64]); p.v = jjhost::from_canon(&part[(size_t)g * 64 + 32]);
-    p.z = jjhost::consts().one; p.t1 = p.u; p.t2 = p.v;
-    total = jjhost::point_add(total, p);
-  }
-  jjhost::to_affine64((uint8_t*)out64, total);
-  return JJ_OK;
+  return jj_msm_fold_partials((size_t)G, part.data(), out64);
 }

@@ -82,3 +82,27 @@ def test_c_example_compiles(tmp_path):
                            os.path.join(ROOT, "examples", "scalar_mul.c"), "-L", lib, "-ljubjub_hip",
                            "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined", "-o", str(out)])
     assert out.exists()
+
+
+def test_msm_fold_partials_host_only():
+    """jj_msm_fold_partials (the last step of an MSM cut across devices / ranks) is a host-only function: partial points incl. the
+    identity, 8-torsion points and P, -P pairs against the oracle's fold (reference `Sum`, src/lib.rs:183-193)."""
+    import numpy as np
+
+    from jubjub_amd import _lib
+    from oracle import c_oracle as O
+    from oracle import jubjub_ref as J
+    from util import pt64, rand_points
+
+    lib = _lib.load()
+    g8 = J.scalar_mul_fast(J.GENERATOR, J.R_MOD)                      # order-8 component of the generator
+    special = np.stack([pt64(J.AFFINE_IDENTITY), pt64(g8), pt64(J.scalar_mul_fast(g8, 4)), pt64(J.GENERATOR), pt64(J.affine_neg(J.GENERATOR))])
+    for count in (0, 1, 2, 8, 64):
+        parts = np.concatenate([rand_points(900 + count, count), special])[: max(count, 0) + (5 if count else 0)]
+        out = np.empty(64, np.uint8)
+        assert lib.jj_msm_fold_partials(ctypes.c_size_t(len(parts)), parts.ctypes.data if len(parts) else None, out.ctypes.data) == 0
+        want = pt64(J.AFFINE_IDENTITY)
+        for p in parts:
+            want = O.point_op("add", want[None, :], p[None, :])[0]
+        assert (out == want).all(), count
+    assert lib.jj_msm_fold_partials(ctypes.c_size_t(1), None, None) != 0
