@@ -159,10 +159,32 @@ int jj_fixedbase_multi_mul(jj_ctx*, const jj_table* const* tables, int nbases, s
 
 /* Multi-scalar multiplication: out = to_affine(sum_i points[i] * scalars[i])  (semantics: iterator Sum of
  * `p * k`, src/lib.rs:183-193 + 873-879; the reference has no MSM algorithm).  n = 0 gives the identity.
- * Pippenger on the device; the last step (Horner over the 16-17 window sums and one inversion, a chain of ~250
- * dependent doublings) runs on the calling host thread, so for every n > 0 this call synchronises the stream even when
- * all pointers are device pointers (the 64-byte result is then copied back to out64 asynchronously). */
+ * The device reduces the terms to a record of partial window sums (two launches for small batches, Pippenger above); the last
+ * step -- adding the partial sums of each window, Horner over the windows (a chain of 252 dependent doublings) and one
+ * inversion -- runs on the calling host thread, so for every n this call waits for the stream even when all pointers are
+ * device pointers (the 64-byte result is then copied to out64 asynchronously). */
 int jj_msm(jj_ctx*, size_t n, const void* scalars32, const void* points64, void* out64);
+/* The same in two halves, so that the host tail of one MSM overlaps the kernels of the next: jj_msm_begin queues all device
+ * work of one MSM plus the copy of its records into a page-locked buffer owned by the job and returns at once (device
+ * pointers; host arrays are staged first); jj_msm_finish waits for THAT job only, runs the host tail and writes the 64-byte
+ * result (host pointer: complete on return; device pointer: copy queued on the context's stream).  Jobs of one context run
+ * in the order they were begun and share its workspaces; they may be finished in any order, each exactly once (finish
+ * releases the job, also on error).  The input arrays must stay valid until the job is finished. */
+typedef struct jj_msm_job jj_msm_job;
+int jj_msm_begin(jj_ctx*, size_t n, const void* scalars32, const void* points64, jj_msm_job** job);
+int jj_msm_finish(jj_msm_job* job, void* out64);
+/* MSM cut across devices or ranks.  jj_msm_partial leaves the RECORD of partial window sums instead of the
+ * point: JJ_MSM_PARTIAL_BYTES bytes (64-byte header: magic, version, number of windows W, partial sums per window, bit mask
+ * of the windows present, n; then W x that many canonical 160-byte extended points (U, V, Z, T1, T2); unused space zeroed), written
+ * to device memory (asynchronous: ready for an all_gather over RCCL) or host memory.  At most 2^24 terms per call.
+ *   part_index = 0, part_count = 1   all windows of the n terms given       (term partition: each rank passes ITS terms)
+ *   part_index = g, part_count = G   windows g, g + G, ... of the n terms    (window partition: each rank passes ALL terms)
+ * jj_msm_combine (host only, no context) adds any number of records -- window by window where their layouts agree, so the
+ * Horner chain runs once per layout -- and returns the affine sum: one copy to the host, one host tail and one inversion
+ * for the whole distributed MSM.  Records of a window partition must come from calls with the same n. */
+#define JJ_MSM_PARTIAL_BYTES 81984u   /* 64 + 64 windows x 8 partial sums x 160 */
+int jj_msm_partial(jj_ctx*, size_t n, const void* scalars32, const void* points64, int part_index, int part_count, void* record);
+int jj_msm_combine(size_t count, const void* records_host, void* out64_host);
 
 /* ---- encodings ----------------------------------------------------------------------------------------- */
 #define JJ_DECOMPRESS_ZIP216          1u  /* reject the two non-canonical encodings (src/lib.rs:469-471, 522-531) */
@@ -193,8 +215,8 @@ int jj_random_points(jj_ctx*, size_t n, uint64_t seed, uint64_t first_index, int
 /* ---- several devices of one node ---------------------------------------------------------- */
 /* One context per listed device, one host thread + stream per device, contiguous shards [g*n/G, (g+1)*n/G); no data-path
  * collective for the independent-batch workloads (north_star: "shard embarrassingly across the 8 GPUs of one node").
- * jj_multi_msm: every device reduces its own terms to one point; the G partial points (64 bytes each) are added on the
- * calling host thread.  Array arguments are HOST pointers (a device pointer is JJ_ERR_INVALID).  A device may be listed
+ * jj_multi_msm: every device reduces its own terms to a record of partial window sums (jj_msm_partial); the records of all
+ * devices meet in one host tail on the calling thread (jj_msm_combine).  Array arguments are HOST pointers (a device pointer is JJ_ERR_INVALID).  A device may be listed
  * more than once.  Processes that keep their batches resident in HBM run one process per GPU instead and exchange the MSM
  * partial points with RCCL all_gather (jubjub_amd/dist.py).  A jj_ctx may be used from several host threads: its entry
  * points serialise on a per-context lock. */

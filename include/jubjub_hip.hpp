@@ -99,11 +99,25 @@ class FieldBatch {
     c_->check((IS_FR ? jj_fr_to_le_bits : jj_fq_to_le_bits)(c_->raw(), len(), v_.data(), out.data()));
     return out;
   }
-  // Field::random (fr.rs:684-688) over the library's counter-based stream (Fr: canonical scalars of units first .. first+n)
+  // Field::random (fr.rs:684-688; bls12_381::Scalar likewise): 64 PRNG bytes per element through from_bytes_wide, for both
+  // fields.  The two 32-byte halves come from two decorrelated streams of the library's counter-based generator (the seed
+  // hashed with a domain tag per half; jubjub_amd/group.py random_stream_seeds is the same function).  Test data only: the
+  // generator is reproducible by design and not a source of secret scalars.
+  static uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    uint64_t z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+  }
   static FieldBatch random(const Context& c, size_t n, uint64_t seed, uint64_t first_index = 0) {
-    static_assert(IS_FR, "jj_synth_scalars generates Fr elements");
+    std::vector<Bytes32> lo(n), hi(n);
+    c.check(jj_synth_bytes32(c.raw(), n, splitmix64(seed ^ 0x6F4C646E72466A6Aull), first_index, lo.data()));
+    c.check(jj_synth_bytes32(c.raw(), n, splitmix64(seed ^ 0x6948646E72466A6Aull), first_index, hi.data()));
+    std::vector<std::array<uint8_t, 64>> wide(n);
+    for (size_t i = 0; i < n; i++) { std::memcpy(wide[i].data(), lo[i].data(), 32); std::memcpy(wide[i].data() + 32, hi[i].data(), 32); }
     FieldBatch r(c, std::vector<Bytes32>(n));
-    c.check(jj_synth_scalars(c.raw(), n, seed, first_index, r.v_.data()));
+    c.check((IS_FR ? jj_fr_from_bytes_wide : jj_fq_from_bytes_wide)(c.raw(), n, wide.data(), r.v_.data()));
     return r;
   }
 

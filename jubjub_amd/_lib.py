@@ -7,6 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("JJ_LIB_PATH") or os.path.join(HERE, "lib", "libjubjub_hip.so")   # JJ_LIB_PATH: A/B builds of the same library
 
 JJ_OK, JJ_ERR_INVALID, JJ_ERR_HIP, JJ_ERR_NOMEM, JJ_ERR_NODEVICE = 0, -1, -2, -3, -4
+MSM_PARTIAL_BYTES = 81984   # JJ_MSM_PARTIAL_BYTES
 
 _vp, _sz, _u8p = C.c_void_p, C.c_size_t, C.c_void_p
 
@@ -36,6 +37,8 @@ _SIGS.update({
     "jj_fixedbase_mul": [_vp, _sz, _vp, _vp],
     "jj_fixedbase_multi_mul": [_vp, C.c_int, _sz, _vp, _vp],
     "jj_msm": [_sz, _vp, _vp, _vp],
+    "jj_msm_begin": [_sz, _vp, _vp, C.POINTER(_vp)],
+    "jj_msm_partial": [_sz, _vp, _vp, C.c_int, C.c_int, _vp],
     "jj_decompress": [_sz, _vp, C.c_uint, _vp, _u8p],
     "jj_compress": [_sz, _vp, _vp],
     "jj_batch_normalize": [_sz, _vp, _vp],
@@ -63,7 +66,7 @@ _SIGS.update({
 
 EXPORTS = sorted(list(_SIGS) + ["jj_ctx_create", "jj_ctx_destroy", "jj_last_error", "jj_version", "jj_device_info", "jj_recommended_wnaf_for_num_scalars",
                                 "jj_fixedbase_table_create", "jj_fr_char_le_bits", "jj_multi_create", "jj_multi_ctx", "jj_multi_last_error",
-                                "jj_msm_fold_partials"])
+                                "jj_msm_fold_partials", "jj_msm_finish", "jj_msm_combine"])
 
 _lib = None
 
@@ -123,6 +126,10 @@ def load():
     lib.jj_multi_last_error.argtypes = [_vp]
     lib.jj_msm_fold_partials.restype = C.c_int
     lib.jj_msm_fold_partials.argtypes = [C.c_size_t, _vp, _vp]
+    lib.jj_msm_finish.restype = C.c_int
+    lib.jj_msm_finish.argtypes = [_vp, _vp]
+    lib.jj_msm_combine.restype = C.c_int
+    lib.jj_msm_combine.argtypes = [C.c_size_t, _vp, _vp]
     lib.jj_fr_char_le_bits.restype = C.c_int
     lib.jj_fr_char_le_bits.argtypes = [C.POINTER(C.c_uint8)]
     lib.jj_device_info.restype = C.c_int

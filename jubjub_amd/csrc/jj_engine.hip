@@ -34,6 +34,15 @@ struct jj_table {
   FbParams fp;
 };
 
+struct jj_ctx;
+struct jj_msm_job {
+  jj_ctx* c = nullptr;
+  hipEvent_t ev = nullptr;
+  uint8_t* host = nullptr;      // page-locked: nrec records, REC_MAX_BYTES apart
+  size_t cap = 0;
+  size_t nrec = 0;
+};
+
 struct jj_ctx {
   std::recursive_mutex mu;       // every entry point locks its context: calls from several host threads are serialised
   int device = 0;
@@ -47,7 +56,6 @@ struct jj_ctx {
   // staging for host-pointer arguments (inputs 0..3, outputs 0..1) and kernel workspaces
   DevBuf in[4], out[2], okb, ws_ext, msm_seg, ws_scratch, ws_tables, ws_tmp[4], msm[8], sqrt_tabs, cursor;
   SqrtTables sqrt_tables{nullptr, nullptr};
-  int msm_window = 0;            // 0 = choose from n (JJ_MSM_WINDOW overrides; 8..16)
   int msm_segments = -1;         // bucket accumulation: 1 = length-sorted segments, 0 = fixed chunks + fix-up, -1 = segments from 2^18 terms
                                  // (2-4 % faster there, slower below: more launches) (JJ_MSM_ACCUM=segments|chunks)
   int msm_seg_len = 0;           // segment length override (JJ_MSM_SEG_LEN; 0 = n / 2^14 clamped to [32, 1024])
@@ -55,9 +63,7 @@ struct jj_ctx {
   int msm_reduce_chunk = 0;      // bucket-reduce chunk length (0 = from the bucket count, see msm_pippenger; JJ_MSM_REDUCE_CHUNK, a power of two)
   int msm_two_pass = -1;         // counting sort in two passes (coarse bin, then low 8 bits): -1 = when the window has >= 13 bits; JJ_MSM_SORT=1pass|2pass
   int msm_fork = -1;             // point half of the MSM conversion on the second stream: -1 = from 2^18 terms, 0 / 1 = never / always (JJ_MSM_FORK)
-  bool msm_timing = false;       // JJ_MSM_TIMING: host-side breakdown of every Pippenger pass on stderr
   int msm_pass_log2 = 24;        // terms per Pippenger pass (JJ_MSM_PASS_LOG2 overrides; for tests)
-  int msm_min_pippenger = 1;     // below this many terms the MSM is var-base ladders + fold (JJ_MSM_NAIVE_BELOW; Pippenger is faster at every size, measured)
   // optional per-call kernel timing (HIP events on the launch stream): e0 | main kernel | e1 | normalise tail | e2
   // pipelined host-buffer path: copy streams + two device slots (caller buffers are page-locked in place)
   struct Pipe {
@@ -67,18 +73,13 @@ struct jj_ctx {
     bool ready = false;
   } pipe;
   size_t pipe_chunk = (size_t)1 << 18;   // elements per pipeline chunk (JJ_PIPE_CHUNK_LOG2)
-  uint8_t* tail_host = nullptr;  // pinned staging for the MSM window sums (host-side Horner) + the two input pointers of the MSM graph
-  // JJ_MSM_GRAPH=1: the ~25 launches of one Pippenger pass are captured once per shape into a hipGraph and replayed.  A graph
-  // is valid for one (n, window, chunking) shape and one generation of the workspaces it points into.  Off by default:
-  // measured on MI355X it does not pay (2^17 terms 0.514 ms with plain launches, 0.528 ms replayed; 2^20: 1.673 / 1.700 ms) --
-  // back-to-back launches on one stream are already pipelined by the runtime, the MSM's idle time is inside its
-  // latency-bound kernels, not between them.
-  struct MsmGraph { hipGraphExec_t exec = nullptr; size_t n = 0; int cbits = 0, seg = 0; u32 L = 0, chunk = 0, P = 0; uint64_t gen = 0, used = 0; };
-  MsmGraph msm_graphs[4];
-  uint64_t alloc_gen = 0, graph_clock = 0;
-  bool msm_graph = false;
-  DevBuf msm_io;
-  uint8_t host_out[64];
+  // MSM jobs (jj_msm_begin / jj_msm_finish): free list of page-locked record buffers + events
+  std::vector<jj_msm_job*> job_pool;
+  DevBuf msm_rec;                // the record of partial window sums a pass leaves on the device
+  uint8_t host_out[8][64];       // results on their way to a device pointer (ring: the copies are asynchronous)
+  int host_out_next = 0;
+  int msm_windows = 0;           // number of windows W (0 = from n; JJ_MSM_WINDOWS, 8..36)
+  int msm_small_max = 1 << 14;   // batches up to this size take the two-launch small-batch path (JJ_MSM_SMALL_MAX; 0 = never)
   bool torsion_ladder = false;   // subgroup test: false = Tate pairing (k_torsion_free), true = multiply by r (reference definition)
   bool fb_const_time = true;     // fixed-base window select: true = lane-staged + ds_bpermute shuffle, false = per-lane LDS gather
   int vb_quad_max = 32768;       // batches up to this size run one scalar-mul per quad of lanes (JJ_VB_QUAD_MAX; 0 = never)
@@ -127,7 +128,6 @@ static int ensure(jj_ctx* c, DevBuf& b, size_t bytes) {
   hipError_t e = hipMalloc(&b.p, want);
   if (e != hipSuccess) { c->err = std::string("hipMalloc failed: ") + hipGetErrorString(e); b.p = nullptr; return JJ_ERR_NOMEM; }
   b.cap = want;
-  c->alloc_gen++;                  // captured graphs point into the workspaces: a (re)allocation invalidates them
   return JJ_OK;
 }
 
@@ -205,6 +205,16 @@ static int pipe_prepare(jj_ctx* c, size_t in_bytes, size_t out_bytes) {
   }
   return JJ_OK;
 }
+// both ends of [p, p + bytes) lie in page-locked host memory known to the runtime
+static bool is_pinned_host(const void* p, size_t bytes) {
+  if (!p || !bytes) return false;
+  for (const uint8_t* q : {(const uint8_t*)p, (const uint8_t*)p + bytes - 1}) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (a.type != hipMemoryTypeHost) return false;
+  }
+  return true;
+}
 static bool all_host(std::initializer_list<const void*> ptrs) { for (const void* p : ptrs) if (!p || is_device_ptr(p)) return false; return true; }
 
 // body(cn, dev_in[k], dev_out[k]) must enqueue the chunk's kernels on c->stream.
@@ -219,9 +229,17 @@ static int run_pipelined(jj_ctx* c, size_t n, const HostIn (&in)[NIN], const Hos
   // page-lock the caller's buffers in place
   const bool dbg = getenv("JJ_PIPE_DEBUG") != nullptr;
   timespec ts0, ts1, ts2, ts3; clock_gettime(CLOCK_MONOTONIC, &ts0);
+  // memory that is page-locked already (hipHostMalloc, or registered by the caller -- jj_multi_* registers the whole batch once
+  // before it cuts it into per-device shards, whose boundaries are not page-aligned) is used as it is
   void* locked[NIN + NOUT]; int nlocked = 0; bool ok = true;
-  for (int k = 0; k < NIN && ok; k++) { if (hipHostRegister(const_cast<void*>(in[k].p), n * in[k].elem, hipHostRegisterDefault) == hipSuccess) locked[nlocked++] = const_cast<void*>(in[k].p); else ok = false; }
-  for (int k = 0; k < NOUT && ok; k++) { if (hipHostRegister(out[k].p, n * out[k].elem, hipHostRegisterDefault) == hipSuccess) locked[nlocked++] = out[k].p; else ok = false; }
+  for (int k = 0; k < NIN && ok; k++) {
+    if (is_pinned_host(in[k].p, n * in[k].elem)) continue;
+    if (hipHostRegister(const_cast<void*>(in[k].p), n * in[k].elem, hipHostRegisterDefault) == hipSuccess) locked[nlocked++] = const_cast<void*>(in[k].p); else ok = false;
+  }
+  for (int k = 0; k < NOUT && ok; k++) {
+    if (is_pinned_host(out[k].p, n * out[k].elem)) continue;
+    if (hipHostRegister(out[k].p, n * out[k].elem, hipHostRegisterDefault) == hipSuccess) locked[nlocked++] = out[k].p; else ok = false;
+  }
   auto unlock = [&]() { for (int k = 0; k < nlocked; k++) (void)hipHostUnregister(locked[k]); };
   if (!ok) { (void)hipGetLastError(); unlock(); return 1; }
   clock_gettime(CLOCK_MONOTONIC, &ts1);
@@ -314,17 +332,15 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
   if (hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming) != hipSuccess) return fail(JJ_ERR_HIP);
   c->stream = c->own_stream;
   if (const char* e = getenv("JJ_PIPE_CHUNK_LOG2")) { int v = atoi(e); if (v >= 8 && v <= 24) c->pipe_chunk = (size_t)1 << v; }
-  if (const char* e = getenv("JJ_MSM_WINDOW")) c->msm_window = atoi(e);
+  if (const char* e = getenv("JJ_MSM_WINDOWS")) c->msm_windows = atoi(e);
+  if (const char* e = getenv("JJ_MSM_SMALL_MAX")) { int v = atoi(e); if (v >= 0 && v <= (1 << 20)) c->msm_small_max = v; }
   if (const char* e = getenv("JJ_MSM_ACCUM")) c->msm_segments = strcmp(e, "chunks") == 0 ? 0 : strcmp(e, "segments") == 0 ? 1 : -1;
   if (const char* e = getenv("JJ_MSM_SEG_LEN")) c->msm_seg_len = atoi(e);
   if (const char* e = getenv("JJ_MSM_CHUNK")) { int v = atoi(e); if (v >= 8 && v <= 1024) c->msm_chunk = v; }
   if (const char* e = getenv("JJ_MSM_REDUCE_CHUNK")) { int v = atoi(e); if (v >= 2 && v <= 256 && (v & (v - 1)) == 0) c->msm_reduce_chunk = v; }
   if (const char* e = getenv("JJ_MSM_SORT")) c->msm_two_pass = !strcmp(e, "2pass") ? 1 : (!strcmp(e, "1pass") ? 0 : -1);
   if (const char* e = getenv("JJ_MSM_FORK")) c->msm_fork = atoi(e) != 0 ? 1 : 0;
-  c->msm_timing = getenv("JJ_MSM_TIMING") != nullptr;
   if (const char* e = getenv("JJ_MSM_PASS_LOG2")) { int v = atoi(e); if (v >= 10 && v <= 24) c->msm_pass_log2 = v; }
-  if (const char* e = getenv("JJ_MSM_NAIVE_BELOW")) { int v = atoi(e); if (v >= 0) c->msm_min_pippenger = v; }
-  if (const char* e = getenv("JJ_MSM_GRAPH")) c->msm_graph = atoi(e) != 0;
   if (const char* e = getenv("JJ_VB_QUAD_MAX")) { int v = atoi(e); if (v >= 0 && v <= (1 << 20)) c->vb_quad_max = v; }
   if (const char* e = getenv("JJ_FB_GATHER_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) c->fb_gather_blocks_per_cu = v; }
   if (const char* e = getenv("JJ_VB_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) c->vb_blocks_per_cu = v; }
@@ -332,8 +348,7 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
   {
     const struct { const void* fn; int bytes; } lds_needs[] = {
       {reinterpret_cast<const void*>(k_fixedbase<true>), FB_LDS_BYTES}, {reinterpret_cast<const void*>(k_fixedbase<false>), FB_LDS_BYTES},
-      {reinterpret_cast<const void*>(k_msm_hist), 32768 * 4}, {reinterpret_cast<const void*>(k_seg_plan), 80 * 1024},
-      {reinterpret_cast<const void*>(k_msm_scatter), 32768 * 4}};
+      {reinterpret_cast<const void*>(k_seg_plan), 80 * 1024}};
     for (const auto& a : lds_needs)
       if (hipFuncSetAttribute(a.fn, hipFuncAttributeMaxDynamicSharedMemorySize, a.bytes) != hipSuccess) return fail(JJ_ERR_HIP);   // the kernels could not launch later
   }
@@ -356,10 +371,9 @@ JJ_API int jj_ctx_destroy(jj_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   DevBuf* all[] = {&c->in[0], &c->in[1], &c->in[2], &c->in[3], &c->out[0], &c->out[1], &c->okb, &c->ws_ext, &c->msm_seg, &c->ws_scratch, &c->ws_tables,
                    &c->ws_tmp[0], &c->ws_tmp[1], &c->ws_tmp[2], &c->ws_tmp[3], &c->msm[0], &c->msm[1], &c->msm[2], &c->msm[3],
-                   &c->msm[4], &c->msm[5], &c->msm[6], &c->msm[7], &c->sqrt_tabs, &c->cursor, &c->msm_io};
-  for (auto& g : c->msm_graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+                   &c->msm[4], &c->msm[5], &c->msm[6], &c->msm[7], &c->sqrt_tabs, &c->cursor, &c->msm_rec};
+  for (jj_msm_job* j : c->job_pool) { if (j->host) (void)hipHostFree(j->host); (void)hipEventDestroy(j->ev); delete j; }
   for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
-  if (c->tail_host) (void)hipHostFree(c->tail_host);
   if (c->pipe.ready) {
     for (int i = 0; i < 2; i++) {
       (void)hipEventDestroy(c->pipe.ev_in[i]); (void)hipEventDestroy(c->pipe.ev_done[i]); (void)hipEventDestroy(c->pipe.ev_out[i]);
@@ -380,11 +394,18 @@ JJ_API int jj_ctx_destroy(jj_ctx* c) {
 // Every call reuses the context's workspaces (window tables, extended SoA, staging buffers), so work queued on the
 // previous launch stream must finish before work on a new one may touch them: the new stream waits on an event recorded
 // on the old one (device-side ordering, no host synchronisation).
+// A caller-owned stream must outlive its selection (include/jubjub_hip.h).  If it has been destroyed all the same, the record
+// on it fails: the error is cleared, the device is drained instead (nothing of the old stream can still be in flight after
+// that), and the context still moves to the new stream -- it must never stay stuck on a dead one.
 static int switch_stream(jj_ctx* c, hipStream_t s) {
-  if (s == c->stream) return JJ_OK;
   JJ_ENTER(c);
-  HIPCHK(c, hipEventRecord(c->order_ev, c->stream));
-  HIPCHK(c, hipStreamWaitEvent(s, c->order_ev, 0));
+  if (s == c->stream) return JJ_OK;
+  bool ordered = hipEventRecord(c->order_ev, c->stream) == hipSuccess && hipStreamWaitEvent(s, c->order_ev, 0) == hipSuccess;
+  if (!ordered) {
+    (void)hipGetLastError();
+    (void)hipDeviceSynchronize();
+    (void)hipGetLastError();
+  }
   c->stream = s;
   return JJ_OK;
 }
@@ -894,223 +915,282 @@ JJ_API int jj_point_sum(jj_ctx* c, size_t n, const void* p, void* out64) {
   if ((rc = finish_out(c, o, &sync))) return rc;
   return finish(c, sync);
 }
-// Pippenger: sort, bucket accumulation and bucket reduction on the device; the W window sums are then copied back
-// and combined on the host (jj_host_tail.h: ~250 dependent doublings, 4x faster there).  Synchronises the stream.
-static int msm_pippenger(jj_ctx* c, size_t n, const void* ds, const void* dp, jjhost::Ext* res) {
-  MsmParams mp;
-  // window sizes whose top window keeps >= 10 scalar bits (or is short only for small n): a 1-2 bit top window would
-  // put n/2 terms into one bucket
-  mp.c = (n >= ((size_t)1 << 18)) ? 16 : (n >= ((size_t)1 << 11) ? 11 : 8);   // measured; 11 | 253, so its top window is a full one
-  if (c->msm_window >= 8 && c->msm_window <= 16) mp.c = c->msm_window;      // one window's histogram must fit LDS
-  mp.W = (253 + mp.c - 1) / mp.c;
-  mp.B = 1u << (mp.c - 1);
+// MSM on the device up to the record of partial window sums (jj_msm_kernels.h); everything here is launches only (the
+// workspaces are grown first), so a pass can be queued behind another one without any host synchronisation in between.
+//   part_w0 / part_stride: the pass owns windows part_w0, part_w0 + part_stride, ... (0 / 1: all of them)
+//   rec_dev: MSM_REC bytes of device memory for the record
+struct MsmGeometry { bool small; MsmParams mp; u32 nblk; };
+static void msm_layout(MsmParams& mp, int W, int w0, int wstride) {
+  mp.W = W; mp.c = 253 / W; mp.r = 253 % W;
+  mp.w0 = w0; mp.wstride = wstride < 1 ? 1 : wstride;
+  mp.Ws = w0 < W ? (W - w0 + mp.wstride - 1) / mp.wstride : 0;
+  mp.B = 1u << (mp.c + (mp.r ? 1 : 0) - 1);
   memset(mp.recode, 0, sizeof mp.recode);
-  for (int w = 0; w < mp.W - 1; w++) { const int bit = mp.c * w + mp.c - 1; mp.recode[bit >> 5] |= 1u << (bit & 31); }
-  const size_t nb = (size_t)mp.W * mp.B;
+  int bit = 0;
+  for (int w = 0; w < W - 1; w++) { const int width = mp.c + (w < mp.r ? 1 : 0); const int b = bit + width - 1; mp.recode[b >> 5] |= 1u << (b & 31); bit += width; }
+}
+// number of windows for n terms (measured on MI355X; JJ_MSM_WINDOWS overrides): the windows tile the 253 scalar bits exactly, so
+// any W is as good as its entry count n W and its bucket count ~ W 2^(253/W - 1) make it
+static int msm_windows_for(jj_ctx* c, size_t n) {
+  if (c->msm_windows >= 8 && c->msm_windows <= 36) return c->msm_windows;
+  if (n >= ((size_t)1 << 22)) return 16;
+  if (n >= ((size_t)1 << 18)) return 16;
+  if (n >= ((size_t)1 << 16)) return 20;
+  return 22;
+}
+
+static int msm_enqueue_small(jj_ctx* c, size_t n, const void* ds, const void* dp, int part_w0, int part_stride, void* rec_dev, int* nblk_out) {
+  MsmParams mp;
+  msm_layout(mp, SM_W, part_w0, part_stride);
+  int rc;
+  if ((rc = ensure(c, c->msm[0], n * 32))) return rc;
+  if ((rc = ensure(c, c->msm[1], n * (size_t)(SM_SLOTS * ENIELS_WORDS) * 4))) return rc;
+  // blocks of 128 quads per window: enough to give every quad at most ~4 terms, at most MSM_REC_BLK
+  const u32 nblk = (u32)std::min<size_t>(MSM_REC_BLK, std::max<size_t>(1, (n + 511) / 512));
+  *nblk_out = (int)nblk;
+  hipLaunchKernelGGL(k_msm_small_tables, dim3(blocks_for(4 * n)), dim3(256), 0, c->stream, n, ds, dp, mp, (u32*)c->msm[1].p, (u32*)c->msm[0].p);
+  hipLaunchKernelGGL(k_msm_small_sum, dim3(nblk, mp.Ws), dim3(4 * MSM_TREE_QUADS), 0, c->stream, n, mp, nblk, (const u32*)c->msm[1].p, (const u32*)c->msm[0].p, (u32*)rec_dev);
+  return JJ_OK;
+}
+
+static int msm_enqueue_pippenger(jj_ctx* c, size_t n, const void* ds, const void* dp, int part_w0, int part_stride, void* rec_dev, int* nblk_out) {
+  MsmParams mp;
+  msm_layout(mp, msm_windows_for(c, n), part_w0, part_stride);
+  const u32 B = mp.B, Ws = (u32)mp.Ws;
+  const size_t nb = (size_t)Ws * B;
   // buckets per reduce chunk (serial depth 2L + ~2c): the reduce is latency-bound, so short chunks (more quads in flight) win
   // as long as the per-chunk double-and-add by the chunk's first index stays small against the 2L additions -- measured:
-  // 32 for the 2^19 buckets of 16-bit windows, 4-8 for the 11- and 8-bit windows of small inputs (-14 % at 2^17 terms,
-  // -23 % at 2^14).  JJ_MSM_REDUCE_CHUNK overrides; never more than one window.
-  const u32 L_auto = nb >= ((size_t)1 << 18) ? 32u : (nb >= ((size_t)1 << 16) ? 8u : 4u);
-  const u32 L = std::min<u32>(c->msm_reduce_chunk ? (u32)c->msm_reduce_chunk : L_auto, mp.B);
-  if (mp.B % L || (L & (L - 1))) { c->err = "inconsistent MSM tuning override (JJ_MSM_REDUCE_CHUNK must be a power of two dividing the bucket count)"; return JJ_ERR_INVALID; }
-  const size_t nchunks = nb / L;
+  // 32 for the 2^19 buckets of 16-bit windows, 4-8 below.  JJ_MSM_REDUCE_CHUNK overrides; never more than one window.
+  // and at least B / 512, so that the 128-quad workgroups of the reduce leave at most 4 partial sums per window to the host
+  const u32 L_auto = std::max<u32>(nb >= ((size_t)1 << 18) ? 32u : (nb >= ((size_t)1 << 16) ? 8u : 4u), B >= 32768 ? 32u : B / (4 * MSM_TREE_QUADS));
+  const u32 L = std::min<u32>(c->msm_reduce_chunk ? (u32)c->msm_reduce_chunk : std::max<u32>(L_auto, 1u), B);
+  if (B % L || (L & (L - 1))) { c->err = "inconsistent MSM tuning override (JJ_MSM_REDUCE_CHUNK must be a power of two dividing the bucket count)"; return JJ_ERR_INVALID; }
+  const u32 K = B / L, nblk = std::min<u32>(MSM_REC_BLK, (K + MSM_TREE_QUADS - 1) / MSM_TREE_QUADS);
+  *nblk_out = (int)nblk;
+  int jbits = 0; while ((1u << jbits) < B) jbits++;
   int rc;
-  DevBuf &kprime = c->msm[0], &niels = c->msm[1], &cnt = c->msm[2], &idx = c->msm[3], &buckets = c->msm[4], &ra = c->msm[5], &tcnt = c->msm[7];
-  const size_t nscan = (nb + SCAN_TILE - 1) / SCAN_TILE;
+  DevBuf &kprime = c->msm[0], &niels = c->msm[1], &offb = c->msm[2], &idx = c->msm[3], &buckets = c->msm[4], &ra = c->msm[5], &tcnt = c->msm[7];
   u32 chunk = MSM_CHUNK_MIN;                           // 16 entries per lane up to 2^19 terms, 32 at 2^20, then proportional to n (measured)
   while (chunk < 256 && ((size_t)chunk << 15) < n) chunk <<= 1;
-  if (n <= ((size_t)1 << 15)) chunk = 8;              // small inputs: more lanes, shorter chains (-8 % at 2^14 terms)
+  if (n <= ((size_t)1 << 15)) chunk = 8;              // small inputs: more lanes, shorter chains
   if (c->msm_chunk) chunk = (u32)c->msm_chunk;
-  const size_t max_chunks = (n * (size_t)mp.W + chunk - 1) / chunk;
-  if ((rc = ensure(c, kprime, n * 32))) return rc;
-  if ((rc = ensure(c, niels, n * (size_t)GNIELS_WORDS * 4))) return rc;
-  if ((rc = ensure(c, cnt, (2 * nb + nscan + 8) * 4))) return rc;  // count | offset (nb+1) | block sums
-  if ((rc = ensure(c, c->ws_tmp[1], 64 + sizeof(BigBucket) * FIXUP_BIG_MAX))) return rc;              // big-bucket work list
-  if ((rc = ensure(c, c->ws_tmp[0], (size_t)5 * NL * 4 * FIXUP_BIG_MAX * FIXUP_BIG_QUADS))) return rc;   // their partial sums
-  if ((rc = ensure(c, idx, n * (size_t)mp.W * 4))) return rc;
-  // sort tiles: enough (tile, window) blocks to fill the GPU, each at least 4096 terms
-  const u32 ntiles = (u32)std::max<size_t>(1, std::min<size_t>((size_t)(c->cus + mp.W - 1) / mp.W, (n + 4095) / 4096));
+  const u32 nchunk = (u32)((n + chunk - 1) / chunk);
+  const bool two_pass = B > 4096 || (B == 4096 && c->msm_two_pass != 0);      // the one-pass plan kernel covers 4096 buckets per window
+  const u32 HB = B >> MSM_LO_BITS;
+  const u32 ptiles = (u32)((n + MSM_P1_TILE - 1) / MSM_P1_TILE);        // the first pass of the two-pass sort orders a whole tile in LDS
+  const size_t pm = (size_t)HB * ptiles;                               // runs per slot
+  // one-pass sort tiles: enough (tile, window) blocks to fill the GPU, each at least 4096 terms
+  const u32 ntiles = (u32)std::max<size_t>(1, std::min<size_t>((size_t)(c->cus + Ws - 1) / Ws, (n + 4095) / 4096));
   const size_t tile = (n + ntiles - 1) / ntiles;
-  // wide windows: two-pass sort (k_msm_part_*); tiles of MSM_P1_TILE terms
-  const bool two_pass = mp.c >= 13 && c->msm_two_pass != 0;
-  const u32 HB = mp.B >> MSM_LO_BITS;
-  const u32 ptiles = (u32)((n + MSM_P1_TILE - 1) / MSM_P1_TILE);        // the first pass orders a whole tile in LDS
-  const size_t ptile = MSM_P1_TILE;
-  const size_t pcount = (size_t)mp.W * HB * ptiles;
-  if ((rc = ensure(c, tcnt, two_pass ? (2 * pcount + pcount / SCAN_TILE + 8) * 4 : (size_t)mp.W * ntiles * mp.B * 4))) return rc;
-  if ((rc = ensure(c, buckets, (size_t)EXT_AOS_WORDS * 4 * nb))) return rc;
-  if ((rc = ensure(c, ra, (size_t)EXT_AOS_WORDS * 4 * std::max(nchunks, std::max(max_chunks, (n * (size_t)mp.W) / 8 + 1))))) return rc;   // first the sort's records, then the chunk heads, then the chunk results of the bucket reduce
-  u32* count = (u32*)cnt.p; u32* offset = count + nb; u32* bsum = offset + nb + 1;
-  const bool use_segments = c->msm_segments == 1 || (c->msm_segments < 0 && n >= ((size_t)1 << 18));   // measured: -5 % at 2^18 terms, +4 % at 2^17
+  const bool use_segments = c->msm_segments == 1 || (c->msm_segments < 0 && n >= ((size_t)1 << 18));
   // segments of at most P entries, sorted by length; P bounds the serial depth of one lane (~ n / 2^14 additions)
   u32 P = (u32)std::min<size_t>(SEG_PMAX, std::max<size_t>(32, n >> 14));
   if (c->msm_seg_len >= 8 && c->msm_seg_len <= SEG_PMAX) P = (u32)c->msm_seg_len;
   const u32 stiles = (u32)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(256, 15000 / (P + 1)), (nb + 255) / 256));   // the plan kernel keeps the tiles x (P+1) matrix in LDS
   const u32 per_tile = (u32)((nb + stiles - 1) / stiles);
-  const size_t max_segs = nb + (n * (size_t)mp.W) / P + 1;
+  const size_t max_segs = nb + (n * (size_t)Ws) / P + 1;
   const size_t bh_words = (size_t)stiles * (P + 1), hdr_words = bh_words + 2 * (P + 2) + 16;
-  if (use_segments && (rc = ensure(c, c->msm_seg, hdr_words * 4 + 16 + nb * sizeof(MergeItem) + max_segs * sizeof(Seg)))) return rc;   // bh [stiles][P+1] | count [P+1] | offset [P+2] | block sums | merge list | segments
-  if (!c->tail_host) HIPCHK(c, hipHostMalloc((void**)&c->tail_host, 160 * 64 + 64, hipHostMallocDefault));
-  if ((rc = ensure(c, c->ws_tmp[3], 160 * 64))) return rc;
-  if ((rc = ensure(c, c->msm_io, 64))) return rc;
-  // everything from here to the copy of the window sums is launches only (no allocation, no synchronisation): it can run
-  // directly on a stream or be recorded into a graph
-  auto enqueue = [&](hipStream_t st, bool allow_fork) -> int {
-    // Large inputs: the point half of the conversion (bandwidth- and multiplier-bound, 55 us at 2^20 terms) runs on the second
-    // stream beside the sort (LDS-bound) and is joined before the accumulation: -45 us at 2^20 terms; the two extra events cost
-    // ~10 us, more than the overlap returns below 2^18 terms.  Not inside a graph capture (JJ_MSM_GRAPH).  JJ_MSM_FORK=0/1 overrides.
-    const bool fork = allow_fork && (c->msm_fork < 0 ? n >= ((size_t)1 << 18) : c->msm_fork != 0);
-    if (fork) {
-      HIPCHK(c, hipEventRecord(c->fork_ev, st));
-      HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->fork_ev, 0));
-      hipLaunchKernelGGL(k_msm_convert, dim3(blocks_for(n)), dim3(256), 0, c->aux_stream, n, (const void* const*)c->msm_io.p, mp, (u32*)kprime.p, (u32*)niels.p, 2);
-      HIPCHK(c, hipEventRecord(c->join_ev, c->aux_stream));
-      hipLaunchKernelGGL(k_msm_convert, dim3(blocks_for(n)), dim3(256), 0, st, n, (const void* const*)c->msm_io.p, mp, (u32*)kprime.p, (u32*)niels.p, 1);
-    } else {
-      hipLaunchKernelGGL(k_msm_convert, dim3(blocks_for(n)), dim3(256), 0, st, n, (const void* const*)c->msm_io.p, mp, (u32*)kprime.p, (u32*)niels.p, 3);
-    }
-    if (two_pass) {
-      // tcnt: counts [pcount] | scanned [pcount + 1] | block sums
-      u32* tc = (u32*)tcnt.p; u32* tcs = tc + pcount; u32* tbs = tcs + pcount + 1;
-      const size_t pscan = (pcount + SCAN_TILE - 1) / SCAN_TILE;
-      u32* rec = (u32*)ra.p; uint8_t* lo8 = (uint8_t*)ra.p + n * (size_t)mp.W * 4;     // the chunk-head buffer is free until the accumulation
-      hipLaunchKernelGGL(k_msm_part_hist, dim3(ptiles, mp.W), dim3(MSM_SORT_THREADS), 0, st, n, ptile, mp, (const u32*)kprime.p, tc);
-      hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)pscan), dim3(256), 0, st, pcount, (const u32*)tc, tbs);
-      hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, pscan, tbs, tcs + pcount);
-      hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)pscan), dim3(256), 0, st, pcount, (const u32*)tc, (const u32*)tbs, tcs);
-      hipLaunchKernelGGL(k_msm_part_scatter, dim3(ptiles, mp.W), dim3(MSM_SORT_THREADS), 0, st, n, ptile, mp, (const u32*)kprime.p, (const u32*)tcs, rec, lo8);
-      hipLaunchKernelGGL(k_msm_part_sort, dim3(mp.W * HB), dim3(MSM_P2_THREADS), 0, st, mp, ptiles, (const u32*)tcs, (const u32*)rec, (const uint8_t*)lo8, (u32*)idx.p, offset);
-    } else {
-      hipLaunchKernelGGL(k_msm_hist, dim3(ntiles, mp.W), dim3(MSM_SORT_THREADS), mp.B * 4, st, n, tile, mp, (const u32*)kprime.p, (u32*)tcnt.p);
-      hipLaunchKernelGGL(k_msm_tile_totals, dim3(blocks_for(nb)), dim3(256), 0, st, nb, mp.B, ntiles, (const u32*)tcnt.p, count);
-      hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)nscan), dim3(256), 0, st, nb, (const u32*)count, bsum);
-      hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, nscan, bsum, offset + nb);
-      hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nscan), dim3(256), 0, st, nb, (const u32*)count, (const u32*)bsum, offset);
-      hipLaunchKernelGGL(k_msm_tile_bases, dim3(blocks_for(nb)), dim3(256), 0, st, nb, mp.B, ntiles, (const u32*)offset, (u32*)tcnt.p);
-      hipLaunchKernelGGL(k_msm_scatter, dim3(ntiles * 8 * ((mp.W + 7) / 8)), dim3(MSM_SORT_THREADS), mp.B * 4, st, n, tile, ntiles, mp, (const u32*)kprime.p, (const u32*)tcnt.p, (u32*)idx.p);
-    }
-    {
-      const ExtAoS head{(u32*)ra.p}, bk{(u32*)buckets.p};
-      u32* counters = (u32*)c->ws_tmp[1].p;                   // [0] heads, [1] merge items, [2] big buckets (work list follows at +64)
-      u32* big_count = counters + 2; BigBucket* big = (BigBucket*)((uint8_t*)c->ws_tmp[1].p + 64);
-      SoA partial = soa_of(c->ws_tmp[0], (size_t)FIXUP_BIG_MAX * FIXUP_BIG_QUADS);
-      HIPCHK(c, hipMemsetAsync(counters, 0, 16, st));
-      if (use_segments) {
-        u32* bh = (u32*)c->msm_seg.p; u32* soff = bh + bh_words + (P + 1);
-        MergeItem* merge = (MergeItem*)(((uintptr_t)(bh + hdr_words) + 15) & ~(uintptr_t)15);
-        Seg* seg = (Seg*)(merge + nb);
-        hipLaunchKernelGGL(k_seg_hist, dim3(stiles), dim3(256), 0, st, nb, per_tile, P, (const u32*)offset, bk, bh);
-        hipLaunchKernelGGL(k_seg_plan, dim3(1), dim3(1024), (bh_words + P + 2) * 4, st, stiles, P, bh, soff + (P + 1));
-        hipLaunchKernelGGL(k_seg_scatter, dim3(stiles), dim3(256), 0, st, nb, per_tile, P, (const u32*)offset, (const u32*)bh, seg, counters, merge, big);
-        if (fork) HIPCHK(c, hipStreamWaitEvent(st, c->join_ev, 0));
-        hipLaunchKernelGGL(k_msm_accumulate_seg, dim3(blocks_for(max_segs)), dim3(256), 0, st, (const u32*)(soff + (P + 1)), (const Seg*)seg, (const u32*)idx.p, (const u32*)niels.p, bk, head);
-        hipLaunchKernelGGL(k_msm_merge, dim3(blocks_for(4 * std::min(nb, max_segs))), dim3(256), 0, st, (const u32*)counters, (const MergeItem*)merge, bk, head);
-      } else {
-        if (fork) HIPCHK(c, hipStreamWaitEvent(st, c->join_ev, 0));
-        hipLaunchKernelGGL(k_msm_accumulate, dim3(blocks_for(max_chunks)), dim3(256), 0, st, nb, chunk, (const u32*)offset, (const u32*)idx.p, (const u32*)niels.p, bk, head);
-        hipLaunchKernelGGL(k_msm_fixup, dim3(blocks_for(4 * nb)), dim3(256), 0, st, nb, chunk, (const u32*)offset, bk, head, big_count, big);
-      }
-      hipLaunchKernelGGL(k_msm_fixup_big, dim3(256), dim3(256), 0, st, (const u32*)big_count, (const BigBucket*)big, bk, head, partial, 0);
-      hipLaunchKernelGGL(k_msm_fixup_big, dim3(256), dim3(256), 0, st, (const u32*)big_count, (const BigBucket*)big, bk, head, partial, 1);
-    }
-    hipLaunchKernelGGL(k_msm_bucket_reduce, dim3(blocks_for(nchunks * 4)), dim3(256), 0, st, nchunks, L, mp.B, mp.c - 1, ExtAoS{(u32*)buckets.p}, soa_of(ra, nchunks));
-    // fold the chunks of each window (B / L of them) to the window sum, copied back for the Horner combine on the host
-    hipLaunchKernelGGL(k_msm_window_fold, dim3(mp.W), dim3(1024), 0, st, (size_t)(mp.B / L), soa_of(ra, nchunks), c->ws_tmp[3].p);
-    HIPCHK(c, hipMemcpyAsync(c->tail_host, c->ws_tmp[3].p, (size_t)160 * mp.W, hipMemcpyDeviceToHost, st));
-    return JJ_OK;
-  };
-  // the caller's two pointers, through pinned memory (asynchronous 16-byte copy)
-  const void** io_host = (const void**)(c->tail_host + 160 * 64);
-  io_host[0] = ds; io_host[1] = dp;
-  HIPCHK(c, hipMemcpyAsync(c->msm_io.p, io_host, 16, hipMemcpyHostToDevice, c->stream));
-  bool done = false;
-  if (c->msm_graph) {
-    // The graph runs on the context's own stream (the legacy null stream, which a caller may have selected, cannot be
-    // captured), ordered after what is queued on the launch stream; this call synchronises anyway for the host tail.
-    jj_ctx::MsmGraph* slot = nullptr;
-    for (auto& g : c->msm_graphs)
-      if (g.exec && g.n == n && g.cbits == mp.c && g.seg == (int)use_segments && g.L == L && g.chunk == chunk && g.P == P && g.gen == c->alloc_gen) slot = &g;
-    if (!slot) {
-      slot = &c->msm_graphs[0];
-      for (auto& g : c->msm_graphs) if (g.used < slot->used) slot = &g;       // least recently used
-      if (slot->exec) { (void)hipGraphExecDestroy(slot->exec); slot->exec = nullptr; }
-      hipGraph_t graph = nullptr;
-      bool ok = hipStreamBeginCapture(c->own_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
-      if (ok) {
-        const int erc = enqueue(c->own_stream, false);
-        ok = hipStreamEndCapture(c->own_stream, &graph) == hipSuccess && erc == JJ_OK && graph;
-      }
-      if (ok) ok = hipGraphInstantiate(&slot->exec, graph, nullptr, nullptr, 0) == hipSuccess;
-      if (graph) (void)hipGraphDestroy(graph);
-      if (ok) { slot->n = n; slot->cbits = mp.c; slot->seg = (int)use_segments; slot->L = L; slot->chunk = chunk; slot->P = P; slot->gen = c->alloc_gen; }
-      else { (void)hipGetLastError(); slot->exec = nullptr; slot = nullptr; c->msm_graph = false; }   // fall back to plain launches for good
-    }
-    if (slot) {
-      slot->used = ++c->graph_clock;
-      if (c->stream != c->own_stream) {
-        HIPCHK(c, hipEventRecord(c->order_ev, c->stream));
-        HIPCHK(c, hipStreamWaitEvent(c->own_stream, c->order_ev, 0));
-      }
-      HIPCHK(c, hipGraphLaunch(slot->exec, c->own_stream));
-      HIPCHK(c, hipStreamSynchronize(c->own_stream));
-      done = true;
-    }
+  if ((rc = ensure(c, kprime, n * 32))) return rc;
+  if ((rc = ensure(c, niels, n * (size_t)GNIELS_WORDS * 4))) return rc;
+  if ((rc = ensure(c, offb, (size_t)Ws * (B + 1) * 4))) return rc;
+  if ((rc = ensure(c, idx, n * (size_t)Ws * 4))) return rc;
+  if ((rc = ensure(c, tcnt, two_pass ? ((size_t)Ws * (2 * pm + 1)) * 4 : (size_t)Ws * ntiles * B * 4))) return rc;
+  if ((rc = ensure(c, buckets, (size_t)EXT_AOS_WORDS * 4 * nb))) return rc;
+  // ra: first the two-pass sort's records (4 + 1 bytes per entry), then the chunk heads / segment heads
+  if ((rc = ensure(c, ra, std::max<size_t>((size_t)EXT_AOS_WORDS * 4 * std::max<size_t>((size_t)Ws * nchunk, (n * (size_t)Ws) / 8 + 1), n * (size_t)Ws * 5 + 64)))) return rc;
+  if ((rc = ensure(c, c->ws_tmp[1], 64 + sizeof(BigBucket) * FIXUP_BIG_MAX))) return rc;              // counters + big-bucket work list
+  if ((rc = ensure(c, c->ws_tmp[0], (size_t)5 * NL * 4 * FIXUP_BIG_MAX * FIXUP_BIG_QUADS))) return rc;   // their partial sums
+  if (use_segments && (rc = ensure(c, c->msm_seg, hdr_words * 4 + 16 + nb * sizeof(MergeItem) + max_segs * sizeof(Seg)))) return rc;   // bh [stiles][P+1] | count [P+1] | offset [P+2] | merge list | segments
+  hipStream_t st = c->stream;
+  u32* off = (u32*)offb.p;
+  u32* counters = (u32*)c->ws_tmp[1].p;                   // MSM_COUNTERS words, cleared by the sort's plan kernel; the work list follows at +64
+  BigBucket* big = (BigBucket*)((uint8_t*)c->ws_tmp[1].p + 64);
+  // Large inputs: the point half of the conversion (bandwidth- and multiplier-bound, 55 us at 2^20 terms) runs on the second
+  // stream beside the sort (LDS-bound) and is joined before the accumulation; the two extra events cost ~10 us, more than the
+  // overlap returns below 2^18 terms.  JJ_MSM_FORK=0/1 overrides.
+  const bool fork = c->msm_fork < 0 ? n >= ((size_t)1 << 18) : c->msm_fork != 0;
+  if (fork) {
+    HIPCHK(c, hipEventRecord(c->fork_ev, st));
+    HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->fork_ev, 0));
+    hipLaunchKernelGGL(k_msm_convert, dim3(blocks_for(n)), dim3(256), 0, c->aux_stream, n, ds, dp, mp, (u32*)kprime.p, (u32*)niels.p, 2);
+    HIPCHK(c, hipEventRecord(c->join_ev, c->aux_stream));
+    hipLaunchKernelGGL(k_msm_convert, dim3(blocks_for(n)), dim3(256), 0, st, n, ds, dp, mp, (u32*)kprime.p, (u32*)niels.p, 1);
+  } else {
+    hipLaunchKernelGGL(k_msm_convert, dim3(blocks_for(n)), dim3(256), 0, st, n, ds, dp, mp, (u32*)kprime.p, (u32*)niels.p, 3);
   }
-  const bool timing = c->msm_timing;                                   // stderr: enqueue / wait / host Horner, microseconds
-  timespec t0, t1, t2, t3;
-  if (timing) clock_gettime(CLOCK_MONOTONIC, &t0);
-  if (!done) {
-    if ((rc = enqueue(c->stream, true))) return rc;
-    if (timing) clock_gettime(CLOCK_MONOTONIC, &t1);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (two_pass) {
+    u32* tc = (u32*)tcnt.p; u32* tcs = tc + (size_t)Ws * pm;
+    u32* rec = (u32*)ra.p; uint8_t* lo8 = (uint8_t*)ra.p + n * (size_t)Ws * 4;     // the head buffer is free until the accumulation
+    hipLaunchKernelGGL(k_msm_part_hist, dim3(ptiles, Ws), dim3(MSM_SORT_THREADS), 0, st, n, (size_t)MSM_P1_TILE, mp, (const u32*)kprime.p, tc);
+    hipLaunchKernelGGL(k_msm_part_plan, dim3(Ws), dim3(1024), 0, st, n, (u32)pm, (const u32*)tc, tcs, counters);
+    hipLaunchKernelGGL(k_msm_part_scatter, dim3(ptiles, Ws), dim3(MSM_SORT_THREADS), 0, st, n, (size_t)MSM_P1_TILE, mp, (const u32*)kprime.p, (const u32*)tcs, rec, lo8);
+    hipLaunchKernelGGL(k_msm_part_sort, dim3(HB, Ws), dim3(MSM_P2_THREADS), 0, st, mp, ptiles, (const u32*)tcs, (const u32*)rec, (const uint8_t*)lo8, (u32*)idx.p, off);
+  } else {
+    hipLaunchKernelGGL(k_msm_hist, dim3(ntiles, Ws), dim3(MSM_SORT_THREADS), B * 4, st, n, tile, mp, (const u32*)kprime.p, (u32*)tcnt.p);
+    hipLaunchKernelGGL(k_msm_plan, dim3(Ws), dim3(1024), 0, st, n, B, ntiles, (u32*)tcnt.p, off, counters);
+    hipLaunchKernelGGL(k_msm_scatter, dim3(ntiles * 8 * ((Ws + 7) / 8)), dim3(MSM_SORT_THREADS), B * 4, st, n, tile, ntiles, mp, (const u32*)kprime.p, (const u32*)tcnt.p, (u32*)idx.p);
   }
-  if (timing) clock_gettime(CLOCK_MONOTONIC, &t2);
-  *res = jjhost::horner(c->tail_host, mp.W, mp.c);
-  if (timing) {
-    clock_gettime(CLOCK_MONOTONIC, &t3);
-    auto us = [](const timespec& a, const timespec& b) { return (b.tv_sec - a.tv_sec) * 1e6 + (b.tv_nsec - a.tv_nsec) * 1e-3; };
-    if (!done) fprintf(stderr, "[jj msm] n=%zu c=%d: enqueue %.1f us, wait %.1f us, host Horner %.1f us\n", n, mp.c, us(t0, t1), us(t1, t2), us(t2, t3));
+  const ExtAoS head{(u32*)ra.p}, bk{(u32*)buckets.p};
+  SoA partial = soa_of(c->ws_tmp[0], (size_t)FIXUP_BIG_MAX * FIXUP_BIG_QUADS);
+  if (use_segments) {
+    u32* bh = (u32*)c->msm_seg.p; u32* soff = bh + bh_words + (P + 1);
+    MergeItem* merge = (MergeItem*)(((uintptr_t)(bh + hdr_words) + 15) & ~(uintptr_t)15);
+    Seg* seg = (Seg*)(merge + nb);
+    hipLaunchKernelGGL(k_seg_hist, dim3(stiles), dim3(256), 0, st, nb, B, per_tile, P, (const u32*)off, bk, bh);
+    hipLaunchKernelGGL(k_seg_plan, dim3(1), dim3(1024), (bh_words + P + 2) * 4, st, stiles, P, bh, soff + (P + 1));
+    hipLaunchKernelGGL(k_seg_scatter, dim3(stiles), dim3(256), 0, st, nb, B, per_tile, P, (const u32*)off, (const u32*)bh, seg, counters, merge, big);
+    if (fork) HIPCHK(c, hipStreamWaitEvent(st, c->join_ev, 0));
+    hipLaunchKernelGGL(k_msm_accumulate_seg, dim3(blocks_for(max_segs)), dim3(256), 0, st, (const u32*)(soff + (P + 1)), (const Seg*)seg, (const u32*)idx.p, (const u32*)niels.p, bk, head);
+    hipLaunchKernelGGL(k_msm_merge, dim3(blocks_for(4 * std::min(nb, max_segs))), dim3(256), 0, st, (const u32*)counters, (const MergeItem*)merge, bk, head);
+  } else {
+    if (fork) HIPCHK(c, hipStreamWaitEvent(st, c->join_ev, 0));
+    hipLaunchKernelGGL(k_msm_accumulate, dim3(blocks_for(nchunk), Ws), dim3(256), 0, st, n, B, chunk, nchunk, (const u32*)off, (const u32*)idx.p, (const u32*)niels.p, bk, head);
+    hipLaunchKernelGGL(k_msm_fixup, dim3(blocks_for(4 * nb)), dim3(256), 0, st, n, B, Ws, chunk, nchunk, (const u32*)off, bk, head, counters, big);
   }
+  hipLaunchKernelGGL(k_msm_fixup_big, dim3(256), dim3(256), 0, st, counters, (const BigBucket*)big, bk, head, partial);
+  if (K > MSM_TREE_QUADS * nblk) hipLaunchKernelGGL(k_msm_reduce_fold<true>, dim3(nblk, Ws), dim3(4 * MSM_TREE_QUADS), 0, st, n, mp, L, nblk, jbits, bk, (u32*)rec_dev);
+  else hipLaunchKernelGGL(k_msm_reduce_fold<false>, dim3(nblk, Ws), dim3(4 * MSM_TREE_QUADS), 0, st, n, mp, L, nblk, jbits, bk, (u32*)rec_dev);
   return JJ_OK;
 }
+// one pass (at most 2^24 terms: 32-bit sort indices), record left at rec_dev
+static int msm_enqueue(jj_ctx* c, size_t n, const void* ds, const void* dp, int part_w0, int part_stride, void* rec_dev, size_t* rec_bytes) {
+  const bool small = n <= (size_t)c->msm_small_max;
+  int nblk = 1;
+  const int rc = small ? msm_enqueue_small(c, n, ds, dp, part_w0, part_stride, rec_dev, &nblk) : msm_enqueue_pippenger(c, n, ds, dp, part_w0, part_stride, rec_dev, &nblk);
+  *rec_bytes = jjhost::rec_bytes(small ? SM_W : msm_windows_for(c, n), nblk);
+  return rc;
+}
+
+// ---- asynchronous jobs: jj_msm_begin queues every pass of one MSM and the copy of its records into the job's own page-locked
+// buffer, then returns; jj_msm_finish waits for that copy only and runs the host tail (window sums, Horner, one inversion),
+// while the kernels of jobs begun meanwhile keep the device busy.  The context's workspaces are shared by all jobs: the stream
+// orders them.
+static int msm_job_get(jj_ctx* c, size_t nrec, jj_msm_job** out) {
+  jj_msm_job* j = nullptr;
+  if (!c->job_pool.empty()) { j = c->job_pool.back(); c->job_pool.pop_back(); }
+  else {
+    j = new jj_msm_job();
+    j->c = c;
+    if (hipEventCreateWithFlags(&j->ev, hipEventDisableTiming) != hipSuccess) { delete j; c->err = "hipEventCreate failed"; return JJ_ERR_HIP; }
+  }
+  const size_t want = std::max<size_t>(nrec, 1) * jjhost::REC_MAX_BYTES;
+  if (j->cap < want) {
+    if (j->host) (void)hipHostFree(j->host);
+    j->host = nullptr; j->cap = 0;
+    if (hipHostMalloc((void**)&j->host, want, hipHostMallocDefault) != hipSuccess) { (void)hipEventDestroy(j->ev); delete j; c->err = "hipHostMalloc failed"; return JJ_ERR_NOMEM; }
+    j->cap = want;
+  }
+  j->nrec = 0;
+  *out = j;
+  return JJ_OK;
+}
+static void msm_job_put(jj_ctx* c, jj_msm_job* j) {
+  if (c->job_pool.size() < 8) { c->job_pool.push_back(j); return; }
+  if (j->host) (void)hipHostFree(j->host);
+  (void)hipEventDestroy(j->ev);
+  delete j;
+}
+static int msm_begin_locked(jj_ctx* c, size_t n, const void* scalars, const void* points, int part_w0, int part_stride, jj_msm_job** out) {
+  const size_t PASS = (size_t)1 << c->msm_pass_log2;
+  const size_t npass = n ? (n + PASS - 1) / PASS : 0;
+  jj_msm_job* j;
+  int rc = msm_job_get(c, npass, &j); if (rc) return rc;
+  if (n) {
+    const void *ds, *dp;
+    if ((rc = stage_in(c, 0, scalars, 32 * n, &ds)) || (rc = stage_in(c, 1, points, 64 * n, &dp)) || (rc = ensure(c, c->msm_rec, jjhost::REC_MAX_BYTES))) { msm_job_put(c, j); return rc; }
+    for (size_t lo = 0; lo < n; lo += PASS) {
+      const size_t cnt = std::min(PASS, n - lo);
+      size_t used = 0;
+      if ((rc = msm_enqueue(c, cnt, (const uint8_t*)ds + lo * 32, (const uint8_t*)dp + lo * 64, part_w0, part_stride, c->msm_rec.p, &used))) { msm_job_put(c, j); return rc; }
+      hipError_t e = hipMemcpyAsync(j->host + j->nrec * jjhost::REC_MAX_BYTES, c->msm_rec.p, used, hipMemcpyDeviceToHost, c->stream);
+      if (e != hipSuccess) { c->err = std::string("hipMemcpyAsync(record) failed: ") + hipGetErrorString(e); msm_job_put(c, j); return JJ_ERR_HIP; }
+      j->nrec++;
+    }
+  }
+  hipError_t e = hipEventRecord(j->ev, c->stream);
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e != hipSuccess) { c->err = std::string("MSM launch failed: ") + hipGetErrorString(e); msm_job_put(c, j); return JJ_ERR_HIP; }
+  *out = j;
+  return JJ_OK;
+}
+JJ_API int jj_msm_begin(jj_ctx* c, size_t n, const void* scalars, const void* points, jj_msm_job** job) {
+  if (!c || !job) return JJ_ERR_INVALID;
+  *job = nullptr;
+  JJ_ENTER(c);
+  return msm_begin_locked(c, n, scalars, points, 0, 1, job);
+}
+// waits for the job's records, host tail, result to out64 (host pointer: written before the call returns; device pointer: a
+// 64-byte copy queued on the context's stream).  The job is released in every case.
+JJ_API int jj_msm_finish(jj_msm_job* j, void* out64) {
+  if (!j || !j->c) return JJ_ERR_INVALID;
+  jj_ctx* c = j->c;
+  if (!out64) { std::lock_guard<std::recursive_mutex> lk(c->mu); msm_job_put(c, j); return JJ_ERR_INVALID; }
+  hipError_t e = hipEventSynchronize(j->ev);                       // no context lock while waiting: other threads may queue work
+  jjhost::Ext total = jjhost::identity();
+  const bool ok = e == hipSuccess && jjhost::combine_records(j->host, j->nrec, jjhost::REC_MAX_BYTES, &total);
+  JJ_ENTER(c);
+  int rc = JJ_OK;
+  if (e != hipSuccess) { c->err = std::string("hipEventSynchronize failed: ") + hipGetErrorString(e); rc = JJ_ERR_HIP; }
+  else if (!ok) { c->err = "MSM record is damaged (bad header)"; rc = JJ_ERR_HIP; }
+  else if (is_device_ptr(out64)) {
+    jjhost::to_affine64(c->host_out[c->host_out_next], total);
+    e = hipMemcpyAsync(out64, c->host_out[c->host_out_next], 64, hipMemcpyHostToDevice, c->stream);
+    c->host_out_next = (c->host_out_next + 1) % 8;
+    if (e != hipSuccess) { c->err = std::string("hipMemcpyAsync failed: ") + hipGetErrorString(e); rc = JJ_ERR_HIP; }
+  } else jjhost::to_affine64((uint8_t*)out64, total);
+  msm_job_put(c, j);
+  return rc;
+}
 JJ_API int jj_msm(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out64) {
-  if (!c) return JJ_ERR_INVALID;
+  if (!c || !out64) return JJ_ERR_INVALID;
+  jj_msm_job* j = nullptr;
+  {
+    JJ_ENTER(c);
+    prof_mark(c, 0);
+    const int rc = msm_begin_locked(c, n, scalars, points, 0, 1, &j);
+    if (rc) return rc;
+  }
+  const int rc = jj_msm_finish(j, out64);
+  { JJ_ENTER(c); prof_mark(c, 1); prof_mark(c, 2); }
+  return rc;
+}
+// First half of an MSM that is cut across devices or ranks: the record of partial window sums, left where the
+// caller wants it (device memory: ready for an all_gather over RCCL; host memory: the call waits for the copy).
+//   part_index / part_count = 0 / 1   all windows of the n terms given (term partition: every rank passes its own terms)
+//   part_index = g, part_count = G    windows g, g + G, ... of the n terms given (window partition: every rank passes ALL terms)
+JJ_API int jj_msm_partial(jj_ctx* c, size_t n, const void* scalars, const void* points, int part_index, int part_count, void* record) {
+  if (!c || !record || part_count < 1 || part_index < 0 || part_index >= part_count) return JJ_ERR_INVALID;
+  if (n > ((size_t)1 << c->msm_pass_log2)) { c->err = "jj_msm_partial takes at most one pass of terms (2^24); cut larger inputs"; return JJ_ERR_INVALID; }
   JJ_ENTER(c);
   int rc; OutRef o;
-  if ((rc = stage_out(c, c->out[0], out64, 64, &o))) return rc;
-  if (n == 0) { if ((rc = write_identity(c, o))) return rc; }
-  else {
+  if ((rc = stage_out(c, c->out[0], record, JJ_MSM_PARTIAL_BYTES, &o))) return rc;
+  static_assert(JJ_MSM_PARTIAL_BYTES == jjhost::REC_MAX_BYTES, "record size");
+  HIPCHK(c, hipMemsetAsync(o.dev, 0, JJ_MSM_PARTIAL_BYTES, c->stream));
+  if (n == 0) {
+    // an empty shard: a valid record without windows
+    uint32_t hdr[MSM_REC_HDR_WORDS] = {MSM_REC_MAGIC, 1u, (uint32_t)SM_W, 1u};
+    memcpy(c->host_out[c->host_out_next], hdr, 64);
+    HIPCHK(c, hipMemcpyAsync(o.dev, c->host_out[c->host_out_next], 64, hipMemcpyHostToDevice, c->stream));
+    c->host_out_next = (c->host_out_next + 1) % 8;
+  } else {
     const void *ds, *dp;
     if ((rc = stage_in(c, 0, scalars, 32 * n, &ds))) return rc;
     if ((rc = stage_in(c, 1, points, 64 * n, &dp))) return rc;
-    prof_mark(c, 0);
-    if (n >= (size_t)c->msm_min_pippenger) {
-      // 32-bit sort indices: at most 2^24 terms per Pippenger pass; larger inputs are folded pass by pass
-      const size_t PASS = (size_t)1 << c->msm_pass_log2;
-      jjhost::Ext total = jjhost::identity();
-      for (size_t lo = 0; lo < n; lo += PASS) {
-        const size_t cnt = std::min(PASS, n - lo);
-        jjhost::Ext r1;
-        if ((rc = msm_pippenger(c, cnt, (const uint8_t*)ds + lo * 32, (const uint8_t*)dp + lo * 64, &r1))) return rc;
-        total = lo ? jjhost::point_add(total, r1) : r1;
-      }
-      prof_mark(c, 1);
-      jjhost::to_affine64(c->host_out, total);
-      HIPCHK(c, hipMemcpyAsync(o.dev, c->host_out, 64, hipMemcpyHostToDevice, c->stream));
-    } else {
-      SoA res;
-      if ((rc = ensure(c, c->ws_tmp[2], (size_t)5 * NL * 4 * n))) return rc;
-      if ((rc = varbase_to_ext(c, n, ds, dp, soa_of(c->ws_tmp[2], n), true))) return rc;
-      if ((rc = sum_reduce(c, n, &c->ws_tmp[2], &c->ws_tmp[3], &res))) return rc;
-      prof_mark(c, 1);
-      if ((rc = normalize_launch(c, 1, res, o.dev, 0))) return rc;
-    }
-    prof_mark(c, 2);
+    size_t used = 0;
+    if ((rc = msm_enqueue(c, n, ds, dp, part_index, part_count, o.dev, &used))) return rc;
   }
   bool sync = false;
   if ((rc = finish_out(c, o, &sync))) return rc;
   return finish(c, sync);
+}
+// Second half: `count` records (HOST memory, JJ_MSM_PARTIAL_BYTES apart: what the ranks' all_gather delivered, copied back once)
+// -> one affine point.  Host only, no context: window sums of all records, one Horner chain per window layout, one inversion.
+JJ_API int jj_msm_combine(size_t count, const void* records_host, void* out64_host) {
+  if (!out64_host || (count && !records_host) || is_device_ptr(out64_host) || (count && is_device_ptr(records_host))) return JJ_ERR_INVALID;
+  jjhost::Ext total = jjhost::identity();
+  if (!jjhost::combine_records((const uint8_t*)records_host, count, JJ_MSM_PARTIAL_BYTES, &total)) return JJ_ERR_INVALID;
+  jjhost::to_affine64((uint8_t*)out64_host, total);
+  return JJ_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------- synthetic inputs
@@ -1257,6 +1337,19 @@ static int multi_run(jj_multi* m, size_t n, Body body) {
   for (int g = 0; g < G; g++) if (rc[g]) { std::lock_guard<std::mutex> lk(m->mu); m->err = "device shard " + std::to_string(g) + ": " + jj_last_error(m->ctx[g]); return rc[g]; }
   return JJ_OK;
 }
+// Page-locks whole caller buffers for the lifetime of one jj_multi_* call.  The per-device shards are cut at element, not page,
+// boundaries: if every device thread registered its own sub-range, neighbouring shards would register the same page twice and the
+// loser (hipErrorHostMemoryAlreadyRegistered) would silently fall back to synchronous pageable staging.  Registered once here,
+// every shard finds its range pinned (run_pipelined / is_pinned_host) and none registers anything.
+struct MultiPin {
+  std::vector<void*> locked;
+  void add(const void* p, size_t bytes) {
+    if (!p || bytes < ((size_t)1 << 20) || is_pinned_host(p, bytes)) return;       // small batches are staged, not pipelined
+    if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) == hipSuccess) locked.push_back(const_cast<void*>(p));
+    else (void)hipGetLastError();                                                    // not fatal: the shards fall back to staging
+  }
+  ~MultiPin() { for (void* p : locked) (void)hipHostUnregister(p); }
+};
 static bool host_args(jj_multi* m, std::initializer_list<const void*> ptrs, size_t n) {
   if (n == 0) return true;
   for (const void* p : ptrs) if (!p || is_device_ptr(p)) { std::lock_guard<std::mutex> lk(m->mu); m->err = "multi-device entry points take host pointers"; return false; }
@@ -1266,6 +1359,8 @@ static bool host_args(jj_multi* m, std::initializer_list<const void*> ptrs, size
 #define U8W(p) ((uint8_t*)(p))
 JJ_API int jj_multi_varbase_mul(jj_multi* m, size_t n, const void* scalars, const void* points, void* out64) {
   if (!m || !host_args(m, {scalars, points, out64}, n)) return JJ_ERR_INVALID;
+  (void)hipSetDevice(m->ctx[0]->device);
+  MultiPin pin; pin.add(scalars, 32 * n); pin.add(points, 64 * n); pin.add(out64, 64 * n);
   return multi_run(m, n, [&](jj_ctx* c, int, size_t lo, size_t hi) { return jj_varbase_mul(c, hi - lo, U8(scalars) + 32 * lo, U8(points) + 64 * lo, U8W(out64) + 64 * lo); });
 }
 JJ_API int jj_multi_fixedbase_table_create(jj_multi* m, const void* base64, int window_bits, jj_mtable** out) {
@@ -1286,10 +1381,14 @@ JJ_API int jj_multi_fixedbase_table_destroy(jj_multi* m, jj_mtable* mt) {
 }
 JJ_API int jj_multi_fixedbase_mul(jj_multi* m, const jj_mtable* mt, size_t n, const void* scalars, void* out64) {
   if (!m || !mt || mt->t.size() != m->ctx.size() || !host_args(m, {scalars, out64}, n)) return JJ_ERR_INVALID;
+  (void)hipSetDevice(m->ctx[0]->device);
+  MultiPin pin; pin.add(scalars, 32 * n); pin.add(out64, 64 * n);
   return multi_run(m, n, [&](jj_ctx* c, int g, size_t lo, size_t hi) { return jj_fixedbase_mul(c, mt->t[g], hi - lo, U8(scalars) + 32 * lo, U8W(out64) + 64 * lo); });
 }
 JJ_API int jj_multi_decompress(jj_multi* m, size_t n, const void* in32, unsigned flags, void* out64, uint8_t* ok) {
   if (!m || !host_args(m, {in32, out64, ok}, n)) return JJ_ERR_INVALID;
+  (void)hipSetDevice(m->ctx[0]->device);
+  MultiPin pin; pin.add(in32, 32 * n); pin.add(out64, 64 * n); pin.add(ok, n);
   return multi_run(m, n, [&](jj_ctx* c, int, size_t lo, size_t hi) { return jj_decompress(c, hi - lo, U8(in32) + 32 * lo, flags, U8W(out64) + 64 * lo, ok + lo); });
 }
 // Last step of an MSM that was cut across devices or processes: the sum of the `count` partial points (canonical
@@ -1309,12 +1408,26 @@ JJ_API int jj_msm_fold_partials(size_t count, const void* parts64, void* out64) 
   jjhost::to_affine64((uint8_t*)out64, total);
   return JJ_OK;
 }
-// sum over ALL terms: every device reduces its shard to one affine point, the partial points are added on the host
+// sum over ALL terms: every device reduces its shard to a record of partial window sums (one per pass of 2^24 terms), the
+// records of all devices meet in ONE host tail: window sums, one Horner chain per window layout, one inversion
 JJ_API int jj_multi_msm(jj_multi* m, size_t n, const void* scalars, const void* points, void* out64) {
   if (!m || !out64 || is_device_ptr(out64) || !host_args(m, {scalars, points}, n)) return JJ_ERR_INVALID;
   const int G = (int)m->ctx.size();
-  std::vector<uint8_t> part((size_t)G * 64);
-  const int rc = multi_run(m, n, [&](jj_ctx* c, int g, size_t lo, size_t hi) { return jj_msm(c, hi - lo, U8(scalars) + 32 * lo, U8(points) + 64 * lo, &part[(size_t)g * 64]); });
+  const size_t PASS = (size_t)1 << m->ctx[0]->msm_pass_log2;
+  std::vector<size_t> first(G + 1, 0);
+  for (int g = 0; g < G; g++) { size_t lo, hi; shard_of(n, g, G, &lo, &hi); first[g + 1] = first[g] + std::max<size_t>(1, (hi - lo + PASS - 1) / PASS); }
+  std::vector<uint8_t> recs(first[G] * (size_t)JJ_MSM_PARTIAL_BYTES);
+  (void)hipSetDevice(m->ctx[0]->device);
+  MultiPin pin; pin.add(scalars, 32 * n); pin.add(points, 64 * n);
+  const int rc = multi_run(m, n, [&](jj_ctx* c, int g, size_t lo, size_t hi) {
+    size_t k = first[g];
+    if (lo == hi) return jj_msm_partial(c, 0, nullptr, nullptr, 0, 1, &recs[k * JJ_MSM_PARTIAL_BYTES]);
+    for (size_t p = lo; p < hi; p += PASS, k++) {
+      const int r2 = jj_msm_partial(c, std::min(PASS, hi - p), U8(scalars) + 32 * p, U8(points) + 64 * p, 0, 1, &recs[k * JJ_MSM_PARTIAL_BYTES]);
+      if (r2) return r2;
+    }
+    return (int)JJ_OK;
+  });
   if (rc) return rc;
-  return jj_msm_fold_partials((size_t)G, part.data(), out64);
+  return jj_msm_combine(first[G], recs.data(), out64);
 }

@@ -1,7 +1,8 @@
-// Host-side finish of a Pippenger MSM: the Horner combination of the W window sums (c doublings per window, about
-// 250 dependent point doublings in all) and the final conversion to affine.  That chain has no parallelism a GPU
-// could use -- a lone wavefront issues one VALU instruction per ~9 cycles, 1.5 us per doubling -- while a host core
-// does the same doubling in ~0.2 us, so the 16-17 window sums (160 bytes each) are copied back and finished here.
+// Host-side finish of an MSM: the device leaves a RECORD of partial window sums (jj_msm_kernels.h: 64-byte header, then for
+// every window up to eight canonical 160-byte extended points); here the partial sums of each window are added -- over one record
+// or over the records of several passes, devices or ranks --, the windows are combined by Horner (252 dependent point doublings in
+// all) and the result is converted to affine.  That chain has no parallelism a GPU could use -- a lone wavefront issues one
+// multiply-add per ~9 cycles, 1.5 us per doubling -- while a host core does the same doubling in ~0.15 us.
 //
 // Plain 4 x 64-bit Montgomery arithmetic (radix 2^256) modulo q; every constant is derived at start-up from q and
 // d = -10240/10241, nothing is tabulated.  Point formulas: the same completed-point formulas as jj_curve.h
@@ -79,11 +80,18 @@ static inline const Consts& consts() {
   }();
   return K;
 }
-// a^(q-2): plain square-and-multiply, once per MSM
+// a^(q-2) with 4-bit fixed windows (252 squarings + 63 + 14 multiplications), once per MSM
 static inline Fe pow_q2(const Fe& a, const Fe& one) {
-  uint64_t e[4] = {QL[0] - 2, QL[1], QL[2], QL[3]};
-  Fe r = one;
-  for (int i = 254; i >= 0; i--) { r = sqr(r); if ((e[i >> 6] >> (i & 63)) & 1) r = mul(r, a); }
+  const uint64_t e[4] = {QL[0] - 2, QL[1], QL[2], QL[3]};
+  Fe tab[16];
+  tab[0] = one; tab[1] = a;
+  for (int i = 2; i < 16; i++) tab[i] = mul(tab[i - 1], a);
+  Fe r = tab[(e[3] >> 60) & 15];
+  for (int i = 62; i >= 0; i--) {
+    r = sqr(sqr(sqr(sqr(r))));
+    const unsigned nib = (unsigned)(e[i >> 4] >> (4 * (i & 15))) & 15u;
+    if (nib) r = mul(r, tab[nib]);
+  }
   return r;
 }
 static inline Fe from_canon(const uint8_t* p) { Fe a; memcpy(a.l, p, 32); return mul(a, consts().r2); }
@@ -107,14 +115,70 @@ static inline Ext ext_from_canon160(const uint8_t* p) {
   return Ext{from_canon(p), from_canon(p + 32), from_canon(p + 64), from_canon(p + 96), from_canon(p + 128)};
 }
 static inline Ext identity() { const Fe z = {{0, 0, 0, 0}}; return Ext{z, consts().one, consts().one, z, z}; }
-// sum_w 2^(c w) * win[w]; win = W canonical 160-byte extended points
-static inline Ext horner(const uint8_t* win160, int W, int c) {
-  Ext acc = ext_from_canon160(win160 + (size_t)160 * (W - 1));
-  for (int w = W - 2; w >= 0; w--) {
-    for (int i = 0; i < c; i++) acc = point_dbl(acc);
-    acc = point_add(acc, ext_from_canon160(win160 + (size_t)160 * w));
+// ---- records of partial window sums (layout: jj_msm_kernels.h MSM_REC_*; include/jubjub_hip.h jj_msm_partial)
+constexpr uint32_t REC_MAGIC = 0x504D4A4Au;       // "JJMP"
+constexpr int REC_HDR_BYTES = 64, REC_BLK = 8, REC_MAX_W = 64;
+constexpr size_t REC_MAX_BYTES = REC_HDR_BYTES + (size_t)REC_MAX_W * REC_BLK * 160;
+// width of window w when W windows tile the 253 bits of a recoded scalar: 253 = W c + r, the r low windows are one bit wider
+static inline int win_width(int W, int w) { const int c = 253 / W, r = 253 % W; return c + (w < r ? 1 : 0); }
+struct RecHeader { uint32_t magic, version, W, nblk; uint64_t mask, n; };
+static inline bool rec_header(const uint8_t* rec, RecHeader* h) {
+  memcpy(h, rec, sizeof(RecHeader));
+  return h->magic == REC_MAGIC && h->version == 1 && h->W >= 1 && h->W <= (uint32_t)REC_MAX_W && h->nblk >= 1 && h->nblk <= (uint32_t)REC_BLK;
+}
+static inline size_t rec_bytes(int W, int nblk) { return REC_HDR_BYTES + (size_t)W * nblk * 160; }
+// Window sums of one window layout; records with the same W (every pass / rank that saw the same number of terms) meet here
+// window by window, so that the Horner chain runs once for all of them.
+struct WindowSums {
+  int W = 0;
+  bool have[REC_MAX_W];
+  Ext sum[REC_MAX_W];
+  bool add_record(const uint8_t* rec) {
+    RecHeader h;
+    if (!rec_header(rec, &h)) return false;
+    if (W == 0) { W = (int)h.W; for (int w = 0; w < W; w++) have[w] = false; }
+    if ((int)h.W != W) return false;
+    for (int w = 0; w < W; w++) {
+      if (!((h.mask >> w) & 1)) continue;
+      for (uint32_t b = 0; b < h.nblk; b++) {
+        const Ext p = ext_from_canon160(rec + REC_HDR_BYTES + ((size_t)w * h.nblk + b) * 160);
+        if (have[w]) sum[w] = point_add(sum[w], p); else { sum[w] = p; have[w] = true; }
+      }
+    }
+    return true;
   }
-  return acc;
+  // sum_w 2^(start_w) S_w by Horner from the top window: width(w) doublings, then + S_w
+  Ext finish() const {
+    Ext acc = identity();
+    bool any = false;
+    for (int w = W - 1; w >= 0; w--) {
+      if (any) for (int i = 0; i < win_width(W, w); i++) acc = point_dbl(acc);
+      if (have[w]) { acc = any ? point_add(acc, sum[w]) : sum[w]; any = true; }
+    }
+    return acc;
+  }
+};
+// `count` records, `stride` bytes apart (any mix of window layouts) -> the sum of the MSMs they stand for; false on a bad header
+static inline bool combine_records(const uint8_t* recs, size_t count, size_t stride, Ext* out) {
+  WindowSums groups[4];
+  int ng = 0;
+  Ext extra = identity();
+  for (size_t i = 0; i < count; i++) {
+    const uint8_t* rec = recs + i * stride;
+    RecHeader h;
+    if (!rec_header(rec, &h)) return false;
+    int g = 0;
+    while (g < ng && groups[g].W != (int)h.W) g++;
+    if (g == ng) {
+      if (ng == 4) { WindowSums one; if (!one.add_record(rec)) return false; extra = point_add(extra, one.finish()); continue; }   // a fifth layout: on its own
+      ng++;
+    }
+    if (!groups[g].add_record(rec)) return false;
+  }
+  Ext total = extra;
+  for (int g = 0; g < ng; g++) total = point_add(total, groups[g].finish());
+  *out = total;
+  return true;
 }
 // canonical (u, v), 64 bytes
 static inline void to_affine64(uint8_t* out, const Ext& p) {

@@ -419,13 +419,17 @@ __global__ void __launch_bounds__(256, JJ_VB_MINWAVES) k_varbase(size_t n, const
   size_t i;
   #pragma unroll 1
   while (next_wave_units(cursor, n, i)) {
-    if (i >= n) continue;                                     // ragged last wave: idle lanes wait for their neighbours
-    u32 k[8];
-    load8(k, scalars, SHARED ? (size_t)0 : i);
-    const Affine P = load_affine(points, i);
-    const Ext r = varbase_windowed(P, k, slot);
-    ext.put(0, i, r.u); ext.put(1, i, r.v); ext.put(2, i, r.z);
-    if constexpr (FIVE) { ext.put(3, i, Fq::carry(r.t1)); ext.put(4, i, Fq::carry(r.t2)); }
+    // ragged last wave: the idle lanes skip the body and meet their neighbours at the end of it, so the cursor draw at the
+    // top of the loop is always executed by the whole wave (no early `continue`: that would rely on the compiler
+    // reconverging the wave at the loop header)
+    if (i < n) {
+      u32 k[8];
+      load8(k, scalars, SHARED ? (size_t)0 : i);
+      const Affine P = load_affine(points, i);
+      const Ext r = varbase_windowed(P, k, slot);
+      ext.put(0, i, r.u); ext.put(1, i, r.v); ext.put(2, i, r.z);
+      if constexpr (FIVE) { ext.put(3, i, Fq::carry(r.t1)); ext.put(4, i, Fq::carry(r.t2)); }
+    }
   }
 }
 // the reference's exact ladder; writes all five projective coordinates canonically (160 B)
@@ -733,349 +737,8 @@ __global__ void __launch_bounds__(256) k_and_bytes(size_t n, uint8_t* a, const u
   a[i] = a[i] & (negate_b ? (b[i] ^ 1) : b[i]);
 }
 
-// ------------------------------------------------------------------------------------------------ K7: Pippenger MSM
-// sum_i k_i P_i with signed c-bit windows (c <= 16): k' = k + sum_{w<W-1} 2^(cw+c-1); digit_w = window_w(k') - 2^(c-1)
-// (top window unsigned).  Pipeline of one pass (host side: msm_pippenger in jj_engine.hip):
-//   k_msm_convert                      recoded scalars (word-major) + affine-Niels entries, one 128-byte line per term
-//   sort by (window, |digit|)          two passes for c >= 13 (k_msm_part_hist / _scatter / _sort), one pass below
-//                                      (k_msm_hist / _scatter with the whole window's histogram in LDS); no global atomics
-//   accumulate                         length-sorted segments, one per lane (k_seg_*, k_msm_accumulate_seg, k_msm_merge), or
-//                                      fixed chunks + fix-up for small inputs (k_msm_accumulate, k_msm_fixup); 7M mixed additions
-//   k_msm_bucket_reduce                running sums per chunk of buckets, on quads of lanes
-//   k_msm_window_fold                  one workgroup per window: tree over the chunk results -> W window sums (160 B each)
-//   host                               Horner over the window sums, one inversion (jj_host_tail.h)
-// The group element equals the reference's `sum of p * k` (src/lib.rs:183-193, 873-879); only +-P (exact on the whole
-// curve) is used.
-struct MsmParams {
-  int c;            // window bits
-  int W;            // number of windows
-  u32 B;            // buckets per window = 2^(c-1)
-  u32 recode[8];    // sum_{w<W-1} 2^(cw+c-1)
-};
-// signed digit of window w: returns |d| (0 = skip) and sign
-static JJ_DEV u32 msm_digit_raw(u32 raw, const MsmParams& mp, int w, u32& neg) {
-  if (w == mp.W - 1) { neg = 0; return raw; }
-  const int d = (int)raw - (int)mp.B;
-  neg = d < 0 ? 1u : 0u;
-  return (u32)(d < 0 ? -d : d);
-}
-// the recoded scalars k' are kept word-major (kp[j * n + i] = word j of term i) so that a block working on one
-// window reads just the one or two words that hold it, coalesced
-static JJ_DEV u32 msm_digit_wm(const u32* kp, size_t n, size_t i, const MsmParams& mp, int w, u32& neg) {
-  const int bit = mp.c * w, wi = bit >> 5, sh = bit & 31;
-  u64 both = kp[(size_t)wi * n + i];
-  if (sh + mp.c > 32 && wi < 7) both |= (u64)kp[(size_t)(wi + 1) * n + i] << 32;
-  return msm_digit_raw((u32)(both >> sh) & ((1u << mp.c) - 1u), mp, w, neg);
-}
-// recode scalars (k' = k + recode, word-major) and convert points to affine-Niels AoS (27 words in a 128-byte record)
-// The two input pointers come through a two-entry device array (io[0] = scalars, io[1] = points) so that a captured graph of
-// the whole MSM does not depend on where the caller's batch lives.
-// what: 1 = scalars, 2 = points, 3 = both (the two halves are independent: the sort needs only the scalars, so the host may run
-// the point half on a second stream beside it)
-__global__ void __launch_bounds__(256) k_msm_convert(size_t n, const void* const* io, MsmParams mp, u32* kprime, u32* niels, int what) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const void* scalars = io[0];
-  const void* points = io[1];
-  if (what & 1) {
-    u32 k[8];
-    load8(k, scalars, i);
-    k[7] &= 0x0fffffffu;
-    u64 cy = 0;
-    _Pragma("unroll") for (int j = 0; j < 8; j++) { const u64 t = (u64)k[j] + mp.recode[j] + cy; kprime[(size_t)j * n + i] = (u32)t; cy = t >> 32; }
-  }
-  if (!(what & 2)) return;
-  const ANiels t = Curve::to_niels(load_affine(points, i));
-  u32 wv[ANIELS_WORDS];
-  _Pragma("unroll") for (int l = 0; l < NL; l++) { wv[l] = t.vpu.l[l]; wv[NL + l] = t.vmu.l[l]; wv[2 * NL + l] = t.t2d.l[l]; }
-  wv[27] = 0;
-  uint4* e = reinterpret_cast<uint4*>(niels + i * GNIELS_WORDS);
-  _Pragma("unroll") for (int v = 0; v < ANIELS_WORDS / 4; v++) e[v] = make_uint4(wv[4 * v], wv[4 * v + 1], wv[4 * v + 2], wv[4 * v + 3]);
-}
-// Counting sort of the (term, window) pairs by (window, |digit|), tile by tile with the histogram of one window
-// (B <= 32768 counters) in LDS: block (t, w) handles terms [t*tile, (t+1)*tile) of window w.
-//   k_msm_hist       : LDS histogram of the tile -> tcount[w][t][b]                      (LDS atomics only)
-//   k_msm_tile_totals: count[w][b] = sum_t tcount[w][t][b]; the usual scan turns count into bucket offsets
-//   k_msm_tile_bases : tcount[w][t][b] <- offset[w][b] + sum_{t' < t} tcount[w][t'][b]   (first slot of the tile's run)
-//   k_msm_scatter    : LDS cursors start at the tile bases; every term takes the next slot of its bucket
-// No global atomics, and the global traffic is coalesced except the final 4-byte index writes.
-constexpr int MSM_SORT_THREADS = 1024;
-#ifndef JJ_MSM_SORT_UNROLL
-#define JJ_MSM_SORT_UNROLL 4
-#endif
-constexpr int MSM_SORT_UNROLL = JJ_MSM_SORT_UNROLL;   // terms per thread and trip: that many loads / LDS atomics / stores in flight
-__global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_hist(size_t n, size_t tile, MsmParams mp, const u32* kp, u32* tcount) {
-  extern __shared__ u32 msm_lds[];
-  const int w = blockIdx.y;
-  for (u32 b = threadIdx.x; b < mp.B; b += MSM_SORT_THREADS) msm_lds[b] = 0;
-  __syncthreads();
-  const size_t lo = (size_t)blockIdx.x * tile, hi = lo + tile < n ? lo + tile : n;
-  for (size_t i0 = lo + threadIdx.x; i0 < hi; i0 += MSM_SORT_UNROLL * MSM_SORT_THREADS) {
-    u32 a[MSM_SORT_UNROLL];
-    _Pragma("unroll") for (int q = 0; q < MSM_SORT_UNROLL; q++) {
-      const size_t i = i0 + (size_t)q * MSM_SORT_THREADS;
-      u32 neg; a[q] = i < hi ? msm_digit_wm(kp, n, i, mp, w, neg) : 0u;
-    }
-    _Pragma("unroll") for (int q = 0; q < MSM_SORT_UNROLL; q++) if (a[q]) atomicAdd(&msm_lds[a[q] - 1], 1u);
-  }
-  __syncthreads();
-  u32* out = tcount + ((size_t)w * gridDim.x + blockIdx.x) * mp.B;
-  for (u32 b = threadIdx.x; b < mp.B; b += MSM_SORT_THREADS) out[b] = msm_lds[b];
-}
-__global__ void __launch_bounds__(256) k_msm_tile_totals(size_t nb, u32 B, u32 ntiles, const u32* tcount, u32* count) {
-  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= nb) return;
-  const size_t w = g / B, b = g % B;
-  u32 s = 0;
-  for (u32 t = 0; t < ntiles; t++) s += tcount[(w * ntiles + t) * B + b];
-  count[g] = s;
-}
-__global__ void __launch_bounds__(256) k_msm_tile_bases(size_t nb, u32 B, u32 ntiles, const u32* offset, u32* tcount) {
-  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= nb) return;
-  const size_t w = g / B, b = g % B;
-  u32 run = offset[g];
-  for (u32 t = 0; t < ntiles; t++) { u32* p = tcount + (w * ntiles + t) * B + b; const u32 c = *p; *p = run; run += c; }
-}
-// idx[slot] = term | sign<<31
-// XCD-aware block mapping: workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  All tiles of one window
-// write into that window's 4-byte index segment, so a window is given to ONE XCD (window = 8 * (j / ntiles) + xcd): the
-// partial-line writes of its tiles then meet in the same L2 and leave it as full lines.
-__global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_scatter(size_t n, size_t tile, u32 ntiles, MsmParams mp, const u32* kp, const u32* tbase, u32* idx) {
-  extern __shared__ u32 msm_lds[];
-  const u32 xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
-  const int w = (int)((j / ntiles) * 8 + xcd);
-  const u32 tile_id = j % ntiles;
-  if (w >= mp.W) return;
-  const u32* base = tbase + ((size_t)w * ntiles + tile_id) * mp.B;
-  for (u32 b = threadIdx.x; b < mp.B; b += MSM_SORT_THREADS) msm_lds[b] = base[b];
-  __syncthreads();
-  const size_t lo = (size_t)tile_id * tile, hi = lo + tile < n ? lo + tile : n;
-  // MSM_SORT_UNROLL terms per trip: the digit loads, then the LDS cursor updates, then the stores (more memory operations in flight)
-  for (size_t i0 = lo + threadIdx.x; i0 < hi; i0 += MSM_SORT_UNROLL * MSM_SORT_THREADS) {
-    u32 a[MSM_SORT_UNROLL], neg[MSM_SORT_UNROLL];
-    _Pragma("unroll") for (int q = 0; q < MSM_SORT_UNROLL; q++) {
-      const size_t i = i0 + (size_t)q * MSM_SORT_THREADS;
-      a[q] = 0; neg[q] = 0;
-      if (i < hi) a[q] = msm_digit_wm(kp, n, i, mp, w, neg[q]);
-    }
-    u32 slot[MSM_SORT_UNROLL];
-    _Pragma("unroll") for (int q = 0; q < MSM_SORT_UNROLL; q++) slot[q] = a[q] ? atomicAdd(&msm_lds[a[q] - 1], 1u) : 0u;
-    _Pragma("unroll") for (int q = 0; q < MSM_SORT_UNROLL; q++) if (a[q]) idx[slot[q]] = (u32)(i0 + (size_t)q * MSM_SORT_THREADS) | (neg[q] << 31);
-  }
-}
-// Two-pass sort for wide windows (c >= 13, i.e. >= 4096 buckets per window).  The single-pass scatter above ends in one 4-byte
-// store per entry into a 4 MB index segment shared by all tiles of the window: every store opens its own cache line and most
-// lines leave L2 partially written.  Here the bucket index is split into a coarse bin (bits 8 and up, <= 128 bins per window) and its
-// low 8 bits:
-//   k_msm_part_hist    : block (tile, window): entries per coarse bin -> tc[window][bin][tile]           (one small scan follows)
-//   k_msm_part_scatter : the same block writes (term | sign << 31) and the low 8 bits into its run of every bin: 128 open lines
-//                        per block, each filled front to back by one CU
-//   k_msm_part_sort    : block (window, bin): counts the 256 low values, writes the bucket offsets of its bin (the offsets of
-//                        the whole sort: no global scan over the buckets), orders the bin in LDS and copies it out coalesced
-// A bin larger than the LDS stage (skewed scalars) is scattered directly; its stores still stay within the one block.
-constexpr int MSM_LO_BITS = 8;
-// low bits of window w's bucket index: 8, except that the short top window (values <= 2^(252 - c (W-1)), recoding carry included)
-// is split so that it still spreads over the window's B / 256 coarse bins
-static JJ_DEV int msm_lo_bits(const MsmParams& mp, int w) {
-  if (w != mp.W - 1) return MSM_LO_BITS;
-  const int lo = (252 - mp.c * (mp.W - 1)) - (mp.c - 1 - MSM_LO_BITS);
-  return lo < 0 ? 0 : (lo > MSM_LO_BITS ? MSM_LO_BITS : lo);
-}
-#ifndef JJ_MSM_P2_THREADS
-#define JJ_MSM_P2_THREADS 512
-#endif
-constexpr int MSM_P2_THREADS = JJ_MSM_P2_THREADS;
-constexpr u32 MSM_P2_CAP = 12288;     // entries staged in LDS (48 KB): 1.5 x the mean bin of a 2^20-term, 16-bit-window pass
-__global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_part_hist(size_t n, size_t tile, MsmParams mp, const u32* kp, u32* tc) {
-  __shared__ u32 h[(MSM_SORT_THREADS / 64) * 128];          // one histogram per wave: fewer same-address collisions
-  const int w = blockIdx.y;
-  const u32 HB = mp.B >> MSM_LO_BITS, wave = threadIdx.x >> 6;
-  const int lo_w = msm_lo_bits(mp, w);
-  for (u32 b = threadIdx.x; b < (MSM_SORT_THREADS / 64) * HB; b += MSM_SORT_THREADS) h[b] = 0;
-  __syncthreads();
-  const size_t lo = (size_t)blockIdx.x * tile, hi = lo + tile < n ? lo + tile : n;
-  for (size_t i0 = lo + threadIdx.x; i0 < hi; i0 += MSM_SORT_UNROLL * MSM_SORT_THREADS) {
-    u32 a[MSM_SORT_UNROLL];
-    _Pragma("unroll") for (int q = 0; q < MSM_SORT_UNROLL; q++) {
-      const size_t i = i0 + (size_t)q * MSM_SORT_THREADS;
-      u32 neg; a[q] = i < hi ? msm_digit_wm(kp, n, i, mp, w, neg) : 0u;
-    }
-    _Pragma("unroll") for (int q = 0; q < MSM_SORT_UNROLL; q++) if (a[q]) atomicAdd(&h[wave * HB + ((a[q] - 1) >> lo_w)], 1u);
-  }
-  __syncthreads();
-  for (u32 b = threadIdx.x; b < HB; b += MSM_SORT_THREADS) {
-    u32 s = 0;
-    for (u32 v = 0; v < MSM_SORT_THREADS / 64; v++) s += h[v * HB + b];
-    tc[((size_t)w * HB + b) * gridDim.x + blockIdx.x] = s;
-  }
-}
-// tile of at most MSM_P1_TILE terms: ranks from one LDS atomic per entry, the tile ordered by bin in LDS, then copied out run by run
-// (consecutive stage slots of one bin are consecutive in rec / lo8: a wave's store touches a few lines instead of 64)
-constexpr u32 MSM_P1_TILE = 8192;
-constexpr int MSM_P1_PER = MSM_P1_TILE / MSM_SORT_THREADS;
-__global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_part_scatter(size_t n, size_t tile, MsmParams mp, const u32* kp, const u32* tc, u32* rec, uint8_t* lo8) {
-  __shared__ u32 cnt[128], delta[128], live_s;
-  __shared__ u32 st_rec[MSM_P1_TILE];
-  __shared__ uint8_t st_lo[MSM_P1_TILE], st_bin[MSM_P1_TILE];
-  const int w = blockIdx.y;
-  const u32 HB = mp.B >> MSM_LO_BITS, tid = threadIdx.x;
-  const int lo_w = msm_lo_bits(mp, w);
-  if (tid < 128) cnt[tid] = 0;
-  __syncthreads();
-  const size_t lo = (size_t)blockIdx.x * tile, hi = lo + tile < n ? lo + tile : n;
-  u32 a[MSM_P1_PER], neg[MSM_P1_PER], rank[MSM_P1_PER];
-  _Pragma("unroll") for (int q = 0; q < MSM_P1_PER; q++) {
-    const size_t i = lo + tid + (size_t)q * MSM_SORT_THREADS;
-    a[q] = 0; neg[q] = 0;
-    if (i < hi) a[q] = msm_digit_wm(kp, n, i, mp, w, neg[q]);
-  }
-  _Pragma("unroll") for (int q = 0; q < MSM_P1_PER; q++) rank[q] = a[q] ? atomicAdd(&cnt[(a[q] - 1) >> lo_w], 1u) : 0u;
-  __syncthreads();
-  if (tid < 64) {                        // exclusive scan of the (at most 128) bin counts: two per lane
-    const u32 v0 = cnt[2 * tid], v1 = cnt[2 * tid + 1], s = v0 + v1;
-    u32 inc = s;
-    _Pragma("unroll") for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, d, 64); if ((int)tid >= d) inc += o; }
-    const u32 l0 = inc - s, l1 = l0 + v0;
-    cnt[2 * tid] = l0; cnt[2 * tid + 1] = l1;
-    // first global slot of this tile's run of the bin, minus the run's first stage slot
-    delta[2 * tid] = (2 * tid < HB ? tc[((size_t)w * HB + 2 * tid) * gridDim.x + blockIdx.x] : 0u) - l0;
-    delta[2 * tid + 1] = (2 * tid + 1 < HB ? tc[((size_t)w * HB + 2 * tid + 1) * gridDim.x + blockIdx.x] : 0u) - l1;
-    if (tid == 63) live_s = inc;         // entries of the tile (terms with a nonzero digit)
-  }
-  __syncthreads();
-  _Pragma("unroll") for (int q = 0; q < MSM_P1_PER; q++) if (a[q]) {
-    const u32 bin = (a[q] - 1) >> lo_w, slot = cnt[bin] + rank[q];
-    st_rec[slot] = (u32)(lo + tid + (size_t)q * MSM_SORT_THREADS) | (neg[q] << 31);
-    st_lo[slot] = (uint8_t)((a[q] - 1) & ((1u << lo_w) - 1u));
-    st_bin[slot] = (uint8_t)bin;
-  }
-  __syncthreads();
-  const u32 live = live_s;
-  for (u32 j = tid; j < live; j += MSM_SORT_THREADS) {
-    const u32 g = j + delta[st_bin[j]];
-    rec[g] = st_rec[j];
-    lo8[g] = st_lo[j];
-  }
-}
-// tc holds the scanned counts: tc[bin * ntiles] is the first entry of bin (= window * HB + coarse bin), tc[nbins * ntiles] the entry count
-__global__ void __launch_bounds__(MSM_P2_THREADS) k_msm_part_sort(MsmParams mp, u32 ntiles, const u32* tc, const u32* rec, const uint8_t* lo8, u32* idx, u32* offset) {
-  constexpr u32 NLO = 1u << MSM_LO_BITS;
-  constexpr int PER = MSM_P2_CAP / MSM_P2_THREADS;
-  __shared__ u32 cnt[NLO];
-  __shared__ u32 stage[MSM_P2_CAP];
-  const u32 bin = blockIdx.x, nbins = gridDim.x, tid = threadIdx.x;
-  const u32 gb = tc[(size_t)bin * ntiles], ge = tc[(size_t)(bin + 1) * ntiles];
-  const bool staged = ge - gb <= MSM_P2_CAP;
-  const u32 HB = mp.B >> MSM_LO_BITS, w = bin / HB, coarse = bin % HB;
-  const int lo_w = msm_lo_bits(mp, (int)w);
-  const u32 nlo = 1u << lo_w;
-  const size_t wbase = (size_t)w * mp.B;
-  if (tid < NLO) cnt[tid] = 0;
-  __syncthreads();
-  // the usual bin fits the stage: every thread takes its PER entries in one round of loads, keeps them in registers and draws
-  // their ranks within the low value from the counting atomics (one LDS atomic per entry)
-  u32 r[PER], b[PER], rank[PER];
-  if (staged) {
-    _Pragma("unroll") for (int q = 0; q < PER; q++) {
-      const u32 i = gb + tid + (u32)q * MSM_P2_THREADS;
-      b[q] = i < ge ? (u32)lo8[i] : ~0u;
-      r[q] = i < ge ? rec[i] : 0u;
-    }
-    _Pragma("unroll") for (int q = 0; q < PER; q++) rank[q] = b[q] != ~0u ? atomicAdd(&cnt[b[q]], 1u) : 0u;
-  } else {
-    // oversized bin (the short top window, skewed scalars): the same rounds of PER loads per thread, stage by stage
-    for (u32 base = gb; base < ge; base += MSM_P2_CAP) {
-      _Pragma("unroll") for (int q = 0; q < PER; q++) { const u32 i = base + tid + (u32)q * MSM_P2_THREADS; b[q] = i < ge ? (u32)lo8[i] : ~0u; }
-      _Pragma("unroll") for (int q = 0; q < PER; q++) if (b[q] != ~0u) atomicAdd(&cnt[b[q]], 1u);
-    }
-  }
-  __syncthreads();
-  // exclusive scan of the 256 counters by the first wave: four per lane, then a shuffle scan over the lane sums
-  if (tid < 64) {
-    u32 v[NLO / 64], s = 0;
-    _Pragma("unroll") for (u32 j = 0; j < NLO / 64; j++) { v[j] = cnt[tid * (NLO / 64) + j]; s += v[j]; }
-    u32 inc = s;
-    _Pragma("unroll") for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, d, 64); if ((int)tid >= d) inc += o; }
-    u32 run = inc - s;
-    _Pragma("unroll") for (u32 j = 0; j < NLO / 64; j++) {
-      const u32 k = tid * (NLO / 64) + j;
-      cnt[k] = run;                                                    // first slot of the low value, relative to gb
-      if (k < nlo) offset[wbase + ((size_t)coarse << lo_w) + k] = gb + run;
-      run += v[j];
-    }
-    // buckets of a short top window above its coarse bins are empty
-    if (coarse + 1 == HB) for (u32 k = (HB << lo_w) + tid; k < mp.B; k += 64) offset[wbase + k] = ge;
-    if (bin + 1 == nbins && tid == 0) offset[(size_t)mp.W * mp.B] = ge;
-  }
-  __syncthreads();
-  if (staged) {
-    _Pragma("unroll") for (int q = 0; q < PER; q++) if (b[q] != ~0u) stage[cnt[b[q]] + rank[q]] = r[q];
-    __syncthreads();
-    for (u32 j = tid; j < ge - gb; j += MSM_P2_THREADS) idx[gb + j] = stage[j];
-  } else {
-    for (u32 base = gb; base < ge; base += MSM_P2_CAP) {
-      _Pragma("unroll") for (int q = 0; q < PER; q++) {
-        const u32 i = base + tid + (u32)q * MSM_P2_THREADS;
-        b[q] = i < ge ? (u32)lo8[i] : ~0u;
-        r[q] = i < ge ? rec[i] : 0u;
-      }
-      _Pragma("unroll") for (int q = 0; q < PER; q++) rank[q] = b[q] != ~0u ? atomicAdd(&cnt[b[q]], 1u) : 0u;
-      _Pragma("unroll") for (int q = 0; q < PER; q++) if (b[q] != ~0u) idx[gb + rank[q]] = r[q];
-    }
-  }
-}
-// exclusive scan of `count` (m entries) into `offset` (m+1 entries), three small passes:
-// (1) per-block sums of SCAN_TILE entries, (2) one block scans the block sums, (3) per-block local scan + base.
-constexpr int SCAN_TILE = 2048;   // entries per 256-thread block (8 per thread)
-__global__ void __launch_bounds__(256) k_scan_block_sums(size_t m, const u32* count, u32* block_sum) {
-  __shared__ u32 red[256];
-  const size_t base = (size_t)blockIdx.x * SCAN_TILE;
-  u32 s = 0;
-  for (int j = threadIdx.x; j < SCAN_TILE; j += 256) { const size_t i = base + j; if (i < m) s += count[i]; }
-  red[threadIdx.x] = s;
-  __syncthreads();
-  for (int d = 128; d > 0; d >>= 1) { if ((int)threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d]; __syncthreads(); }
-  if (threadIdx.x == 0) block_sum[blockIdx.x] = red[0];
-}
-__global__ void __launch_bounds__(1024) k_scan_top(size_t nblocks, u32* block_sum, u32* total_out) {
-  __shared__ u32 part[1024];
-  const size_t per = (nblocks + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < nblocks ? lo + per : nblocks;
-  u32 s = 0;
-  for (size_t j = lo; j < hi; j++) s += block_sum[j];
-  part[threadIdx.x] = s;
-  __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {
-    const u32 v = (int)threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
-    __syncthreads();
-    part[threadIdx.x] += v;
-    __syncthreads();
-  }
-  u32 run = part[threadIdx.x] - s;
-  for (size_t j = lo; j < hi; j++) { const u32 c = block_sum[j]; block_sum[j] = run; run += c; }
-  if (threadIdx.x == 1023) *total_out = part[1023];
-}
-__global__ void __launch_bounds__(256) k_scan_apply(size_t m, const u32* count, const u32* block_base, u32* offset) {
-  __shared__ u32 part[256];
-  const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * (SCAN_TILE / 256);
-  u32 v[SCAN_TILE / 256]; u32 s = 0;
-  _Pragma("unroll") for (int j = 0; j < SCAN_TILE / 256; j++) { v[j] = (base + j < m) ? count[base + j] : 0u; s += v[j]; }
-  part[threadIdx.x] = s;
-  __syncthreads();
-  for (int d = 1; d < 256; d <<= 1) {
-    const u32 x = (int)threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
-    __syncthreads();
-    part[threadIdx.x] += x;
-    __syncthreads();
-  }
-  u32 run = block_base[blockIdx.x] + part[threadIdx.x] - s;
-  _Pragma("unroll") for (int j = 0; j < SCAN_TILE / 256; j++) { if (base + j < m) offset[base + j] = run; run += v[j]; }
-}
-// Balanced bucket accumulation: the sorted entry list (M entries, bucket-major) is cut into fixed chunks of
-// `chunk` entries, one lane per chunk, so every lane performs the same number of mixed additions whatever the
-// bucket-size distribution.  A run that starts at a bucket start is written to buckets[b]; the run a chunk
-// inherits from the previous chunk goes to head[t] and is merged by k_msm_fixup.
-constexpr int MSM_CHUNK_MIN = 16;   // entries per lane; the host scales it with n so that the narrow top window keeps few heads per bucket
+// ------------------------------------------------------------------------------------------------ point records + quad-lane point operations
+// (shared by the small-batch ladder and the MSM kernels in jj_msm_kernels.h)
 static JJ_DEV void soa_put_ext(const SoA& s, size_t i, const Ext& e);
 // Buckets and chunk heads are written from divergent code (a lane flushes whenever its run of equal buckets ends), so
 // they are kept as one 192-byte record per point (U V Z T1 T2, 9 limbs each, 3 words of padding): 12 16-byte
@@ -1097,175 +760,6 @@ static JJ_DEV Ext aos_ext(const ExtAoS& a, size_t i) {
   Ext e;
   _Pragma("unroll") for (int l = 0; l < NL; l++) { e.u.l[l] = w[l]; e.v.l[l] = w[NL + l]; e.z.l[l] = w[2 * NL + l]; e.t1.l[l] = w[3 * NL + l]; e.t2.l[l] = w[4 * NL + l]; }
   return e;
-}
-__global__ void __launch_bounds__(256) k_msm_accumulate(size_t nb, u32 chunk, const u32* offset, const u32* idx, const u32* niels, ExtAoS buckets, ExtAoS head) {
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t M = offset[nb];                              // number of non-zero digits
-  const size_t start = t * chunk;
-  if (start >= M) return;
-  const size_t end = start + chunk < M ? start + chunk : M;
-  // bucket containing `start`: largest b with offset[b] <= start
-  size_t lo = 0, hi = nb;
-  while (hi - lo > 1) { const size_t mid = (lo + hi) >> 1; if (offset[mid] <= start) lo = mid; else hi = mid; }
-  size_t b = lo;
-  u32 nxt = offset[b + 1];
-  while (nxt <= start) { b++; nxt = offset[b + 1]; }     // skip empty buckets that share the offset
-  bool inherited = offset[b] < start;                       // first run continues a bucket begun in an earlier chunk
-  Ext acc = Curve::identity();
-  bool any = false;
-  #pragma unroll 1
-  for (size_t pos = start; pos < end; pos++) {
-    if (pos >= nxt) {
-      if (inherited) { aos_put_ext(head, t, acc); inherited = false; } else if (any) aos_put_ext(buckets, b, acc);
-      acc = Curve::identity(); any = false;
-      do { b++; nxt = offset[b + 1]; } while (nxt <= pos);
-    }
-    const u32 e = idx[pos];
-    const ANiels p = lds_aniels(niels + (size_t)(e & 0x7fffffffu) * GNIELS_WORDS);
-    acc = Curve::add_signed<true>(acc, p, (e >> 31) ? ~0u : 0u);
-    any = true;
-  }
-  if (inherited) aos_put_ext(head, t, acc); else aos_put_ext(buckets, b, acc);
-}
-// buckets[b] (+)= heads of the chunks that continue bucket b; empty buckets become the identity.
-// A bucket with more than FIXUP_SERIAL_MAX heads (heavily skewed digit distribution: repeated scalars, or a narrow
-// top window) is appended to a work list instead and reduced by a whole workgroup in k_msm_fixup_big; if the list is
-// full the lane falls back to the serial loop (slow but correct).
-constexpr u32 FIXUP_SERIAL_MAX = 32;
-constexpr u32 FIXUP_BIG_MAX = 2048;       // work-list capacity
-constexpr u32 FIXUP_BIG_QUADS = 64;       // quads (of 4 lanes) per big bucket
-struct BigBucket { u32 bucket, t_first, t_last, pad; };
-static JJ_DEV Ext soa_ext(const SoA& s, size_t i);
-static JJ_DEV Ext quad_add_ext(const Ext& p, const Ext& q, u32 role);
-// one quad of lanes per bucket (the chain of head additions is latency-bound: quad_add_ext is ~2.4x shorter than the per-lane addition)
-__global__ void __launch_bounds__(256) k_msm_fixup(size_t nb, u32 chunk, const u32* offset, ExtAoS buckets, ExtAoS head, u32* big_count, BigBucket* big) {
-  const size_t b = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
-  const u32 role = threadIdx.x & 3u;
-  if (b >= nb) return;
-  const u32 lo = offset[b], hi = offset[b + 1];
-  if (lo == hi) { if (role == 0) aos_put_ext(buckets, b, Curve::identity()); return; }
-  const size_t t_first = lo / chunk + 1, t_last = (hi - 1) / chunk;
-  if (t_first > t_last) return;
-  if (t_last - t_first + 1 > FIXUP_SERIAL_MAX) {
-    u32 slot = role == 0 ? atomicAdd(big_count, 1u) : 0u;
-    slot = (u32)__shfl((int)slot, (int)(threadIdx.x & 60u), 64);          // the quad leader's slot
-    if (slot < FIXUP_BIG_MAX) {
-      if (role == 0) { big[slot].bucket = (u32)b; big[slot].t_first = (u32)t_first; big[slot].t_last = (u32)t_last; big[slot].pad = 0; }
-      return;
-    }
-  }
-  Ext acc = aos_ext(buckets, b);   // the bucket's own first run (written by the chunk that contains offset[b])
-  #pragma unroll 1
-  for (size_t t = t_first; t <= t_last; t++) acc = quad_add_ext(acc, aos_ext(head, t), role);
-  if (role == 0) aos_put_ext(buckets, b, acc);
-}
-// ---- Segment-sorted accumulation (default).  Every non-empty bucket is cut into segments of at most P entries, the
-// segments are counting-sorted by length (longest first), and each lane adds up one segment: lanes of a wave run the
-// same number of iterations, no lane ever switches buckets inside its loop, and a bucket with a single segment (the
-// common case) is finished by its lane.  Buckets with several segments (narrow top window, repeated scalars) get their
-// extra segments as `head` partials that k_msm_merge (few) or k_msm_fixup_big (many) folds in.
-#ifndef JJ_MSM_ACC_MINBLOCKS
-#define JJ_MSM_ACC_MINBLOCKS 1        // resident 256-thread blocks per CU the accumulate kernel is compiled for: 1 = no register cap (137 VGPRs,
-#endif                                // 3 waves per SIMD); capping at 128 (4 waves) changes nothing, 96 (5 waves) spills (profiles/r2_msm_acc_occupancy.txt)
-constexpr int SEG_PMAX = 1024;
-struct Seg { u32 start, len, dst, pad; };            // dst: bucket index, or 0x80000000 | head index
-struct MergeItem { u32 bucket, h0, k, pad; };         // buckets[bucket] += head[h0 .. h0 + k)
-// pass 1: per-block histogram of segment lengths, key = P - len (longer first); empty buckets become the identity
-__global__ void __launch_bounds__(256) k_seg_hist(size_t nb, u32 per_tile, u32 P, const u32* offset, ExtAoS buckets, u32* bh) {
-  __shared__ u32 hist[SEG_PMAX + 1];
-  for (u32 k = threadIdx.x; k <= P; k += 256) hist[k] = 0;
-  __syncthreads();
-  const size_t base = (size_t)blockIdx.x * per_tile;
-  for (u32 j = threadIdx.x; j < per_tile; j += 256) {
-    const size_t b = base + j;
-    if (b >= nb) break;
-    const u32 c = offset[b + 1] - offset[b];
-    if (c == 0) { aos_put_ext(buckets, b, Curve::identity()); continue; }
-    const u32 full = c / P, rem = c - full * P;
-    if (full) atomicAdd(&hist[0], full);
-    if (rem) atomicAdd(&hist[P - rem], 1u);
-  }
-  __syncthreads();
-  for (u32 k = threadIdx.x; k <= P; k += 256) bh[(size_t)blockIdx.x * (P + 1) + k] = hist[k];
-}
-// between the passes, one workgroup: per-key totals over the blocks, exclusive scan over the keys, and each block's
-// first slot per key written back into bh (the whole matrix, tiles x (P+1) <= 16384 words, sits in LDS)
-__global__ void __launch_bounds__(1024) k_seg_plan(u32 tiles, u32 P, u32* bh, u32* total_out) {
-  extern __shared__ u32 msm_lds[];
-  u32* m = msm_lds;                       // [tiles][P+1]
-  u32* off = msm_lds + (size_t)tiles * (P + 1);   // [P+2]
-  const u32 K = P + 1;
-  for (u32 i = threadIdx.x; i < tiles * K; i += 1024) m[i] = bh[i];
-  __syncthreads();
-  for (u32 k = threadIdx.x; k < K; k += 1024) { u32 s = 0; for (u32 t = 0; t < tiles; t++) s += m[t * K + k]; off[k] = s; }
-  __syncthreads();
-  if (threadIdx.x == 0) { u32 run = 0; for (u32 k = 0; k < K; k++) { const u32 c = off[k]; off[k] = run; run += c; } *total_out = run; }
-  __syncthreads();
-  for (u32 k = threadIdx.x; k < K; k += 1024) { u32 run = off[k]; for (u32 t = 0; t < tiles; t++) { const u32 c = m[t * K + k]; m[t * K + k] = run; run += c; } }
-  __syncthreads();
-  for (u32 i = threadIdx.x; i < tiles * K; i += 1024) bh[i] = m[i];
-}
-// pass 2: bh now holds each block's first slot per key; every segment takes the next slot of its key
-__global__ void __launch_bounds__(256) k_seg_scatter(size_t nb, u32 per_tile, u32 P, const u32* offset, const u32* bh, Seg* seg,
-                                                      u32* counters /* [0] heads, [1] merge items, [2] big buckets */, MergeItem* merge, BigBucket* big) {
-  __shared__ u32 cur[SEG_PMAX + 1];
-  for (u32 k = threadIdx.x; k <= P; k += 256) cur[k] = bh[(size_t)blockIdx.x * (P + 1) + k];
-  __syncthreads();
-  const size_t base = (size_t)blockIdx.x * per_tile;
-  for (u32 j = threadIdx.x; j < per_tile; j += 256) {
-    const size_t b = base + j;
-    if (b >= nb) break;
-    const u32 lo = offset[b], c = offset[b + 1] - lo;
-    if (c == 0) continue;
-    const u32 full = c / P, rem = c - full * P, nseg = full + (rem ? 1u : 0u);
-    u32 h0 = 0;
-    if (nseg > 1) {
-      h0 = atomicAdd(&counters[0], nseg - 1);
-      bool listed = false;
-      if (nseg - 1 > FIXUP_SERIAL_MAX) {
-        const u32 slot = atomicAdd(&counters[2], 1u);
-        if (slot < FIXUP_BIG_MAX) { big[slot].bucket = (u32)b; big[slot].t_first = h0; big[slot].t_last = h0 + nseg - 2; big[slot].pad = 0; listed = true; }
-      }
-      if (!listed) { const u32 m = atomicAdd(&counters[1], 1u); merge[m].bucket = (u32)b; merge[m].h0 = h0; merge[m].k = nseg - 1; merge[m].pad = 0; }
-    }
-    for (u32 sgi = 0; sgi < nseg; sgi++) {
-      const u32 len = sgi < full ? P : rem;
-      const u32 slot = atomicAdd(&cur[P - len], 1u);
-      Seg sg; sg.start = lo + sgi * P; sg.len = len; sg.dst = sgi == 0 ? (u32)b : (0x80000000u | (h0 + sgi - 1)); sg.pad = 0;
-      seg[slot] = sg;
-    }
-  }
-}
-__global__ void __launch_bounds__(256, JJ_MSM_ACC_MINBLOCKS) k_msm_accumulate_seg(const u32* nseg_total, const Seg* seg, const u32* idx, const u32* niels, ExtAoS buckets, ExtAoS head) {
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= *nseg_total) return;
-  const Seg sg = seg[t];
-  Ext acc = Curve::identity();
-  const u32* ip = idx + sg.start;
-  // software pipeline: the entry of term k+1 (a dependent 4-byte index load, then a random 128-byte gather) is in flight
-  // while term k is added
-  u32 e = ip[0];
-  ANiels p = lds_aniels(niels + (size_t)(e & 0x7fffffffu) * GNIELS_WORDS);
-  u32 e_next = sg.len > 1 ? ip[1] : e;
-  #pragma unroll 1
-  for (u32 k = 0; k < sg.len; k++) {
-    const ANiels p_next = lds_aniels(niels + (size_t)(e_next & 0x7fffffffu) * GNIELS_WORDS);
-    const u32 e_next2 = k + 2 < sg.len ? ip[k + 2] : e_next;
-    acc = Curve::add_signed<true>(acc, p, (e >> 31) ? ~0u : 0u);
-    e = e_next; p = p_next; e_next = e_next2;
-  }
-  if (sg.dst >> 31) aos_put_ext(head, sg.dst & 0x7fffffffu, acc); else aos_put_ext(buckets, sg.dst, acc);
-}
-// buckets with a few extra segments: one quad of lanes folds them in
-__global__ void __launch_bounds__(256) k_msm_merge(const u32* counters, const MergeItem* merge, ExtAoS buckets, ExtAoS head) {
-  const size_t m = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
-  const u32 role = threadIdx.x & 3u;
-  if (m >= counters[1]) return;
-  const MergeItem it = merge[m];
-  Ext acc = aos_ext(buckets, it.bucket);
-  #pragma unroll 1
-  for (u32 j = 0; j < it.k; j++) acc = quad_add_ext(acc, aos_ext(head, (size_t)it.h0 + j), role);
-  if (role == 0) aos_put_ext(buckets, it.bucket, acc);
 }
 static JJ_DEV Ext soa_ext(const SoA& s, size_t i) { Ext e; e.u = s.get(0, i); e.v = s.get(1, i); e.z = s.get(2, i); e.t1 = s.get(3, i); e.t2 = s.get(4, i); return e; }
 static JJ_DEV void soa_put_ext(const SoA& s, size_t i, const Ext& e) {
@@ -1432,99 +926,8 @@ __global__ void __launch_bounds__(256) k_varbase_quad(size_t n, const void* scal
 }
 
 // One workgroup per listed big bucket: FIXUP_BIG_QUADS quads each fold a strided share of the bucket's heads into a
-// partial (stage 0, written to `partial[item][quad]`); stage 1 (one quad per item) folds the partials into the bucket.
-__global__ void __launch_bounds__(256) k_msm_fixup_big(const u32* big_count, const BigBucket* big, ExtAoS buckets, ExtAoS head, SoA partial, int stage) {
-  u32 cnt = *big_count; if (cnt > FIXUP_BIG_MAX) cnt = FIXUP_BIG_MAX;
-  const u32 role = threadIdx.x & 3u, quad = threadIdx.x >> 2;
-  #pragma unroll 1
-  for (u32 item = blockIdx.x; item < cnt; item += gridDim.x) {     // usually cnt == 0: the launch is a no-op
-    const BigBucket bb = big[item];
-    if (stage == 0) {
-      Ext acc = Curve::identity();
-      #pragma unroll 1
-      for (size_t t = (size_t)bb.t_first + quad; t <= bb.t_last; t += FIXUP_BIG_QUADS) acc = quad_add_ext(acc, aos_ext(head, t), role);
-      if (role == 0) soa_put_ext(partial, (size_t)item * FIXUP_BIG_QUADS + quad, acc);
-    } else if (quad == 0) {
-      Ext acc = aos_ext(buckets, bb.bucket);
-      const u32 nh = bb.t_last - bb.t_first + 1, used = nh < FIXUP_BIG_QUADS ? nh : FIXUP_BIG_QUADS;
-      #pragma unroll 1
-      for (u32 q = 0; q < used; q++) acc = quad_add_ext(acc, soa_ext(partial, (size_t)item * FIXUP_BIG_QUADS + q), role);
-      if (role == 0) aos_put_ext(buckets, bb.bucket, acc);
-    }
-  }
-}
-// The reduction kernels below are short and latency-bound (few independent chains), so each logical thread is a
-// quad of lanes running quad_dbl / quad_add_ext.
-// chunk of L consecutive buckets j0..j0+L-1 of one window (bucket j holds digit value j+1):
-// sum (j+1) b_j = T + j0 * S with T = sum (j-j0+1) b_j (running sums) and S = sum b_j.
-__global__ void __launch_bounds__(256) k_msm_bucket_reduce(size_t nchunks, u32 L, u32 B, int jbits, ExtAoS buckets, SoA out) {
-  const size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
-  const u32 role = threadIdx.x & 3u;
-  if (t >= nchunks) return;
-  const size_t first = t * L;               // global bucket index (window-major)
-  const u32 j0 = (u32)(first % B);          // index inside the window
-  // every point travels with T = t1*t2; T of the next bucket is the side product of the current addition
-  Ext running = Curve::identity(), total = Curve::identity();
-  Fe Tr = Fq::zero(), Tt = Fq::zero(), dummy;
-  Ext bk = aos_ext(buckets, first + L - 1);
-  Fe Tb = Fq::mul(bk.t1, bk.t2);                       // stored t1, t2 are carried
-  #pragma unroll 1
-  for (int j = (int)L - 1; j >= 0; j--) {
-    const Ext nx = aos_ext(buckets, first + (j > 0 ? j - 1 : 0));
-    Fe Tn;
-    running = quad_add_ext_t(running, Tr, bk, Tb, role, Tr, nx.t1, nx.t2, Tn);
-    total = quad_add_ext_t(total, Tt, running, Tr, role, Tt, Tr, Tr, dummy);
-    bk = nx; Tb = Tn;
-  }
-  // total += j0 * running   (j0 < B = 2^jbits).  j0 is a multiple of the chunk length L = 2^lb: double-and-add over the
-  // jbits - lb significant bits, then lb plain doublings (no additions for bits that are zero by construction)
-  const int lb = __ffs((int)L) - 1;
-  Ext m = Curve::identity();
-  Fe Tm = Fq::zero();
-  #pragma unroll 1
-  for (int bit = jbits - 1; bit >= lb; bit--) {
-    m = quad_dbl_t(m, role, Tm);
-    Ext sel = Curve::identity();
-    const u32 mask = ((j0 >> bit) & 1u) ? ~0u : 0u;
-    sel.u = Fq::select(sel.u, running.u, mask); sel.v = Fq::select(sel.v, running.v, mask); sel.z = Fq::select(sel.z, running.z, mask);
-    const Fe Ts = Fq::select(Fq::zero(), Tr, mask);
-    m = quad_add_ext_t(m, Tm, sel, Ts, role, Tm, Tr, Tr, dummy);
-  }
-  #pragma unroll 1
-  for (int bit = 0; bit < lb; bit++) m = quad_dbl_t(m, role, Tm);
-  total = quad_add_ext_t(total, Tt, m, Tm, role, Tt, Tr, Tr, dummy);
-  if (role == 0) soa_put_ext(out, t, total);
-}
-// Window sums: one workgroup per window folds the window's chunk results (per_window of them, contiguous in `in`) into one
-// point.  Each of the 256 quads first adds up its strided share, then a binary tree over the quads runs through LDS: depth
-// per_window / 256 + 8 additions in one launch (a fan-in-4 fold per launch took 4 additions and one launch per level).  The sum
-// leaves as a canonical 160-byte extended point for the host-side Horner (jj_host_tail.h).
-__global__ void __launch_bounds__(1024) k_msm_window_fold(size_t per_window, SoA in, void* out160) {
-  __shared__ u32 st[256 * EXT_AOS_WORDS];
-  const ExtAoS lds{st};
-  const u32 role = threadIdx.x & 3u, quad = threadIdx.x >> 2;
-  const size_t base = (size_t)blockIdx.x * per_window;
-  const u32 live = per_window < 256 ? (u32)per_window : 256u;          // quads that hold a partial sum
-  Ext acc = quad < live ? soa_ext(in, base + quad) : Curve::identity();
-  #pragma unroll 1
-  for (size_t j = (size_t)quad + 256; j < per_window; j += 256) acc = quad_add_ext(acc, soa_ext(in, base + j), role);
-  #pragma unroll 1
-  for (u32 s = 128; s > 0; s >>= 1) {
-    if (quad >= s && quad < 2 * s && quad < live && role == 0) aos_put_ext(lds, quad, acc);     // upper half hands over
-    __syncthreads();
-    if (quad < s && quad + s < live) acc = quad_add_ext(acc, aos_ext(lds, quad + s), role);
-    __syncthreads();
-  }
-  if (quad == 0 && role == 0) {
-    const size_t i = blockIdx.x;
-    u32 w[8];
-    Fq::to_words(w, acc.u); store8(out160, 5 * i, w);
-    Fq::to_words(w, acc.v); store8(out160, 5 * i + 1, w);
-    Fq::to_words(w, acc.z); store8(out160, 5 * i + 2, w);
-    Fq::to_words(w, Fq::carry(acc.t1)); store8(out160, 5 * i + 3, w);
-    Fq::to_words(w, Fq::carry(acc.t2)); store8(out160, 5 * i + 4, w);
-  }
-}
+
+#include "jj_msm_kernels.h"
 
 // ------------------------------------------------------------------------------------------------ synthetic inputs
 // Counter-based generator of SURVEY 8(d): word j of unit i is splitmix64(seed + i * stride + j), so any index can be

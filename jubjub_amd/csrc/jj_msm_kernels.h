@@ -1,0 +1,767 @@
+// Multi-scalar multiplication kernels (gfx950).  Included by jj_kernels.h after the point records and the quad-lane point
+// operations; launched by msm_* in jj_engine.hip.
+//
+// sum_i k_i P_i  (reference semantics: the iterator `Sum` of `p * k`, src/lib.rs:183-193 + 873-879; the reference has no MSM
+// algorithm of its own).  Only +-P is used, so the result is exact on the whole curve (cofactor-8 points, scalars >= r).
+//
+// Windows.  k (252 bits) is recoded as k' = k + sum_w 2^(start_w + width_w - 1) over all windows but the top one; W windows
+// TILE the 253 bits of k' EXACTLY (253 = W c + r: the r low windows are c + 1 bits wide, the others c bits), so there is never a
+// short top window whose few buckets would collect n entries each (round 2 needed c | 253, i.e. c = 11, for that).  Window w < W-1
+// holds the signed digit raw - 2^(width-1) in [-2^(width-1), 2^(width-1)); the top window is unsigned and, because k < 2^252, at
+// most 2^(width-1): every window needs 2^(width-1) buckets (bucket |d| - 1), B = 2^(c_max - 1) slots per window are allocated.
+//
+// A pass may own a SUBSET of the windows (w0 + s * wstride, s < Ws: the by-window partition of a multi-GPU MSM);
+// everything below is indexed by the slot s, only the digit extraction uses the window w itself.
+//
+// Two algorithms produce the same output record (per window at most MSM_REC_BLK partial sums, canonical 160-byte extended points;
+// the host adds them, runs Horner over the windows and inverts once: jj_host_tail.h):
+//   small batches (<= ~2^14 terms)   k_msm_small_tables + k_msm_small_sum: per-term table {0..8}P, 64 windows of 3-4 bits, every
+//                                    window is a tree sum over the terms' table entries on quads of lanes -- two launches
+//   Pippenger                        k_msm_convert; counting sort by (window, |digit|) without global atomics, one pass with the
+//                                    window's histogram in LDS (k_msm_hist / _plan / _scatter) or two passes for >= 4096 buckets
+//                                    per window (k_msm_part_hist / _plan / _scatter / _sort); bucket accumulation over fixed
+//                                    chunks (k_msm_accumulate + k_msm_fixup) or length-sorted segments (k_seg_*,
+//                                    k_msm_accumulate_seg, k_msm_merge); k_msm_fixup_big; k_msm_reduce_fold
+#pragma once
+// (inside namespace jj: this file is included from the middle of jj_kernels.h)
+
+constexpr int MSM_REC_BLK = 8;                    // at most this many partial sums per window in the output record
+constexpr int MSM_TREE_QUADS = 128;               // quads of the 512-thread workgroups that end in a quad_tree_sum (158 VGPRs: two waves per SIMD)
+constexpr int MSM_REC_HDR_WORDS = 16;             // 64-byte header: magic, version, W, nblk, window mask (2 words), n (2 words)
+constexpr u32 MSM_REC_MAGIC = 0x504D4A4Au;        // "JJMP"
+
+struct MsmParams {
+  int W;                  // windows tiling bits [0, 253) of k'
+  int c, r;               // 253 = W c + r: windows w < r are c + 1 bits wide, the others c bits
+  int Ws, w0, wstride;    // windows of this pass: w0 + s * wstride for s < Ws
+  u32 B;                  // bucket slots per window = 2^(cmax - 1), cmax = c + (r > 0)
+  u32 recode[8];          // sum over w < W - 1 of 2^(start_w + width_w - 1)
+};
+static JJ_DEV int msm_win_start(const MsmParams& mp, int w) { return w < mp.r ? w * (mp.c + 1) : mp.r * (mp.c + 1) + (w - mp.r) * mp.c; }
+static JJ_DEV int msm_win_width(const MsmParams& mp, int w) { return mp.c + (w < mp.r ? 1 : 0); }
+static JJ_DEV int msm_slot_window(const MsmParams& mp, int s) { return mp.w0 + s * mp.wstride; }
+// signed digit of window w from its raw bits: returns |d| (0 = no contribution) and the sign
+static JJ_DEV u32 msm_digit_raw(u32 raw, const MsmParams& mp, int w, int width, u32& neg) {
+  if (w == mp.W - 1) { neg = 0; return raw; }
+  const int d = (int)raw - (int)(1u << (width - 1));
+  neg = d < 0 ? 1u : 0u;
+  return (u32)(d < 0 ? -d : d);
+}
+// the recoded scalars k' are kept word-major (kp[j * n + i] = word j of term i) so that a block working on one
+// window reads just the one or two words that hold it, coalesced
+static JJ_DEV u32 msm_digit_wm(const u32* kp, size_t n, size_t i, const MsmParams& mp, int w, u32& neg) {
+  const int bit = msm_win_start(mp, w), width = msm_win_width(mp, w), wi = bit >> 5, sh = bit & 31;
+  u64 both = kp[(size_t)wi * n + i];
+  if (sh + width > 32 && wi < 7) both |= (u64)kp[(size_t)(wi + 1) * n + i] << 32;
+  return msm_digit_raw((u32)(both >> sh) & ((1u << width) - 1u), mp, w, width, neg);
+}
+// the same from the eight words of one k' held in registers
+static JJ_DEV u32 msm_digit_reg(const u32 (&k)[8], const MsmParams& mp, int w, u32& neg) {
+  const int bit = msm_win_start(mp, w), width = msm_win_width(mp, w), wi = bit >> 5, sh = bit & 31;
+  u32 lo = k[0], hi = k[1];
+  _Pragma("unroll") for (int q = 1; q < 8; q++) { lo = (wi == q) ? k[q] : lo; hi = (wi == q) ? (q < 7 ? k[q + 1] : 0u) : hi; }
+  const u64 both = ((u64)hi << 32) | lo;
+  return msm_digit_raw((u32)(both >> sh) & ((1u << width) - 1u), mp, w, width, neg);
+}
+static JJ_DEV void msm_recode(u32 (&k)[8], const MsmParams& mp) {
+  k[7] &= 0x0fffffffu;
+  u64 cy = 0;
+  _Pragma("unroll") for (int j = 0; j < 8; j++) { const u64 t = (u64)k[j] + mp.recode[j] + cy; k[j] = (u32)t; cy = t >> 32; }
+}
+// header of the output record, written by one thread of the kernel that produces the window sums
+static JJ_DEV void msm_write_header(u32* hdr, const MsmParams& mp, u32 nblk, size_t n) {
+  u64 mask = 0;
+  for (int s = 0; s < mp.Ws; s++) mask |= 1ull << msm_slot_window(mp, s);
+  hdr[0] = MSM_REC_MAGIC; hdr[1] = 1u; hdr[2] = (u32)mp.W; hdr[3] = nblk;
+  hdr[4] = (u32)mask; hdr[5] = (u32)(mask >> 32); hdr[6] = (u32)n; hdr[7] = (u32)((u64)n >> 32);
+  for (int j = 8; j < MSM_REC_HDR_WORDS; j++) hdr[j] = 0;
+}
+// one partial window sum leaves as a canonical 160-byte extended point (U, V, Z, T1, T2)
+static JJ_DEV void msm_store_partial(void* points160, int w, u32 nblk, u32 blk, const Ext& acc) {
+  const size_t i = (size_t)w * nblk + blk;
+  u32 wd[8];
+  Fq::to_words(wd, acc.u); store8(points160, 5 * i, wd);
+  Fq::to_words(wd, acc.v); store8(points160, 5 * i + 1, wd);
+  Fq::to_words(wd, acc.z); store8(points160, 5 * i + 2, wd);
+  Fq::to_words(wd, Fq::carry(acc.t1)); store8(points160, 5 * i + 3, wd);
+  Fq::to_words(wd, Fq::carry(acc.t2)); store8(points160, 5 * i + 4, wd);
+}
+
+// ---- quad-lane tree over the MSM_TREE_QUADS quads of a 512-thread workgroup through LDS: every quad hands in a point and
+// T = t1 * t2; quad 0 ends up with the sum of the first `live` quads' points.  7 levels of three-round additions.
+// A point waits in LDS in the form the first multiplication round of the addition consumes, (V - U, V + U, T, Z): lane r of
+// the receiving quad reads coordinate r only (one indexed read, 9 words), which keeps the tree at ~100 VGPRs.
+constexpr int LDS_PT_WORDS = 4 * NL;     // 36 words = 144 B per waiting point
+static JJ_DEV void lds_put_pt(u32* st, u32 slot, const Ext& e, const Fe& T) {
+  const Fe vmu = Fq::sub(e.v, e.u), vpu = Fq::carry(Fq::add(e.v, e.u));
+  u32* p = st + (size_t)slot * LDS_PT_WORDS;
+  _Pragma("unroll") for (int l = 0; l < NL; l++) { p[l] = vmu.l[l]; p[NL + l] = vpu.l[l]; p[2 * NL + l] = T.l[l]; p[3 * NL + l] = e.z.l[l]; }
+}
+// p + q for q waiting in LDS; same rounds as quad_add_ext_t without the side product
+static JJ_DEV Ext quad_add_lds_t(const Ext& p, const Fe& Tp, const u32* st, u32 slot, u32 role, Fe& Tout) {
+  const u32* q = st + (size_t)slot * LDS_PT_WORDS + role * NL;
+  Fe qb;
+  _Pragma("unroll") for (int l = 0; l < NL; l++) qb.l[l] = q[l];
+  const Fe r1 = Fq::mul(role_select4(Fq::sub(p.v, p.u), Fq::add(p.v, p.u), Tp, p.z, role), qb);
+  const Fe a = quad_bcast<0>(r1), b = quad_bcast<1>(r1), tt = quad_bcast<2>(r1), zz = quad_bcast<3>(r1);
+  const Fe c = Fq::mul(tt, Fq::konst(FqP::D2));
+  return quad_add_finish(a, b, c, Fq::add(zz, zz), role, Tout);
+}
+static JJ_DEV void quad_tree_sum(u32* st, u32 quad, u32 role, u32 live, Ext& acc, Fe& T) {
+  #pragma unroll 1
+  for (u32 s = MSM_TREE_QUADS / 2; s > 0; s >>= 1) {
+    if (s >= live) continue;                                        // uniform over the workgroup: nothing to hand over at this level
+    if (quad >= s && quad < 2 * s && quad < live && role == 0) lds_put_pt(st, quad, acc, T);     // upper half hands over
+    __syncthreads();
+    if (quad < s && quad + s < live) acc = quad_add_lds_t(acc, T, st, quad + s, role, T);
+    __syncthreads();
+  }
+}
+
+// ================================================================================================ small batches
+// One quad of lanes per term builds the term's table {0 .. 8} P (extended-Niels, 144 B per entry, entry 0 = the identity so
+// that a zero digit is a plain table read) and stores the recoded scalar; then one workgroup per (window, block of terms) adds
+// up the entries the terms' digits select: every quad takes a strided share of the terms (two multiplication rounds per
+// addition), and the quads of a workgroup are folded through LDS.  With W = 64 the windows are 3 or 4 bits wide: digits in [-8, 8].
+constexpr int SM_W = 64;                 // windows of the small-batch layout (253 = 64 * 3 + 61: 61 windows of 4 bits, 3 of 3 bits)
+constexpr int SM_SLOTS = 9;              // table entries per term: multiples 0 .. 8
+__global__ void __launch_bounds__(256) k_msm_small_tables(size_t n, const void* scalars, const void* points, MsmParams mp, u32* tables, u32* kprime) {
+  const size_t q = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  const u32 role = threadIdx.x & 3u;
+  if (q >= n) return;                                       // whole quads leave together
+  u32 k[8];
+  load8(k, scalars, q);
+  msm_recode(k, mp);
+  if (role == 0) store8(kprime, q, k);
+  const Affine P = load_affine(points, q);
+  const ANiels pn = Curve::to_niels(P);
+  Ext cur = Curve::from_affine(P);
+  Fe T = Fq::mul(P.u, P.v);
+  u32* slot = tables + q * (size_t)(SM_SLOTS * ENIELS_WORDS);
+  ENiels en;
+  en.vpu = pn.vpu; en.vmu = pn.vmu; en.z2 = Fq::add(Fq::one(), Fq::one()); en.t2d = pn.t2d;
+  if (role == 0) { store_eniels(slot, Curve::eniels_identity()); store_eniels(slot + ENIELS_WORDS, en); }
+  #pragma unroll 1
+  for (int j = 2; j < SM_SLOTS; j++) {
+    cur = quad_add_aniels(cur, T, pn, role, T);
+    en.vpu = Fq::carry(Fq::add(cur.v, cur.u)); en.vmu = Fq::sub(cur.v, cur.u); en.z2 = Fq::add(cur.z, cur.z);
+    en.t2d = Fq::mul(T, Fq::konst(FqP::D2));
+    if (role == 0) store_eniels(slot + j * ENIELS_WORDS, en);
+  }
+}
+__global__ void __launch_bounds__(4 * MSM_TREE_QUADS) k_msm_small_sum(size_t n, MsmParams mp, u32 nblk, const u32* tables, const u32* kprime, u32* rec) {
+  __shared__ __attribute__((aligned(16))) u32 st[MSM_TREE_QUADS * LDS_PT_WORDS];
+  const u32 role = threadIdx.x & 3u, quad = threadIdx.x >> 2, blk = blockIdx.x;
+  const int w = msm_slot_window(mp, (int)blockIdx.y);
+  if (blk == 0 && blockIdx.y == 0 && threadIdx.x == 0) msm_write_header(rec, mp, nblk, n);
+  const size_t first = (size_t)blk * MSM_TREE_QUADS + quad, stride = (size_t)MSM_TREE_QUADS * nblk;
+  Ext acc = Curve::identity();
+  Fe T = Fq::zero();
+  // the entry of the quad's next term is fetched (index arithmetic on k', then one 144-byte line) while the current one is added
+  u32 kq[8];
+  ENiels e = Curve::eniels_identity();
+  u32 neg = 0;
+  if (first < n) {
+    load8(kq, kprime, first);
+    const u32 a = msm_digit_reg(kq, mp, w, neg);
+    e = load_eniels(tables + (first * SM_SLOTS + a) * (size_t)ENIELS_WORDS);
+  }
+  #pragma unroll 1
+  for (size_t i = first; i < n; i += stride) {
+    const ENiels cur = e;
+    const u32 cneg = neg;
+    const size_t nx = i + stride;
+    if (nx < n) {
+      load8(kq, kprime, nx);
+      const u32 a = msm_digit_reg(kq, mp, w, neg);
+      e = load_eniels(tables + (nx * SM_SLOTS + a) * (size_t)ENIELS_WORDS);
+    }
+    acc = quad_add_eniels(acc, T, cur, cneg, role, T);
+  }
+  const size_t base = (size_t)blk * MSM_TREE_QUADS;
+  const u32 live = base >= n ? 0u : (n - base < MSM_TREE_QUADS ? (u32)(n - base) : (u32)MSM_TREE_QUADS);      // quads of this block that hold a term
+  quad_tree_sum(st, quad, role, live, acc, T);
+  if (quad == 0 && role == 0) msm_store_partial(rec + MSM_REC_HDR_WORDS, w, nblk, blk, acc);   // identity when the block has no term
+}
+
+// ================================================================================================ Pippenger: conversion
+// recode scalars (k' word-major) and convert points to affine-Niels AoS (27 words in a 128-byte record)
+// what: 1 = scalars, 2 = points, 3 = both (the two halves are independent: the sort needs only the scalars, so the host may run
+// the point half on a second stream beside it)
+__global__ void __launch_bounds__(256) k_msm_convert(size_t n, const void* scalars, const void* points, MsmParams mp, u32* kprime, u32* niels, int what) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (what & 1) {
+    u32 k[8];
+    load8(k, scalars, i);
+    msm_recode(k, mp);
+    _Pragma("unroll") for (int j = 0; j < 8; j++) kprime[(size_t)j * n + i] = k[j];
+  }
+  if (!(what & 2)) return;
+  const ANiels t = Curve::to_niels(load_affine(points, i));
+  u32 wv[ANIELS_WORDS];
+  _Pragma("unroll") for (int l = 0; l < NL; l++) { wv[l] = t.vpu.l[l]; wv[NL + l] = t.vmu.l[l]; wv[2 * NL + l] = t.t2d.l[l]; }
+  wv[27] = 0;
+  uint4* e = reinterpret_cast<uint4*>(niels + i * GNIELS_WORDS);
+  _Pragma("unroll") for (int v = 0; v < ANIELS_WORDS / 4; v++) e[v] = make_uint4(wv[4 * v], wv[4 * v + 1], wv[4 * v + 2], wv[4 * v + 3]);
+}
+
+// ================================================================================================ Pippenger: counting sort
+// Entries of slot s live in [s n, (s + 1) n) of idx (every term contributes at most one entry per window), and
+// off[s (B + 1) + j] is the first entry of bucket j of slot s (j = B: the end of the slot's entries): the windows are independent,
+// no scan crosses a window.
+// One pass (B <= 4096), tile by tile with the histogram of one window in LDS: block (t, s) handles terms [t tile, (t+1) tile):
+//   k_msm_hist    : LDS histogram of the tile -> tcount[s][t][b]                                            (LDS atomics only)
+//   k_msm_plan    : one block per slot: bucket totals over the tiles, exclusive scan -> off, and tcount[s][t][b] <- first
+//                   slot of the tile's run of bucket b; block 0 also clears the fix-up counters of the pass
+//   k_msm_scatter : LDS cursors start at the tile bases; every term takes the next slot of its bucket
+constexpr int MSM_SORT_THREADS = 1024;
+#ifndef JJ_MSM_SORT_UNROLL
+#define JJ_MSM_SORT_UNROLL 4
+#endif
+constexpr int MSM_SORT_UNROLL = JJ_MSM_SORT_UNROLL;   // terms per thread and trip: that many loads / LDS atomics / stores in flight
+constexpr int MSM_COUNTERS = 8;                       // [0] heads, [1] merge items, [2] big buckets, [3] big-bucket blocks done
+__global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_hist(size_t n, size_t tile, MsmParams mp, const u32* kp, u32* tcount) {
+  extern __shared__ u32 msm_lds[];
+  const int w = msm_slot_window(mp, (int)blockIdx.y);
+  for (u32 b = threadIdx.x; b < mp.B; b += MSM_SORT_THREADS) msm_lds[b] = 0;
+  __syncthreads();
+  const size_t lo = (size_t)blockIdx.x * tile, hi = lo + tile < n ? lo + tile : n;
+  for (size_t i0 = lo + threadIdx.x; i0 < hi; i0 += MSM_SORT_UNROLL * MSM_SORT_THREADS) {
+    u32 a[MSM_SORT_UNROLL];
+    _Pragma("unroll") for (int q = 0; q < MSM_SORT_UNROLL; q++) {
+      const size_t i = i0 + (size_t)q * MSM_SORT_THREADS;
+      u32 neg; a[q] = i < hi ? msm_digit_wm(kp, n, i, mp, w, neg) : 0u;
+    }
+    _Pragma("unroll") for (int q = 0; q < MSM_SORT_UNROLL; q++) if (a[q]) atomicAdd(&msm_lds[a[q] - 1], 1u);
+  }
+  __syncthreads();
+  u32* out = tcount + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * mp.B;
+  for (u32 b = threadIdx.x; b < mp.B; b += MSM_SORT_THREADS) out[b] = msm_lds[b];
+}
+// exclusive scan of one value per thread over a 1024-thread workgroup (wave shuffles, then the 16 wave totals); returns the
+// thread's prefix, *total = the workgroup sum.  `part` is 17 words of LDS.
+static JJ_DEV u32 block_exclusive_scan_1024(u32 v, u32* part, u32* total) {
+  const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  u32 inc = v;
+  _Pragma("unroll") for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += o; }
+  if (lane == 63) part[wave] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0) { u32 run = 0; for (int k = 0; k < 16; k++) { const u32 c = part[k]; part[k] = run; run += c; } part[16] = run; }
+  __syncthreads();
+  const u32 r = part[wave] + inc - v;
+  *total = part[16];
+  __syncthreads();
+  return r;
+}
+constexpr int MSM_PLAN_PER = 4;      // buckets per thread of the plan kernel: B <= 4096
+__global__ void __launch_bounds__(1024) k_msm_plan(size_t n, u32 B, u32 ntiles, u32* tcount, u32* off, u32* counters) {
+  __shared__ u32 part[17];
+  const u32 s = blockIdx.x;
+  if (s == 0 && threadIdx.x < MSM_COUNTERS) counters[threadIdx.x] = 0;
+  u32* tc = tcount + (size_t)s * ntiles * B;
+  const u32 b0 = threadIdx.x * MSM_PLAN_PER;
+  u32 tot[MSM_PLAN_PER], sum = 0;
+  _Pragma("unroll") for (int j = 0; j < MSM_PLAN_PER; j++) {
+    tot[j] = 0;
+    if (b0 + j < B) for (u32 t = 0; t < ntiles; t++) tot[j] += tc[(size_t)t * B + b0 + j];
+    sum += tot[j];
+  }
+  u32 total;
+  u32 run = (u32)(s * n) + block_exclusive_scan_1024(sum, part, &total);
+  u32* o = off + (size_t)s * (B + 1);
+  _Pragma("unroll") for (int j = 0; j < MSM_PLAN_PER; j++) {
+    if (b0 + j >= B) break;
+    o[b0 + j] = run;
+    u32 r2 = run;
+    for (u32 t = 0; t < ntiles; t++) { u32* p = tc + (size_t)t * B + b0 + j; const u32 c = *p; *p = r2; r2 += c; }
+    run += tot[j];
+  }
+  if (threadIdx.x == 0) o[B] = (u32)(s * n) + total;
+}
+// idx[slot] = term | sign<<31
+// XCD-aware block mapping: workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  All tiles of one window
+// write into that window's 4-byte index segment, so a window is given to ONE XCD (slot = 8 * (j / ntiles) + xcd): the
+// partial-line writes of its tiles then meet in the same L2 and leave it as full lines.
+__global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_scatter(size_t n, size_t tile, u32 ntiles, MsmParams mp, const u32* kp, const u32* tbase, u32* idx) {
+  extern __shared__ u32 msm_lds[];
+  const u32 xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+  const int s = (int)((j / ntiles) * 8 + xcd);
+  const u32 tile_id = j % ntiles;
+  if (s >= mp.Ws) return;
+  const int w = msm_slot_window(mp, s);
+  const u32* base = tbase + ((size_t)s * ntiles + tile_id) * mp.B;
+  for (u32 b = threadIdx.x; b < mp.B; b += MSM_SORT_THREADS) msm_lds[b] = base[b];
+  __syncthreads();
+  const size_t lo = (size_t)tile_id * tile, hi = lo + tile < n ? lo + tile : n;
+  // MSM_SORT_UNROLL terms per trip: the digit loads, then the LDS cursor updates, then the stores (more memory operations in flight)
+  for (size_t i0 = lo + threadIdx.x; i0 < hi; i0 += MSM_SORT_UNROLL * MSM_SORT_THREADS) {
+    u32 a[MSM_SORT_UNROLL], neg[MSM_SORT_UNROLL];
+    _Pragma("unroll") for (int q = 0; q < MSM_SORT_UNROLL; q++) {
+      const size_t i = i0 + (size_t)q * MSM_SORT_THREADS;
+      a[q] = 0; neg[q] = 0;
+      if (i < hi) a[q] = msm_digit_wm(kp, n, i, mp, w, neg[q]);
+    }
+    u32 slot[MSM_SORT_UNROLL];
+    _Pragma("unroll") for (int q = 0; q < MSM_SORT_UNROLL; q++) slot[q] = a[q] ? atomicAdd(&msm_lds[a[q] - 1], 1u) : 0u;
+    _Pragma("unroll") for (int q = 0; q < MSM_SORT_UNROLL; q++) if (a[q]) idx[slot[q]] = (u32)(i0 + (size_t)q * MSM_SORT_THREADS) | (neg[q] << 31);
+  }
+}
+// Two-pass sort for wide windows (>= 4096 buckets per window).  The single-pass scatter above ends in one 4-byte store per
+// entry into an index segment shared by all tiles of the window: every store opens its own cache line and most lines leave L2
+// partially written.  Here the bucket index is split into a coarse bin (bits 8 and up, <= 128 bins per window) and its low 8 bits:
+//   k_msm_part_hist    : block (tile, slot): entries per coarse bin -> tc[slot][bin][tile]
+//   k_msm_part_plan    : one block per slot: exclusive scan over (bin, tile) -> first entry of every run; clears the counters
+//   k_msm_part_scatter : block (tile, slot) writes (term | sign << 31) and the low 8 bits into its run of every bin: 128 open
+//                        lines per block, each filled front to back by one CU
+//   k_msm_part_sort    : block (bin, slot): counts the 256 low values, writes the bucket offsets of its bin (the offsets of
+//                        the whole sort: no scan over the buckets), orders the bin in LDS and copies it out coalesced
+// A bin larger than the LDS stage (skewed scalars) is scattered directly; its stores still stay within the one block.
+constexpr int MSM_LO_BITS = 8;
+#ifndef JJ_MSM_P2_THREADS
+#define JJ_MSM_P2_THREADS 512
+#endif
+constexpr int MSM_P2_THREADS = JJ_MSM_P2_THREADS;
+constexpr u32 MSM_P2_CAP = 12288;     // entries staged in LDS (48 KB): 1.5 x the mean bin of a 2^20-term, 16-bit-window pass
+__global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_part_hist(size_t n, size_t tile, MsmParams mp, const u32* kp, u32* tc) {
+  __shared__ u32 h[(MSM_SORT_THREADS / 64) * 128];          // one histogram per wave: fewer same-address collisions
+  const int w = msm_slot_window(mp, (int)blockIdx.y);
+  const u32 HB = mp.B >> MSM_LO_BITS, wave = threadIdx.x >> 6;
+  for (u32 b = threadIdx.x; b < (MSM_SORT_THREADS / 64) * HB; b += MSM_SORT_THREADS) h[b] = 0;
+  __syncthreads();
+  const size_t lo = (size_t)blockIdx.x * tile, hi = lo + tile < n ? lo + tile : n;
+  for (size_t i0 = lo + threadIdx.x; i0 < hi; i0 += MSM_SORT_UNROLL * MSM_SORT_THREADS) {
+    u32 a[MSM_SORT_UNROLL];
+    _Pragma("unroll") for (int q = 0; q < MSM_SORT_UNROLL; q++) {
+      const size_t i = i0 + (size_t)q * MSM_SORT_THREADS;
+      u32 neg; a[q] = i < hi ? msm_digit_wm(kp, n, i, mp, w, neg) : 0u;
+    }
+    _Pragma("unroll") for (int q = 0; q < MSM_SORT_UNROLL; q++) if (a[q]) atomicAdd(&h[wave * HB + ((a[q] - 1) >> MSM_LO_BITS)], 1u);
+  }
+  __syncthreads();
+  for (u32 b = threadIdx.x; b < HB; b += MSM_SORT_THREADS) {
+    u32 sm = 0;
+    for (u32 v = 0; v < MSM_SORT_THREADS / 64; v++) sm += h[v * HB + b];
+    tc[((size_t)blockIdx.y * HB + b) * gridDim.x + blockIdx.x] = sm;
+  }
+}
+// tcs[s (m + 1) + k], m = HB ptiles: first entry of run k = bin * ptiles + tile of slot s; k = m: the end of the slot's entries
+__global__ void __launch_bounds__(1024) k_msm_part_plan(size_t n, u32 m, const u32* tc, u32* tcs, u32* counters) {
+  __shared__ u32 part[17];
+  const u32 s = blockIdx.x;
+  if (s == 0 && threadIdx.x < MSM_COUNTERS) counters[threadIdx.x] = 0;
+  const u32* in = tc + (size_t)s * m;
+  u32* out = tcs + (size_t)s * (m + 1);
+  const u32 per = (m + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < m ? lo + per : m;
+  u32 sum = 0;
+  for (u32 k = lo; k < hi; k++) sum += in[k];
+  u32 total;
+  u32 run = (u32)(s * n) + block_exclusive_scan_1024(lo < m ? sum : 0u, part, &total);
+  for (u32 k = lo; k < hi; k++) { out[k] = run; run += in[k]; }
+  if (threadIdx.x == 0) out[m] = (u32)(s * n) + total;
+}
+// tile of at most MSM_P1_TILE terms: ranks from one LDS atomic per entry, the tile ordered by bin in LDS, then copied out run by run
+// (consecutive stage slots of one bin are consecutive in rec / lo8: a wave's store touches a few lines instead of 64)
+constexpr u32 MSM_P1_TILE = 8192;
+constexpr int MSM_P1_PER = MSM_P1_TILE / MSM_SORT_THREADS;
+__global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_part_scatter(size_t n, size_t tile, MsmParams mp, const u32* kp, const u32* tcs, u32* rec, uint8_t* lo8) {
+  __shared__ u32 cnt[128], delta[128], live_s;
+  __shared__ u32 st_rec[MSM_P1_TILE];
+  __shared__ uint8_t st_lo[MSM_P1_TILE], st_bin[MSM_P1_TILE];
+  const int w = msm_slot_window(mp, (int)blockIdx.y);
+  const u32 HB = mp.B >> MSM_LO_BITS, tid = threadIdx.x;
+  const u32* run0 = tcs + (size_t)blockIdx.y * ((size_t)HB * gridDim.x + 1);
+  if (tid < 128) cnt[tid] = 0;
+  __syncthreads();
+  const size_t lo = (size_t)blockIdx.x * tile, hi = lo + tile < n ? lo + tile : n;
+  u32 a[MSM_P1_PER], neg[MSM_P1_PER], rank[MSM_P1_PER];
+  _Pragma("unroll") for (int q = 0; q < MSM_P1_PER; q++) {
+    const size_t i = lo + tid + (size_t)q * MSM_SORT_THREADS;
+    a[q] = 0; neg[q] = 0;
+    if (i < hi) a[q] = msm_digit_wm(kp, n, i, mp, w, neg[q]);
+  }
+  _Pragma("unroll") for (int q = 0; q < MSM_P1_PER; q++) rank[q] = a[q] ? atomicAdd(&cnt[(a[q] - 1) >> MSM_LO_BITS], 1u) : 0u;
+  __syncthreads();
+  if (tid < 64) {                        // exclusive scan of the (at most 128) bin counts: two per lane
+    const u32 v0 = cnt[2 * tid], v1 = cnt[2 * tid + 1], sm = v0 + v1;
+    u32 inc = sm;
+    _Pragma("unroll") for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, d, 64); if ((int)tid >= d) inc += o; }
+    const u32 l0 = inc - sm, l1 = l0 + v0;
+    cnt[2 * tid] = l0; cnt[2 * tid + 1] = l1;
+    // first global slot of this tile's run of the bin, minus the run's first stage slot
+    delta[2 * tid] = (2 * tid < HB ? run0[(size_t)(2 * tid) * gridDim.x + blockIdx.x] : 0u) - l0;
+    delta[2 * tid + 1] = (2 * tid + 1 < HB ? run0[(size_t)(2 * tid + 1) * gridDim.x + blockIdx.x] : 0u) - l1;
+    if (tid == 63) live_s = inc;         // entries of the tile (terms with a nonzero digit)
+  }
+  __syncthreads();
+  _Pragma("unroll") for (int q = 0; q < MSM_P1_PER; q++) if (a[q]) {
+    const u32 bin = (a[q] - 1) >> MSM_LO_BITS, slot = cnt[bin] + rank[q];
+    st_rec[slot] = (u32)(lo + tid + (size_t)q * MSM_SORT_THREADS) | (neg[q] << 31);
+    st_lo[slot] = (uint8_t)((a[q] - 1) & ((1u << MSM_LO_BITS) - 1u));
+    st_bin[slot] = (uint8_t)bin;
+  }
+  __syncthreads();
+  const u32 live = live_s;
+  for (u32 j = tid; j < live; j += MSM_SORT_THREADS) {
+    const u32 g = j + delta[st_bin[j]];
+    rec[g] = st_rec[j];
+    lo8[g] = st_lo[j];
+  }
+}
+__global__ void __launch_bounds__(MSM_P2_THREADS) k_msm_part_sort(MsmParams mp, u32 ptiles, const u32* tcs, const u32* rec, const uint8_t* lo8, u32* idx, u32* off) {
+  constexpr u32 NLO = 1u << MSM_LO_BITS;
+  constexpr int PER = MSM_P2_CAP / MSM_P2_THREADS;
+  __shared__ u32 cnt[NLO];
+  __shared__ u32 stage[MSM_P2_CAP];
+  const u32 coarse = blockIdx.x, HB = gridDim.x, s = blockIdx.y, tid = threadIdx.x;
+  const u32* run0 = tcs + (size_t)s * ((size_t)HB * ptiles + 1);
+  const u32 gb = run0[(size_t)coarse * ptiles], ge = run0[(size_t)(coarse + 1) * ptiles];
+  const bool staged = ge - gb <= MSM_P2_CAP;
+  u32* o = off + (size_t)s * (mp.B + 1);
+  if (tid < NLO) cnt[tid] = 0;
+  __syncthreads();
+  // the usual bin fits the stage: every thread takes its PER entries in one round of loads, keeps them in registers and draws
+  // their ranks within the low value from the counting atomics (one LDS atomic per entry)
+  u32 r[PER], b[PER], rank[PER];
+  if (staged) {
+    _Pragma("unroll") for (int q = 0; q < PER; q++) {
+      const u32 i = gb + tid + (u32)q * MSM_P2_THREADS;
+      b[q] = i < ge ? (u32)lo8[i] : ~0u;
+      r[q] = i < ge ? rec[i] : 0u;
+    }
+    _Pragma("unroll") for (int q = 0; q < PER; q++) rank[q] = b[q] != ~0u ? atomicAdd(&cnt[b[q]], 1u) : 0u;
+  } else {
+    // oversized bin (skewed scalars): the same rounds of PER loads per thread, stage by stage
+    for (u32 base = gb; base < ge; base += MSM_P2_CAP) {
+      _Pragma("unroll") for (int q = 0; q < PER; q++) { const u32 i = base + tid + (u32)q * MSM_P2_THREADS; b[q] = i < ge ? (u32)lo8[i] : ~0u; }
+      _Pragma("unroll") for (int q = 0; q < PER; q++) if (b[q] != ~0u) atomicAdd(&cnt[b[q]], 1u);
+    }
+  }
+  __syncthreads();
+  // exclusive scan of the 256 counters by the first wave: four per lane, then a shuffle scan over the lane sums
+  if (tid < 64) {
+    u32 v[NLO / 64], sm = 0;
+    _Pragma("unroll") for (u32 j = 0; j < NLO / 64; j++) { v[j] = cnt[tid * (NLO / 64) + j]; sm += v[j]; }
+    u32 inc = sm;
+    _Pragma("unroll") for (int d = 1; d < 64; d <<= 1) { const u32 x = __shfl_up(inc, d, 64); if ((int)tid >= d) inc += x; }
+    u32 run = inc - sm;
+    _Pragma("unroll") for (u32 j = 0; j < NLO / 64; j++) {
+      const u32 k = tid * (NLO / 64) + j;
+      cnt[k] = run;                                                    // first slot of the low value, relative to gb
+      o[((size_t)coarse << MSM_LO_BITS) + k] = gb + run;
+      run += v[j];
+    }
+    if (coarse + 1 == HB && tid == 0) o[mp.B] = ge;
+  }
+  __syncthreads();
+  if (staged) {
+    _Pragma("unroll") for (int q = 0; q < PER; q++) if (b[q] != ~0u) stage[cnt[b[q]] + rank[q]] = r[q];
+    __syncthreads();
+    for (u32 j = tid; j < ge - gb; j += MSM_P2_THREADS) idx[gb + j] = stage[j];
+  } else {
+    for (u32 base = gb; base < ge; base += MSM_P2_CAP) {
+      _Pragma("unroll") for (int q = 0; q < PER; q++) {
+        const u32 i = base + tid + (u32)q * MSM_P2_THREADS;
+        b[q] = i < ge ? (u32)lo8[i] : ~0u;
+        r[q] = i < ge ? rec[i] : 0u;
+      }
+      _Pragma("unroll") for (int q = 0; q < PER; q++) rank[q] = b[q] != ~0u ? atomicAdd(&cnt[b[q]], 1u) : 0u;
+      _Pragma("unroll") for (int q = 0; q < PER; q++) if (b[q] != ~0u) idx[gb + rank[q]] = r[q];
+    }
+  }
+}
+
+// ================================================================================================ Pippenger: bucket accumulation
+// Balanced accumulation over fixed chunks: the sorted entries of a slot are cut into chunks of `chunk` entries, one lane per
+// chunk, so every lane performs the same number of mixed additions whatever the bucket-size distribution.  A run that starts at a
+// bucket start is written to buckets[s B + b]; the run a chunk inherits from the previous chunk goes to head[s nchunk + t] and is
+// merged by k_msm_fixup.
+constexpr int MSM_CHUNK_MIN = 16;
+__global__ void __launch_bounds__(256) k_msm_accumulate(size_t n, u32 B, u32 chunk, u32 nchunk, const u32* off, const u32* idx, const u32* niels, ExtAoS buckets, ExtAoS head) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 s = blockIdx.y;
+  const u32* o = off + (size_t)s * (B + 1);
+  const size_t M = o[B];                                    // end of the slot's entries
+  const size_t start = (size_t)s * n + t * chunk;
+  if (t >= nchunk || start >= M) return;
+  const size_t end = start + chunk < M ? start + chunk : M;
+  // bucket containing `start`: largest b with o[b] <= start
+  size_t lo = 0, hi = B;
+  while (hi - lo > 1) { const size_t mid = (lo + hi) >> 1; if (o[mid] <= start) lo = mid; else hi = mid; }
+  size_t b = lo;
+  u32 nxt = o[b + 1];
+  while (nxt <= start) { b++; nxt = o[b + 1]; }          // skip empty buckets that share the offset
+  bool inherited = o[b] < start;                            // first run continues a bucket begun in an earlier chunk
+  Ext acc = Curve::identity();
+  bool any = false;
+  const size_t bk0 = (size_t)s * B, hd = (size_t)s * nchunk + t;
+  #pragma unroll 1
+  for (size_t pos = start; pos < end; pos++) {
+    if (pos >= nxt) {
+      if (inherited) { aos_put_ext(head, hd, acc); inherited = false; } else if (any) aos_put_ext(buckets, bk0 + b, acc);
+      acc = Curve::identity(); any = false;
+      do { b++; nxt = o[b + 1]; } while (nxt <= pos);
+    }
+    const u32 e = idx[pos];
+    const ANiels p = lds_aniels(niels + (size_t)(e & 0x7fffffffu) * GNIELS_WORDS);
+    acc = Curve::add_signed<true>(acc, p, (e >> 31) ? ~0u : 0u);
+    any = true;
+  }
+  if (inherited) aos_put_ext(head, hd, acc); else aos_put_ext(buckets, bk0 + b, acc);
+}
+// buckets[b] (+)= heads of the chunks that continue bucket b; empty buckets become the identity.
+// A bucket with more than FIXUP_SERIAL_MAX heads (heavily skewed digit distribution: repeated scalars) is appended to a work
+// list instead and reduced by a whole workgroup in k_msm_fixup_big; if the list is full the quad falls back to the serial loop
+// (slow but correct).  One quad of lanes per bucket; the next head is fetched while the current one is added.
+constexpr u32 FIXUP_SERIAL_MAX = 32;
+constexpr u32 FIXUP_BIG_MAX = 2048;       // work-list capacity
+constexpr u32 FIXUP_BIG_QUADS = 64;       // quads (of 4 lanes) per big bucket
+struct BigBucket { u32 bucket, t_first, t_last, pad; };
+__global__ void __launch_bounds__(256) k_msm_fixup(size_t n, u32 B, u32 Ws, u32 chunk, u32 nchunk, const u32* off, ExtAoS buckets, ExtAoS head, u32* counters, BigBucket* big) {
+  const size_t g = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  const u32 role = threadIdx.x & 3u;
+  if (g >= (size_t)Ws * B) return;
+  const u32 s = (u32)(g / B), j = (u32)(g % B);
+  const u32* o = off + (size_t)s * (B + 1);
+  const u32 base = (u32)(s * n), lo = o[j] - base, hi = o[j + 1] - base;
+  if (lo == hi) { if (role == 0) aos_put_ext(buckets, g, Curve::identity()); return; }
+  const size_t t_first = (size_t)s * nchunk + lo / chunk + 1, t_last = (size_t)s * nchunk + (hi - 1) / chunk;
+  if (t_first > t_last) return;
+  if (t_last - t_first + 1 > FIXUP_SERIAL_MAX) {
+    u32 slot = role == 0 ? atomicAdd(&counters[2], 1u) : 0u;
+    slot = (u32)__shfl((int)slot, (int)(threadIdx.x & 60u), 64);          // the quad leader's slot
+    if (slot < FIXUP_BIG_MAX) {
+      if (role == 0) { big[slot].bucket = (u32)g; big[slot].t_first = (u32)t_first; big[slot].t_last = (u32)t_last; big[slot].pad = 0; }
+      return;
+    }
+  }
+  Ext acc = aos_ext(buckets, g);   // the bucket's own first run (written by the chunk that contains its first entry)
+  Ext nx = aos_ext(head, t_first);
+  #pragma unroll 1
+  for (size_t t = t_first; t <= t_last; t++) {
+    const Ext cur = nx;
+    if (t < t_last) nx = aos_ext(head, t + 1);
+    acc = quad_add_ext(acc, cur, role);
+  }
+  if (role == 0) aos_put_ext(buckets, g, acc);
+}
+// ---- Segment-sorted accumulation (large inputs).  Every non-empty bucket is cut into segments of at most P entries, the
+// segments are counting-sorted by length (longest first), and each lane adds up one segment: lanes of a wave run the
+// same number of iterations, no lane ever switches buckets inside its loop, and a bucket with a single segment (the
+// common case) is finished by its lane.  Buckets with several segments (repeated scalars) get their extra segments as `head`
+// partials that k_msm_merge (few) or k_msm_fixup_big (many) folds in.
+#ifndef JJ_MSM_ACC_MINBLOCKS
+#define JJ_MSM_ACC_MINBLOCKS 1        // resident 256-thread blocks per CU the accumulate kernel is compiled for: 1 = no register cap (137 VGPRs,
+#endif                                // 3 waves per SIMD); capping at 128 (4 waves) changes nothing, 96 (5 waves) spills (profiles/r2_msm_acc_occupancy.txt)
+constexpr int SEG_PMAX = 1024;
+struct Seg { u32 start, len, dst, pad; };            // dst: bucket index, or 0x80000000 | head index
+struct MergeItem { u32 bucket, h0, k, pad; };         // buckets[bucket] += head[h0 .. h0 + k)
+// bucket g = s B + j of the pass: its entries are [lo, lo + c)
+static JJ_DEV void seg_bucket(const u32* off, u32 B, size_t g, u32& lo, u32& c) {
+  const size_t s = g / B, j = g % B;
+  const u32* o = off + s * (B + 1);
+  lo = o[j]; c = o[j + 1] - lo;
+}
+// pass 1: per-block histogram of segment lengths, key = P - len (longer first); empty buckets become the identity
+__global__ void __launch_bounds__(256) k_seg_hist(size_t nb, u32 B, u32 per_tile, u32 P, const u32* off, ExtAoS buckets, u32* bh) {
+  __shared__ u32 hist[SEG_PMAX + 1];
+  for (u32 k = threadIdx.x; k <= P; k += 256) hist[k] = 0;
+  __syncthreads();
+  const size_t base = (size_t)blockIdx.x * per_tile;
+  for (u32 j = threadIdx.x; j < per_tile; j += 256) {
+    const size_t b = base + j;
+    if (b >= nb) break;
+    u32 lo, c; seg_bucket(off, B, b, lo, c);
+    if (c == 0) { aos_put_ext(buckets, b, Curve::identity()); continue; }
+    const u32 full = c / P, rem = c - full * P;
+    if (full) atomicAdd(&hist[0], full);
+    if (rem) atomicAdd(&hist[P - rem], 1u);
+  }
+  __syncthreads();
+  for (u32 k = threadIdx.x; k <= P; k += 256) bh[(size_t)blockIdx.x * (P + 1) + k] = hist[k];
+}
+// between the passes, one workgroup: per-key totals over the blocks, exclusive scan over the keys, and each block's
+// first slot per key written back into bh (the whole matrix, tiles x (P+1) <= 16384 words, sits in LDS)
+__global__ void __launch_bounds__(1024) k_seg_plan(u32 tiles, u32 P, u32* bh, u32* total_out) {
+  extern __shared__ u32 msm_lds[];
+  u32* m = msm_lds;                       // [tiles][P+1]
+  u32* offk = msm_lds + (size_t)tiles * (P + 1);   // [P+2]
+  const u32 K = P + 1;
+  for (u32 i = threadIdx.x; i < tiles * K; i += 1024) m[i] = bh[i];
+  __syncthreads();
+  for (u32 k = threadIdx.x; k < K; k += 1024) { u32 sm = 0; for (u32 t = 0; t < tiles; t++) sm += m[t * K + k]; offk[k] = sm; }
+  __syncthreads();
+  if (threadIdx.x == 0) { u32 run = 0; for (u32 k = 0; k < K; k++) { const u32 c = offk[k]; offk[k] = run; run += c; } *total_out = run; }
+  __syncthreads();
+  for (u32 k = threadIdx.x; k < K; k += 1024) { u32 run = offk[k]; for (u32 t = 0; t < tiles; t++) { const u32 c = m[t * K + k]; m[t * K + k] = run; run += c; } }
+  __syncthreads();
+  for (u32 i = threadIdx.x; i < tiles * K; i += 1024) bh[i] = m[i];
+}
+// pass 2: bh now holds each block's first slot per key; every segment takes the next slot of its key
+__global__ void __launch_bounds__(256) k_seg_scatter(size_t nb, u32 B, u32 per_tile, u32 P, const u32* off, const u32* bh, Seg* seg,
+                                                      u32* counters /* [0] heads, [1] merge items, [2] big buckets */, MergeItem* merge, BigBucket* big) {
+  __shared__ u32 cur[SEG_PMAX + 1];
+  for (u32 k = threadIdx.x; k <= P; k += 256) cur[k] = bh[(size_t)blockIdx.x * (P + 1) + k];
+  __syncthreads();
+  const size_t base = (size_t)blockIdx.x * per_tile;
+  for (u32 j = threadIdx.x; j < per_tile; j += 256) {
+    const size_t b = base + j;
+    if (b >= nb) break;
+    u32 lo, c; seg_bucket(off, B, b, lo, c);
+    if (c == 0) continue;
+    const u32 full = c / P, rem = c - full * P, nseg = full + (rem ? 1u : 0u);
+    u32 h0 = 0;
+    if (nseg > 1) {
+      h0 = atomicAdd(&counters[0], nseg - 1);
+      bool listed = false;
+      if (nseg - 1 > FIXUP_SERIAL_MAX) {
+        const u32 slot = atomicAdd(&counters[2], 1u);
+        if (slot < FIXUP_BIG_MAX) { big[slot].bucket = (u32)b; big[slot].t_first = h0; big[slot].t_last = h0 + nseg - 2; big[slot].pad = 0; listed = true; }
+      }
+      if (!listed) { const u32 mi = atomicAdd(&counters[1], 1u); merge[mi].bucket = (u32)b; merge[mi].h0 = h0; merge[mi].k = nseg - 1; merge[mi].pad = 0; }
+    }
+    for (u32 sgi = 0; sgi < nseg; sgi++) {
+      const u32 len = sgi < full ? P : rem;
+      const u32 slot = atomicAdd(&cur[P - len], 1u);
+      Seg sg; sg.start = lo + sgi * P; sg.len = len; sg.dst = sgi == 0 ? (u32)b : (0x80000000u | (h0 + sgi - 1)); sg.pad = 0;
+      seg[slot] = sg;
+    }
+  }
+}
+__global__ void __launch_bounds__(256, JJ_MSM_ACC_MINBLOCKS) k_msm_accumulate_seg(const u32* nseg_total, const Seg* seg, const u32* idx, const u32* niels, ExtAoS buckets, ExtAoS head) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= *nseg_total) return;
+  const Seg sg = seg[t];
+  Ext acc = Curve::identity();
+  const u32* ip = idx + sg.start;
+  // software pipeline: the entry of term k+1 (a dependent 4-byte index load, then a random 128-byte gather) is in flight
+  // while term k is added
+  u32 e = ip[0];
+  ANiels p = lds_aniels(niels + (size_t)(e & 0x7fffffffu) * GNIELS_WORDS);
+  u32 e_next = sg.len > 1 ? ip[1] : e;
+  #pragma unroll 1
+  for (u32 k = 0; k < sg.len; k++) {
+    const ANiels p_next = lds_aniels(niels + (size_t)(e_next & 0x7fffffffu) * GNIELS_WORDS);
+    const u32 e_next2 = k + 2 < sg.len ? ip[k + 2] : e_next;
+    acc = Curve::add_signed<true>(acc, p, (e >> 31) ? ~0u : 0u);
+    e = e_next; p = p_next; e_next = e_next2;
+  }
+  if (sg.dst >> 31) aos_put_ext(head, sg.dst & 0x7fffffffu, acc); else aos_put_ext(buckets, sg.dst, acc);
+}
+// buckets with a few extra segments: one quad of lanes folds them in
+__global__ void __launch_bounds__(256) k_msm_merge(const u32* counters, const MergeItem* merge, ExtAoS buckets, ExtAoS head) {
+  const size_t m = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  const u32 role = threadIdx.x & 3u;
+  if (m >= counters[1]) return;
+  const MergeItem it = merge[m];
+  Ext acc = aos_ext(buckets, it.bucket);
+  #pragma unroll 1
+  for (u32 j = 0; j < it.k; j++) acc = quad_add_ext(acc, aos_ext(head, (size_t)it.h0 + j), role);
+  if (role == 0) aos_put_ext(buckets, it.bucket, acc);
+}
+// Big buckets, one launch: every workgroup folds a strided share of the listed buckets' heads into FIXUP_BIG_QUADS partials each
+// (written to `partial[item][quad]`); the LAST workgroup to finish (a device-side counter) folds the partials of every item
+// into its bucket.  The list is empty for anything but heavily repeated scalars, and the launch is then a no-op.
+__global__ void __launch_bounds__(256) k_msm_fixup_big(u32* counters, const BigBucket* big, ExtAoS buckets, ExtAoS head, SoA partial) {
+  __shared__ u32 last_s;
+  u32 cnt = counters[2]; if (cnt > FIXUP_BIG_MAX) cnt = FIXUP_BIG_MAX;
+  if (cnt == 0) return;
+  const u32 role = threadIdx.x & 3u, quad = threadIdx.x >> 2;
+  #pragma unroll 1
+  for (u32 item = blockIdx.x; item < cnt; item += gridDim.x) {
+    const BigBucket bb = big[item];
+    Ext acc = Curve::identity();
+    #pragma unroll 1
+    for (size_t t = (size_t)bb.t_first + quad; t <= bb.t_last; t += FIXUP_BIG_QUADS) acc = quad_add_ext(acc, aos_ext(head, t), role);
+    if (role == 0) soa_put_ext(partial, (size_t)item * FIXUP_BIG_QUADS + quad, acc);
+  }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last_s = atomicAdd(&counters[3], 1u) == gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (!last_s) return;
+  __threadfence();
+  #pragma unroll 1
+  for (u32 item = quad; item < cnt; item += FIXUP_BIG_QUADS) {
+    const BigBucket bb = big[item];
+    Ext acc = aos_ext(buckets, bb.bucket);
+    const u32 nh = bb.t_last - bb.t_first + 1, used = nh < FIXUP_BIG_QUADS ? nh : FIXUP_BIG_QUADS;
+    #pragma unroll 1
+    for (u32 q = 0; q < used; q++) acc = quad_add_ext(acc, soa_ext(partial, (size_t)item * FIXUP_BIG_QUADS + q), role);
+    if (role == 0) aos_put_ext(buckets, bb.bucket, acc);
+  }
+}
+
+// ================================================================================================ Pippenger: bucket reduction
+// sum_j (j + 1) b_j of every window, on quads of lanes (the chains are latency-bound).  A chunk of L consecutive buckets j0 ..
+// j0 + L - 1 contributes T + j0 S with T = sum (j - j0 + 1) b_j (running sums) and S = sum b_j; j0 S is a double-and-add over
+// the significant bits of j0 (a multiple of L = 2^lb: lb plain doublings at the end).  Block (blk, s) takes the chunks blk * 128 +
+// quad (+ 128 nblk ...) of slot s, its 128 quads are folded through LDS, and quad 0 writes one partial window sum into the
+// output record: the host adds the at most MSM_REC_BLK partials of a window (jj_host_tail.h).  Windows narrower than the widest
+// one use only the first 2^(width-1) of their B bucket slots; the chunks above are skipped.
+// chunk k of slot s: T + j0 S, and its t1 * t2
+static JJ_DEV Ext msm_reduce_chunk(const MsmParams& mp, u32 s, u32 k, u32 L, int lb, int jbits, const ExtAoS& buckets, u32 role, Fe& Tout) {
+  const size_t first = (size_t)s * mp.B + (size_t)k * L;       // bucket index of the pass
+  const u32 j0 = k * L;                                        // index inside the window
+  // every point travels with T = t1*t2; T of the next bucket is the side product of the current addition
+  Ext running = Curve::identity(), total = Curve::identity();
+  Fe Tr = Fq::zero(), Tt = Fq::zero(), dummy;
+  Ext bk = aos_ext(buckets, first + L - 1);
+  Fe Tb = Fq::mul(bk.t1, bk.t2);                       // stored t1, t2 are carried
+  #pragma unroll 1
+  for (int j = (int)L - 1; j >= 0; j--) {
+    const Ext nx = aos_ext(buckets, first + (j > 0 ? j - 1 : 0));
+    Fe Tn;
+    running = quad_add_ext_t(running, Tr, bk, Tb, role, Tr, nx.t1, nx.t2, Tn);
+    total = quad_add_ext_t(total, Tt, running, Tr, role, Tt, Tr, Tr, dummy);
+    bk = nx; Tb = Tn;
+  }
+  // total += j0 * running   (j0 < B = 2^jbits).  j0 is a multiple of the chunk length L = 2^lb: double-and-add over the
+  // jbits - lb significant bits, then lb plain doublings (no additions for bits that are zero by construction)
+  if (j0) {
+    Ext m = Curve::identity();
+    Fe Tm = Fq::zero();
+    #pragma unroll 1
+    for (int bit = jbits - 1; bit >= lb; bit--) {
+      m = quad_dbl_t(m, role, Tm);
+      Ext sel = Curve::identity();
+      const u32 mask = ((j0 >> bit) & 1u) ? ~0u : 0u;
+      sel.u = Fq::select(sel.u, running.u, mask); sel.v = Fq::select(sel.v, running.v, mask); sel.z = Fq::select(sel.z, running.z, mask);
+      const Fe Ts = Fq::select(Fq::zero(), Tr, mask);
+      m = quad_add_ext_t(m, Tm, sel, Ts, role, Tm, Tr, Tr, dummy);
+    }
+    #pragma unroll 1
+    for (int bit = 0; bit < lb; bit++) m = quad_dbl_t(m, role, Tm);
+    total = quad_add_ext_t(total, Tt, m, Tm, role, Tt, Tr, Tr, dummy);
+  }
+  Tout = Tt;
+  return total;
+}
+// MULTI: a quad may own several chunks (only with tuning overrides that leave more than MSM_TREE_QUADS * MSM_REC_BLK chunks per window)
+template <bool MULTI>
+__global__ void __launch_bounds__(4 * MSM_TREE_QUADS) k_msm_reduce_fold(size_t n, MsmParams mp, u32 L, u32 nblk, int jbits, ExtAoS buckets, u32* rec) {
+  __shared__ __attribute__((aligned(16))) u32 st[MSM_TREE_QUADS * LDS_PT_WORDS];
+  const u32 role = threadIdx.x & 3u, quad = threadIdx.x >> 2, blk = blockIdx.x, s = blockIdx.y;
+  const int w = msm_slot_window(mp, (int)s);
+  if (blk == 0 && s == 0 && threadIdx.x == 0) msm_write_header(rec, mp, nblk, n);
+  const u32 Bw = 1u << (msm_win_width(mp, w) - 1);
+  const u32 Kw = (Bw + L - 1) / L;                              // chunks of this window that hold buckets
+  const int lb = __ffs((int)L) - 1;
+  Ext acc = Curve::identity();
+  Fe Tacc = Fq::zero();
+  const u32 k0 = blk * MSM_TREE_QUADS + quad;
+  if (k0 < Kw) acc = msm_reduce_chunk(mp, s, k0, L, lb, jbits, buckets, role, Tacc);
+  if constexpr (MULTI) {
+    #pragma unroll 1
+    for (u32 k = k0 + MSM_TREE_QUADS * nblk; k < Kw; k += MSM_TREE_QUADS * nblk) {
+      Fe Tt, dummy;
+      const Ext total = msm_reduce_chunk(mp, s, k, L, lb, jbits, buckets, role, Tt);
+      acc = quad_add_ext_t(acc, Tacc, total, Tt, role, Tacc, Tt, Tt, dummy);
+    }
+  }
+  const u32 base = blk * MSM_TREE_QUADS;
+  const u32 live = base >= Kw ? 0u : (Kw - base < (u32)MSM_TREE_QUADS ? Kw - base : (u32)MSM_TREE_QUADS);
+  quad_tree_sum(st, quad, role, live, acc, Tacc);
+  if (quad == 0 && role == 0) msm_store_partial(rec + MSM_REC_HDR_WORDS, w, nblk, blk, acc);
+}
+

@@ -72,6 +72,14 @@ class FixedBaseTable:
             pass
 
 
+class MsmJob:
+    """Handle of an MSM in flight (Engine.msm_begin); finished exactly once by Engine.msm_finish."""
+
+    def __init__(self, handle, keep):
+        self._h = handle
+        self._keep = keep
+
+
 class Engine:
     def __init__(self, device=0):
         self._mu = threading.RLock()      # stream selection + call form one critical section per Engine (see _locked below)
@@ -277,6 +285,50 @@ class Engine:
 
     def msm(self, scalars, points):
         return self._sum_like("jj_msm", [scalars, points], [32, 64])
+
+    def msm_begin(self, scalars, points):
+        """Queues one MSM (jj_msm_begin) and returns a job; msm_finish(job) waits for it and runs the host tail.  Several jobs
+        may be in flight: the host tail of one overlaps the kernels of the next.  The inputs are kept alive by the job."""
+        a, p = _Arg(scalars, 32), _Arg(points, 64)
+        if a.n != p.n:
+            raise ValueError("length mismatch: %d vs %d" % (a.n, p.n))
+        self._bind_stream([a, p])
+        h = C.c_void_p()
+        self._check(self._lib.jj_msm_begin(self._ctx, C.c_size_t(a.n), a.ptr, p.ptr, C.byref(h)))
+        return MsmJob(h, (a.keep, p.keep))
+
+    def msm_finish(self, job):
+        """-> the 64-byte affine sum as a numpy array (host memory)."""
+        if job._h is None:
+            raise JubjubError("MSM job already finished")
+        out = np.empty((64,), np.uint8)
+        h, job._h, job._keep = job._h, None, None
+        self._check(self._lib.jj_msm_finish(h, out.ctypes.data))
+        return out
+
+    def msm_partial(self, scalars, points, part_index=0, part_count=1):
+        """First half of an MSM cut across devices / ranks (jj_msm_partial): the record of partial window sums
+        (MSM_PARTIAL_BYTES bytes, same kind of array as the inputs: a CUDA tensor is ready for all_gather over RCCL).
+        part_index = g, part_count = G: windows g, g + G, ... of ALL the terms given (window partition); 0 / 1: all windows
+        of the terms given (term partition)."""
+        a, p = _Arg(scalars, 32), _Arg(points, 64)
+        if a.n != p.n:
+            raise ValueError("length mismatch: %d vs %d" % (a.n, p.n))
+        self._bind_stream([a, p])
+        out, optr = self._alloc(a, _lib.MSM_PARTIAL_BYTES, 1)
+        self._check(self._lib.jj_msm_partial(self._ctx, C.c_size_t(a.n), a.ptr, p.ptr, C.c_int(part_index), C.c_int(part_count), optr))
+        return out
+
+    def msm_combine(self, records):
+        """Second half (jj_msm_combine, host only): any number of records (count x MSM_PARTIAL_BYTES bytes; numpy, or a torch
+        tensor on any device: copied to the host once) -> the 64-byte affine sum as a numpy array."""
+        is_torch = type(records).__module__.startswith("torch")
+        host = np.ascontiguousarray((records.detach().cpu().numpy() if is_torch else np.asarray(records)).reshape(-1, _lib.MSM_PARTIAL_BYTES), dtype=np.uint8)
+        out = np.empty((64,), np.uint8)
+        rc = self._lib.jj_msm_combine(C.c_size_t(host.shape[0]), host.ctypes.data if host.shape[0] else None, out.ctypes.data)
+        if rc:
+            raise JubjubError("jj_msm_combine failed (%d): damaged or mismatched MSM records" % rc)
+        return out
 
     # -------------------------------------------------------------- encodings
     def decompress(self, enc, flags=FLAG_ZIP216):

@@ -21,6 +21,23 @@ FR_MODULUS_BYTES = bytes([183, 44, 247, 214, 94, 14, 151, 208, 130, 16, 200, 204
                           59, 103, 6, 169, 175, 51, 101, 234, 180, 125, 14])                      # reference src/lib.rs:73-76
 
 
+_M64 = (1 << 64) - 1
+
+
+def _splitmix64(x):
+    x = (x + 0x9E3779B97F4A7C15) & _M64
+    z = x
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
+
+def random_stream_seeds(seed):
+    """seeds of the two 32-byte halves Field::random feeds to from_bytes_wide: splitmix64(seed ^ tag), tags "jjFrndLo" / "jjFrndHi"
+    (little-endian ASCII).  include/jubjub_hip.hpp FieldBatch::random uses the same two streams."""
+    return _splitmix64((seed ^ 0x6F4C646E72466A6A) & _M64), _splitmix64((seed ^ 0x6948646E72466A6A) & _M64)
+
+
 def _as_rows(x, width):
     if type(x).__module__.startswith("torch"):
         return x.reshape(-1, width)
@@ -83,12 +100,13 @@ class _Field:
         return self.engine.to_le_bits(self._name, self.data)
 
     @classmethod
-    def random(cls, engine, n, seed, first_index=0):        # Field::random (src/fr.rs:684-688): 64 PRNG bytes -> from_bytes_wide
-        if cls._name == "fr":
-            return cls(engine, engine.synth_scalars(n, seed, first_index))
-        import numpy as np
-
-        wide = np.concatenate([engine.synth_bytes32(n, seed, first_index), engine.synth_bytes32(n, seed ^ 0xA5A5A5A5, first_index)], axis=1)
+    def random(cls, engine, n, seed, first_index=0):
+        """Field::random (src/fr.rs:684-688; Fq = bls12_381::Scalar does the same): 64 PRNG bytes through from_bytes_wide, for
+        BOTH fields (no truncate-and-subtract bias).  The two 32-byte halves of unit i come from two decorrelated counter
+        streams of the library's splitmix64 generator (the seed hashed with a domain tag per half: random_stream_seeds).
+        The generator is counter-based and reproducible: it makes TEST DATA, it is not a source of secret scalars."""
+        lo_seed, hi_seed = random_stream_seeds(seed)
+        wide = np.concatenate([engine.synth_bytes32(n, lo_seed, first_index), engine.synth_bytes32(n, hi_seed, first_index)], axis=1)
         return cls(engine, engine.from_bytes_wide(cls._name, wide))
 
     def __eq__(self, o):

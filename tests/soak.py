@@ -18,15 +18,17 @@ from util import pt64  # noqa: E402
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 SEED0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 eng = Engine(0)
+os.environ["JJ_MSM_SMALL_MAX"] = "0"
 os.environ["JJ_MSM_ACCUM"] = "segments"      # second context: the large-input MSM accumulation scheme forced on small inputs
 os.environ["JJ_VB_QUAD_MAX"] = "0"           # ... and the per-lane var-base kernel instead of the per-quad one
 eng_alt = Engine(0)
-del os.environ["JJ_MSM_ACCUM"], os.environ["JJ_VB_QUAD_MAX"]
-eng_wide = []                                # wide MSM windows (the default only from 2^18 terms) and with them the two-pass sort
-for wbits_msm in (13, 16):
-    os.environ["JJ_MSM_WINDOW"] = str(wbits_msm)
+del os.environ["JJ_MSM_ACCUM"], os.environ["JJ_VB_QUAD_MAX"], os.environ["JJ_MSM_SMALL_MAX"]
+eng_wide = []                                # Pippenger with 16 / 19 / 23 windows (two-pass and one-pass sort) forced on every size
+os.environ["JJ_MSM_SMALL_MAX"] = "0"
+for nwin_msm in (16, 19, 23):
+    os.environ["JJ_MSM_WINDOWS"] = str(nwin_msm)
     eng_wide.append(Engine(0))
-del os.environ["JJ_MSM_WINDOW"]
+del os.environ["JJ_MSM_WINDOWS"], os.environ["JJ_MSM_SMALL_MAX"]
 base = pt64(J.GENERATOR)
 G8 = J.scalar_mul_fast(J.GENERATOR, J.R_MOD)             # order-8 component of the generator
 TORS = np.stack([pt64(J.scalar_mul_fast(G8, j) if j else J.AFFINE_IDENTITY) for j in range(8)])
@@ -61,7 +63,7 @@ while time.time() < t_end:
     want_msm = O.msm(S[:m], P[:m])
     assert (eng.msm(S[:m], P[:m]) == want_msm).all(), ("msm", rnd)
     assert (eng_alt.msm(S[:m], P[:m]) == want_msm).all(), ("msm segments", rnd)
-    assert (eng_wide[rnd & 1].msm(S[:m], P[:m]) == want_msm).all(), ("msm wide windows", rnd)
+    assert (eng_wide[rnd % 3].msm(S[:m], P[:m]) == want_msm).all(), ("msm wide windows", rnd)
     enc = O.compress(P)
     bad = rng.integers(0, n, size=max(1, n // 10))
     enc[bad] = rng.integers(0, 256, size=(len(bad), 32), dtype=np.uint8)

@@ -272,16 +272,27 @@ def test_msm(eng):
         assert (eng.msm(S, P) == O.msm(S, P)).all(), n
 
 
-def test_msm_ladder_fold_path(monkeypatch):
-    """JJ_MSM_NAIVE_BELOW: sizes below the threshold use var-base ladders (five coordinates) and a fold instead of Pippenger."""
+@pytest.mark.parametrize("small_max", ["0", "100000"])
+def test_msm_small_batch_path_and_pippenger_on_the_same_inputs(monkeypatch, small_max):
+    """JJ_MSM_SMALL_MAX: the two-launch small-batch path (per-term tables, 64 windows of 3-4 bits; default up to 2^14 terms) and
+    Pippenger, each forced over every size: ragged sizes around the 128-quad workgroups, edge scalars, identity / torsion points."""
     from jubjub_amd import Engine
 
-    monkeypatch.setenv("JJ_MSM_NAIVE_BELOW", "100000")
+    monkeypatch.setenv("JJ_MSM_SMALL_MAX", small_max)
     e2 = Engine(0)
-    for n in (1, 2, 33, 700, 40000):
+    for n in (1, 2, 33, 127, 128, 129, 511, 513, 700, 1025, 4097, 40000):
         S = rand_scalars(112 + n, n, full_width=True)
         P = rand_points(113 + n, n, subgroup=(n % 2 == 0))
-        assert (e2.msm(S, P) == O.msm(S, P)).all(), n
+        assert (e2.msm(S, P) == O.msm(S, P)).all(), (small_max, n)
+    m = len(EDGE_SCALARS)
+    S = arr32(EDGE_SCALARS)
+    g8 = J.scalar_mul_fast(J.GENERATOR, J.R_MOD)
+    special = arr64([J.AFFINE_IDENTITY, g8, J.scalar_mul_fast(g8, 4), J.GENERATOR, J.affine_neg(J.GENERATOR)])
+    for k in range(len(special)):
+        P = np.repeat(special[k:k + 1], m, axis=0)
+        assert (e2.msm(S, P) == O.msm(S, P)).all(), (small_max, "special", k)
+        for i in range(0, m, 5):                                                  # single terms: every edge scalar on its own
+            assert (e2.msm(S[i:i + 1], P[i:i + 1]) == O.msm(S[i:i + 1], P[i:i + 1])).all(), (small_max, k, i)
     e2.close()
 
 
@@ -293,6 +304,7 @@ def test_msm_both_accumulation_schemes(monkeypatch, mode):
 
     monkeypatch.setenv("JJ_MSM_ACCUM", mode)
     monkeypatch.setenv("JJ_MSM_SEG_LEN", "8")
+    monkeypatch.setenv("JJ_MSM_SMALL_MAX", "0")
     e2 = Engine(0)
     for n in (1, 5, 300, 4099, 70000):
         S = rand_scalars(212 + n, n, full_width=True)
@@ -322,20 +334,26 @@ def test_msm_skewed_buckets(eng):
     assert to_pt(eng.msm(Z, P)) == J.AFFINE_IDENTITY
 
 
-@pytest.mark.parametrize("window", [13, 14, 15, 16])
+@pytest.mark.parametrize("window", [16, 17, 19, 20, 21, 23, 28, 32])
 @pytest.mark.parametrize("sort", ["2pass", "1pass"])
-def test_msm_wide_windows_both_sorts(monkeypatch, window, sort):
-    """Windows of 13-16 bits (the default from 2^18 terms) forced on small inputs, with the two-pass sort (coarse bin, then the low
-    bits in LDS) and the single-pass one: ragged sizes, a bin far larger than the LDS stage (equal scalars), zero digits."""
+def test_msm_window_counts_both_sorts(monkeypatch, window, sort):
+    """JJ_MSM_WINDOWS: W windows tiling the 253 scalar bits exactly (16: 13 windows of 16 bits + 3 of 15, the default from 2^18
+    terms; 21: one of 13 bits + 20 of 12; 23: all 11 bits; ...) forced on small inputs, with the two-pass sort (coarse bin, then
+    the low bits in LDS; always taken above 4096 buckets per window) and the single-pass one (JJ_MSM_SORT decides at exactly 4096):
+    ragged sizes, a bin far larger than the LDS stage (equal scalars), zero digits, the largest top-window digit."""
     from jubjub_amd import Engine
 
-    monkeypatch.setenv("JJ_MSM_WINDOW", str(window))
+    monkeypatch.setenv("JJ_MSM_WINDOWS", str(window))
     monkeypatch.setenv("JJ_MSM_SORT", sort)
+    monkeypatch.setenv("JJ_MSM_SMALL_MAX", "0")
     e2 = Engine(0)
     for n in (1, 2, 300, 8191, 8193, 30000):
         S = rand_scalars(512 + n + window, n, full_width=True)
         P = rand_points(513 + n, n, subgroup=(n % 2 == 0))
         assert (e2.msm(S, P) == O.msm(S, P)).all(), (window, sort, n)
+    if sort == "1pass" and window not in (16, 20, 23, 32):
+        e2.close()
+        return                                                   # the skewed cases below once per bucket-count class
     n = 20000
     P = rand_points(61, n)
     S = np.repeat(rand_scalars(62, 1, full_width=True), n, axis=0)      # one bucket per window holds every term
@@ -356,6 +374,7 @@ def test_msm_point_conversion_on_second_stream(monkeypatch, fork):
     from jubjub_amd import Engine
 
     monkeypatch.setenv("JJ_MSM_FORK", fork)
+    monkeypatch.setenv("JJ_MSM_SMALL_MAX", "0")
     e2 = Engine(0)
     for n in (1, 300, 5000, 40000, 2000, 40001):
         S = rand_scalars(712 + n, n, full_width=True)
@@ -373,7 +392,74 @@ def test_msm_multipass(monkeypatch):
     n = 10000
     S, P = rand_scalars(41, n, full_width=True), rand_points(42, n)
     assert (e2.msm(S, P) == O.msm(S, P)).all()
+    n = 4096 * 2 + 77                                       # the last pass is small: two window layouts meet in one host tail
+    assert (e2.msm(S[:n], P[:n]) == O.msm(S[:n], P[:n])).all()
     e2.close()
+
+
+def test_msm_async_jobs_interleaved(eng):
+    """jj_msm_begin / jj_msm_finish: several MSMs of different sizes (small-batch path, one-pass and two-pass Pippenger, empty)
+    queued back to back on one context, finished out of order, each exactly once; the host tail of one job runs while the
+    kernels of the next are in flight.  Device-resident and host inputs."""
+    import torch
+
+    sizes = (3000, 0, 1, 40000, 129, 70000, 17000)
+    data = [(rand_scalars(900 + n, n, full_width=True), rand_points(901 + n, n)) for n in sizes]
+    want = [O.msm(S, P) for S, P in data]
+    jobs = [eng.msm_begin(S, P) for S, P in data]                         # host arrays: staged at begin
+    for k in (3, 0, 6, 1, 5, 2, 4):
+        assert (eng.msm_finish(jobs[k]) == want[k]).all(), ("host", sizes[k])
+    with pytest.raises(Exception):
+        eng.msm_finish(jobs[0])                                           # a job is finished once
+    dev = torch.device("cuda", 0)
+    dd = [(torch.from_numpy(S).to(dev), torch.from_numpy(P).to(dev)) for S, P in data]
+    for depth in (2, 4):                                                  # a sliding window of jobs in flight, as bench.py runs them
+        pending, got = [], []
+        for S, P in dd * 2:
+            pending.append(eng.msm_begin(S, P))
+            if len(pending) == depth:
+                got.append(eng.msm_finish(pending.pop(0)))
+        got += [eng.msm_finish(j) for j in pending]
+        for k, g in enumerate(got):
+            assert (g == want[k % len(sizes)]).all(), ("device", depth, k)
+
+
+@pytest.mark.parametrize("G", [2, 3, 8])
+def test_msm_partial_records_term_and_window_partition(eng, G):
+    """jj_msm_partial + jj_msm_combine: the MSM cut G ways by terms (every part: all windows of its own terms) and by windows (every
+    part: windows g, g + G, ... of all terms), records gathered and combined in one host tail; small-batch and Pippenger sizes,
+    uneven shards (parts of different window layouts), an empty part."""
+    from jubjub_amd import _lib
+    from jubjub_amd.dist import shard_bounds
+
+    for n in (5, 1000, 20000, 70000):
+        S, P = rand_scalars(950 + n, n, full_width=True), rand_points(951 + n, n)
+        want = O.msm(S, P)
+        recs = np.stack([eng.msm_partial(S, P, g, G) for g in range(G)])
+        assert recs.shape == (G, _lib.MSM_PARTIAL_BYTES)
+        assert (eng.msm_combine(recs) == want).all(), ("windows", n, G)
+        parts = []
+        for g in range(G):
+            lo, hi = shard_bounds(n, g, G)
+            parts.append(eng.msm_partial(S[lo:hi], P[lo:hi]))
+        assert (eng.msm_combine(np.stack(parts)) == want).all(), ("terms", n, G)
+    # uneven cut: a Pippenger part, a small-batch part and an empty one
+    n = 40000
+    S, P = rand_scalars(977, n), rand_points(978, n)
+    parts = [eng.msm_partial(S[:30000], P[:30000]), eng.msm_partial(S[30000:], P[30000:]), eng.msm_partial(S[:0], P[:0])]
+    assert (eng.msm_combine(np.stack(parts)) == O.msm(S, P)).all()
+    assert to_pt(eng.msm_combine(np.zeros((0, _lib.MSM_PARTIAL_BYTES), np.uint8))) == J.AFFINE_IDENTITY
+    bad = parts[0].copy()
+    bad[0] ^= 1                                                            # damaged magic
+    with pytest.raises(Exception):
+        eng.msm_combine(bad[None, :])
+    # device-resident: the record is a CUDA tensor (what all_gather moves), combined after one copy to the host
+    import torch
+
+    dev = torch.device("cuda", 0)
+    Sd, Pd = torch.from_numpy(S).to(dev), torch.from_numpy(P).to(dev)
+    recs = torch.stack([eng.msm_partial(Sd, Pd, g, G) for g in range(G)])
+    assert recs.is_cuda and (eng.msm_combine(recs) == O.msm(S, P)).all()
 
 
 def test_serialization_golden(eng, golden):
@@ -641,24 +727,14 @@ def test_group_mirror_random_and_bits(eng):
     from jubjub_amd import group as G
 
     k = G.Fr.random(eng, 40, 7, first_index=3)
-    assert (k.data == arr32([J.synth_scalar(3 + i, 7) for i in range(40)])).all()
+    lo_seed, hi_seed = G.random_stream_seeds(7)
+    wide = lambda i: int.from_bytes(J.synth_bytes32(3 + i, lo_seed) + J.synth_bytes32(3 + i, hi_seed), "little")   # 64 PRNG bytes, from_bytes_wide
+    assert (k.data == arr32([wide(i) % R for i in range(40)])).all()
     bits = k.to_le_bits()
     assert all(int("".join(str(b) for b in row[::-1]), 2) == to_int(x) for row, x in zip(bits, k.data))
     p = G.Points.random(eng, 40, 9, subgroup=True)
     assert p.is_prime_order().all() and p.is_on_curve().all()
     q = G.Fq.random(eng, 8, 5)
-    assert all(to_int(x) < Q for x in q.data)
-
-
-def test_msm_graph_replay(monkeypatch):
-    """JJ_MSM_GRAPH=1: one captured hipGraph per MSM shape, replayed with different inputs, sizes and workspace generations"""
-    from jubjub_amd import Engine
-
-    monkeypatch.setenv("JJ_MSM_GRAPH", "1")
-    e2 = Engine(0)
-    for n in (300, 300, 5000, 300, 70000, 5000):            # repeats hit the cache, new sizes grow the workspaces (new generation)
-        S, Pn = rand_scalars(1000 + n, n, full_width=True), rand_points(2000 + n, n)
-        assert (e2.msm(S, Pn) == O.msm(S, Pn)).all(), n
-        S2, P2 = rand_scalars(3000 + n, n), rand_points(4000 + n, n)      # same shape, other buffers
-        assert (e2.msm(S2, P2) == O.msm(S2, P2)).all(), n
-    e2.close()
+    lo_seed, hi_seed = G.random_stream_seeds(5)
+    assert (q.data == arr32([int.from_bytes(J.synth_bytes32(i, lo_seed) + J.synth_bytes32(i, hi_seed), "little") % Q for i in range(8)])).all()
+    assert lo_seed != hi_seed and G.random_stream_seeds(6) != (lo_seed, hi_seed)
