@@ -12,7 +12,11 @@ N > 1: one process per GPU.  When this script is started WITHOUT a launcher (no 
 the N ranks itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT) and relays rank 0's single JSON
 line; under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` it uses the ranks it is given.
 --scaling weak   : every rank runs 2^log2n units (independent shards, no data-path collective; the MSM workload all-gathers
-                   one 64-byte partial point per rank over RCCL and folds them on every rank).
+                   one 8 KB record of window sums per rank over RCCL, copies the gathered records to the host once and runs ONE
+                   host tail -- window sums, Horner, one inversion -- on every rank).
+--msm-partition  : terms  = rank g owns terms [g n/G, (g+1) n/G) and all their windows;
+                   window = rank g owns windows g, g + G, ... of ALL terms (every rank holds the whole batch; strong scaling only).
+--msm-async D    : N = 1: D MSMs in flight (jj_msm_begin / jj_msm_finish): the host tail of one overlaps the kernels of the next.
 --scaling strong : 2^log2n units IN TOTAL, cut into contiguous shards (BASELINE configs[3]: 2^20-term MSM over 8 GPUs;
                    configs[4]: 2^26 encodings over 8 GPUs with --log2n 26).
 Rank 0 prints ONE JSON line.
@@ -61,6 +65,7 @@ WORK = {
     "fixedbase": {"S": 0, "M": 43 * 7, "bytes": 32 + 64},
     # Pippenger, c = 16: per term 2M load + 2M to_niels + 16 windows x 7M mixed add; bucket reduce 2 x 10M per bucket
     # (16 x 2^15 buckets / 2^20 terms -> +10M); the 240-doubling Horner tail is per MSM (on the host), not per term
+    # (the entry below is the 16-window case, 2^18 terms and more; run() recomputes it from the window count of the record)
     "msm": {"S": 0, "M": 2 + 2 + 16 * 7 + 10, "bytes": 32 + 64},
     # k_decompress (the flag kernels run after it and show up in tail_ms): two decode passes (2 x (1M + 1S + 1M)), shared
     # inversion (3M + (253S+61M)/32), u^2 1M, sqrt = a^((t-1)/2) (220S + 52M, sliding windows) + 2M + 24S + 6M digit
@@ -87,10 +92,20 @@ GEN_U = 0x62EDCBB8BF3787C88B0F03DDD60A8187CAF55D1B29BF81AFE4B3D35DF1A7ADFE   # g
 SAMPLE_STRIDE = 1 << 10
 # edge encodings injected into the decoder's input at fixed global indices: (index, kind)
 INJECT_FIRST, INJECT_STEP = 1000, 4096
+# JJ_BENCH_FAULT_INJECT=1 flips one bit of the CHECKER's expected values (never of the product's output): the run must then report
+# "verified": false and exit with status 3 (tests/test_gpu_dist.py::test_bench_exits_3_when_verification_fails)
+FAULT = os.environ.get("JJ_BENCH_FAULT_INJECT") == "1"
 
 
 def imad32(s, m):
     return 100 * s + 128 * m
+
+
+def host_bytes(x):
+    """numpy view of a small result that may be a numpy array or a torch tensor on any device"""
+    import numpy as np
+
+    return x.cpu().numpy() if hasattr(x, "cpu") else np.asarray(x)
 
 
 def parse():
@@ -108,6 +123,8 @@ def parse():
     ap.add_argument("--fb-window", type=int, default=0, help="fixed-base window bits: 0/6 = LDS-staged constant-time table (default), 8..16 = table gathered from L2 / Infinity Cache")
     ap.add_argument("--decompress-flags", type=int, default=13,
                     help="jj_decompress flags: 1 ZIP-216 | 2 torsion-free (order-8 Tate pairing; JJ_TORSION_CHECK=ladder for the [r]P ladder) | 4 reject small order | 8 clear cofactor (default 13 = BASELINE config 5: decode + small-order check + mul_by_cofactor)")
+    ap.add_argument("--msm-partition", default="terms", choices=["terms", "window"], help="multi-rank MSM: cut by terms or by windows (see the module docstring)")
+    ap.add_argument("--msm-async", type=int, default=1, help="N = 1 MSM workload: jobs in flight (1 = synchronous jj_msm calls)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target wall time of each CPU baseline sample")
     return ap.parse_args()
@@ -202,19 +219,26 @@ def verify_sample(wl, a, lo, n, out, ok, msm_inputs):
         idx = sorted(set(idx) | {i - lo for i in range(INJECT_FIRST, INJECT_FIRST + INJECT_STEP * len(inj), INJECT_STEP) if lo <= i < lo + n})
         enc = np.stack([np.frombuffer(decoder_input_for(lo + i, inj), dtype=np.uint8) for i in idx])
         eo, ek = O.decompress(enc, a.decompress_flags)
+        if FAULT:
+            eo = eo.copy(); eo.reshape(-1)[0] ^= 1
         got_o, got_k = out[idx].cpu().numpy(), ok[idx].cpu().numpy()
         return bool((got_k == ek).all() and (got_o == eo).all()), len(idx)
     if wl == "msm":
         # the whole shard: the oracle's OpenMP MSM over the terms rank 0 reduced (inputs copied back once, outside the timed region)
         s, p = msm_inputs
         want = O.msm(s.cpu().numpy(), p.cpu().numpy())
-        return bool((out.cpu().numpy().reshape(64) == want.reshape(64)).all()), int(s.shape[0])
+        if FAULT:
+            want = want.copy(); want.reshape(-1)[0] ^= 1
+        got = out.cpu().numpy() if hasattr(out, "cpu") else np.asarray(out)
+        return bool((got.reshape(64) == want.reshape(64)).all()), int(s.shape[0])
     scal = np.stack([b32(J.synth_scalar(lo + i, SEED)) for i in idx])
     if wl == "fixedbase":
         want = O.fixedbase_mul(scal, pt64((GEN_U, 11)))
     else:
         pts = np.stack([pt64(J.synth_point(lo + i, POINT_SEED)[0]) for i in idx])
         want = O.varbase_mul(scal, pts)
+    if FAULT:
+        want = want.copy(); want.reshape(-1)[0] ^= 1
     return bool((out[idx].cpu().numpy() == want).all()), len(idx)
 
 
@@ -310,7 +334,10 @@ def run(a):
     torch.cuda.set_device(dev)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
+        if "MASTER_PORT" not in os.environ:                    # 1-rank plumbing runs without a launcher: any free port
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
         if a.backend == "nccl":
@@ -327,7 +354,12 @@ def run(a):
     wl = a.workload
     log2n = a.log2n if a.log2n is not None else DEFAULT_LOG2N[wl]
     total = (1 << log2n) * (n_gpus if a.scaling == "weak" else 1)
-    lo, hi = shard_bounds(total, rank, n_gpus)
+    by_window = wl == "msm" and a.msm_partition == "window" and n_gpus > 1
+    if by_window and a.scaling != "strong":
+        if rank == 0:
+            print("bench.py: --msm-partition window cuts ONE batch by windows: use it with --scaling strong", file=sys.stderr)
+        return 2
+    lo, hi = (0, total) if by_window else shard_bounds(total, rank, n_gpus)     # window partition: every rank holds the whole batch
     n = hi - lo
     passes = a.passes or PASSES[wl]
 
@@ -366,20 +398,29 @@ def run(a):
             return eng.fixedbase_mul(table, scalars)
         if wl == "decompress":
             return eng.decompress(enc, a.decompress_flags)
-        part = eng.msm(scalars, points)                             # one partial point per rank
-        if distributed:
-            if a.backend == "nccl":
-                parts = [torch.empty_like(part) for _ in range(world)]
-                dist.all_gather(parts, part)                        # 64 B per rank over RCCL/xGMI; EC addition is not a reduce op
-                part = eng.fold_partials(torch.stack(parts))        # world partial points -> one, on the host like the rest of the MSM's tail
-            else:
-                parts = [torch.empty(64, dtype=torch.uint8) for _ in range(world)]
-                dist.all_gather(parts, part.cpu())
-                part = eng.fold_partials(torch.stack(parts))
-        return part
+        if not distributed:
+            return eng.msm(scalars, points)
+        # every rank: its record of window sums (8 KB, stays on the device), all_gather, ONE copy to the host, ONE host tail
+        rec = eng.msm_partial(scalars, points, rank, world) if by_window else eng.msm_partial(scalars, points)
+        if a.backend == "nccl":
+            recs = [torch.empty_like(rec) for _ in range(world)]
+            dist.all_gather(recs, rec)                          # RCCL over xGMI; EC addition is not a reduce op
+            return eng.msm_combine(torch.stack(recs))
+        recs = [torch.empty(rec.shape, dtype=torch.uint8) for _ in range(world)]
+        dist.all_gather(recs, rec.cpu())
+        return eng.msm_combine(torch.stack(recs))
 
     def step():
         o = None
+        if wl == "msm" and not distributed and a.msm_async > 1:
+            pend = []                                           # a sliding window of jobs: begin the next before finishing the oldest
+            for _ in range(passes):
+                pend.append(eng.msm_begin(scalars, points))
+                if len(pend) == a.msm_async:
+                    o = eng.msm_finish(pend.pop(0))
+            for j in pend:
+                o = eng.msm_finish(j)
+            return o
         for _ in range(passes):
             o = one_pass()
         return o
@@ -419,11 +460,28 @@ def run(a):
             wl, log2n, "per GPU" if a.scaling == "weak" else "in total over %d GPU(s)" % n_gpus, passes, {"varbase": 1, "fixedbase": 2, "msm": 3, "decompress": 4}[wl]),
             "units_per_step": units_per_step, "passes_per_step": passes, "ms_per_pass": dt / a.steps / passes * 1e3,
             "scalars": "jj_synth_scalars: canonical Fr from splitmix64(seed + 4 i + j)", "points": "jj_random_points: Group::random rejection sampling (full group, order 8r), affine 64 B",
-            "parallelism": "contiguous shards, one process per GPU" + ("; all_gather of 64 B partial points (%s)" % a.backend if wl == "msm" else "; no data-path collective")},
+            "parallelism": ("window partition: rank g owns windows g, g + G, ... of all terms" if by_window else "contiguous shards, one process per GPU") +
+                           ("; all_gather of one 8 KB record of window sums per rank (%s), one host tail" % a.backend if wl == "msm" else "; no data-path collective")},
+        "rccl_world_size": dist.get_world_size() if distributed else 1,
     }
+    if wl == "msm":
+        res["config"]["msm_partition"] = a.msm_partition if n_gpus > 1 else None
+        res["config"]["msm_jobs_in_flight"] = a.msm_async if not distributed else 1
     rc = 0
     if rank == 0:
         w = dict(WORK[wl])
+        if wl == "msm":
+            # field operations of the algorithm this run used, from the window count W of a record (small batches: W = 64, per-term
+            # table of 8 entries (7 x 9M) + W mixed-form additions of 8M; Pippenger: W additions of 7M + 2 x 9M per bucket)
+            hdr = eng.msm_partial(scalars[: min(n, 1 << 24)], points[: min(n, 1 << 24)])[:16].cpu().numpy().view("<u4")
+            W = int(hdr[2])
+            if W == 64:
+                w["M"] = 2 + 2 + 7 * 9 + W * 8
+            else:
+                c_, r_ = divmod(253, W)
+                buckets = r_ * (1 << c_) + (W - r_) * (1 << (c_ - 1))
+                w["M"] = 2 + 2 + W * 7 + -(-(buckets * 18) // n)
+            res["config"]["msm_windows"] = W
         if wl == "fixedbase" and a.fb_window >= 8:
             w["M"] = -(-253 // a.fb_window) * 7              # ceil(253/w) mixed additions
         if main_ms:
@@ -454,17 +512,26 @@ def run(a):
             "build_id": build_id(),
         }
         if wl == "msm":
-            res["msm_result"] = bytes(out.cpu().numpy().reshape(64).tolist()).hex()     # the point every rank ends up with
+            res["msm_result"] = bytes(host_bytes(out).reshape(64).tolist()).hex()     # the point every rank ends up with
         if not a.no_verify:
             o, k = (out if isinstance(out, tuple) else (out, None))
-            if wl == "msm" and n_gpus > 1:
-                # the timed output is the all-rank fold; rank 0's own shard is re-reduced and compared with the oracle here,
-                # the folded point of a whole multi-rank run is compared in tests/test_gpu_dist.py
+            if wl == "msm" and n_gpus > 1 and not by_window:
+                # the timed output is the all-rank sum; rank 0's own shard is re-reduced and compared with the oracle here,
+                # the sum of a whole multi-rank run is compared in tests/test_gpu_dist.py
                 o = eng.msm(scalars, points)
-                res["verified_note"] = "rank 0's shard vs the oracle (the all-rank fold is checked by tests/test_gpu_dist.py)"
+                res["verified_note"] = "rank 0's shard vs the oracle (the all-rank sum is checked by tests/test_gpu_dist.py)"
             okv, cnt = verify_sample(wl, a, lo, n, o, k, (scalars, points))
             res["verified"], res["verified_units"] = okv, cnt
-            if not okv:
+            # every unit of the timed output against a fresh pass over the same inputs, compared on the device (the oracle sample
+            # above checks one unit in 2^10; this ties all the others to a second, independent run)
+            o2 = one_pass()
+            o2v, k2 = (o2 if isinstance(o2, tuple) else (o2, None))
+            if wl == "msm":
+                same = bool((host_bytes(out) == host_bytes(o2v)).all())
+            else:
+                same = bool(torch.equal(o, o2v)) and (k2 is None or bool(torch.equal(k, k2)))
+            res["all_units_equal_second_pass"] = same
+            if not (okv and same):
                 rc = 3
         if wl == "varbase" and not a.no_extras and n_gpus == 1:
             # the other half of BASELINE.json's metric at ITS config (2^24 fixed-base scalar-muls), same process, outside the timed region above

@@ -174,15 +174,15 @@ typedef struct jj_msm_job jj_msm_job;
 int jj_msm_begin(jj_ctx*, size_t n, const void* scalars32, const void* points64, jj_msm_job** job);
 int jj_msm_finish(jj_msm_job* job, void* out64);
 /* MSM cut across devices or ranks.  jj_msm_partial leaves the RECORD of partial window sums instead of the
- * point: JJ_MSM_PARTIAL_BYTES bytes (64-byte header: magic, version, number of windows W, partial sums per window, bit mask
- * of the windows present, n; then W x that many canonical 160-byte extended points (U, V, Z, T1, T2); unused space zeroed), written
- * to device memory (asynchronous: ready for an all_gather over RCCL) or host memory.  At most 2^24 terms per call.
+ * point: JJ_MSM_PARTIAL_BYTES bytes (64-byte header: magic, version, number of windows W, 1, bit mask of the windows
+ * present, n; then one 128-byte point per window: U, V, Z and T = T1 T2, each the 256-bit little-endian integer of
+ * value x 2^256 mod q, the Montgomery form of the host tail; unused space zeroed), written to device memory (asynchronous: ready for an all_gather over RCCL) or host memory.  At most 2^24 terms per call.
  *   part_index = 0, part_count = 1   all windows of the n terms given       (term partition: each rank passes ITS terms)
  *   part_index = g, part_count = G   windows g, g + G, ... of the n terms    (window partition: each rank passes ALL terms)
  * jj_msm_combine (host only, no context) adds any number of records -- window by window where their layouts agree, so the
  * Horner chain runs once per layout -- and returns the affine sum: one copy to the host, one host tail and one inversion
  * for the whole distributed MSM.  Records of a window partition must come from calls with the same n. */
-#define JJ_MSM_PARTIAL_BYTES 81984u   /* 64 + 64 windows x 8 partial sums x 160 */
+#define JJ_MSM_PARTIAL_BYTES 8256u   /* 64 + 64 windows x 128 */
 int jj_msm_partial(jj_ctx*, size_t n, const void* scalars32, const void* points64, int part_index, int part_count, void* record);
 int jj_msm_combine(size_t count, const void* records_host, void* out64_host);
 

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("JJ_LIB_PATH") or os.path.join(HERE, "lib", "libjubjub_hip.so")   # JJ_LIB_PATH: A/B builds of the same library
 
 JJ_OK, JJ_ERR_INVALID, JJ_ERR_HIP, JJ_ERR_NOMEM, JJ_ERR_NODEVICE = 0, -1, -2, -3, -4
-MSM_PARTIAL_BYTES = 81984   # JJ_MSM_PARTIAL_BYTES
+MSM_PARTIAL_BYTES = 8256   # JJ_MSM_PARTIAL_BYTES
 
 _vp, _sz, _u8p = C.c_void_p, C.c_size_t, C.c_void_p
 

@@ -78,6 +78,7 @@ struct jj_ctx {
   DevBuf msm_rec;                // the record of partial window sums a pass leaves on the device
   uint8_t host_out[8][64];       // results on their way to a device pointer (ring: the copies are asynchronous)
   int host_out_next = 0;
+  int msm_small_blk = 4;         // small-batch path: at most this many 64-quad workgroups per window (JJ_MSM_SMALL_BLK, 1..64; 4 x 64 windows = one per CU)
   int msm_windows = 0;           // number of windows W (0 = from n; JJ_MSM_WINDOWS, 8..36)
   int msm_small_max = 1 << 14;   // batches up to this size take the two-launch small-batch path (JJ_MSM_SMALL_MAX; 0 = never)
   bool torsion_ladder = false;   // subgroup test: false = Tate pairing (k_torsion_free), true = multiply by r (reference definition)
@@ -333,6 +334,7 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
   c->stream = c->own_stream;
   if (const char* e = getenv("JJ_PIPE_CHUNK_LOG2")) { int v = atoi(e); if (v >= 8 && v <= 24) c->pipe_chunk = (size_t)1 << v; }
   if (const char* e = getenv("JJ_MSM_WINDOWS")) c->msm_windows = atoi(e);
+  if (const char* e = getenv("JJ_MSM_SMALL_BLK")) { int v = atoi(e); if (v >= 1 && v <= MSM_TREE_QUADS) c->msm_small_blk = v; }
   if (const char* e = getenv("JJ_MSM_SMALL_MAX")) { int v = atoi(e); if (v >= 0 && v <= (1 << 20)) c->msm_small_max = v; }
   if (const char* e = getenv("JJ_MSM_ACCUM")) c->msm_segments = strcmp(e, "chunks") == 0 ? 0 : strcmp(e, "segments") == 0 ? 1 : -1;
   if (const char* e = getenv("JJ_MSM_SEG_LEN")) c->msm_seg_len = atoi(e);
@@ -933,27 +935,30 @@ static void msm_layout(MsmParams& mp, int W, int w0, int wstride) {
 // any W is as good as its entry count n W and its bucket count ~ W 2^(253/W - 1) make it
 static int msm_windows_for(jj_ctx* c, size_t n) {
   if (c->msm_windows >= 8 && c->msm_windows <= 36) return c->msm_windows;
-  if (n >= ((size_t)1 << 22)) return 16;
-  if (n >= ((size_t)1 << 18)) return 16;
-  if (n >= ((size_t)1 << 16)) return 20;
-  return 22;
+  // measured (experiments/misc/msm_sweep*.sh, profiles/r3_msm_window_sweep.txt): 16 windows (13 of 16 bits, 3 of 15) from 2^18 terms;
+  // below, 23 windows of 11 bits: wider windows cut the additions but their buckets (4096+ per window) make the latency-bound
+  // fix-up and reduce chains longer than the additions they save
+  return n >= ((size_t)1 << 18) ? 16 : 23;
 }
-
-static int msm_enqueue_small(jj_ctx* c, size_t n, const void* ds, const void* dp, int part_w0, int part_stride, void* rec_dev, int* nblk_out) {
+// counters (MSM_COUNTER_WORDS words, cleared by the first kernel of a pass) | big-bucket work list | workgroup partial sums
+constexpr size_t MSM_BIG_OFF = 512, MSM_PART_OFF = MSM_BIG_OFF + sizeof(BigBucket) * FIXUP_BIG_MAX;
+static int msm_ensure_ctl(jj_ctx* c) { return ensure(c, c->ws_tmp[1], MSM_PART_OFF + (size_t)64 * MSM_TREE_QUADS * MSM_PART_WORDS * 4); }
+static int msm_enqueue_small(jj_ctx* c, size_t n, const void* ds, const void* dp, int part_w0, int part_stride, void* rec_dev) {
   MsmParams mp;
   msm_layout(mp, SM_W, part_w0, part_stride);
   int rc;
   if ((rc = ensure(c, c->msm[0], n * 32))) return rc;
   if ((rc = ensure(c, c->msm[1], n * (size_t)(SM_SLOTS * ENIELS_WORDS) * 4))) return rc;
-  // blocks of 128 quads per window: enough to give every quad at most ~4 terms, at most MSM_REC_BLK
-  const u32 nblk = (u32)std::min<size_t>(MSM_REC_BLK, std::max<size_t>(1, (n + 511) / 512));
-  *nblk_out = (int)nblk;
-  hipLaunchKernelGGL(k_msm_small_tables, dim3(blocks_for(4 * n)), dim3(256), 0, c->stream, n, ds, dp, mp, (u32*)c->msm[1].p, (u32*)c->msm[0].p);
-  hipLaunchKernelGGL(k_msm_small_sum, dim3(nblk, mp.Ws), dim3(4 * MSM_TREE_QUADS), 0, c->stream, n, mp, nblk, (const u32*)c->msm[1].p, (const u32*)c->msm[0].p, (u32*)rec_dev);
+  if ((rc = msm_ensure_ctl(c))) return rc;
+  u32* counters = (u32*)c->ws_tmp[1].p; u32* part = (u32*)((uint8_t*)c->ws_tmp[1].p + MSM_PART_OFF);
+  // workgroups of 64 quads per window: about 4 terms per quad, at most msm_small_blk (4 x 64 windows = one workgroup per CU)
+  const u32 nblk = (u32)std::min<size_t>(c->msm_small_blk, std::max<size_t>(1, (n + 255) / 256));
+  hipLaunchKernelGGL(k_msm_small_tables, dim3(blocks_for(4 * n)), dim3(256), 0, c->stream, n, ds, dp, mp, (u32*)c->msm[1].p, (u32*)c->msm[0].p, counters);
+  hipLaunchKernelGGL(k_msm_small_sum, dim3(nblk, mp.Ws), dim3(4 * MSM_TREE_QUADS), 0, c->stream, n, mp, nblk, (const u32*)c->msm[1].p, (const u32*)c->msm[0].p, part, counters, (u32*)rec_dev);
   return JJ_OK;
 }
 
-static int msm_enqueue_pippenger(jj_ctx* c, size_t n, const void* ds, const void* dp, int part_w0, int part_stride, void* rec_dev, int* nblk_out) {
+static int msm_enqueue_pippenger(jj_ctx* c, size_t n, const void* ds, const void* dp, int part_w0, int part_stride, void* rec_dev) {
   MsmParams mp;
   msm_layout(mp, msm_windows_for(c, n), part_w0, part_stride);
   const u32 B = mp.B, Ws = (u32)mp.Ws;
@@ -961,12 +966,10 @@ static int msm_enqueue_pippenger(jj_ctx* c, size_t n, const void* ds, const void
   // buckets per reduce chunk (serial depth 2L + ~2c): the reduce is latency-bound, so short chunks (more quads in flight) win
   // as long as the per-chunk double-and-add by the chunk's first index stays small against the 2L additions -- measured:
   // 32 for the 2^19 buckets of 16-bit windows, 4-8 below.  JJ_MSM_REDUCE_CHUNK overrides; never more than one window.
-  // and at least B / 512, so that the 128-quad workgroups of the reduce leave at most 4 partial sums per window to the host
-  const u32 L_auto = std::max<u32>(nb >= ((size_t)1 << 18) ? 32u : (nb >= ((size_t)1 << 16) ? 8u : 4u), B >= 32768 ? 32u : B / (4 * MSM_TREE_QUADS));
-  const u32 L = std::min<u32>(c->msm_reduce_chunk ? (u32)c->msm_reduce_chunk : std::max<u32>(L_auto, 1u), B);
+  const u32 L_auto = nb >= ((size_t)1 << 18) ? 32u : (nb >= ((size_t)1 << 16) ? 8u : 4u);
+  const u32 L = std::min<u32>(c->msm_reduce_chunk ? (u32)c->msm_reduce_chunk : L_auto, B);
   if (B % L || (L & (L - 1))) { c->err = "inconsistent MSM tuning override (JJ_MSM_REDUCE_CHUNK must be a power of two dividing the bucket count)"; return JJ_ERR_INVALID; }
-  const u32 K = B / L, nblk = std::min<u32>(MSM_REC_BLK, (K + MSM_TREE_QUADS - 1) / MSM_TREE_QUADS);
-  *nblk_out = (int)nblk;
+  const u32 K = B / L, nblk = std::min<u32>(MSM_TREE_QUADS, (K + MSM_TREE_QUADS - 1) / MSM_TREE_QUADS);      // workgroups of 64 quads per window
   int jbits = 0; while ((1u << jbits) < B) jbits++;
   int rc;
   DevBuf &kprime = c->msm[0], &niels = c->msm[1], &offb = c->msm[2], &idx = c->msm[3], &buckets = c->msm[4], &ra = c->msm[5], &tcnt = c->msm[7];
@@ -998,13 +1001,14 @@ static int msm_enqueue_pippenger(jj_ctx* c, size_t n, const void* ds, const void
   if ((rc = ensure(c, buckets, (size_t)EXT_AOS_WORDS * 4 * nb))) return rc;
   // ra: first the two-pass sort's records (4 + 1 bytes per entry), then the chunk heads / segment heads
   if ((rc = ensure(c, ra, std::max<size_t>((size_t)EXT_AOS_WORDS * 4 * std::max<size_t>((size_t)Ws * nchunk, (n * (size_t)Ws) / 8 + 1), n * (size_t)Ws * 5 + 64)))) return rc;
-  if ((rc = ensure(c, c->ws_tmp[1], 64 + sizeof(BigBucket) * FIXUP_BIG_MAX))) return rc;              // counters + big-bucket work list
+  if ((rc = msm_ensure_ctl(c))) return rc;                                                              // counters, big-bucket work list, workgroup partial sums
   if ((rc = ensure(c, c->ws_tmp[0], (size_t)5 * NL * 4 * FIXUP_BIG_MAX * FIXUP_BIG_QUADS))) return rc;   // their partial sums
   if (use_segments && (rc = ensure(c, c->msm_seg, hdr_words * 4 + 16 + nb * sizeof(MergeItem) + max_segs * sizeof(Seg)))) return rc;   // bh [stiles][P+1] | count [P+1] | offset [P+2] | merge list | segments
   hipStream_t st = c->stream;
   u32* off = (u32*)offb.p;
-  u32* counters = (u32*)c->ws_tmp[1].p;                   // MSM_COUNTERS words, cleared by the sort's plan kernel; the work list follows at +64
-  BigBucket* big = (BigBucket*)((uint8_t*)c->ws_tmp[1].p + 64);
+  u32* counters = (u32*)c->ws_tmp[1].p;                   // cleared by the sort's plan kernel
+  BigBucket* big = (BigBucket*)((uint8_t*)c->ws_tmp[1].p + MSM_BIG_OFF);
+  u32* part = (u32*)((uint8_t*)c->ws_tmp[1].p + MSM_PART_OFF);
   // Large inputs: the point half of the conversion (bandwidth- and multiplier-bound, 55 us at 2^20 terms) runs on the second
   // stream beside the sort (LDS-bound) and is joined before the accumulation; the two extra events cost ~10 us, more than the
   // overlap returns below 2^18 terms.  JJ_MSM_FORK=0/1 overrides.
@@ -1048,17 +1052,15 @@ static int msm_enqueue_pippenger(jj_ctx* c, size_t n, const void* ds, const void
     hipLaunchKernelGGL(k_msm_fixup, dim3(blocks_for(4 * nb)), dim3(256), 0, st, n, B, Ws, chunk, nchunk, (const u32*)off, bk, head, counters, big);
   }
   hipLaunchKernelGGL(k_msm_fixup_big, dim3(256), dim3(256), 0, st, counters, (const BigBucket*)big, bk, head, partial);
-  if (K > MSM_TREE_QUADS * nblk) hipLaunchKernelGGL(k_msm_reduce_fold<true>, dim3(nblk, Ws), dim3(4 * MSM_TREE_QUADS), 0, st, n, mp, L, nblk, jbits, bk, (u32*)rec_dev);
-  else hipLaunchKernelGGL(k_msm_reduce_fold<false>, dim3(nblk, Ws), dim3(4 * MSM_TREE_QUADS), 0, st, n, mp, L, nblk, jbits, bk, (u32*)rec_dev);
+  if (K > MSM_TREE_QUADS * nblk) hipLaunchKernelGGL(k_msm_reduce_fold<true>, dim3(nblk, Ws), dim3(4 * MSM_TREE_QUADS), 0, st, n, mp, L, nblk, jbits, bk, part, counters, (u32*)rec_dev);
+  else hipLaunchKernelGGL(k_msm_reduce_fold<false>, dim3(nblk, Ws), dim3(4 * MSM_TREE_QUADS), 0, st, n, mp, L, nblk, jbits, bk, part, counters, (u32*)rec_dev);
   return JJ_OK;
 }
 // one pass (at most 2^24 terms: 32-bit sort indices), record left at rec_dev
 static int msm_enqueue(jj_ctx* c, size_t n, const void* ds, const void* dp, int part_w0, int part_stride, void* rec_dev, size_t* rec_bytes) {
   const bool small = n <= (size_t)c->msm_small_max;
-  int nblk = 1;
-  const int rc = small ? msm_enqueue_small(c, n, ds, dp, part_w0, part_stride, rec_dev, &nblk) : msm_enqueue_pippenger(c, n, ds, dp, part_w0, part_stride, rec_dev, &nblk);
-  *rec_bytes = jjhost::rec_bytes(small ? SM_W : msm_windows_for(c, n), nblk);
-  return rc;
+  *rec_bytes = jjhost::rec_bytes(small ? SM_W : msm_windows_for(c, n));
+  return small ? msm_enqueue_small(c, n, ds, dp, part_w0, part_stride, rec_dev) : msm_enqueue_pippenger(c, n, ds, dp, part_w0, part_stride, rec_dev);
 }
 
 // ---- asynchronous jobs: jj_msm_begin queues every pass of one MSM and the copy of its records into the job's own page-locked
@@ -1168,7 +1170,7 @@ JJ_API int jj_msm_partial(jj_ctx* c, size_t n, const void* scalars, const void* 
   HIPCHK(c, hipMemsetAsync(o.dev, 0, JJ_MSM_PARTIAL_BYTES, c->stream));
   if (n == 0) {
     // an empty shard: a valid record without windows
-    uint32_t hdr[MSM_REC_HDR_WORDS] = {MSM_REC_MAGIC, 1u, (uint32_t)SM_W, 1u};
+    uint32_t hdr[MSM_REC_HDR_WORDS] = {MSM_REC_MAGIC, 2u, (uint32_t)SM_W, 1u};
     memcpy(c->host_out[c->host_out_next], hdr, 64);
     HIPCHK(c, hipMemcpyAsync(o.dev, c->host_out[c->host_out_next], 64, hipMemcpyHostToDevice, c->stream));
     c->host_out_next = (c->host_out_next + 1) % 8;

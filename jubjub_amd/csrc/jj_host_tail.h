@@ -1,7 +1,7 @@
-// Host-side finish of an MSM: the device leaves a RECORD of partial window sums (jj_msm_kernels.h: 64-byte header, then for
-// every window up to eight canonical 160-byte extended points); here the partial sums of each window are added -- over one record
-// or over the records of several passes, devices or ranks --, the windows are combined by Horner (252 dependent point doublings in
-// all) and the result is converted to affine.  That chain has no parallelism a GPU could use -- a lone wavefront issues one
+// Host-side finish of an MSM: the device leaves a RECORD of window sums (jj_msm_kernels.h: 64-byte header, then one 128-byte
+// point per window: U, V, Z, T = T1 T2, already in the 4 x 64-bit Montgomery form used here); the window sums of several records
+// (passes, devices, ranks) are added window by window, the windows are combined by Horner (252 dependent point doublings in all)
+// and the result is converted to affine.  That chain has no parallelism a GPU could use -- a lone wavefront issues one
 // multiply-add per ~9 cycles, 1.5 us per doubling -- while a host core does the same doubling in ~0.15 us.
 //
 // Plain 4 x 64-bit Montgomery arithmetic (radix 2^256) modulo q; every constant is derived at start-up from q and
@@ -117,16 +117,24 @@ static inline Ext ext_from_canon160(const uint8_t* p) {
 static inline Ext identity() { const Fe z = {{0, 0, 0, 0}}; return Ext{z, consts().one, consts().one, z, z}; }
 // ---- records of partial window sums (layout: jj_msm_kernels.h MSM_REC_*; include/jubjub_hip.h jj_msm_partial)
 constexpr uint32_t REC_MAGIC = 0x504D4A4Au;       // "JJMP"
-constexpr int REC_HDR_BYTES = 64, REC_BLK = 8, REC_MAX_W = 64;
-constexpr size_t REC_MAX_BYTES = REC_HDR_BYTES + (size_t)REC_MAX_W * REC_BLK * 160;
+constexpr int REC_HDR_BYTES = 64, REC_PT_BYTES = 128, REC_MAX_W = 64;
+constexpr size_t REC_MAX_BYTES = REC_HDR_BYTES + (size_t)REC_MAX_W * REC_PT_BYTES;
 // width of window w when W windows tile the 253 bits of a recoded scalar: 253 = W c + r, the r low windows are one bit wider
 static inline int win_width(int W, int w) { const int c = 253 / W, r = 253 % W; return c + (w < r ? 1 : 0); }
 struct RecHeader { uint32_t magic, version, W, nblk; uint64_t mask, n; };
 static inline bool rec_header(const uint8_t* rec, RecHeader* h) {
   memcpy(h, rec, sizeof(RecHeader));
-  return h->magic == REC_MAGIC && h->version == 1 && h->W >= 1 && h->W <= (uint32_t)REC_MAX_W && h->nblk >= 1 && h->nblk <= (uint32_t)REC_BLK;
+  return h->magic == REC_MAGIC && h->version == 2 && h->W >= 1 && h->W <= (uint32_t)REC_MAX_W && h->nblk == 1;
 }
-static inline size_t rec_bytes(int W, int nblk) { return REC_HDR_BYTES + (size_t)W * nblk * 160; }
+static inline size_t rec_bytes(int W) { return REC_HDR_BYTES + (size_t)W * REC_PT_BYTES; }
+// a window's point: four field elements in Montgomery form, each below q (checked: a damaged record must not reach the arithmetic)
+static inline bool ext_from_record(const uint8_t* p, Ext* out) {
+  Fe c[4];
+  memcpy(c, p, 128);
+  for (int i = 0; i < 4; i++) if (geq_q(c[i].l)) return false;
+  *out = Ext{c[0], c[1], c[2], c[3], consts().one};           // t1 * t2 = T
+  return true;
+}
 // Window sums of one window layout; records with the same W (every pass / rank that saw the same number of terms) meet here
 // window by window, so that the Horner chain runs once for all of them.
 struct WindowSums {
@@ -140,10 +148,9 @@ struct WindowSums {
     if ((int)h.W != W) return false;
     for (int w = 0; w < W; w++) {
       if (!((h.mask >> w) & 1)) continue;
-      for (uint32_t b = 0; b < h.nblk; b++) {
-        const Ext p = ext_from_canon160(rec + REC_HDR_BYTES + ((size_t)w * h.nblk + b) * 160);
-        if (have[w]) sum[w] = point_add(sum[w], p); else { sum[w] = p; have[w] = true; }
-      }
+      Ext p;
+      if (!ext_from_record(rec + REC_HDR_BYTES + (size_t)w * REC_PT_BYTES, &p)) return false;
+      if (have[w]) sum[w] = point_add(sum[w], p); else { sum[w] = p; have[w] = true; }
     }
     return true;
   }

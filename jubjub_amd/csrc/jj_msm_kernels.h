@@ -13,8 +13,8 @@
 // A pass may own a SUBSET of the windows (w0 + s * wstride, s < Ws: the by-window partition of a multi-GPU MSM);
 // everything below is indexed by the slot s, only the digit extraction uses the window w itself.
 //
-// Two algorithms produce the same output record (per window at most MSM_REC_BLK partial sums, canonical 160-byte extended points;
-// the host adds them, runs Horner over the windows and inverts once: jj_host_tail.h):
+// Two algorithms produce the same output record (one point per window: U, V, Z and T = T1 T2 as 4 x 32 bytes in the host tail's
+// own Montgomery form, radix 2^256; the host runs Horner over the windows and inverts once: jj_host_tail.h):
 //   small batches (<= ~2^14 terms)   k_msm_small_tables + k_msm_small_sum: per-term table {0..8}P, 64 windows of 3-4 bits, every
 //                                    window is a tree sum over the terms' table entries on quads of lanes -- two launches
 //   Pippenger                        k_msm_convert; counting sort by (window, |digit|) without global atomics, one pass with the
@@ -25,9 +25,14 @@
 #pragma once
 // (inside namespace jj: this file is included from the middle of jj_kernels.h)
 
-constexpr int MSM_REC_BLK = 8;                    // at most this many partial sums per window in the output record
-constexpr int MSM_TREE_QUADS = 128;               // quads of the 512-thread workgroups that end in a quad_tree_sum (158 VGPRs: two waves per SIMD)
-constexpr int MSM_REC_HDR_WORDS = 16;             // 64-byte header: magic, version, W, nblk, window mask (2 words), n (2 words)
+// The kernels that end in a window sum are chains of dependent point operations on quads of lanes: they run fastest at ONE wave
+// per SIMD (measured: a second wave per SIMD slows each by ~1.45x), so their workgroups are 256 threads = 64 quads, as many
+// workgroups per window as the work needs, and the LAST workgroup of a window to finish (a device-side counter) folds the
+// window's partial sums and writes the window's point into the record.
+constexpr int MSM_TREE_QUADS = 64;
+constexpr int MSM_REC_HDR_WORDS = 16;             // 64-byte header: magic, version, W, 1, window mask (2 words), n (2 words)
+constexpr int MSM_REC_PT_WORDS = 32;              // one window: U, V, Z, T, 8 words each
+constexpr int MSM_PART_WORDS = 56;                // a workgroup's partial sum on its way to the window's last workgroup: U V Z T1 T2 T + pad
 constexpr u32 MSM_REC_MAGIC = 0x504D4A4Au;        // "JJMP"
 
 struct MsmParams {
@@ -69,26 +74,27 @@ static JJ_DEV void msm_recode(u32 (&k)[8], const MsmParams& mp) {
   _Pragma("unroll") for (int j = 0; j < 8; j++) { const u64 t = (u64)k[j] + mp.recode[j] + cy; k[j] = (u32)t; cy = t >> 32; }
 }
 // header of the output record, written by one thread of the kernel that produces the window sums
-static JJ_DEV void msm_write_header(u32* hdr, const MsmParams& mp, u32 nblk, size_t n) {
+static JJ_DEV void msm_write_header(u32* hdr, const MsmParams& mp, size_t n) {
   u64 mask = 0;
   for (int s = 0; s < mp.Ws; s++) mask |= 1ull << msm_slot_window(mp, s);
-  hdr[0] = MSM_REC_MAGIC; hdr[1] = 1u; hdr[2] = (u32)mp.W; hdr[3] = nblk;
+  hdr[0] = MSM_REC_MAGIC; hdr[1] = 2u; hdr[2] = (u32)mp.W; hdr[3] = 1u;
   hdr[4] = (u32)mask; hdr[5] = (u32)(mask >> 32); hdr[6] = (u32)n; hdr[7] = (u32)((u64)n >> 32);
   for (int j = 8; j < MSM_REC_HDR_WORDS; j++) hdr[j] = 0;
 }
-// one partial window sum leaves as a canonical 160-byte extended point (U, V, Z, T1, T2)
-static JJ_DEV void msm_store_partial(void* points160, int w, u32 nblk, u32 blk, const Ext& acc) {
-  const size_t i = (size_t)w * nblk + blk;
+// a window's point leaves as (U, V, Z, T = T1 T2), each the canonical integer of value * 2^256 mod q: the host tail's Montgomery
+// form (jj_host_tail.h), so the host starts its Horner chain without a single conversion product
+static JJ_DEV void msm_store_window(u32* points, int w, const Ext& acc, const Fe& T) {
+  const Fe hr = Fq::konst(FqP::HOST_R);
+  u32* dst = points + (size_t)w * MSM_REC_PT_WORDS;
   u32 wd[8];
-  Fq::to_words(wd, acc.u); store8(points160, 5 * i, wd);
-  Fq::to_words(wd, acc.v); store8(points160, 5 * i + 1, wd);
-  Fq::to_words(wd, acc.z); store8(points160, 5 * i + 2, wd);
-  Fq::to_words(wd, Fq::carry(acc.t1)); store8(points160, 5 * i + 3, wd);
-  Fq::to_words(wd, Fq::carry(acc.t2)); store8(points160, 5 * i + 4, wd);
+  Fq::pack(wd, Fq::canon_plain_product(Fq::mul(acc.u, hr))); store8(dst, 0, wd);
+  Fq::pack(wd, Fq::canon_plain_product(Fq::mul(acc.v, hr))); store8(dst, 1, wd);
+  Fq::pack(wd, Fq::canon_plain_product(Fq::mul(acc.z, hr))); store8(dst, 2, wd);
+  Fq::pack(wd, Fq::canon_plain_product(Fq::mul(T, hr))); store8(dst, 3, wd);
 }
 
-// ---- quad-lane tree over the MSM_TREE_QUADS quads of a 512-thread workgroup through LDS: every quad hands in a point and
-// T = t1 * t2; quad 0 ends up with the sum of the first `live` quads' points.  7 levels of three-round additions.
+// ---- quad-lane tree over the MSM_TREE_QUADS quads of a 256-thread workgroup through LDS: every quad hands in a point and
+// T = t1 * t2; quad 0 ends up with the sum of the first `live` quads' points.  6 levels of three-round additions.
 // A point waits in LDS in the form the first multiplication round of the addition consumes, (V - U, V + U, T, Z): lane r of
 // the receiving quad reads coordinate r only (one indexed read, 9 words), which keeps the tree at ~100 VGPRs.
 constexpr int LDS_PT_WORDS = 4 * NL;     // 36 words = 144 B per waiting point
@@ -118,14 +124,42 @@ static JJ_DEV void quad_tree_sum(u32* st, u32 quad, u32 role, u32 live, Ext& acc
   }
 }
 
+// Workgroup (blk, s) of nblk holds its sum in quad 0.  With several workgroups per window each parks its sum in `part`; the last
+// one to arrive (counter MSM_COUNTERS + s, cleared by the first kernel of the pass) folds all of them and writes the window's point.
+constexpr int MSM_COUNTERS = 8;                       // [0] heads, [1] merge items, [2] big buckets, [3] big-bucket blocks done; then one arrival counter per slot
+constexpr int MSM_COUNTER_WORDS = MSM_COUNTERS + 64;
+static JJ_DEV void msm_finish_window(u32* st, u32 quad, u32 role, u32 nblk, u32 blk, u32 s, int w, Ext& acc, Fe& T, u32* part, u32* counters, u32* rec) {
+  __shared__ u32 last_s;
+  if (nblk > 1) {
+    if (quad == 0 && role == 0) {
+      const Fe t1 = Fq::carry(acc.t1), t2 = Fq::carry(acc.t2);
+      u32* p = part + ((size_t)s * nblk + blk) * MSM_PART_WORDS;
+      _Pragma("unroll") for (int l = 0; l < NL; l++) { p[l] = acc.u.l[l]; p[NL + l] = acc.v.l[l]; p[2 * NL + l] = acc.z.l[l]; p[3 * NL + l] = t1.l[l]; p[4 * NL + l] = t2.l[l]; p[5 * NL + l] = T.l[l]; }
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last_s = atomicAdd(&counters[MSM_COUNTERS + s], 1u) == nblk - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!last_s) return;
+    __threadfence();
+    if (quad < nblk) {
+      const u32* p = part + ((size_t)s * nblk + quad) * MSM_PART_WORDS;
+      _Pragma("unroll") for (int l = 0; l < NL; l++) { acc.u.l[l] = p[l]; acc.v.l[l] = p[NL + l]; acc.z.l[l] = p[2 * NL + l]; acc.t1.l[l] = p[3 * NL + l]; acc.t2.l[l] = p[4 * NL + l]; T.l[l] = p[5 * NL + l]; }
+    }
+    quad_tree_sum(st, quad, role, nblk, acc, T);
+  }
+  if (quad == 0 && role == 0) msm_store_window(rec + MSM_REC_HDR_WORDS, w, acc, T);
+}
+
 // ================================================================================================ small batches
 // One quad of lanes per term builds the term's table {0 .. 8} P (extended-Niels, 144 B per entry, entry 0 = the identity so
 // that a zero digit is a plain table read) and stores the recoded scalar; then one workgroup per (window, block of terms) adds
 // up the entries the terms' digits select: every quad takes a strided share of the terms (two multiplication rounds per
-// addition), and the quads of a workgroup are folded through LDS.  With W = 64 the windows are 3 or 4 bits wide: digits in [-8, 8].
+// addition), the quads of a workgroup are folded through LDS, and the last workgroup of the window folds the workgroups' sums.  With W = 64 the windows are 3 or 4 bits wide: digits in [-8, 8].
 constexpr int SM_W = 64;                 // windows of the small-batch layout (253 = 64 * 3 + 61: 61 windows of 4 bits, 3 of 3 bits)
 constexpr int SM_SLOTS = 9;              // table entries per term: multiples 0 .. 8
-__global__ void __launch_bounds__(256) k_msm_small_tables(size_t n, const void* scalars, const void* points, MsmParams mp, u32* tables, u32* kprime) {
+__global__ void __launch_bounds__(256) k_msm_small_tables(size_t n, const void* scalars, const void* points, MsmParams mp, u32* tables, u32* kprime, u32* counters) {
+  if (blockIdx.x == 0 && threadIdx.x < MSM_COUNTER_WORDS) counters[threadIdx.x] = 0;
   const size_t q = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
   const u32 role = threadIdx.x & 3u;
   if (q >= n) return;                                       // whole quads leave together
@@ -149,11 +183,11 @@ __global__ void __launch_bounds__(256) k_msm_small_tables(size_t n, const void* 
     if (role == 0) store_eniels(slot + j * ENIELS_WORDS, en);
   }
 }
-__global__ void __launch_bounds__(4 * MSM_TREE_QUADS) k_msm_small_sum(size_t n, MsmParams mp, u32 nblk, const u32* tables, const u32* kprime, u32* rec) {
+__global__ void __launch_bounds__(4 * MSM_TREE_QUADS) k_msm_small_sum(size_t n, MsmParams mp, u32 nblk, const u32* tables, const u32* kprime, u32* part, u32* counters, u32* rec) {
   __shared__ __attribute__((aligned(16))) u32 st[MSM_TREE_QUADS * LDS_PT_WORDS];
   const u32 role = threadIdx.x & 3u, quad = threadIdx.x >> 2, blk = blockIdx.x;
   const int w = msm_slot_window(mp, (int)blockIdx.y);
-  if (blk == 0 && blockIdx.y == 0 && threadIdx.x == 0) msm_write_header(rec, mp, nblk, n);
+  if (blk == 0 && blockIdx.y == 0 && threadIdx.x == 0) msm_write_header(rec, mp, n);
   const size_t first = (size_t)blk * MSM_TREE_QUADS + quad, stride = (size_t)MSM_TREE_QUADS * nblk;
   Ext acc = Curve::identity();
   Fe T = Fq::zero();
@@ -180,8 +214,8 @@ __global__ void __launch_bounds__(4 * MSM_TREE_QUADS) k_msm_small_sum(size_t n, 
   }
   const size_t base = (size_t)blk * MSM_TREE_QUADS;
   const u32 live = base >= n ? 0u : (n - base < MSM_TREE_QUADS ? (u32)(n - base) : (u32)MSM_TREE_QUADS);      // quads of this block that hold a term
-  quad_tree_sum(st, quad, role, live, acc, T);
-  if (quad == 0 && role == 0) msm_store_partial(rec + MSM_REC_HDR_WORDS, w, nblk, blk, acc);   // identity when the block has no term
+  quad_tree_sum(st, quad, role, live, acc, T);                                            // identity when the block has no term
+  msm_finish_window(st, quad, role, nblk, blk, blockIdx.y, w, acc, T, part, counters, rec);
 }
 
 // ================================================================================================ Pippenger: conversion
@@ -220,7 +254,6 @@ constexpr int MSM_SORT_THREADS = 1024;
 #define JJ_MSM_SORT_UNROLL 4
 #endif
 constexpr int MSM_SORT_UNROLL = JJ_MSM_SORT_UNROLL;   // terms per thread and trip: that many loads / LDS atomics / stores in flight
-constexpr int MSM_COUNTERS = 8;                       // [0] heads, [1] merge items, [2] big buckets, [3] big-bucket blocks done
 __global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_hist(size_t n, size_t tile, MsmParams mp, const u32* kp, u32* tcount) {
   extern __shared__ u32 msm_lds[];
   const int w = msm_slot_window(mp, (int)blockIdx.y);
@@ -258,7 +291,7 @@ constexpr int MSM_PLAN_PER = 4;      // buckets per thread of the plan kernel: B
 __global__ void __launch_bounds__(1024) k_msm_plan(size_t n, u32 B, u32 ntiles, u32* tcount, u32* off, u32* counters) {
   __shared__ u32 part[17];
   const u32 s = blockIdx.x;
-  if (s == 0 && threadIdx.x < MSM_COUNTERS) counters[threadIdx.x] = 0;
+  if (s == 0 && threadIdx.x < MSM_COUNTER_WORDS) counters[threadIdx.x] = 0;
   u32* tc = tcount + (size_t)s * ntiles * B;
   const u32 b0 = threadIdx.x * MSM_PLAN_PER;
   u32 tot[MSM_PLAN_PER], sum = 0;
@@ -349,7 +382,7 @@ __global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_part_hist(size_t n, si
 __global__ void __launch_bounds__(1024) k_msm_part_plan(size_t n, u32 m, const u32* tc, u32* tcs, u32* counters) {
   __shared__ u32 part[17];
   const u32 s = blockIdx.x;
-  if (s == 0 && threadIdx.x < MSM_COUNTERS) counters[threadIdx.x] = 0;
+  if (s == 0 && threadIdx.x < MSM_COUNTER_WORDS) counters[threadIdx.x] = 0;
   const u32* in = tc + (size_t)s * m;
   u32* out = tcs + (size_t)s * (m + 1);
   const u32 per = (m + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < m ? lo + per : m;
@@ -695,10 +728,10 @@ __global__ void __launch_bounds__(256) k_msm_fixup_big(u32* counters, const BigB
 // ================================================================================================ Pippenger: bucket reduction
 // sum_j (j + 1) b_j of every window, on quads of lanes (the chains are latency-bound).  A chunk of L consecutive buckets j0 ..
 // j0 + L - 1 contributes T + j0 S with T = sum (j - j0 + 1) b_j (running sums) and S = sum b_j; j0 S is a double-and-add over
-// the significant bits of j0 (a multiple of L = 2^lb: lb plain doublings at the end).  Block (blk, s) takes the chunks blk * 128 +
-// quad (+ 128 nblk ...) of slot s, its 128 quads are folded through LDS, and quad 0 writes one partial window sum into the
-// output record: the host adds the at most MSM_REC_BLK partials of a window (jj_host_tail.h).  Windows narrower than the widest
-// one use only the first 2^(width-1) of their B bucket slots; the chunks above are skipped.
+// the significant bits of j0 (a multiple of L = 2^lb: lb plain doublings at the end).  Block (blk, s) takes the chunks blk * 64 +
+// quad (+ 64 nblk ...) of slot s, its 64 quads are folded through LDS, and the last block of the window folds the blocks' sums
+// and writes the window's point into the output record (msm_finish_window).  Windows narrower than the widest one use only the
+// first 2^(width-1) of their B bucket slots; the chunks above are skipped.
 // chunk k of slot s: T + j0 S, and its t1 * t2
 static JJ_DEV Ext msm_reduce_chunk(const MsmParams& mp, u32 s, u32 k, u32 L, int lb, int jbits, const ExtAoS& buckets, u32 role, Fe& Tout) {
   const size_t first = (size_t)s * mp.B + (size_t)k * L;       // bucket index of the pass
@@ -737,13 +770,13 @@ static JJ_DEV Ext msm_reduce_chunk(const MsmParams& mp, u32 s, u32 k, u32 L, int
   Tout = Tt;
   return total;
 }
-// MULTI: a quad may own several chunks (only with tuning overrides that leave more than MSM_TREE_QUADS * MSM_REC_BLK chunks per window)
+// MULTI: a quad may own several chunks (only with tuning overrides that leave more than 64 * 64 chunks per window)
 template <bool MULTI>
-__global__ void __launch_bounds__(4 * MSM_TREE_QUADS) k_msm_reduce_fold(size_t n, MsmParams mp, u32 L, u32 nblk, int jbits, ExtAoS buckets, u32* rec) {
+__global__ void __launch_bounds__(4 * MSM_TREE_QUADS) k_msm_reduce_fold(size_t n, MsmParams mp, u32 L, u32 nblk, int jbits, ExtAoS buckets, u32* part, u32* counters, u32* rec) {
   __shared__ __attribute__((aligned(16))) u32 st[MSM_TREE_QUADS * LDS_PT_WORDS];
   const u32 role = threadIdx.x & 3u, quad = threadIdx.x >> 2, blk = blockIdx.x, s = blockIdx.y;
   const int w = msm_slot_window(mp, (int)s);
-  if (blk == 0 && s == 0 && threadIdx.x == 0) msm_write_header(rec, mp, nblk, n);
+  if (blk == 0 && s == 0 && threadIdx.x == 0) msm_write_header(rec, mp, n);
   const u32 Bw = 1u << (msm_win_width(mp, w) - 1);
   const u32 Kw = (Bw + L - 1) / L;                              // chunks of this window that hold buckets
   const int lb = __ffs((int)L) - 1;
@@ -762,6 +795,6 @@ __global__ void __launch_bounds__(4 * MSM_TREE_QUADS) k_msm_reduce_fold(size_t n
   const u32 base = blk * MSM_TREE_QUADS;
   const u32 live = base >= Kw ? 0u : (Kw - base < (u32)MSM_TREE_QUADS ? Kw - base : (u32)MSM_TREE_QUADS);
   quad_tree_sum(st, quad, role, live, acc, Tacc);
-  if (quad == 0 && role == 0) msm_store_partial(rec + MSM_REC_HDR_WORDS, w, nblk, blk, acc);
+  msm_finish_window(st, quad, role, nblk, blk, s, w, acc, Tacc, part, counters, rec);
 }
 

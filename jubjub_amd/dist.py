@@ -46,28 +46,35 @@ def decompress_sharded(engine, enc, flags=1, group=None):
     return sharded_map(lambda e: engine.decompress(e, flags), [enc], group)
 
 
-def msm_distributed(engine, scalars, points, group=None, presharded=False):
-    """sum_i points[i] * scalars[i] over ALL ranks' terms; every rank returns the same 64-byte affine point.
-
-    presharded=False: every rank holds the full arrays and reduces its own contiguous slice.
-    presharded=True : every rank passes only its own terms."""
+def msm_distributed(engine, scalars, points, group=None, presharded=False, partition="terms"):
+    """MSM over all ranks.  Every rank reduces its share to a RECORD of window sums that stays on its device
+    (engine.msm_partial: 8 KB), the records are all-gathered (RCCL: elliptic-curve addition is not a reduction operator), copied to
+    the host ONCE, and every rank runs ONE host tail over all of them (engine.msm_combine: window sums added window by window, one
+    Horner chain, one inversion).
+      partition="terms"   rank g owns the terms [g n/G, (g+1) n/G) and all their windows (presharded: the arrays given are already
+                          this rank's terms)
+      partition="window"  rank g owns windows g, g + G, ... of ALL terms (every rank holds the whole batch): its sort and bucket
+                          reduce shrink G-fold, which term sharding does not give
+    Returns the 64-byte affine sum as a numpy array (host memory) on every rank."""
     import torch
     import torch.distributed as dist
 
     rank, world = _rank_world(group)
-    if not presharded:
-        lo, hi = shard_bounds(len(scalars), rank, world)
-        scalars, points = scalars[lo:hi], points[lo:hi]
-    part = engine.msm(scalars, points)                      # 64 bytes, identity for an empty shard
+    if partition == "window":
+        rec = engine.msm_partial(scalars, points, rank, world)
+    elif partition == "terms":
+        if not presharded:
+            lo, hi = shard_bounds(len(scalars), rank, world)
+            scalars, points = scalars[lo:hi], points[lo:hi]
+        rec = engine.msm_partial(scalars, points)                # a valid record without windows for an empty shard
+    else:
+        raise ValueError("partition must be 'terms' or 'window'")
     if world == 1:
-        return part
-    is_torch = type(part).__module__.startswith("torch")
-    t = part if is_torch else torch.from_numpy(part.copy())
-    t = t.reshape(64).contiguous()
+        return engine.msm_combine(rec)
+    is_torch = type(rec).__module__.startswith("torch")
+    t = rec if is_torch else torch.from_numpy(rec.copy())
+    t = t.reshape(-1).contiguous()
     gathered = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(gathered, t, group=group)               # world x 64 B; latency-bound, not bandwidth-bound
+    dist.all_gather(gathered, t, group=group)                   # world x 8 KB; latency-bound, not bandwidth-bound
     stacked = torch.stack(gathered)
-    # world partial points -> one: a short dependent chain, done on the host by the library's MSM tail when the engine offers it
-    fold = getattr(engine, "fold_partials", None) or engine.point_sum
-    total = fold(stacked if is_torch else stacked.numpy())
-    return total
+    return engine.msm_combine(stacked if is_torch else stacked.numpy())

@@ -40,6 +40,24 @@ class OracleEngine:
     def point_sum(self, p):
         return self.O.point_sum(np.asarray(p))
 
+    def msm_partial(self, s, p, part_index=0, part_count=1):
+        """the record of window sums jj_msm_partial leaves, built by the oracle (tests/util.py)"""
+        from util import oracle_msm_record
+
+        return oracle_msm_record(np.asarray(s), np.asarray(p), part_index, part_count)
+
+    def msm_combine(self, records):
+        """the product's host-only jj_msm_combine (no GPU involved): the real second half of the distributed MSM"""
+        import ctypes
+
+        from jubjub_amd import _lib
+
+        recs = np.ascontiguousarray(np.asarray(records, dtype=np.uint8).reshape(-1, _lib.MSM_PARTIAL_BYTES))
+        out = np.empty(64, np.uint8)
+        rc = _lib.load().jj_msm_combine(ctypes.c_size_t(len(recs)), recs.ctypes.data if len(recs) else None, out.ctypes.data)
+        assert rc == 0, rc
+        return out
+
 
 def _free_port():
     s = socket.socket()
@@ -63,7 +81,8 @@ def _worker(rank, world, port, n, q):
         total = jd.msm_distributed(eng, S, P)
         pre = jd.msm_distributed(eng, S[lo:hi], P[lo:hi], presharded=True)
         empty = jd.msm_distributed(eng, S[:1], P[:1])          # rank 1 gets an empty shard
-        q.put((rank, lo, hi, out.tobytes(), bytes(total), bytes(pre), bytes(empty)))
+        bywin = jd.msm_distributed(eng, S, P, partition="window")     # every rank: all terms, windows rank, rank + world, ...
+        q.put((rank, lo, hi, out.tobytes(), bytes(total), bytes(pre), bytes(empty), bytes(bywin)))
     finally:
         dist.destroy_process_group()
 
@@ -106,3 +125,49 @@ def test_world2_gloo_sharding_and_msm():
     for r in res:
         assert r[4] == want_msm and r[5] == want_msm    # every rank holds the full MSM
         assert r[6] == bytes(O.msm(S[:1], P[:1]))
+        assert r[7] == want_msm                         # window partition: same point
+
+
+def test_msm_combine_host_only():
+    """jj_msm_combine against oracle-built records: one record, a term partition into records of the same layout, a window
+    partition (disjoint window masks), mixed window layouts in one call, edge scalars on special points, damaged records."""
+    import ctypes
+
+    from jubjub_amd import _lib
+    from oracle import c_oracle as O
+    from oracle import jubjub_ref as J
+    from util import EDGE_SCALARS, arr32, arr64, oracle_msm_record, rand_points, rand_scalars
+
+    lib = _lib.load()
+
+    def combine(recs):
+        recs = np.ascontiguousarray(np.stack(recs)) if len(recs) else np.zeros((0, _lib.MSM_PARTIAL_BYTES), np.uint8)
+        out = np.empty(64, np.uint8)
+        rc = lib.jj_msm_combine(ctypes.c_size_t(len(recs)), recs.ctypes.data if len(recs) else None, out.ctypes.data)
+        return rc, out
+
+    n = 21
+    S, P = rand_scalars(300, n, full_width=True), rand_points(301, n)
+    want = O.msm(S, P)
+    for W in (64, 23, 16):
+        rc, out = combine([oracle_msm_record(S, P, W=W)])
+        assert rc == 0 and (out == want).all(), W
+        rc, out = combine([oracle_msm_record(S, P, g, 3, W=W) for g in range(3)])           # window partition
+        assert rc == 0 and (out == want).all(), W
+        rc, out = combine([oracle_msm_record(S[:8], P[:8], W=W), oracle_msm_record(S[8:], P[8:], W=W)])   # term partition
+        assert rc == 0 and (out == want).all(), W
+    rc, out = combine([oracle_msm_record(S[:8], P[:8], W=64), oracle_msm_record(S[8:15], P[8:15], W=23), oracle_msm_record(S[15:], P[15:], W=16)])
+    assert rc == 0 and (out == want).all()                                                # three layouts in one call
+    g8 = J.scalar_mul_fast(J.GENERATOR, J.R_MOD)
+    Se = arr32(EDGE_SCALARS)
+    Pe = arr64(([J.AFFINE_IDENTITY, g8, J.scalar_mul_fast(g8, 4), J.GENERATOR, J.affine_neg(J.GENERATOR)] * 5)[: len(EDGE_SCALARS)])
+    rc, out = combine([oracle_msm_record(Se, Pe, W=23)])
+    assert rc == 0 and (out == O.msm(Se, Pe)).all()
+    rc, out = combine([])
+    assert rc == 0 and bytes(out[:32]) == bytes(32) and out[32] == 1 and not out[33:].any()           # the identity
+    bad = oracle_msm_record(S, P)
+    bad[8] = 65                                                                            # W out of range
+    assert combine([bad])[0] != 0
+    bad = oracle_msm_record(S, P)
+    bad[64 + 31] = 0xFF                                                                    # a coordinate >= q
+    assert combine([bad])[0] != 0

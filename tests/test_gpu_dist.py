@@ -20,6 +20,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
 
 
+def free_port():
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def run_bench(args, env_extra, timeout=900):
     env = dict(os.environ, **env_extra)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
@@ -48,6 +56,39 @@ def test_self_spawned_two_ranks_msm_strong_scaling_over_gloo():
     assert res["n_gpus"] == 2 and res["scaling"] == "strong" and res["verified"] is True
     assert res["config"]["units_per_step"] == 2 * (1 << 12)
     assert res["msm_result"] == oracle_msm(1 << 12)
+    assert res["rccl_world_size"] == 2 and res["config"]["msm_partition"] == "terms"
+
+
+@pytest.mark.parametrize("log2n", [12, 16])
+def test_self_spawned_two_ranks_msm_window_partition(log2n):
+    """--msm-partition window: both ranks hold ALL terms, rank g reduces windows g, g + 2, ...; the records of window sums are
+    all-gathered and combined in one host tail; the point equals the oracle's MSM over all terms (small-batch path and Pippenger)"""
+    res = run_bench(["--gpus", "2", "--workload", "msm", "--scaling", "strong", "--msm-partition", "window", "--log2n", str(log2n), "--steps", "2",
+                     "--warmup", "1", "--passes", "2", "--backend", "gloo", "--no-cpu-baseline"], {"JJ_BENCH_FORCE_DEVICE": "0"})
+    assert res["n_gpus"] == 2 and res["verified"] is True and res["all_units_equal_second_pass"] is True
+    assert res["verified_units"] == 1 << log2n                         # the timed output IS the whole MSM here: checked over all terms
+    assert res["config"]["msm_partition"] == "window" and res["rccl_world_size"] == 2
+    assert res["msm_result"] == oracle_msm(1 << log2n)
+
+
+def test_bench_exits_3_when_verification_fails():
+    """fault injection in the CHECKER (one bit of the oracle's expected values flipped, the product untouched): bench.py must print
+    "verified": false and exit with status 3, for the default workload and the MSM"""
+    env = dict(os.environ, JJ_BENCH_FAULT_INJECT="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    for extra in (["--log2n", "12", "--no-extras"], ["--workload", "msm", "--log2n", "12", "--passes", "2"]):
+        r = subprocess.run([sys.executable, BENCH, "--steps", "1", "--warmup", "0", "--no-cpu-baseline"] + extra, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+        res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+        assert res["verified"] is False and res["all_units_equal_second_pass"] is True
+
+
+def test_msm_async_pipeline_in_bench():
+    """--msm-async 3: three MSMs in flight on one context; same point, verified"""
+    res = run_bench(["--workload", "msm", "--log2n", "15", "--steps", "2", "--warmup", "1", "--passes", "7", "--msm-async", "3", "--no-cpu-baseline"], {})
+    assert res["verified"] is True and res["config"]["msm_jobs_in_flight"] == 3
+    assert res["msm_result"] == oracle_msm(1 << 15)
 
 
 def test_self_spawned_two_ranks_weak_scaling_independent_shards():
@@ -63,8 +104,8 @@ def test_self_spawned_two_ranks_weak_scaling_independent_shards():
 def test_one_rank_rccl_all_gather_leg():
     """the RCCL (backend nccl) exchange itself, with the one rank a 1-GPU box can hold"""
     res = run_bench(["--gpus", "1", "--workload", "msm", "--log2n", "12", "--steps", "2", "--warmup", "1", "--passes", "2", "--no-cpu-baseline"],
-                    {"JJ_BENCH_FORCE_DIST": "1", "MASTER_PORT": "29611"})
-    assert res["n_gpus"] == 1 and res["verified"] is True
+                    {"JJ_BENCH_FORCE_DIST": "1", "MASTER_PORT": str(free_port())})
+    assert res["n_gpus"] == 1 and res["verified"] is True and res["rccl_world_size"] == 1
     assert res["msm_result"] == oracle_msm(1 << 12)
     assert "all_gather" in res["config"]["parallelism"]
 
@@ -89,7 +130,7 @@ def test_under_torch_distributed_run_launcher():
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29617", BENCH, "--gpus", "2", "--workload", "fixedbase", "--log2n", "14", "--steps", "2", "--warmup", "1",
+                        "--master-port", str(free_port()), BENCH, "--gpus", "2", "--workload", "fixedbase", "--log2n", "14", "--steps", "2", "--warmup", "1",
                         "--backend", "gloo", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -59,3 +59,57 @@ def torsion_points(golden):
 
 EDGE_SCALARS = [0, 1, 2, 7, 8, 9, 15, 16, 17, R - 1, R, R + 1, (1 << 252) - 1, (1 << 252) - 2, 1 << 251, (1 << 251) - 1,
                 int("8" * 63, 16), int("7" * 63, 16), int("f" * 63, 16), (1 << 255) | 5, (1 << 256) - 1, (0xF << 252) | 12345]
+
+
+# ---- MSM records (include/jubjub_hip.h jj_msm_partial / jj_msm_combine), built by the oracle: lets the CPU tests drive the
+# host-only jj_msm_combine and the distributed logic without a GPU
+MSM_PARTIAL_BYTES = 8256
+MSM_REC_MAGIC = 0x504D4A4A
+
+
+def msm_window_layout(W):
+    """(start, width) of the W windows that tile the 253 bits of a recoded scalar: 253 = W c + r, the r low windows are c + 1 bits"""
+    c, r = divmod(253, W)
+    out, bit = [], 0
+    for w in range(W):
+        width = c + (1 if w < r else 0)
+        out.append((bit, width))
+        bit += width
+    assert bit == 253
+    return out
+
+
+def msm_signed_digits(k, W):
+    """digits d_w with k mod 2^252 = sum_w d_w 2^(start_w): signed for w < W - 1, the top one unsigned"""
+    lay = msm_window_layout(W)
+    kp = (k & ((1 << 252) - 1)) + sum(1 << (s + wd - 1) for s, wd in lay[:-1])
+    ds = []
+    for w, (s, wd) in enumerate(lay):
+        raw = (kp >> s) & ((1 << wd) - 1)
+        ds.append(raw if w == W - 1 else raw - (1 << (wd - 1)))
+    assert sum(d << lay[w][0] for w, d in enumerate(ds)) == k & ((1 << 252) - 1)
+    return ds
+
+
+def oracle_msm_record(S, P, part_index=0, part_count=1, W=64):
+    """the record jj_msm_partial would leave for these terms: window sums S_w = sum_i d_{i,w} P_i of the windows this part owns, each
+    as (U, V, Z, T) = (u, v, 1, u v) in the host tail's Montgomery form (value * 2^256 mod q, 32 little-endian bytes)"""
+    n = len(S)
+    digs = [msm_signed_digits(to_int(S[i]), W) for i in range(n)]
+    pts = [to_pt(P[i]) for i in range(n)]
+    rec = np.zeros(MSM_PARTIAL_BYTES, np.uint8)
+    mask = 0
+    for w in range(part_index, W, part_count):
+        mask |= 1 << w
+        acc = J.AFFINE_IDENTITY
+        for i in range(n):
+            d = digs[i][w]
+            if d:
+                t = J.scalar_mul_fast(pts[i], abs(d))
+                acc = J.affine_add_fast(acc, J.affine_neg(t) if d < 0 else t)
+        coords = (acc[0], acc[1], 1, acc[0] * acc[1] % Q)
+        for k, x in enumerate(coords):
+            rec[64 + w * 128 + 32 * k: 64 + w * 128 + 32 * k + 32] = b32((x << 256) % Q)
+    hdr = np.array([MSM_REC_MAGIC, 2, W, 1, mask & 0xFFFFFFFF, mask >> 32, n & 0xFFFFFFFF, n >> 32], dtype="<u4")
+    rec[:32] = np.frombuffer(hdr.tobytes(), np.uint8)
+    return rec

@@ -69,6 +69,7 @@ def field_block(name, p, extra=""):
     s += arr("ONE", limbs(MONT % p))  # R mod p  (Montgomery 1)
     s += arr("R2", limbs((MONT * MONT) % p))  # to-Montgomery multiplier
     s += arr("R2_256", limbs(((1 << 256) * MONT * MONT) % p))  # converts hi half of a 512-bit value: x*2^256 -> Montgomery
+    s += arr("HOST_R", limbs((1 << 256) % p))   # 2^256 mod p as a PLAIN integer: mul(a, HOST_R) = value(a) * 2^256, the 4 x 64-bit Montgomery form of the host tail
     s += arr("NEGP_DIGITS", signed_digits(-p))   # -p as the digits a Montgomery product emits (limbs 0..7 in [0, 2^29), signed top limb)
     s += arr("PM2", words32(p - 2, 8))  # exponent for inversion
     s += "  static constexpr int PBITS = %d;\n" % p.bit_length()
