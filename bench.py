@@ -446,6 +446,9 @@ def run(a):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    # a second, untimed pass over the same inputs on EVERY rank (the MSM's pass holds a collective): rank 0 compares all its units
+    # with the timed output below
+    out2 = None if a.no_verify else one_pass()
     units_per_step = total * passes
     value = units_per_step * a.steps / dt
     res = {
@@ -497,6 +500,7 @@ def run(a):
         res["roofline"] = {
             "bound": "valu_int32", "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TIMAD32/s",
             "frac": achieved / peak,
+            "frac_min": (n * work_main / (min(main_ms) * 1e-3) / peak) if main_ms else None,     # the fastest dispatch of the timed region
             # multiply-adds actually issued by the signed 9x29-bit representation (153 per mul, 117 per square) / measured peak
             "mad_issue_frac": n * (153 * w["M"] + 117 * w["S"]) / (kern_ms * 1e-3) / peak,
             "traffic": traffic["bytes_per_launch"] if traffic else None,
@@ -524,8 +528,7 @@ def run(a):
             res["verified"], res["verified_units"] = okv, cnt
             # every unit of the timed output against a fresh pass over the same inputs, compared on the device (the oracle sample
             # above checks one unit in 2^10; this ties all the others to a second, independent run)
-            o2 = one_pass()
-            o2v, k2 = (o2 if isinstance(o2, tuple) else (o2, None))
+            o2v, k2 = (out2 if isinstance(out2, tuple) else (out2, None))
             if wl == "msm":
                 same = bool((host_bytes(out) == host_bytes(o2v)).all())
             else:
@@ -574,6 +577,28 @@ def run(a):
                 res["fixed_base_wide_window"]["verified"], _ = verify_sample("fixedbase", a, 0, fn, fo, None, None)
             wt.close()
             del fs, fo
+        if wl == "varbase" and not a.no_extras and n_gpus == 1:
+            # the constant-time ladder (jj_varbase_mul_ct: table {P, 2P} in registers, signed 2-bit windows, mask selects) on the same batch
+            for _ in range(2):
+                co = eng.varbase_mul_ct(scalars, points)
+            torch.cuda.synchronize(dev)
+            eng.profile(True)
+            t1 = time.perf_counter()
+            for _ in range(4):
+                co = eng.varbase_mul_ct(scalars, points)
+            torch.cuda.synchronize(dev)
+            cdt = (time.perf_counter() - t1) / 4
+            cm, _ct = eng.profile_read()
+            eng.profile(False)
+            ckm = sum(cm) / max(len(cm), 1)
+            cw = {"S": 252 * 3 + 3, "M": 2 + 4 + 4 + 252 * 4 + 128 * 8}      # 2 from_words, 2 to_niels + 1 doubling, 252 doublings, 128 additions
+            res["varbase_constant_time"] = {"value": n / cdt, "unit": "scalar-muls/s per GPU", "units_per_pass": n, "ms_per_pass": cdt * 1e3, "kernel_ms": ckm,
+                                            "roofline_frac": n * imad32(cw["S"], cw["M"]) / (ckm * 1e-3) / peak, "work_per_unit": cw,
+                                            "relative_to_default": (n / cdt) / value,
+                                            "note": "no scalar-dependent address or branch: the reference's conditional_select discipline (src/lib.rs:334-343, 357-379)"}
+            if not a.no_verify:
+                res["varbase_constant_time"]["verified"], _ = verify_sample("varbase", a, lo, n, co, None, None)
+                res["varbase_constant_time"]["equals_default_ladder_all_units"] = bool(torch.equal(co, out))
         if not a.no_cpu_baseline and n_gpus == 1:
             res["cpu_baseline"] = cpu_baseline(wl, a.cpu_seconds)
         print(json.dumps(res))

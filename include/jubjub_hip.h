@@ -131,6 +131,11 @@ int jj_point_sum(jj_ctx*, size_t n, const void* p, void* out64);
 int jj_varbase_mul(jj_ctx*, size_t n, const void* scalars32, const void* points64, void* out64);
 /* same, result written as 32-byte compressed encodings (to_bytes of the product, src/lib.rs:455-464, 1419-1421) */
 int jj_varbase_mul_compressed(jj_ctx*, size_t n, const void* scalars32, const void* points64, void* out32);
+/* Constant-time variant for SECRET scalars: same result, but neither the instruction stream nor any memory address depends on
+ * the scalar -- the reference's own discipline (conditional_select ladder, src/lib.rs:334-343, 357-379).  The table {P, 2P} is
+ * held in registers (no table in memory), windows are signed 2-bit digits picked with bit masks: 127 additions + 252 doublings,
+ * about 1.3x the time of jj_varbase_mul. */
+int jj_varbase_mul_ct(jj_ctx*, size_t n, const void* scalars32, const void* points64, void* out64);
 /* One scalar, many bases: out[i] = points[i] * scalar (the `Wnaf::scalar(..).base(..)` reuse pattern of the group crate,
  * cf. WnafGroup src/lib.rs:1318-1336).  Same kernel as jj_varbase_mul after broadcasting the 32-byte scalar. */
 int jj_varbase_mul_scalar(jj_ctx*, size_t n, const void* scalar32, const void* points64, void* out64);

@@ -684,6 +684,27 @@ JJ_API int jj_varbase_mul_scalar(jj_ctx* c, size_t n, const void* scalar32, cons
   if ((rc = finish_out(c, o, &sync))) return rc;
   return finish(c, sync);
 }
+// constant-time ladder: table {P, 2P} in registers, signed 2-bit windows, mask selects (k_varbase_ct)
+JJ_API int jj_varbase_mul_ct(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out) {
+  if (!c) return JJ_ERR_INVALID;
+  JJ_ENTER(c);
+  const void *ds, *dp; int rc; OutRef o;
+  if ((rc = stage_in(c, 0, scalars, 32 * n, &ds))) return rc;
+  if ((rc = stage_in(c, 1, points, 64 * n, &dp))) return rc;
+  if ((rc = stage_out(c, c->out[0], out, 64 * n, &o))) return rc;
+  if ((rc = ensure_ext(c, n, 3))) return rc;
+  SoA ext = soa_of(c->ws_ext, n);
+  if (n) {
+    prof_mark(c, 0);
+    hipLaunchKernelGGL(k_varbase_ct, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, ds, dp, ext);
+    prof_mark(c, 1);
+    if ((rc = normalize_launch(c, n, ext, o.dev, 0))) return rc;
+    prof_mark(c, 2);
+  }
+  bool sync = false;
+  if ((rc = finish_out(c, o, &sync))) return rc;
+  return finish(c, sync);
+}
 JJ_API int jj_varbase_mul_exact(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out160) {
   if (!c) return JJ_ERR_INVALID;
   JJ_ENTER(c);

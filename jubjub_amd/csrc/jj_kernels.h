@@ -458,6 +458,55 @@ __global__ void __launch_bounds__(256) k_varbase_exact(size_t n, const void* sca
   Fq::to_words(w, acc.t2); store8(out160, 5 * i + 4, w);
 }
 
+// Constant-time variable-base ladder (jj_varbase_mul_ct): for SECRET scalars on variable bases.  The default ladder above reads
+// its per-lane table at a digit-dependent address; the reference ladder (src/lib.rs:357-379 with conditional_select, 334-343) has
+// neither secret-dependent branches nor addresses.  Here the table is {P, 2P} as extended-Niels entries held in REGISTERS (there
+// is no table in memory at all), windows are signed 2-bit digits d in {-2, -1, 0, 1} (k' = k + sum 2^(2i+1); the top window holds
+// the recoding carry: 0 or 1), the entry |d| P is picked with bit masks, a zero digit adds the identity entry, the sign goes
+// through Curve::add_signed, and the digits come off a left-aligned shift register: one fixed instruction stream, no load or store
+// inside the loop.  127 additions + 252 doublings (reference: 252 + 252), same group element.
+constexpr int CT_NWIN = 127;          // 126 signed 2-bit windows over bits 0..251 + the carry window
+static JJ_DEV Ext varbase_ct(const Affine& P, u32 (&k)[8]) {
+  const Ext p1 = Curve::from_affine(P);
+  const ENiels e1 = Curve::to_niels<true>(p1);
+  const ENiels e2 = Curve::to_niels<true>(Curve::dbl(p1));
+  const ENiels idn = Curve::eniels_identity();
+  // recode: k' = (k mod 2^252) + sum_{i<126} 2^(2i+1) = k + 0xaaa...a (252 bits)
+  k[7] &= 0x0fffffffu;
+  {
+    u64 cy = 0;
+    _Pragma("unroll") for (int j = 0; j < 8; j++) { const u64 t = (u64)k[j] + (j < 7 ? 0xaaaaaaaau : 0x0aaaaaaau) + cy; k[j] = (u32)t; cy = t >> 32; }
+  }
+  // top window: bit 252 (0 or 1), unsigned
+  const u32 top = (k[7] >> 28) & 1u;
+  Ext acc = Curve::add<true>(Curve::identity(), Curve::select(idn, e1, 0u - top));
+  // left-align bit 251 at bit 255; every window is then the top two bits of ks[7]
+  u32 ks[8];
+  _Pragma("unroll") for (int q = 7; q >= 1; q--) ks[q] = (k[q] << 4) | (k[q - 1] >> 28);
+  ks[0] = k[0] << 4;
+  #pragma unroll 1
+  for (int i = CT_NWIN - 2; i >= 0; i--) {
+    const int d = (int)(ks[7] >> 30) - 2;                    // window - 2 in [-2, 1]
+    _Pragma("unroll") for (int q = 7; q >= 1; q--) ks[q] = (ks[q] << 2) | (ks[q - 1] >> 30);
+    ks[0] <<= 2;
+    const u32 sgn = (u32)(d >> 31);                          // all-ones iff negative
+    const u32 a = ((u32)d ^ sgn) - sgn;                      // |d| in {0, 1, 2}
+    const ENiels e = Curve::select(Curve::select(idn, e1, 0u - (a & 1u)), e2, 0u - (a >> 1));
+    acc = Curve::dbl(Curve::dbl(acc));
+    acc = Curve::add_signed<true>(acc, e, sgn);
+  }
+  return acc;
+}
+__global__ void __launch_bounds__(256) k_varbase_ct(size_t n, const void* scalars, const void* points, SoA ext) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 k[8];
+  load8(k, scalars, i);
+  const Affine P = load_affine(points, i);
+  const Ext r = varbase_ct(P, k);
+  ext.put(0, i, r.u); ext.put(1, i, r.v); ext.put(2, i, r.z);
+}
+
 // ------------------------------------------------------------------------------------------------ K4: fixed-base
 // Signed 6-bit windows: k = sum_{i<42} d_i 64^i + d_42 64^42, d_i in [-32,31], d_42 in {0,1} (k' = k + 0x820820..).
 // Table[i][j] = j * 64^i * B as AffineNiels (27 limbs + 1 pad = 112 B), i < 42, j <= 32 (j = 0: the identity entry, so

@@ -239,6 +239,10 @@ class Engine:
     def varbase_mul(self, scalars, points):
         return self._call("jj_varbase_mul", [scalars, points], [32, 64], [64])
 
+    def varbase_mul_ct(self, scalars, points):
+        """constant-time ladder for secret scalars (jj_varbase_mul_ct): no scalar-dependent address or branch"""
+        return self._call("jj_varbase_mul_ct", [scalars, points], [32, 64], [64])
+
     def varbase_mul_scalar(self, scalar, points):
         """points[i] * scalar for one 32-byte scalar (numpy or torch), every point of the batch."""
         a, p = _Arg(scalar, 32), _Arg(points, 64)

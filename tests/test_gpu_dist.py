@@ -28,7 +28,7 @@ def free_port():
         return s.getsockname()[1]
 
 
-def run_bench(args, env_extra, timeout=900):
+def run_bench(args, env_extra, timeout=400):
     env = dict(os.environ, **env_extra)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
@@ -131,7 +131,7 @@ def test_under_torch_distributed_run_launcher():
         env.pop(k, None)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(free_port()), BENCH, "--gpus", "2", "--workload", "fixedbase", "--log2n", "14", "--steps", "2", "--warmup", "1",
-                        "--backend", "gloo", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+                        "--backend", "gloo", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=400)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout                      # exactly one JSON line, from rank 0

@@ -171,6 +171,27 @@ def test_varbase_per_lane_and_per_quad_kernels(golden, monkeypatch):
         e2.close()
 
 
+def test_varbase_constant_time_ladder(eng, golden):
+    """jj_varbase_mul_ct (table {P, 2P} in registers, signed 2-bit windows, mask selects: no scalar-dependent address or branch, the
+    reference's conditional_select discipline, src/lib.rs:334-343, 357-379): every edge scalar on random / torsion / generator /
+    identity points, random inputs, ragged and empty batches -- the same points as the default ladder and the oracle."""
+    pts = np.concatenate([rand_points(3, 8), torsion_points(golden), arr64([J.GENERATOR, J.AFFINE_IDENTITY])])
+    S = np.stack([b32(k) for k in EDGE_SCALARS for _ in pts])
+    Pn = np.stack([p for _ in EDGE_SCALARS for p in pts])
+    S = np.concatenate([S, rand_scalars(151, 3000, full_width=True)])
+    Pn = np.concatenate([Pn, rand_points(152, 3000)])
+    want = O.varbase_mul(S, Pn)
+    got = eng.varbase_mul_ct(S, Pn)
+    assert (got == want).all()
+    assert (got == eng.varbase_mul(S, Pn)).all()
+    for m in (0, 1, 63, 64, 65, 257):
+        assert (eng.varbase_mul_ct(S[:m], Pn[:m]) == want[:m]).all(), m
+    # two-bit patterns: every window value in every position class
+    pat = arr32([int(d * 64, 4) & ((1 << 252) - 1) for d in "0123"] + [int("0123" * 16, 4), int("3210" * 16, 4), int("2" * 63, 4) * 4 + 3])
+    Pq = rand_points(153, len(pat))
+    assert (eng.varbase_mul_ct(pat, Pq) == O.varbase_mul(pat, Pq)).all()
+
+
 def test_varbase_random(eng):
     n = 3000   # not a multiple of the block size; exercises the grid-stride tail
     S = rand_scalars(5, n, full_width=True)
