@@ -61,8 +61,8 @@ WORK = {
     # k_varbase: 2 from_words + to_niels(P) 2M; table {1..16}P: to_niels 2M + 15 x (mixed add 7M + to_niels 2M);
     # 51 additions x 8M; 250 doublings x (3S + 4M: 2UV is a product here, jj_curve.h).   normalisation tail: tail_work() below
     "varbase": {"S": 250 * 3, "M": 2 + 2 + 2 + 15 * 9 + 51 * 8 + 250 * 4, "bytes": 32 + 64 + 64},
-    # k_fixedbase: 43 mixed additions x 7M
-    "fixedbase": {"S": 0, "M": 43 * 7, "bytes": 32 + 64},
+    # k_fixedbase_comb (default, --fb-window 0/7): 32 mixed additions x 7M + three doublings (3S + 4M each); --fb-window 6: k_fixedbase, 43 x 7M
+    "fixedbase": {"S": 9, "M": 32 * 7 + 12, "bytes": 32 + 64},
     # Pippenger, c = 16: per term 2M load + 2M to_niels + 16 windows x 7M mixed add; bucket reduce 2 x 10M per bucket
     # (16 x 2^15 buckets / 2^20 terms -> +10M); the 240-doubling Horner tail is per MSM (on the host), not per term
     # (the entry below is the 16-window case, 2^18 terms and more; run() recomputes it from the window count of the record)
@@ -120,7 +120,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="varbase workload: skip the fixed-base side measurements (clean per-kernel profiles)")
-    ap.add_argument("--fb-window", type=int, default=0, help="fixed-base window bits: 0/6 = LDS-staged constant-time table (default), 8..16 = table gathered from L2 / Infinity Cache")
+    ap.add_argument("--fb-window", type=int, default=0, help="fixed-base table: 0/7 = signed comb in LDS (default: 32 additions + 3 doublings), 6 = signed 6-bit windows in LDS (43 additions), both with the constant-time shuffle select; 8..16 = table gathered from L2 / Infinity Cache")
     ap.add_argument("--decompress-flags", type=int, default=13,
                     help="jj_decompress flags: 1 ZIP-216 | 2 torsion-free (order-8 Tate pairing; JJ_TORSION_CHECK=ladder for the [r]P ladder) | 4 reject small order | 8 clear cofactor (default 13 = BASELINE config 5: decode + small-order check + mul_by_cofactor)")
     ap.add_argument("--msm-partition", default="terms", choices=["terms", "window"], help="multi-rank MSM: cut by terms or by windows (see the module docstring)")
@@ -486,7 +486,9 @@ def run(a):
                 w["M"] = 2 + 2 + W * 7 + -(-(buckets * 18) // n)
             res["config"]["msm_windows"] = W
         if wl == "fixedbase" and a.fb_window >= 8:
-            w["M"] = -(-253 // a.fb_window) * 7              # ceil(253/w) mixed additions
+            w["S"], w["M"] = 0, -(-253 // a.fb_window) * 7   # ceil(253/w) mixed additions
+        if wl == "fixedbase" and a.fb_window == 6:
+            w["S"], w["M"] = 0, 43 * 7
         if main_ms:
             kern_ms = sum(main_ms) / len(main_ms)
             tail = sum(tail_ms) / len(tail_ms)
@@ -505,7 +507,7 @@ def run(a):
             "mad_issue_frac": n * (153 * w["M"] + 117 * w["S"]) / (kern_ms * 1e-3) / peak,
             "traffic": traffic["bytes_per_launch"] if traffic else None,
             "traffic_detail": traffic if traffic else traffic_note,
-            "kernel": {"varbase": "k_varbase", "fixedbase": "k_fixedbase" if a.fb_window < 8 else "k_fixedbase_gather(w=%d)" % a.fb_window, "msm": "whole MSM: k_msm_accumulate(_seg) + sort / fix-up / reduce; Horner on the host", "decompress": "k_decompress"}[wl],
+            "kernel": {"varbase": "k_varbase", "fixedbase": ("k_fixedbase_comb" if a.fb_window in (0, 7) else "k_fixedbase") if a.fb_window < 8 else "k_fixedbase_gather(w=%d)" % a.fb_window, "msm": "whole MSM: k_msm_accumulate(_seg) + sort / fix-up / reduce; Horner on the host", "decompress": "k_decompress"}[wl],
             "kernel_ms": kern_ms, "tail_ms": tail, "units_per_launch": n,
             "work_per_unit": {"field_squares": w["S"], "field_muls": w["M"], "imad32": work_main, "convention": "M=128,S=100 (SURVEY 8d); the kernel named above only",
                               "tail_kernel": {"field_squares": tail_s, "field_muls": tail_m, "imad32": imad32(tail_s, tail_m)}},
@@ -558,7 +560,7 @@ def run(a):
             fkm = sum(fm) / max(len(fm), 1)
             res["fixed_base"] = {"value": fn / fdt, "unit": "scalar-muls/s per GPU", "units_per_pass": fn, "ms_per_pass": fdt * 1e3, "kernel_ms": fkm,
                                  "roofline_frac": fn * imad32(fw["S"], fw["M"]) / (fkm * 1e-3) / peak,
-                                 "window_select": "LDS-staged table, ds_bpermute constant-time select"}
+                                 "window_select": "signed comb (8 teeth, 8 column blocks: 32 additions + 3 doublings), 140 KiB table staged in LDS, ds_bpermute constant-time select"}
             if not a.no_verify:
                 res["fixed_base"]["verified"], _ = verify_sample("fixedbase", a, 0, fn, fo, None, None)
             wt = eng.fixedbase_table(base, 16)                      # wide-window alternative (64 MB table in the Infinity Cache, per-lane gather)

@@ -29,7 +29,7 @@ struct DevBuf {
 
 struct jj_table {
   u32* dev = nullptr;      // entries x ANIELS_WORDS
-  int window_bits = FB_W;  // 6: LDS-staged table (k_fixedbase); 8..16: table gathered from L2 / Infinity Cache (k_fixedbase_gather)
+  int window_bits = FB_W;  // 7: signed comb in LDS (k_fixedbase_comb: 8 teeth, the default); 6: LDS-staged window table (k_fixedbase); 8..16: table gathered from L2 / Infinity Cache (k_fixedbase_gather)
   int device = -1;         // the table lives in this device's memory: only contexts of the same device may use it
   FbParams fp;
 };
@@ -83,6 +83,7 @@ struct jj_ctx {
   int msm_small_max = 1 << 14;   // batches up to this size take the two-launch small-batch path (JJ_MSM_SMALL_MAX; 0 = never)
   bool torsion_ladder = false;   // subgroup test: false = Tate pairing (k_torsion_free), true = multiply by r (reference definition)
   bool fb_const_time = true;     // fixed-base window select: true = lane-staged + ds_bpermute shuffle, false = per-lane LDS gather
+  int fb_default_kind = 7;       // what window_bits = 0 means: 7 = signed comb (32 additions + 3 doublings), 6 = signed 6-bit windows (43 additions); JJ_FIXEDBASE_DEFAULT
   int vb_quad_max = 32768;       // batches up to this size run one scalar-mul per quad of lanes (JJ_VB_QUAD_MAX; 0 = never)
   int fb_gather_blocks_per_cu = 3;   // wide-window fixed-base kernel: resident blocks of 256 per CU (JJ_FB_GATHER_BLOCKS_PER_CU)
   int vb_blocks_per_cu = 2;      // var-base ladder: resident blocks of 256 per CU (the ladder holds ~190 VGPRs: 2 waves per SIMD); JJ_VB_BLOCKS_PER_CU
@@ -350,12 +351,14 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
   {
     const struct { const void* fn; int bytes; } lds_needs[] = {
       {reinterpret_cast<const void*>(k_fixedbase<true>), FB_LDS_BYTES}, {reinterpret_cast<const void*>(k_fixedbase<false>), FB_LDS_BYTES},
+      {reinterpret_cast<const void*>(k_fixedbase_comb<true>), FBC_LDS_BYTES}, {reinterpret_cast<const void*>(k_fixedbase_comb<false>), FBC_LDS_BYTES},
       {reinterpret_cast<const void*>(k_seg_plan), 80 * 1024}};
     for (const auto& a : lds_needs)
       if (hipFuncSetAttribute(a.fn, hipFuncAttributeMaxDynamicSharedMemorySize, a.bytes) != hipSuccess) return fail(JJ_ERR_HIP);   // the kernels could not launch later
   }
   if (const char* e = getenv("JJ_TORSION_CHECK")) c->torsion_ladder = strcmp(e, "ladder") == 0;
   if (const char* e = getenv("JJ_FIXEDBASE_SELECT")) c->fb_const_time = strcmp(e, "gather") != 0;
+  if (const char* e = getenv("JJ_FIXEDBASE_DEFAULT")) { int v = atoi(e); if (v == 6 || v == 7) c->fb_default_kind = v; }
   // square-root tables (64 KiB dlog + 36 KiB powers), built on the device
   if (hipMalloc(&c->sqrt_tabs.p, 65536 + 4 * 256 * NL * 4) != hipSuccess) { c->sqrt_tabs.p = nullptr; return fail(JJ_ERR_NOMEM); }
   c->sqrt_tabs.cap = 65536 + 4 * 256 * NL * 4;
@@ -794,10 +797,53 @@ static int build_window_table(jj_ctx* c, const uint8_t base[64], int w, int W, u
   *out_dev = dev; *out_entries = ne;
   return JJ_OK;
 }
+// Signed-comb table (layout of k_fixedbase_comb): 8 tables T_{j1}[idx] = 2^(4 j1) (2^224 + sum_{i<7} (2 idx_i - 1) 2^(32 i)) B of 128
+// entries, then T_0 - B and T_0 + B.  Built on the GPU through the library's own entry points: Q_i = 2^(32 i) B and
+// R_{j1,i} = 2^(4 j1) Q_i by the var-base ladder (no scalar reaches bit 252), then seven rounds of batched point additions.
+static int build_comb_table(jj_ctx* c, const uint8_t base[64], u32** out_dev) {
+  int rc;
+  std::vector<uint8_t> s1((size_t)FBC_TEETH * 32, 0), p1((size_t)FBC_TEETH * 64), q((size_t)FBC_TEETH * 64);
+  for (int i = 0; i < FBC_TEETH; i++) { const int bit = FBC_SPACING * i; s1[(size_t)i * 32 + (bit >> 3)] = (uint8_t)(1u << (bit & 7)); memcpy(&p1[(size_t)i * 64], base, 64); }
+  if ((rc = jj_varbase_mul(c, FBC_TEETH, s1.data(), p1.data(), q.data()))) return rc;
+  const size_t nr = (size_t)FBC_BLOCKS * FBC_TEETH;
+  std::vector<uint8_t> s2(nr * 32, 0), p2(nr * 64), r(nr * 64), nrg(nr * 64);
+  for (int j1 = 0; j1 < FBC_BLOCKS; j1++)
+    for (int i = 0; i < FBC_TEETH; i++) {
+      const size_t e = (size_t)j1 * FBC_TEETH + i; const int bit = FBC_COLS * j1;
+      s2[e * 32 + (bit >> 3)] = (uint8_t)(1u << (bit & 7));
+      memcpy(&p2[e * 64], &q[(size_t)i * 64], 64);
+    }
+  if ((rc = jj_varbase_mul(c, nr, s2.data(), p2.data(), r.data()))) return rc;
+  if ((rc = jj_point_neg(c, nr, r.data(), nrg.data()))) return rc;
+  const size_t ne = (size_t)FBC_BLOCKS * FBC_TENT;
+  std::vector<uint8_t> acc(ne * 64), opnd(ne * 64), all((size_t)FBC_ENTRIES * 64);
+  for (size_t e = 0; e < ne; e++) memcpy(&acc[e * 64], &r[((e / FBC_TENT) * FBC_TEETH + (FBC_TEETH - 1)) * 64], 64);     // the top tooth, always +
+  for (int i = 0; i < FBC_TEETH - 1; i++) {
+    for (size_t e = 0; e < ne; e++) {
+      const size_t src = ((e / FBC_TENT) * FBC_TEETH + i) * 64;
+      memcpy(&opnd[e * 64], ((e >> i) & 1) ? &r[src] : &nrg[src], 64);
+    }
+    if ((rc = jj_point_add(c, ne, acc.data(), opnd.data(), acc.data()))) return rc;
+  }
+  memcpy(all.data(), acc.data(), ne * 64);
+  std::vector<uint8_t> b64((size_t)FBC_TENT * 64);
+  for (int e = 0; e < FBC_TENT; e++) memcpy(&b64[(size_t)e * 64], base, 64);
+  if ((rc = jj_point_sub(c, FBC_TENT, acc.data(), b64.data(), &all[ne * 64]))) return rc;                    // T_0 - B
+  if ((rc = jj_point_add(c, FBC_TENT, acc.data(), b64.data(), &all[(ne + FBC_TENT) * 64]))) return rc;       // T_0 + B
+  u32* dev = nullptr;
+  if (hipMalloc((void**)&dev, (size_t)FBC_LDS_BYTES) != hipSuccess) { c->err = "hipMalloc(table) failed"; return JJ_ERR_NOMEM; }
+  const void* dpts;
+  if ((rc = stage_in(c, 0, all.data(), (size_t)FBC_ENTRIES * 64, &dpts))) { (void)hipFree(dev); return rc; }
+  hipLaunchKernelGGL(k_affine_to_table, dim3(blocks_for(FBC_ENTRIES)), dim3(256), 0, c->stream, (size_t)FBC_ENTRIES, dpts, dev, ANIELS_WORDS);
+  rc = finish(c, true);
+  if (rc) { (void)hipFree(dev); return rc; }
+  *out_dev = dev;
+  return JJ_OK;
+}
 JJ_API int jj_fixedbase_table_create(jj_ctx* c, const void* base64, int window_bits, jj_table** out) {
   if (!c || !out || !base64) return JJ_ERR_INVALID;
-  if (window_bits == 0) window_bits = FB_W;
-  if (window_bits != FB_W && (window_bits < 8 || window_bits > 16)) { c->err = "window_bits must be 0 or 6 (LDS-staged table) or 8..16 (table gathered from L2 / Infinity Cache)"; return JJ_ERR_INVALID; }
+  if (window_bits == 0) window_bits = c->fb_default_kind;
+  if (window_bits != FB_W && window_bits != 7 && (window_bits < 8 || window_bits > 16)) { c->err = "window_bits must be 0 (default), 7 (signed comb in LDS), 6 (window table in LDS) or 8..16 (table gathered from L2 / Infinity Cache)"; return JJ_ERR_INVALID; }
   JJ_ENTER(c);
   uint8_t base[64];
   if (is_device_ptr(base64)) { HIPCHK(c, hipMemcpy(base, base64, 64, hipMemcpyDeviceToHost)); } else memcpy(base, base64, 64);
@@ -805,7 +851,9 @@ JJ_API int jj_fixedbase_table_create(jj_ctx* c, const void* base64, int window_b
   t->window_bits = window_bits;
   t->device = c->device;
   size_t ne = 0; int rc;
-  if (window_bits == FB_W) {
+  if (window_bits == 7) {
+    rc = build_comb_table(c, base, &t->dev);
+  } else if (window_bits == FB_W) {
     // 42 windows x 32 entries + the carry entry 2^252 B  (layout of k_fixedbase)
     rc = build_window_table(c, base, FB_W, FB_NWIN, FB_ENT, 1, &t->dev, &ne);
   } else {
@@ -830,7 +878,10 @@ JJ_API int jj_fixedbase_table_destroy(jj_ctx* c, jj_table* t) {
 }
 static int fixedbase_launch(jj_ctx* c, const jj_table* t, size_t n, const void* ds, SoA ext, int chain = 0) {
   const unsigned blocks = (unsigned)std::min((size_t)c->cus, (n + 511) / 512);   // one 512-thread workgroup per CU (LDS-bound)
-  if (t->window_bits != FB_W) {
+  if (t->window_bits == 7) {
+    if (c->fb_const_time) hipLaunchKernelGGL(k_fixedbase_comb<true>, dim3(blocks), dim3(512), FBC_LDS_BYTES, c->stream, n, ds, (const u32*)t->dev, ext, chain);
+    else hipLaunchKernelGGL(k_fixedbase_comb<false>, dim3(blocks), dim3(512), FBC_LDS_BYTES, c->stream, n, ds, (const u32*)t->dev, ext, chain);
+  } else if (t->window_bits != FB_W) {
     const unsigned gblocks = (unsigned)std::min((size_t)c->cus * c->fb_gather_blocks_per_cu, (n + 255) / 256);
     hipLaunchKernelGGL(k_fixedbase_gather, dim3(gblocks), dim3(256), 0, c->stream, n, ds, (const u32*)t->dev, t->fp, ext, chain);
   } else if (c->fb_const_time) hipLaunchKernelGGL(k_fixedbase<true>, dim3(blocks), dim3(512), FB_LDS_BYTES, c->stream, n, ds, (const u32*)t->dev, ext, chain);

@@ -621,6 +621,126 @@ __global__ void __launch_bounds__(512) k_fixedbase(size_t n, const void* scalars
     }
   }
 }
+// ---- Signed comb (jj_fixedbase_table_create window_bits = 7; the default): 8 teeth 32 bits apart, 8 column blocks.
+// k (252 bits) is made odd, kk = k | 1, and written with digits +-1 only: kk = sum_{p<256} s_p 2^p, s_255 = +1, s_p = +1 iff bit
+// p + 1 of kk is set (p < 255).  Column j (0..31) collects the eight signs s_{j + 32 i}, i.e. bit j of the eight 32-bit words of
+// kk >> 1 | 2^255: its value is +-(2^224 + sum_{i<7} +-2^(32 i)) = sign x one of 128 table entries T[idx],
+// idx_i = (s_{j+32i} == s_{j+224}).  Columns are grouped in 8 blocks of four (j = 4 j1 + j0) with their own tables
+// T_{j1} = 2^(4 j1) T:   kk B = sum_{j0<4} 2^j0 sum_{j1<8} +-T_{j1}[idx_{4 j1 + j0}]      -- 32 mixed additions and 3 doublings
+// (signed 6-bit windows above: 43 additions).  For an even k the last addition (column 0) takes its entry from T_0 -+ B instead of
+// T_0 (two more tables), which removes the B that kk = k + 1 added: no extra addition.  10 tables x 128 entries x 112 B = 140 KiB
+// of LDS.  Constant-time select: a table is staged as two halves of 64 entries, lane L holds entries L and 64 + L, both halves
+// are shuffled with ds_bpermute and the top index bit picks one with bit masks.  Same group element as the reference's
+// AffineNielsPoint::multiply (src/lib.rs:272-310) for every base point of the curve (only sums of multiples of B are formed; no
+// assumption on its order).
+constexpr int FBC_TEETH = 8, FBC_SPACING = 32, FBC_BLOCKS = 8, FBC_COLS = 4;      // 8 x 32 = 256 signed bits; 8 blocks x 4 columns
+constexpr int FBC_TENT = 128;                                // entries per table: 2^(teeth - 1)
+constexpr int FBC_TABLES = FBC_BLOCKS + 2;                   // + T_0 - B, T_0 + B
+constexpr int FBC_ENTRIES = FBC_TABLES * FBC_TENT;
+constexpr int FBC_LDS_BYTES = FBC_ENTRIES * ANIELS_WORDS * 4;
+template <bool CT>
+__global__ void __launch_bounds__(512) k_fixedbase_comb(size_t n, const void* scalars, const u32* table, SoA ext, int chain) {
+  extern __shared__ __attribute__((aligned(16))) u32 lds[];
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(table);
+    uint4* dst = reinterpret_cast<uint4*>(lds);
+    for (int v = threadIdx.x; v < FBC_LDS_BYTES / 16; v += blockDim.x) dst[v] = src[v];
+  }
+  __syncthreads();
+  const size_t T = (size_t)gridDim.x * blockDim.x;
+  const u32 lane = threadIdx.x & 63u;
+  const size_t n_round = (n + 63) & ~(size_t)63;            // whole waves stay in the loop so shuffles see all lanes
+  #pragma unroll 1
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n_round; idx += T) {
+    const bool live = idx < n;
+    u32 k[8];
+    if (live) load8(k, scalars, idx); else zero8(k);
+    k[7] &= 0x0fffffffu;
+    const u32 even = 0u - ((k[0] & 1u) ^ 1u);                // all-ones iff k is even
+    // sw = (kk >> 1) | 2^255, kk = k | 1: tooth i is word i, column j is bit j of every word
+    u32 sw[8];
+    _Pragma("unroll") for (int q = 0; q < 7; q++) sw[q] = (k[q] >> 1) | (k[q + 1] << 31);
+    sw[7] = (k[7] >> 1) | 0x80000000u;
+    // 8 x 32 bit-matrix transpose (three masked-swap stages on the eight words: every byte lane is an 8 x 8 transpose): afterwards
+    // column j is byte j >> 3 of word j & 7, bit i of the byte = tooth i
+    u32 a[8];
+    _Pragma("unroll") for (int i = 0; i < 8; i++) a[i] = sw[i];
+    _Pragma("unroll") for (int i = 0; i < 8; i += 2) { const u32 t = ((a[i] >> 1) ^ a[i + 1]) & 0x55555555u; a[i + 1] ^= t; a[i] ^= t << 1; }
+    _Pragma("unroll") for (int i = 0; i < 8; i++) { if (i & 2) continue; const u32 t = ((a[i] >> 2) ^ a[i + 2]) & 0x33333333u; a[i + 2] ^= t; a[i] ^= t << 2; }
+    _Pragma("unroll") for (int i = 0; i < 4; i++) { const u32 t = ((a[i] >> 4) ^ a[i + 4]) & 0x0f0f0f0fu; a[i + 4] ^= t; a[i] ^= t << 4; }
+    // a column whose top tooth is -1 is minus the entry of the complemented bits: complement the low 7 bits of those bytes; the top
+    // bit stays (1 = the entry is added, 0 = subtracted)
+    _Pragma("unroll") for (int i = 0; i < 8; i++) { const u32 m = (~a[i] >> 7) & 0x01010101u; a[i] ^= (m << 7) - m; }
+    // digits in the order the steps consume them, step 0 in the top byte of pk[7]: phase ph adds the columns j0 = 3 - ph of the
+    // blocks j1 = 7 .. 0 (column 4 j1 + j0 = byte j1 >> 1 of word j0 + 4 (j1 & 1)), a doubling between the phases
+    u32 pk[8];
+    _Pragma("unroll") for (int ph = 0; ph < 4; ph++) {
+      const u32 hi = a[(3 - ph) + 4], lo = a[3 - ph];
+      pk[7 - 2 * ph] = (hi & 0xff000000u) | ((lo >> 8) & 0x00ff0000u) | ((hi >> 8) & 0x0000ff00u) | ((lo >> 16) & 0x000000ffu);
+      pk[6 - 2 * ph] = ((hi << 16) & 0xff000000u) | ((lo << 8) & 0x00ff0000u) | ((hi << 8) & 0x0000ff00u) | (lo & 0x000000ffu);
+    }
+    auto next_digit = [&](u32& j, u32& negmask) {
+      const u32 d = pk[7] >> 24;
+      _Pragma("unroll") for (int q = 7; q >= 1; q--) pk[q] = (pk[q] << 8) | (pk[q - 1] >> 24);
+      pk[0] <<= 8;
+      j = d & 127u;
+      negmask = (d >> 7) - 1u;                                // top tooth +: 0, -: all-ones
+    };
+    auto bperm = [&](const ANiels& mine, u32 j) -> ANiels {
+      const int src = (int)((j & 63u) << 2);                 // byte address of lane j mod 64
+      ANiels e;
+      _Pragma("unroll") for (int l = 0; l < NL; l++) {
+        e.vpu.l[l] = (u32)__builtin_amdgcn_ds_bpermute(src, (int)mine.vpu.l[l]);
+        e.vmu.l[l] = (u32)__builtin_amdgcn_ds_bpermute(src, (int)mine.vmu.l[l]);
+        e.t2d.l[l] = (u32)__builtin_amdgcn_ds_bpermute(src, (int)mine.t2d.l[l]);
+      }
+      return e;
+    };
+    auto fetch = [&](int tab, u32 j) -> ANiels {
+      const u32* tb = lds + (size_t)tab * FBC_TENT * ANIELS_WORDS;
+      if constexpr (CT) {
+        const ANiels lo = bperm(lds_aniels(tb + (size_t)lane * ANIELS_WORDS), j);
+        return Curve::select(lo, bperm(lds_aniels(tb + (size_t)(64 + lane) * ANIELS_WORDS), j), 0u - (j >> 6));
+      } else return lds_aniels(tb + (size_t)j * ANIELS_WORDS);
+    };
+    // column 0: T_0 for an odd k, T_0 - B (+ digit) or T_0 + B (- digit) for an even one: sign * (T_0 -+ B) = +-T_0 - B
+    auto fetch_last = [&](u32 j, u32 negmask) -> ANiels {
+      if constexpr (CT) {
+        // the choice of table depends on THIS lane's scalar while the staged entries belong to the lanes they came from: every
+        // lane stages and shuffles all three tables in turn (fixed addresses), keeping the one its parity and sign call for
+        ANiels e = fetch(0, j);
+        e = Curve::select(e, fetch(FBC_BLOCKS, j), even & ~negmask);
+        e = Curve::select(e, fetch(FBC_BLOCKS + 1, j), even & negmask);
+        return e;
+      } else {
+        const u32 tab = even ? (negmask ? (u32)FBC_BLOCKS + 1u : (u32)FBC_BLOCKS) : 0u;
+        return lds_aniels(lds + ((size_t)tab * FBC_TENT + j) * ANIELS_WORDS);
+      }
+    };
+    Ext acc = Curve::identity();
+    u32 j, neg0, neg1;
+    ANiels e0, e1;
+    next_digit(j, neg0);
+    e0 = fetch(FBC_BLOCKS - 1, j);
+    // 32 steps, two per trip with two entry register sets (the entry of step t + 1 is fetched before the addition of step t); step t
+    // uses table 7 - (t & 7); after every 8 steps (one column of every block) the sum is doubled
+    #pragma unroll 1
+    for (int t = 0; t < 32; t += 2) {
+      next_digit(j, neg1);
+      e1 = (t + 1 == 31) ? fetch_last(j, neg1) : fetch(FBC_BLOCKS - 1 - ((t + 1) & 7), j);
+      acc = Curve::add_signed<true>(acc, e0, neg0);
+      if (t + 2 < 32) { next_digit(j, neg0); e0 = fetch(FBC_BLOCKS - 1 - ((t + 2) & 7), j); }
+      acc = Curve::add_signed<true>(acc, e1, neg1);
+      if (((t + 2) & 7) == 0 && t + 2 < 32) acc = Curve::dbl(acc);
+    }
+    // sums over several bases (chain): the previous sum is added after the comb -- the doublings between the phases must not touch it
+    if ((chain & 1) && live) acc = Curve::add<true>(acc, Curve::to_niels<false>(soa_ext(ext, idx)));
+    if (live) {
+      ext.put(0, idx, acc.u); ext.put(1, idx, acc.v); ext.put(2, idx, acc.z);
+      if (chain & 2) { ext.put(3, idx, Fq::carry(acc.t1)); ext.put(4, idx, Fq::carry(acc.t2)); }
+    }
+  }
+}
 // Wide-window variant: table of (j+1) * 2^(w i) * B for w = 8..12 (0.5 - 5 MB) kept in global memory, L2-resident;
 // each lane gathers its entry (7 x dwordx4 of one 128-byte line) one window ahead of its use.  Fewer additions than the LDS
 // kernel (w = 10: 26 instead of 43) at the price of a secret-dependent address (documented as variable-time).

@@ -255,14 +255,45 @@ def test_fixedbase(eng):
     for base in (J.GENERATOR, to_pt(O.point_op("mul_by_cofactor", arr64([J.GENERATOR]))[0]), to_pt(rand_points(9, 1)[0])):
         S = np.concatenate([arr32(EDGE_SCALARS), rand_scalars(10, 2500, full_width=True)])
         want = O.fixedbase_mul(S, pt64(base))
-        for wbits in (0, 8, 10, 12):          # 0/6: LDS-staged constant-time table; 8..12: L2-resident wide windows
+        for wbits in (0, 7, 6, 8, 10, 12):    # 0 = 7: signed comb in LDS; 6: LDS window table (both constant-time selects); 8..12: L2-resident wide windows
             tab = eng.fixedbase_table(pt64(base), wbits)
             got = eng.fixedbase_mul(tab, S)
             assert (got == want).all(), wbits
             assert eng.fixedbase_mul(tab, S[:0]).shape == (0, 64)
             tab.close()
     with pytest.raises(Exception):
-        eng.fixedbase_table(pt64(J.GENERATOR), 7)
+        eng.fixedbase_table(pt64(J.GENERATOR), 5)
+
+
+@pytest.mark.parametrize("select", ["shuffle", "gather"])
+def test_fixedbase_signed_comb(monkeypatch, golden, select):
+    """k_fixedbase_comb (8 teeth, 8 column blocks, 32 additions + 3 doublings; even scalars take the last entry from T_0 -+ B):
+    every parity / sign class of the last column, scalars whose comb columns are all +, all -, alternating, 0, 1, 2, r - 1, r,
+    2^252 - 1, top bits set; bases of every kind (generator, prime-order, 8-torsion, order 2, identity); ragged waves; the
+    constant-time shuffle select and the per-lane LDS gather; and the chained (multi-base) form."""
+    from jubjub_amd import Engine
+
+    monkeypatch.setenv("JJ_FIXEDBASE_SELECT", select)
+    e2 = Engine(0)
+    comb = [0, 1, 2, 3, 4, (1 << 252) - 1, (1 << 252) - 2, 1 << 251, (1 << 251) + 1, sum(1 << (32 * i) for i in range(8)) & ((1 << 252) - 1), sum(1 << (32 * i + 1) for i in range(8)) & ((1 << 252) - 1), sum(0x88888888 << (32 * i) for i in range(8)) & ((1 << 252) - 1),
+            int("5" * 63, 16), int("a" * 62, 16), (1 << 224) - 1, 1 << 224, (1 << 224) + 2, (1 << 32) - 1, 1 << 32, (1 << 31) | 1, R - 1, R, R + 1, 8 * R - 1]
+    S = np.concatenate([arr32(EDGE_SCALARS), arr32([k & ((1 << 256) - 1) for k in comb]), rand_scalars(171, 1500, full_width=True)])
+    tors = torsion_points(golden)
+    bases = [pt64(J.GENERATOR), O.point_op("mul_by_cofactor", arr64([J.GENERATOR]))[0], rand_points(172, 1)[0], tors[1], tors[4], pt64(J.AFFINE_IDENTITY)]
+    for b in bases:
+        tab = e2.fixedbase_table(b, 7)
+        want = O.fixedbase_mul(S, b)
+        assert (e2.fixedbase_mul(tab, S) == want).all()
+        for m in (1, 63, 64, 65, 129):
+            assert (e2.fixedbase_mul(tab, S[:m]) == want[:m]).all(), m
+        tab.close()
+    t1, t2, t3 = e2.fixedbase_table(bases[0], 7), e2.fixedbase_table(bases[2], 7), e2.fixedbase_table(bases[1], 6)
+    S3 = np.stack([S, S[::-1].copy(), np.roll(S, 7, axis=0)])
+    want = O.point_op("add", O.point_op("add", O.fixedbase_mul(S3[0], bases[0]), O.fixedbase_mul(S3[1], bases[2])), O.fixedbase_mul(S3[2], bases[1]))
+    assert (e2.fixedbase_multi_mul([t1, t2, t3], S3) == want).all()
+    for t in (t1, t2, t3):
+        t.close()
+    e2.close()
 
 
 def test_fixedbase_multi_base_sums(eng):
