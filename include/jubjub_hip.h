@@ -145,9 +145,12 @@ int jj_varbase_mul_scalar(jj_ctx*, size_t n, const void* scalar32, const void* p
 int jj_varbase_mul_exact(jj_ctx*, size_t n, const void* scalars32, const void* points64, void* out160);
 
 /* Fixed-base: `AffineNielsPoint * Fr` / multiply_bits (src/lib.rs:272-310) for one base point.
- * The table holds signed-window multiples (j+1) * 2^(w i) * B of the base as affine-Niels triples.
- *   window_bits 0 or 6 : 147 KiB table staged in LDS, window entry selected with a ds_bpermute shuffle
- *                        (constant-time: no secret-dependent address) — 43 mixed additions per scalar;
+ * The table holds multiples of the base as affine-Niels triples.
+ *   window_bits 0 or 7 : signed comb, 8 teeth x 8 column blocks, 140 KiB table staged in LDS: 32 mixed additions + 3 doublings
+ *                        per scalar; the entry (one of 128) is selected with two ds_bpermute shuffles and a mask (constant-time:
+ *                        no secret-dependent address);
+ *   window_bits 6      : signed 6-bit windows, 152 KiB table staged in LDS, one ds_bpermute shuffle per entry (constant-time) —
+ *                        43 mixed additions per scalar;
  *   window_bits 8..16  : wider windows (0.6 MB .. 64 MB table, one 128-byte line per entry) kept in L2 / Infinity Cache and gathered per lane
  *                        (variable-time addressing) — ceil(253/w) additions per scalar.
  * A table lives in the memory of the device of the context that built it and serves every context of that device; a context of
@@ -161,6 +164,16 @@ int jj_fixedbase_mul_compressed(jj_ctx*, const jj_table* t, size_t n, const void
  * e.g. value commitments v*G_v + r*G_r or windowed Pedersen sums.  One pass per base; the accumulator stays in
  * extended coordinates between the passes, so there is a single normalisation. */
 int jj_fixedbase_multi_mul(jj_ctx*, const jj_table* const* tables, int nbases, size_t n, const void* scalars32, void* out64);
+
+/* The same sums when the scalars are SHORT, in one pass over one shared LDS table set (Pedersen-style windowed sums, value
+ * commitments v*G_v with 64-bit v, ...; the primitive is AffineNielsPoint::multiply_bits, src/lib.rs:297-301, which takes a bit
+ * slice):   out[i] = sum_{b < nbases} bases[b] * (scalars32[b * n + i] mod 2^scalar_bits[b])
+ * The 42 six-bit window slots of the LDS-staged table are divided among the bases (base b takes ceil((scalar_bits[b] + 2) / 6)
+ * of them; the sum must not exceed 42, e.g. 3 bases x 64 bits, 2 x 124, 6 x 40), one accumulator per lane walks all of them:
+ * 43 additions per unit whatever nbases is (jj_fixedbase_multi_mul: 32-43 per base), constant-time shuffle select.  The table
+ * is destroyed with jj_fixedbase_table_destroy. */
+int jj_fixedbase_composite_create(jj_ctx*, int nbases, const void* bases64, const int* scalar_bits, jj_table** out);
+int jj_fixedbase_composite_mul(jj_ctx*, const jj_table* t, size_t n, const void* scalars32, void* out64);
 
 /* Multi-scalar multiplication: out = to_affine(sum_i points[i] * scalars[i])  (semantics: iterator Sum of
  * `p * k`, src/lib.rs:183-193 + 873-879; the reference has no MSM algorithm).  n = 0 gives the identity.

@@ -37,6 +37,8 @@ _SIGS.update({
     "jj_fixedbase_table_destroy": [_vp],
     "jj_fixedbase_mul": [_vp, _sz, _vp, _vp],
     "jj_fixedbase_multi_mul": [_vp, C.c_int, _sz, _vp, _vp],
+    "jj_fixedbase_composite_create": [C.c_int, _vp, C.POINTER(C.c_int), C.POINTER(_vp)],
+    "jj_fixedbase_composite_mul": [_vp, _sz, _vp, _vp],
     "jj_msm": [_sz, _vp, _vp, _vp],
     "jj_msm_begin": [_sz, _vp, _vp, C.POINTER(_vp)],
     "jj_msm_partial": [_sz, _vp, _vp, C.c_int, C.c_int, _vp],

@@ -32,6 +32,8 @@ struct jj_table {
   int window_bits = FB_W;  // 7: signed comb in LDS (k_fixedbase_comb: 8 teeth, the default); 6: LDS-staged window table (k_fixedbase); 8..16: table gathered from L2 / Infinity Cache (k_fixedbase_gather)
   int device = -1;         // the table lives in this device's memory: only contexts of the same device may use it
   FbParams fp;
+  FbxParams fx;            // composite table (several bases with short scalars, layout of k_fixedbase): fx.nb > 0
+  jj_table() { memset(&fx, 0, sizeof fx); }
 };
 
 struct jj_ctx;
@@ -939,6 +941,68 @@ JJ_API int jj_fixedbase_multi_mul(jj_ctx* c, const jj_table* const* tables, int 
       const int chain = (j > 0 ? 1 : 0) | (j + 1 < nbases ? 2 : 0);
       if ((rc = fixedbase_launch(c, tables[j], n, (const uint8_t*)ds + (size_t)j * n * 32, ext, chain))) return rc;
     }
+    prof_mark(c, 1);
+    if ((rc = normalize_launch(c, n, ext, o.dev, 0))) return rc;
+    prof_mark(c, 2);
+  }
+  bool sync = false;
+  if ((rc = finish_out(c, o, &sync))) return rc;
+  return finish(c, sync);
+}
+// ---- several bases, short scalars, one pass (k_pack_composite + k_fixedbase on a composite table)
+JJ_API int jj_fixedbase_composite_create(jj_ctx* c, int nbases, const void* bases64, const int* scalar_bits, jj_table** out) {
+  if (!c || !out || !bases64 || !scalar_bits || nbases < 1 || nbases > FBX_MAX_BASES) return JJ_ERR_INVALID;
+  JJ_ENTER(c);
+  jj_table* t = new jj_table();
+  t->window_bits = FB_W;
+  t->device = c->device;
+  int slots = 0;
+  for (int b = 0; b < nbases; b++) {
+    if (scalar_bits[b] < 1 || scalar_bits[b] > 250) { c->err = "composite table: scalar_bits must be 1..250"; delete t; return JJ_ERR_INVALID; }
+    t->fx.off[b] = slots; t->fx.bits[b] = scalar_bits[b];
+    slots += (scalar_bits[b] + 2 + FB_W - 1) / FB_W;                 // 6 W >= bits + 2: the field's recoding never carries out of it
+  }
+  if (slots > FB_NWIN) { c->err = "composite table: the bases need more than 42 six-bit windows (sum of ceil((bits + 2) / 6))"; delete t; return JJ_ERR_INVALID; }
+  t->fx.nb = nbases;
+  std::vector<uint8_t> bases((size_t)nbases * 64);
+  if (is_device_ptr(bases64)) { HIPCHK(c, hipMemcpy(bases.data(), bases64, bases.size(), hipMemcpyDeviceToHost)); } else memcpy(bases.data(), bases64, bases.size());
+  // Q_s = 64^(local window) B_b for every slot in use, then j Q_s for j = 0 .. 32; unused slots and the carry entry hold the identity
+  int rc;
+  std::vector<uint8_t> s1((size_t)slots * 32, 0), p1((size_t)slots * 64), q((size_t)slots * 64);
+  for (int b = 0, sl = 0; b < nbases; b++) {
+    const int W = (b + 1 < nbases ? t->fx.off[b + 1] : slots) - t->fx.off[b];
+    for (int i = 0; i < W; i++, sl++) { const int bit = FB_W * i; s1[(size_t)sl * 32 + (bit >> 3)] = (uint8_t)(1u << (bit & 7)); memcpy(&p1[(size_t)sl * 64], &bases[(size_t)b * 64], 64); }
+  }
+  if ((rc = jj_varbase_mul(c, slots, s1.data(), p1.data(), q.data()))) { delete t; return rc; }
+  const size_t ne = (size_t)slots * FB_ENT;
+  std::vector<uint8_t> s2(ne * 32, 0), p2(ne * 64), aff((size_t)FB_ENTRIES * 64, 0);
+  for (size_t e = 0; e < ne; e++) { s2[e * 32] = (uint8_t)(e % FB_ENT); memcpy(&p2[e * 64], &q[(e / FB_ENT) * 64], 64); }
+  for (size_t e = 0; e < (size_t)FB_ENTRIES; e++) aff[e * 64 + 32] = 1;                    // affine identity (0, 1)
+  if ((rc = jj_varbase_mul(c, ne, s2.data(), p2.data(), aff.data()))) { delete t; return rc; }
+  for (size_t e = ne; e < (size_t)FB_ENTRIES; e++) { memset(&aff[e * 64], 0, 64); aff[e * 64 + 32] = 1; }
+  if (hipMalloc((void**)&t->dev, (size_t)FB_LDS_BYTES) != hipSuccess) { c->err = "hipMalloc(table) failed"; delete t; return JJ_ERR_NOMEM; }
+  const void* dpts;
+  if ((rc = stage_in(c, 0, aff.data(), (size_t)FB_ENTRIES * 64, &dpts))) { (void)hipFree(t->dev); delete t; return rc; }
+  hipLaunchKernelGGL(k_affine_to_table, dim3(blocks_for(FB_ENTRIES)), dim3(256), 0, c->stream, (size_t)FB_ENTRIES, dpts, t->dev, ANIELS_WORDS);
+  rc = finish(c, true);
+  if (rc) { (void)hipFree(t->dev); delete t; return rc; }
+  *out = t;
+  return JJ_OK;
+}
+JJ_API int jj_fixedbase_composite_mul(jj_ctx* c, const jj_table* t, size_t n, const void* scalars, void* out64) {
+  if (!c || !t || t->fx.nb < 1) return JJ_ERR_INVALID;
+  JJ_ENTER(c);
+  if (t->device != c->device) { c->err = "fixed-base table belongs to another device"; return JJ_ERR_INVALID; }
+  const void* ds; int rc; OutRef o;
+  if ((rc = stage_in(c, 0, scalars, 32 * n * (size_t)t->fx.nb, &ds))) return rc;
+  if ((rc = stage_out(c, c->out[0], out64, 64 * n, &o))) return rc;
+  if ((rc = ensure_ext(c, n, 3))) return rc;
+  if ((rc = ensure(c, c->ws_tmp[2], 32 * std::max<size_t>(n, 1)))) return rc;
+  SoA ext = soa_of(c->ws_ext, n);
+  if (n) {
+    prof_mark(c, 0);
+    hipLaunchKernelGGL(k_pack_composite, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, ds, t->fx, c->ws_tmp[2].p);
+    if ((rc = fixedbase_launch(c, t, n, c->ws_tmp[2].p, ext))) return rc;
     prof_mark(c, 1);
     if ((rc = normalize_launch(c, n, ext, o.dev, 0))) return rc;
     prof_mark(c, 2);

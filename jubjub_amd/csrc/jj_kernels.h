@@ -741,6 +741,39 @@ __global__ void __launch_bounds__(512) k_fixedbase_comb(size_t n, const void* sc
     }
   }
 }
+// ---- Several fixed bases with SHORT scalars in ONE pass over ONE LDS table set (Pedersen-style sums
+// sum_b k_b B_b built from AffineNielsPoint::multiply_bits, reference src/lib.rs:297-301).  The windows of k_fixedbase need not
+// belong to one base: a composite table gives window slots [off_b, off_b + W_b) to base b (entries j 64^(i - off_b) B_b), and
+// the short scalars are packed into one 252-bit virtual scalar, field b at bit 6 off_b.  With 6 W_b >= bits_b + 2 the signed
+// recoding of a field never carries into the next field (k' of the field stays below 64^W_b), so k_fixedbase -- one accumulator
+// per lane, 43 additions, constant-time shuffle select -- computes sum_b (k_b mod 2^bits_b) B_b unchanged.
+constexpr int FBX_MAX_BASES = 21;      // 42 window slots, at least two per base
+struct FbxParams { int nb; int off[FBX_MAX_BASES]; int bits[FBX_MAX_BASES]; };
+__global__ void __launch_bounds__(256) k_pack_composite(size_t n, const void* scalars, FbxParams fx, void* virt32) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 v[8];
+  zero8(v);
+  #pragma unroll 1
+  for (int b = 0; b < fx.nb; b++) {
+    u32 k[8];
+    load8(k, scalars, (size_t)b * n + i);
+    const int bits = fx.bits[b], sh = 6 * fx.off[b], ws = sh >> 5, bs = sh & 31;
+    _Pragma("unroll") for (int q = 0; q < 8; q++) {                  // keep the low `bits` bits
+      const int lo = 32 * q;
+      const u32 m = bits >= lo + 32 ? ~0u : (bits <= lo ? 0u : ((1u << (bits - lo)) - 1u));
+      k[q] &= m;
+    }
+    _Pragma("unroll") for (int q = 0; q < 8; q++) {                  // v |= k << sh   (a field never reaches bit 252)
+      const int src = q - ws;
+      u32 lo = 0, hi = 0;
+      _Pragma("unroll") for (int r = 0; r < 8; r++) { lo = (r == src) ? k[r] : lo; hi = (r == src - 1) ? k[r] : hi; }
+      v[q] |= (lo << bs) | (bs ? (hi >> (32 - bs)) : 0u);
+    }
+  }
+  store8(virt32, i, v);
+}
+
 // Wide-window variant: table of (j+1) * 2^(w i) * B for w = 8..12 (0.5 - 5 MB) kept in global memory, L2-resident;
 // each lane gathers its entry (7 x dwordx4 of one 128-byte line) one window ahead of its use.  Fewer additions than the LDS
 // kernel (w = 10: 26 instead of 43) at the price of a secret-dependent address (documented as variable-time).

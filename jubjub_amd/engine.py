@@ -287,6 +287,32 @@ class Engine:
         self._check(self._lib.jj_fixedbase_multi_mul(self._ctx, handles, C.c_int(nb), C.c_size_t(n), a.ptr, optr))
         return out
 
+    def fixedbase_composite_table(self, bases, scalar_bits):
+        """One LDS table set for several bases with short scalars (jj_fixedbase_composite_create): bases (nb, 64) bytes, scalar_bits a
+        list of nb bit lengths with sum(ceil((bits + 2) / 6)) <= 42."""
+        a = _Arg(bases, 64)
+        if a.n != len(scalar_bits) or a.n < 1:
+            raise ValueError("one bit length per base")
+        self._bind_stream([a])
+        bits = (C.c_int * a.n)(*[int(b) for b in scalar_bits])
+        h = C.c_void_p()
+        self._check(self._lib.jj_fixedbase_composite_create(self._ctx, C.c_int(a.n), a.ptr, bits, C.byref(h)))
+        t = FixedBaseTable(self, h)
+        t.nbases = a.n
+        return t
+
+    def fixedbase_composite_mul(self, table, scalars):
+        """out[i] = sum_b bases[b] * (scalars[b][i] mod 2^bits[b]) in ONE pass (43 additions per unit); scalars: (nb, n, 32) bytes."""
+        a = _Arg(scalars, 32)
+        nb = table.nbases
+        if a.n % nb:
+            raise ValueError("scalars must hold nbases x n x 32 bytes")
+        n = a.n // nb
+        self._bind_stream([a])
+        out, optr = self._alloc(a, n, 64)
+        self._check(self._lib.jj_fixedbase_composite_mul(self._ctx, table._h, C.c_size_t(n), a.ptr, optr))
+        return out
+
     def msm(self, scalars, points):
         return self._sum_like("jj_msm", [scalars, points], [32, 64])
 

@@ -317,6 +317,34 @@ def test_fixedbase_multi_base_sums(eng):
     tab.close()
 
 
+@pytest.mark.parametrize("bits", [[64, 64, 64], [124, 124], [40] * 6, [1, 250 - 9], [10] * 21, [250]])
+def test_fixedbase_composite_short_scalars_one_pass(eng, bits):
+    """jj_fixedbase_composite_*: several bases with short scalars through ONE LDS table set and one accumulator per lane (SURVEY
+    8(f)-4), against the oracle's AffineNielsPoint ladders on the masked scalars folded with point additions
+    (multiply_bits, reference src/lib.rs:297-301): field-boundary patterns (all ones, top bit only, zero), bits above the field
+    ignored, full-group bases."""
+    nb, n = len(bits), 700
+    bases = rand_points(300 + nb, nb)
+    S = np.stack([rand_scalars(310 + b, n, full_width=True) for b in range(nb)])
+    for b in range(nb):
+        S[b, 0] = 0xFF                                                          # all ones: the field holds 2^bits - 1, the rest is ignored
+        S[b, 1] = b32(1 << (bits[b] - 1))
+        S[b, 2] = 0
+        S[b, 3] = b32((1 << bits[b]) - 1)
+    tab = eng.fixedbase_composite_table(bases, bits)
+    got = eng.fixedbase_composite_mul(tab, S)
+    want = None
+    for b in range(nb):
+        masked = arr32([to_int(x) & ((1 << bits[b]) - 1) for x in S[b]])
+        term = O.fixedbase_mul(masked, bases[b])
+        want = term if want is None else O.point_op("add", want, term)
+    assert (got == want).all(), bits
+    assert eng.fixedbase_composite_mul(tab, S[:, :0]).shape == (0, 64)
+    tab.close()
+    with pytest.raises(Exception):
+        eng.fixedbase_composite_table(rand_points(1, 4), [64, 64, 64, 64])     # 44 windows: does not fit the 42 slots
+
+
 def test_msm(eng):
     for n in (0, 1, 2, 3, 7, 33, 127, 511, 512, 1000, 2047, 2048, 5000, 32767, 32768, 40000):
         S = rand_scalars(12 + n, n, full_width=True)
@@ -790,3 +818,16 @@ def test_group_mirror_random_and_bits(eng):
     lo_seed, hi_seed = G.random_stream_seeds(5)
     assert (q.data == arr32([int.from_bytes(J.synth_bytes32(i, lo_seed) + J.synth_bytes32(i, hi_seed), "little") % Q for i in range(8)])).all()
     assert lo_seed != hi_seed and G.random_stream_seeds(6) != (lo_seed, hi_seed)
+
+
+def test_config0_shape_on_the_gpu(eng):
+    """BASELINE.json configs[0] (the reference's own CPU benches, benches/fq_bench.rs:25-33 and point_bench.rs:6-11) as a parity case:
+    1024 random Fq pairs (64 PRNG bytes each through from_bytes_wide, as tests/common.rs:15-21) multiplied, and 1024 random
+    extended points doubled, GPU vs the oracle; the CPU timing of the same shape is tests/config1_cpu.py (profiles/r3_config1_cpu.txt)."""
+    rng = np.random.default_rng(1024)
+    wide_a, wide_b = rng.integers(0, 256, size=(1024, 64), dtype=np.uint8), rng.integers(0, 256, size=(1024, 64), dtype=np.uint8)
+    a, b = eng.from_bytes_wide("fq", wide_a), eng.from_bytes_wide("fq", wide_b)
+    assert (a == O.from_bytes_wide(O.FQ, wide_a)).all() and (b == O.from_bytes_wide(O.FQ, wide_b)).all()
+    assert (eng.field_binary("fq", "mul", a, b) == O.field_op(O.FQ, "mul", a, b)[0]).all()
+    pts = rand_points(1025, 1024)
+    assert (eng.point_double(pts) == O.point_op("double", pts)).all()

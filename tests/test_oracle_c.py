@@ -2,6 +2,7 @@
 Pins the C oracle (oracle/jubjub_oracle.c via oracle/c_oracle.py) against the reference's golden
 vectors and cross-checks it against the Python big-int oracle on seeded random inputs.
 """
+import os
 import random
 
 import numpy as np
@@ -250,3 +251,16 @@ def test_committed_oracle_vectors():
     for m in v["msm"]:
         got = O.msm(np.stack([fx(s) for s in m["scalars"]]), np.stack([fx(p) for p in m["points"]]))
         assert (got == fx(m["out"])).all()
+
+
+def test_config0_cpu_script_runs():
+    """tests/config1_cpu.py (BASELINE.json configs[0] on the CPU port: 1k Fq multiplications + 1k ExtendedPoint::double, the shape
+    of benches/fq_bench.rs:25-33 and point_bench.rs:6-11) runs and prints two positive ns/op figures"""
+    import re
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "config1_cpu.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    vals = [float(v) for v in re.findall(r"([0-9.]+) ns/op", r.stdout)]
+    assert len(vals) == 2 and all(v > 0 for v in vals), r.stdout
