@@ -71,7 +71,11 @@ int jj_peak_imad32(jj_ctx* ctx, double* out_per_sec);
 /* ---- fields: Fq (base, = bls12_381::Scalar, src/lib.rs:62) and Fr (scalar, src/fr.rs) ------------------------ */
 /* Elements are 32-byte little-endian integers; inputs are reduced mod p like from_raw (src/fr.rs:347-349),
  * outputs are canonical.  reference: add 638-647, sub 620-634, mul 592-616, neg 651-665, square 353-381,
- * double 261-263, invert 438-540 (ok=0 & out=0 for zero), sqrt 384-399 (Fr) / Tonelli-Shanks (Fq, bls12_381). */
+ * double 261-263, invert 438-540 (ok=0 & out=0 for zero), sqrt 384-399 (Fr) / Tonelli-Shanks (Fq, bls12_381).
+ * jj_fq_sqrt returns the root that ff 0.13's sqrt_tonelli_shanks is RECALLED to return (that crate is not part of the reference
+ * tree and no reference test stores a raw Fq root), so WHICH of the two roots comes back is parity-UNVERIFIED; that it is a root
+ * (or ok = 0 for a non-residue) is checked.  Point decompression does not depend on it: the encoding's sign bit picks the root
+ * (src/lib.rs:518-520), and that path is pinned by the reference's vectors. */
 int jj_fq_add(jj_ctx*, size_t n, const void* a, const void* b, void* out);
 int jj_fq_sub(jj_ctx*, size_t n, const void* a, const void* b, void* out);
 int jj_fq_mul(jj_ctx*, size_t n, const void* a, const void* b, void* out);

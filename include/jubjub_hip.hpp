@@ -289,4 +289,79 @@ inline Bytes64 msm(const Context& c, const AffineBatch& points, const FrBatch& s
   return out;
 }
 
+// The same sum with the host tail of one MSM overlapping the kernels of the next (jj_msm_begin / jj_msm_finish): the job owns copies
+// of its inputs until it is finished
+class MsmJob {
+ public:
+  MsmJob(const Context& c, const AffineBatch& points, const FrBatch& scalars) : c_(&c), s_(scalars.to_bytes()), p_(points.coords()) {
+    if (p_.size() != s_.size()) throw Error(JJ_ERR_INVALID, "length mismatch");
+    c.check(jj_msm_begin(c.raw(), p_.size(), s_.data(), p_.data(), &job_));
+  }
+  MsmJob(const MsmJob&) = delete;
+  MsmJob& operator=(const MsmJob&) = delete;
+  ~MsmJob() { if (job_) { Bytes64 sink; (void)jj_msm_finish(job_, sink.data()); } }
+  Bytes64 finish() {
+    if (!job_) throw Error(JJ_ERR_INVALID, "MSM job already finished");
+    Bytes64 out;
+    jj_msm_job* j = job_;
+    job_ = nullptr;
+    c_->check(jj_msm_finish(j, out.data()));
+    return out;
+  }
+
+ private:
+  const Context* c_;
+  std::vector<Bytes32> s_;
+  std::vector<Bytes64> p_;
+  jj_msm_job* job_ = nullptr;
+};
+// MSM cut into parts (jj_msm_partial / jj_msm_combine): part g of G by windows (every part sees all terms) or all windows of a slice
+// of the terms; the records are combined in one host tail
+using MsmRecord = std::array<uint8_t, JJ_MSM_PARTIAL_BYTES>;
+inline MsmRecord msm_partial(const Context& c, const AffineBatch& points, const FrBatch& scalars, int part_index = 0, int part_count = 1) {
+  if (points.len() != scalars.len()) throw Error(JJ_ERR_INVALID, "length mismatch");
+  MsmRecord rec;
+  c.check(jj_msm_partial(c.raw(), points.len(), scalars.to_bytes().data(), points.coords().data(), part_index, part_count, rec.data()));
+  return rec;
+}
+inline Bytes64 msm_combine(const std::vector<MsmRecord>& records) {
+  Bytes64 out;
+  const int rc = jj_msm_combine(records.size(), records.empty() ? nullptr : records.data(), out.data());
+  if (rc) throw Error(rc, "jj_msm_combine: damaged or mismatched records");
+  return out;
+}
+// `ExtendedPoint * Fr` with the reference's constant-time discipline (lib.rs:334-343, 357-379): no scalar-dependent address or branch
+inline AffineBatch multiply_ct(const Context& c, const AffineBatch& points, const FrBatch& scalars) {
+  if (points.len() != scalars.len()) throw Error(JJ_ERR_INVALID, "length mismatch");
+  std::vector<Bytes64> out(points.len());
+  c.check(jj_varbase_mul_ct(c.raw(), points.len(), scalars.to_bytes().data(), points.coords().data(), out.data()));
+  return AffineBatch(c, std::move(out));
+}
+// several fixed bases with short scalars through one LDS table set, one pass (sums of multiply_bits, lib.rs:297-301)
+class CompositeBase {
+ public:
+  CompositeBase(const Context& c, const std::vector<Bytes64>& bases, const std::vector<int>& scalar_bits) : c_(&c), nb_(bases.size()) {
+    if (bases.empty() || bases.size() != scalar_bits.size()) throw Error(JJ_ERR_INVALID, "one bit length per base");
+    c.check(jj_fixedbase_composite_create(c.raw(), (int)bases.size(), bases.data(), scalar_bits.data(), &t_));
+  }
+  ~CompositeBase() { if (t_) jj_fixedbase_table_destroy(c_->raw(), t_); }
+  CompositeBase(const CompositeBase&) = delete;
+  CompositeBase& operator=(const CompositeBase&) = delete;
+  // scalars[b][i]: only the low scalar_bits[b] bits are used
+  AffineBatch multiply_bits(const std::vector<std::vector<Bytes32>>& scalars) const {
+    if (scalars.size() != nb_) throw Error(JJ_ERR_INVALID, "bases / scalars mismatch");
+    const size_t n = scalars[0].size();
+    std::vector<Bytes32> flat;
+    for (const auto& v : scalars) { if (v.size() != n) throw Error(JJ_ERR_INVALID, "length mismatch"); flat.insert(flat.end(), v.begin(), v.end()); }
+    std::vector<Bytes64> out(n);
+    c_->check(jj_fixedbase_composite_mul(c_->raw(), t_, n, flat.data(), out.data()));
+    return AffineBatch(*c_, std::move(out));
+  }
+
+ private:
+  const Context* c_;
+  size_t nb_;
+  jj_table* t_ = nullptr;
+};
+
 }  // namespace jubjub

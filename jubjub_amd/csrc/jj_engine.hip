@@ -606,7 +606,7 @@ JJ_API int jj_is_small_order(jj_ctx* c, size_t n, const void* p, uint8_t* out) {
 JJ_API int jj_is_on_curve(jj_ctx* c, size_t n, const void* p, uint8_t* out) { return point_op<PT_IS_ON_CURVE>(c, n, p, nullptr, out, 1); }
 
 // ---------------------------------------------------------------------------------------------------- var-base
-// launch geometry of the windowed ladder: persistent grid, one 1152-byte table slot per lane
+// launch geometry of the windowed ladder: persistent grid, one 2448-byte table slot (17 entries x 144 B) per lane
 static void varbase_geometry(jj_ctx* c, size_t n, unsigned* blocks, size_t* threads) {
   const size_t max_threads = (size_t)c->cus * 256 * c->vb_blocks_per_cu;   // k blocks of 256 per CU = k waves / SIMD
   size_t t = std::min(max_threads, ((n + 255) / 256) * 256);

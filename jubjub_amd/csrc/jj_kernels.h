@@ -309,8 +309,10 @@ __global__ void __launch_bounds__(256) k_ext160_to_soa(size_t n, const void* ext
 // Signed fixed-window ladder (w = 5 by default), one scalar-mul per lane.  k (low 252 bits) is recoded as
 // k = sum_i d_i 2^(w i) with signed w-bit digits d_i in [-2^(w-1), 2^(w-1)) (top digit unsigned), obtained from
 // k' = k + sum 2^(w i + w - 1) as digit = window(k') - 2^(w-1).
-// The lane's table {1..2^(w-1)}P (ExtendedNiels, 144 B each) lives in a per-lane slot of a global workspace (L2/MALL
-// resident); the entry for the next window is fetched before the w doublings that precede its use.
+// The lane's table {0..2^(w-1)}P (ExtendedNiels, 144 B each: 17 entries = 2448 B per lane) lives in a per-lane slot of a global
+// workspace; the resident lanes hold ~320 MB of tables, far more than the 4 MB L2 of an XCD, so every entry read comes from
+// HBM / Infinity Cache (14.7 KB of fabric traffic per scalar-mul, PMC-measured, hidden behind the multiply-adds: DESIGN.md 7).
+// The entry for the next window is fetched before the w doublings that precede its use.
 // Group element equals the reference ladder's (src/lib.rs:357-379, 831-833); negation is exact on the whole curve.
 #ifndef JJ_VB_MINWAVES
 #define JJ_VB_MINWAVES 2

@@ -201,6 +201,27 @@ int main(int argc, char** argv) {
       CHECK(FrBatch::from_bytes(c, k.to_bytes()).all_some());
       CHECK(AffineBatch::random(c, 50, 0x4a55, 105, true) == AffineBatch(c, std::vector<Bytes64>(p.coords().begin() + 100, p.coords().begin() + 150)));
     }
+    // round-3 entry points through the mirror: the constant-time ladder, the MSM in two halves / in parts, several short-scalar bases
+    {
+      std::puts("multiply_ct / MsmJob / msm_partial + msm_combine / CompositeBase");
+      const AffineBatch p = AffineBatch::random(c, 500, 0x77, 0, false);
+      const FrBatch k = FrBatch::random(c, 500, 0x78, 0);
+      CHECK(multiply_ct(c, p, k) == p * k);
+      const Bytes64 want = msm(c, p, k);
+      MsmJob j1(c, p, k), j2(c, p, k);
+      CHECK(j2.finish() == want);
+      CHECK(j1.finish() == want);
+      std::vector<MsmRecord> recs;
+      for (int g = 0; g < 3; g++) recs.push_back(msm_partial(c, p, k, g, 3));
+      CHECK(msm_combine(recs) == want);
+      CHECK((p * k).sum() == want);
+      std::vector<Bytes64> bases(p.coords().begin(), p.coords().begin() + 3);
+      CompositeBase cb(c, bases, {64, 64, 64});
+      std::vector<std::vector<Bytes32>> ks(3, std::vector<Bytes32>(200));
+      for (int b = 0; b < 3; b++) for (size_t i = 0; i < 200; i++) { ks[b][i] = Bytes32{}; for (int q = 0; q < 8; q++) ks[b][i][q] = k.to_bytes()[(b * 100 + i) % 500][q]; }
+      FixedBase f0(c, bases[0]), f1(c, bases[1]), f2(c, bases[2]);
+      CHECK(cb.multiply_bits(ks) == fixedbase_multi_mul({&f0, &f1, &f2}, ks));
+    }
     // error behaviour: length mismatch is rejected like the assert at src/lib.rs:841
     bool threw = false;
     try { AffineBatch::generator(c, 2) * FrBatch::from_u64(c, {1}); } catch (const Error&) { threw = true; }

@@ -47,8 +47,9 @@ while time.time() < t_end:
     want_vb = O.varbase_mul(S, P)
     assert (eng.varbase_mul(S, P) == want_vb).all(), ("varbase", rnd)
     assert (eng_alt.varbase_mul(S, P) == want_vb).all(), ("varbase per-lane", rnd)
+    assert (eng.varbase_mul_ct(S, P) == want_vb).all(), ("varbase constant-time", rnd)
     bp = P[int(rng.integers(0, n))]
-    wbits = [0, 8, 10, 12, 13, 14, 16, 0][rnd % 8]        # LDS table and every wide-window class (16 bits: the 64 MB table)
+    wbits = [0, 8, 10, 12, 13, 14, 16, 6][rnd % 8]        # comb (0), LDS window table (6) and every wide-window class (16 bits: the 64 MB table)
     tab = eng.fixedbase_table(bp, wbits)
     assert (eng.fixedbase_mul(tab, S) == O.fixedbase_mul(S, bp)).all(), ("fixedbase", rnd, wbits)
     if rnd % 2 == 0:                                          # sums over two fixed bases; one scalar with many bases
@@ -64,6 +65,26 @@ while time.time() < t_end:
     assert (eng.msm(S[:m], P[:m]) == want_msm).all(), ("msm", rnd)
     assert (eng_alt.msm(S[:m], P[:m]) == want_msm).all(), ("msm segments", rnd)
     assert (eng_wide[rnd % 3].msm(S[:m], P[:m]) == want_msm).all(), ("msm wide windows", rnd)
+    G = 2 + rnd % 5                                           # the MSM in parts: by windows, by terms, and as overlapping asynchronous jobs
+    assert (eng.msm_combine(np.stack([eng.msm_partial(S[:m], P[:m], g, G) for g in range(G)])) == want_msm).all(), ("msm window partition", rnd)
+    cut = [m * g // G for g in range(G + 1)]
+    assert (eng_alt.msm_combine(np.stack([eng_alt.msm_partial(S[cut[g]:cut[g + 1]], P[cut[g]:cut[g + 1]]) for g in range(G)])) == want_msm).all(), ("msm term partition", rnd)
+    jobs = [eng.msm_begin(S[:m >> k], P[:m >> k]) for k in range(3)]
+    for k in (1, 0, 2):
+        assert (eng.msm_finish(jobs[k]) == O.msm(S[:m >> k], P[:m >> k])).all(), ("msm async", rnd, k)
+    if rnd % 2 == 1:                                          # several short-scalar bases through one composite table
+        bits = [[64, 64, 64], [124, 124], [40] * 6, [10] * 21][rnd // 2 % 4]
+        nbs = len(bits)
+        ct = eng.fixedbase_composite_table(P[:nbs], bits)
+        q3 = min(n, 2000)
+        Sc = np.stack([np.roll(S[:q3], b, axis=0) for b in range(nbs)])
+        wantc = None
+        for b in range(nbs):
+            msk = np.frombuffer(((1 << bits[b]) - 1).to_bytes(32, "little"), dtype=np.uint8)
+            term = O.fixedbase_mul(Sc[b] & msk, P[b])
+            wantc = term if wantc is None else O.point_op("add", wantc, term)
+        assert (eng.fixedbase_composite_mul(ct, Sc) == wantc).all(), ("composite", rnd)
+        ct.close()
     enc = O.compress(P)
     bad = rng.integers(0, n, size=max(1, n // 10))
     enc[bad] = rng.integers(0, 256, size=(len(bad), 32), dtype=np.uint8)

@@ -1,14 +1,19 @@
 #!/bin/bash
 # Runs LOCALLY after tools/refresh_round.sh came back through gpurun_out/: copies the round's evidence into profiles/.
 set -e
-TAG=${1:-r2}
+TAG=${1:-r3}
 cd "$(dirname "$0")/.."
 for f in gpurun_out/profiles_$TAG/*; do
   b=$(basename $f)
   case $b in ${TAG}_*_kernel_stats.txt|${TAG}_*_pmc.txt|${TAG}_*_bench.json|traffic.json|${TAG}_kernel_resources.txt|${TAG}_instr_mix.txt) cp $f profiles/;; esac
 done
-for f in default dec1 dec3 msm20 msm22 msm17 fb16; do cp gpurun_out/${TAG}_bench_$f.json profiles/${TAG}_bench_$f.json; done
+for f in default dec1 dec3 msm20 msm22 msm17 msm20_async2 msm17_async2 msm10 fb16 fb6; do cp gpurun_out/${TAG}_bench_$f.json profiles/${TAG}_bench_$f.json; done
 BID=$(python3 -c "import json; print(json.load(open('profiles/traffic.json'))['build_id'])")
-(echo "# commit $(cat profiles/BUILD_COMMIT) | build_id $BID | MI355X gfx950"; echo "# command: python tools/latency.py   (median wall time per C-ABI call, device-resident inputs)"; grep -v amdgpu gpurun_out/${TAG}_latency.txt) > profiles/${TAG}_latency.txt
-(echo "# commit $(cat profiles/BUILD_COMMIT) | build_id $BID | MI355X gfx950"; echo "# command: python tests/soak.py 240 2000   (randomised differential soak of every entry point against the C oracle; last rounds and verdict)"; grep -v amdgpu gpurun_out/${TAG}_soak.txt | tail -6) > profiles/${TAG}_soak.txt
+HDR="# commit $(cat profiles/BUILD_COMMIT) | build_id $BID | MI355X gfx950"
+cp gpurun_out/${TAG}_msm17_kernel_stats.txt profiles/${TAG}_msm17_kernel_stats.txt
+(echo "$HDR"; echo "# command: python tools/latency.py   (median wall time per C-ABI call, device-resident inputs)"; grep -v amdgpu gpurun_out/${TAG}_latency.txt) > profiles/${TAG}_latency.txt
+(echo "$HDR"; echo "# command: python tools/composite_bench.py 22"; grep -v amdgpu gpurun_out/${TAG}_fixedbase_composite.txt) > profiles/${TAG}_fixedbase_composite.txt
+(echo "$HDR"; echo "# command: python experiments/misc/msm_partition_cost.py 20 8"; grep -v amdgpu gpurun_out/${TAG}_msm_partition_cost.txt) > profiles/${TAG}_msm_partition_cost.txt
+(echo "$HDR"; echo "# command: python tests/config1_cpu.py   (BASELINE.json configs[0] on the CPU port of the reference algorithm, host of the GPU box)"; cat gpurun_out/${TAG}_config1_cpu.txt) > profiles/${TAG}_config1_cpu.txt
+(echo "$HDR"; echo "# command: python tests/soak.py 240 3000   (randomised differential soak of every entry point against the C oracle; last rounds and verdict)"; grep -v amdgpu gpurun_out/${TAG}_soak.txt | tail -6) > profiles/${TAG}_soak.txt
 python3 tools/design_numbers.py $TAG

@@ -7,7 +7,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
 
 
 def line(name):
@@ -25,7 +25,7 @@ def pmc(wl):
             "bytes": g(r"=>\s+(\d+) B per unit")}
 
 
-for name in ("varbase_bench", "fixedbase_bench", "msm_bench", "decompress_bench", "bench_default", "bench_dec1", "bench_dec3", "bench_msm20", "bench_msm17", "bench_msm22", "bench_fb16"):
+for name in ("varbase_bench", "fixedbase_bench", "msm_bench", "decompress_bench", "bench_default", "bench_dec1", "bench_dec3", "bench_msm20", "bench_msm17", "bench_msm22", "bench_msm20_async2", "bench_msm17_async2", "bench_msm10", "bench_fb16", "bench_fb6"):
     d = line(name)
     if not d:
         continue
@@ -39,6 +39,11 @@ if d:
         print("default.fixed_base      %.1f M/s  kernel %.3f ms  frac %.3f  verified %s" % (fb["value"] / 1e6, fb["kernel_ms"], fb["roofline_frac"], fb.get("verified")))
     if fw:
         print("default.wide_window     %.1f M/s  verified %s" % (fw["value"] / 1e6, fw.get("verified")))
+    ct = d.get("varbase_constant_time")
+    if ct:
+        print("default.constant_time   %.1f M/s  kernel %.3f ms  frac %.3f  x%.3f of the default ladder  verified %s  equal on all units %s" % (
+            ct["value"] / 1e6, ct["kernel_ms"], ct["roofline_frac"], ct["relative_to_default"], ct.get("verified"), ct.get("equals_default_ladder_all_units")))
+    print("default.frac_min        %.4f (fastest dispatch), frac %.4f" % (d["roofline"].get("frac_min") or 0, d["roofline"]["frac"]))
     if cb:
         print("cpu_baseline            one thread %.0f /s, %d threads %.0f /s (x%.1f); %s, logical %d, cgroup quota %s" % (
             cb["single_thread"]["value"], cb["all_cores"]["threads"], cb["all_cores"]["value"], cb["all_cores"]["speedup_over_one_thread"],

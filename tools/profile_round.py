@@ -2,7 +2,7 @@
 """
 Collects the round's profiling evidence on the GPU box in ONE go and at ONE build, and stamps every file with the build:
 
-  python tools/profile_round.py --tag r2 [--workloads varbase,fixedbase,msm,decompress] [--skip-pmc]
+  python tools/profile_round.py --tag r3 [--workloads varbase,fixedbase,msm,decompress] [--skip-pmc]
 
   profiles/<tag>_<workload>_kernel_stats.txt   rocprofv3 --kernel-trace --stats summary of `python bench.py --workload <w> ...`
   profiles/<tag>_<workload>_bench.json         the JSON line that same command printed (roofline.kernel_ms to compare with)
@@ -30,7 +30,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (build_id, WORK)
 
-DOMINANT = {"varbase": "k_varbase<", "fixedbase": "k_fixedbase<", "msm": "k_msm_accumulate_seg", "decompress": "k_decompress<"}
+DOMINANT = {"varbase": "k_varbase<", "fixedbase": "k_fixedbase_comb<", "msm": "k_msm_accumulate_seg", "decompress": "k_decompress<"}
 SQ_SET = "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES"
 
 
@@ -98,7 +98,7 @@ def pmc_pass(tag, wl, counters, scratch, bench_args):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--tag", default="r2")
+    ap.add_argument("--tag", default="r3")
     ap.add_argument("--workloads", default="varbase,fixedbase,msm,decompress")
     ap.add_argument("--skip-pmc", action="store_true")
     a = ap.parse_args()

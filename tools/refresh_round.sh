@@ -1,8 +1,8 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (through gpurun): the whole evidence set of a round at one build.
-#   gpurun -- 'bash tools/refresh_round.sh r2'     then locally: bash tools/collect_round.sh r2
+#   gpurun -- 'bash tools/refresh_round.sh r3'     then locally: bash tools/collect_round.sh r3
 set -e
-TAG=${1:-r2}
+TAG=${1:-r3}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -13,7 +13,15 @@ python bench.py --workload decompress --decompress-flags 3 --no-cpu-baseline > g
 python bench.py --workload msm --log2n 22 --no-cpu-baseline --no-verify > gpurun_out/${TAG}_bench_msm22.json 2>/dev/null
 python bench.py --workload msm --no-cpu-baseline > gpurun_out/${TAG}_bench_msm20.json 2>/dev/null      # without the profiler's per-dispatch overhead
 python bench.py --workload msm --log2n 17 --no-cpu-baseline > gpurun_out/${TAG}_bench_msm17.json 2>/dev/null
+python bench.py --workload msm --msm-async 2 --no-cpu-baseline > gpurun_out/${TAG}_bench_msm20_async2.json 2>/dev/null   # two jobs in flight (jj_msm_begin / _finish)
+python bench.py --workload msm --log2n 17 --msm-async 2 --no-cpu-baseline > gpurun_out/${TAG}_bench_msm17_async2.json 2>/dev/null
+python bench.py --workload msm --log2n 10 --no-cpu-baseline > gpurun_out/${TAG}_bench_msm10.json 2>/dev/null           # small-batch path
 python bench.py --workload fixedbase --fb-window 16 --no-cpu-baseline > gpurun_out/${TAG}_bench_fb16.json 2>/dev/null
+python bench.py --workload fixedbase --fb-window 6 --no-cpu-baseline > gpurun_out/${TAG}_bench_fb6.json 2>/dev/null      # round 2's kernel: signed 6-bit windows
+bash tools/msm_profile.sh $TAG 17 > gpurun_out/${TAG}_msm17_profile.log 2>&1                                             # gpurun_out/<tag>_msm17_kernel_stats.txt
 python tools/latency.py > gpurun_out/${TAG}_latency.txt 2>&1
-timeout 600 python tests/soak.py 240 2000 > gpurun_out/${TAG}_soak.txt 2>&1 || echo "SOAK FAILED" >> gpurun_out/${TAG}_soak.txt
+python tools/composite_bench.py 22 > gpurun_out/${TAG}_fixedbase_composite.txt 2>&1
+python experiments/misc/msm_partition_cost.py 20 8 > gpurun_out/${TAG}_msm_partition_cost.txt 2>&1
+(python tests/config1_cpu.py; lscpu | grep -E "^CPU\(s\)|Model name") > gpurun_out/${TAG}_config1_cpu.txt 2>&1
+timeout 600 python tests/soak.py 240 3000 > gpurun_out/${TAG}_soak.txt 2>&1 || echo "SOAK FAILED" >> gpurun_out/${TAG}_soak.txt
 tail -1 gpurun_out/${TAG}_profile.log
