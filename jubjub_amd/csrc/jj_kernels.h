@@ -363,7 +363,14 @@ static JJ_DEV u32 vb_window(const u32 (&k)[8], int i) {
 // digit is a plain table read instead of a 36-instruction select (the sign is applied inside Curve::add_signed).
 constexpr int VB_SLOTS = VB_TABLE + 1;
 
+// JJ_VB_PROBE_SHARED_READS (experiments only, WRONG results): every lane reads the table of lane 0 of its workgroup, so the reads
+// hit the caches: what the ladder would cost without its table traffic (profiles/r3_varbase_traffic_probe.txt)
 static JJ_DEV Ext varbase_windowed(const Affine& P, u32 (&k)[8], u32* slot) {
+#ifdef JJ_VB_PROBE_SHARED_READS
+  const u32* rslot = slot - (size_t)threadIdx.x * (size_t)((1 << (JJ_VB_W - 1)) + 1) * (4 * NL);
+#else
+  const u32* rslot = slot;
+#endif
   const ANiels pn = Curve::to_niels(P);
   Ext cur = Curve::from_affine(P);
   store_eniels(slot, Curve::eniels_identity());
@@ -376,7 +383,7 @@ static JJ_DEV Ext varbase_windowed(const Affine& P, u32 (&k)[8], u32* slot) {
   recode_signed(k);
   // top window: unsigned digit (0 .. 2^(253 - w (NWIN-1)))
   u32 a = vb_window(k, VB_NWIN - 1), neg = 0;
-  ENiels e = load_eniels(slot + a * ENIELS_WORDS);
+  ENiels e = load_eniels(rslot + a * ENIELS_WORDS);
   Ext acc = Curve::identity();
   #pragma unroll 1
   for (int i = VB_NWIN - 1; i >= 0; i--) {
@@ -385,7 +392,7 @@ static JJ_DEV Ext varbase_windowed(const Affine& P, u32 (&k)[8], u32* slot) {
     if (i > 0) {                                             // fetch the next window's entry before the doublings
       const int d = (int)vb_window(k, i - 1) - VB_TABLE;
       neg = d < 0; a = (u32)(d < 0 ? -d : d);
-      e = load_eniels(slot + a * ENIELS_WORDS);
+      e = load_eniels(rslot + a * ENIELS_WORDS);
     }
     acc = Curve::add_signed<true>(acc, s, smask);
     if (i > 0) {
