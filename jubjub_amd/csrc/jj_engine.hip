@@ -1111,7 +1111,7 @@ static int msm_enqueue_pippenger(jj_ctx* c, size_t n, const void* ds, const void
   DevBuf &kprime = c->msm[0], &niels = c->msm[1], &offb = c->msm[2], &idx = c->msm[3], &buckets = c->msm[4], &ra = c->msm[5], &tcnt = c->msm[7];
   u32 chunk = MSM_CHUNK_MIN;                           // 16 entries per lane up to 2^19 terms, 32 at 2^20, then proportional to n (measured)
   while (chunk < 256 && ((size_t)chunk << 15) < n) chunk <<= 1;
-  if (n <= ((size_t)1 << 15)) chunk = 8;              // small inputs: more lanes, shorter chains
+  if (n < ((size_t)1 << 15)) chunk = 8;               // small inputs (only reached with the small-batch path switched off): more lanes, shorter chains
   if (c->msm_chunk) chunk = (u32)c->msm_chunk;
   const u32 nchunk = (u32)((n + chunk - 1) / chunk);
   const bool two_pass = B > 4096 || (B == 4096 && c->msm_two_pass != 0);      // the one-pass plan kernel covers 4096 buckets per window

@@ -528,6 +528,11 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(size_t n, u32 B, u32 chu
   Ext acc = Curve::identity();
   bool any = false;
   const size_t bk0 = (size_t)s * B, hd = (size_t)s * nchunk + t;
+  // software pipeline (as in k_msm_accumulate_seg): the entry of term pos + 1 -- a dependent 4-byte index load, then a random
+  // 128-byte gather -- is in flight while term pos is added
+  u32 e = idx[start];
+  ANiels p = lds_aniels(niels + (size_t)(e & 0x7fffffffu) * GNIELS_WORDS);
+  u32 e_next = start + 1 < end ? idx[start + 1] : e;
   #pragma unroll 1
   for (size_t pos = start; pos < end; pos++) {
     if (pos >= nxt) {
@@ -535,10 +540,11 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(size_t n, u32 B, u32 chu
       acc = Curve::identity(); any = false;
       do { b++; nxt = o[b + 1]; } while (nxt <= pos);
     }
-    const u32 e = idx[pos];
-    const ANiels p = lds_aniels(niels + (size_t)(e & 0x7fffffffu) * GNIELS_WORDS);
+    const ANiels p_next = lds_aniels(niels + (size_t)(e_next & 0x7fffffffu) * GNIELS_WORDS);
+    const u32 e_next2 = pos + 2 < end ? idx[pos + 2] : e_next;
     acc = Curve::add_signed<true>(acc, p, (e >> 31) ? ~0u : 0u);
     any = true;
+    e = e_next; p = p_next; e_next = e_next2;
   }
   if (inherited) aos_put_ext(head, hd, acc); else aos_put_ext(buckets, bk0 + b, acc);
 }
