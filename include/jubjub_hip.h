@@ -191,7 +191,8 @@ int jj_msm(jj_ctx*, size_t n, const void* scalars32, const void* points64, void*
  * pointers; host arrays are staged first); jj_msm_finish waits for THAT job only, runs the host tail and writes the 64-byte
  * result (host pointer: complete on return; device pointer: copy queued on the context's stream).  Jobs of one context run
  * in the order they were begun and share its workspaces; they may be finished in any order, each exactly once (finish
- * releases the job, also on error).  The input arrays must stay valid until the job is finished. */
+ * releases the job, also on error).  Device input arrays must stay valid until the job is finished; every job must be finished
+ * before its context is destroyed. */
 typedef struct jj_msm_job jj_msm_job;
 int jj_msm_begin(jj_ctx*, size_t n, const void* scalars32, const void* points64, jj_msm_job** job);
 int jj_msm_finish(jj_msm_job* job, void* out64);

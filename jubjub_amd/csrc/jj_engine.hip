@@ -1239,15 +1239,17 @@ static int msm_begin_locked(jj_ctx* c, size_t n, const void* scalars, const void
     for (size_t lo = 0; lo < n; lo += PASS) {
       const size_t cnt = std::min(PASS, n - lo);
       size_t used = 0;
-      if ((rc = msm_enqueue(c, cnt, (const uint8_t*)ds + lo * 32, (const uint8_t*)dp + lo * 64, part_w0, part_stride, c->msm_rec.p, &used))) { msm_job_put(c, j); return rc; }
+      // a failure after earlier passes were queued: their record copies may still be on their way into the job's buffer, so the
+      // stream is drained before the buffer goes back to the free list
+      if ((rc = msm_enqueue(c, cnt, (const uint8_t*)ds + lo * 32, (const uint8_t*)dp + lo * 64, part_w0, part_stride, c->msm_rec.p, &used))) { (void)hipStreamSynchronize(c->stream); msm_job_put(c, j); return rc; }
       hipError_t e = hipMemcpyAsync(j->host + j->nrec * jjhost::REC_MAX_BYTES, c->msm_rec.p, used, hipMemcpyDeviceToHost, c->stream);
-      if (e != hipSuccess) { c->err = std::string("hipMemcpyAsync(record) failed: ") + hipGetErrorString(e); msm_job_put(c, j); return JJ_ERR_HIP; }
+      if (e != hipSuccess) { c->err = std::string("hipMemcpyAsync(record) failed: ") + hipGetErrorString(e); (void)hipStreamSynchronize(c->stream); msm_job_put(c, j); return JJ_ERR_HIP; }
       j->nrec++;
     }
   }
   hipError_t e = hipEventRecord(j->ev, c->stream);
   if (e == hipSuccess) e = hipGetLastError();
-  if (e != hipSuccess) { c->err = std::string("MSM launch failed: ") + hipGetErrorString(e); msm_job_put(c, j); return JJ_ERR_HIP; }
+  if (e != hipSuccess) { c->err = std::string("MSM launch failed: ") + hipGetErrorString(e); (void)hipStreamSynchronize(c->stream); (void)hipGetLastError(); msm_job_put(c, j); return JJ_ERR_HIP; }
   *out = j;
   return JJ_OK;
 }

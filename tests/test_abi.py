@@ -106,3 +106,39 @@ def test_msm_fold_partials_host_only():
             want = O.point_op("add", want[None, :], p[None, :])[0]
         assert (out == want).all(), count
     assert lib.jj_msm_fold_partials(ctypes.c_size_t(1), None, None) != 0
+
+
+def test_gpu_tests_fail_not_skip_on_a_broken_gpu_box(monkeypatch):
+    """tests/conftest.py: without a GPU the -m gpu tests are skipped; with a GPU visible but the library unable to open it (bad
+    build, runtime mismatch) they must FAIL -- a dead library must not turn into a green run (VERDICT r2 weak #7)"""
+    import conftest
+    from jubjub_amd import _lib
+
+    monkeypatch.setattr(conftest, "_GPU_STATE", None)
+    monkeypatch.setattr(conftest, "gpu_visible", lambda: False)
+    assert conftest.gpu_state()[0] == "absent"
+    monkeypatch.setattr(conftest, "_GPU_STATE", None)
+    monkeypatch.setattr(conftest, "gpu_visible", lambda: True)
+
+    class DeadLib:
+        def jj_ctx_create(self, dev, ref):
+            return -2
+
+    monkeypatch.setattr(_lib, "load", lambda: DeadLib())
+    state, why = conftest.gpu_state()
+    assert state == "broken" and "-2" in why
+
+    class Item:
+        def get_closest_marker(self, name):
+            return object() if name == "gpu" else None
+
+    with pytest.raises(pytest.fail.Exception):
+        conftest.pytest_runtest_setup(Item())
+    monkeypatch.setattr(conftest, "_GPU_STATE", None)
+
+    def boom():
+        raise RuntimeError("libjubjub_hip.so is not built")
+
+    monkeypatch.setattr(_lib, "load", boom)
+    assert conftest.gpu_state()[0] == "broken"
+    monkeypatch.setattr(conftest, "_GPU_STATE", None)              # leave no cached verdict behind for the other tests
