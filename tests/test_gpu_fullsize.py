@@ -203,3 +203,31 @@ def test_field_ops_2p20_vs_oracle(env, fname, which, p):
     out, ok = eng.field_unary_ok(fname, "from_bytes", a)
     eo, ek = O.from_bytes(which, a)
     assert (ok == ek).all() and (out == eo).all()
+
+
+def test_independent_algorithms_agree_2p22(env):
+    """round-3 kernels against their independent siblings over whole batches, compared on the device: the signed comb, the signed
+    6-bit window table and the 12-bit gathered table give the same 2^22 points; the constant-time ladder (table in registers,
+    2-bit windows) gives the same 2^18 points as the default ladder (per-lane tables, 5-bit windows) on full-group points; the
+    composite table (3 x 64-bit scalars, one pass) equals three comb passes"""
+    eng, dev, g, base, table = env
+    n = 1 << 22
+    k = rand_scalars(dev, g, n)
+    a = eng.fixedbase_mul(table, k)                                # default = comb
+    for wbits in (6, 12):
+        t2 = eng.fixedbase_table(base, wbits)
+        assert bool(torch.equal(eng.fixedbase_mul(t2, k), a)), wbits
+        t2.close()
+    m = 1 << 18
+    P = a[:m]                                                      # full-group points
+    k2 = rand_scalars(dev, g, m, bits252=False)                    # top bits set: ignored by both ladders
+    assert bool(torch.equal(eng.varbase_mul_ct(k2, P), eng.varbase_mul(k2, P)))
+    bases = a[:3].contiguous()
+    ct = eng.fixedbase_composite_table(bases, [64, 64, 64])
+    S = rand_scalars(dev, g, 3 * m).reshape(3, m, 32)
+    Sm = S.clone()
+    Sm[:, :, 8:] = 0                                               # the low 64 bits: what the composite table uses
+    tabs = [eng.fixedbase_table(bases[i], 0) for i in range(3)]
+    assert bool(torch.equal(eng.fixedbase_composite_mul(ct, S), eng.fixedbase_multi_mul(tabs, Sm)))
+    for t in tabs + [ct]:
+        t.close()
