@@ -17,6 +17,9 @@ line; under `python -m torch.distributed.run --nproc-per-node N ... bench.py --g
 --msm-partition  : terms  = rank g owns terms [g n/G, (g+1) n/G) and all their windows;
                    window = rank g owns windows g, g + G, ... of ALL terms (every rank holds the whole batch; strong scaling only).
 --msm-async D    : N = 1: D MSMs in flight (jj_msm_begin / jj_msm_finish): the host tail of one overlaps the kernels of the next.
+--msm-contexts K : N = 1: K contexts (streams + workspaces) on the one GPU, one host thread each, the step's MSMs dealt among them:
+                   sustained throughput (the dependent chains of one MSM leave most of the GPU idle); `ms_per_pass` is then the
+                   aggregate time per MSM, not the latency of one.
 --scaling strong : 2^log2n units IN TOTAL, cut into contiguous shards (BASELINE configs[3]: 2^20-term MSM over 8 GPUs;
                    configs[4]: 2^26 encodings over 8 GPUs with --log2n 26).
 Rank 0 prints ONE JSON line.
@@ -124,7 +127,9 @@ def parse():
     ap.add_argument("--decompress-flags", type=int, default=13,
                     help="jj_decompress flags: 1 ZIP-216 | 2 torsion-free (order-8 Tate pairing; JJ_TORSION_CHECK=ladder for the [r]P ladder) | 4 reject small order | 8 clear cofactor (default 13 = BASELINE config 5: decode + small-order check + mul_by_cofactor)")
     ap.add_argument("--msm-partition", default="terms", choices=["terms", "window"], help="multi-rank MSM: cut by terms or by windows (see the module docstring)")
-    ap.add_argument("--msm-async", type=int, default=1, help="N = 1 MSM workload: jobs in flight (1 = synchronous jj_msm calls)")
+    ap.add_argument("--msm-async", type=int, default=1, help="N = 1 MSM workload: jobs in flight per context (1 = synchronous jj_msm calls)")
+    ap.add_argument("--msm-contexts", type=int, default=1, help="N = 1 MSM workload: contexts (each with its own stream and workspaces) driven by as many host threads on the one GPU: "
+                    "the latency-bound tails of one MSM overlap the sort / accumulation of another")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target wall time of each CPU baseline sample")
     return ap.parse_args()
@@ -410,8 +415,44 @@ def run(a):
         dist.all_gather(recs, rec.cpu())
         return eng.msm_combine(torch.stack(recs))
 
+    # --msm-contexts K: K engines on this GPU, each driven by its own host thread on its own torch stream
+    msm_engs = [eng]
+    if wl == "msm" and not distributed and a.msm_contexts > 1:
+        import threading
+
+        msm_engs += [Engine(dev_index) for _ in range(a.msm_contexts - 1)]
+        msm_streams = [torch.cuda.Stream(dev) for _ in msm_engs]
+
+    def msm_series(e, count):
+        """`count` MSMs on engine e, --msm-async jobs in flight; returns the last point"""
+        o, pend = None, []
+        for _ in range(count):
+            if a.msm_async > 1:
+                pend.append(e.msm_begin(scalars, points))
+                if len(pend) == a.msm_async:
+                    o = e.msm_finish(pend.pop(0))
+            else:
+                o = e.msm(scalars, points)
+        for j in pend:
+            o = e.msm_finish(j)
+        return o
+
     def step():
         o = None
+        if len(msm_engs) > 1:
+            K = len(msm_engs)
+            outs = [None] * K
+
+            def work(i):
+                with torch.cuda.stream(msm_streams[i]):
+                    outs[i] = msm_series(msm_engs[i], passes // K + (1 if i < passes % K else 0))
+                msm_streams[i].synchronize()
+
+            torch.cuda.synchronize(dev)
+            th = [threading.Thread(target=work, args=(i,)) for i in range(K)]
+            [t.start() for t in th]
+            [t.join() for t in th]
+            return outs[0]
         if wl == "msm" and not distributed and a.msm_async > 1:
             pend = []                                           # a sliding window of jobs: begin the next before finishing the oldest
             for _ in range(passes):
@@ -470,6 +511,7 @@ def run(a):
     if wl == "msm":
         res["config"]["msm_partition"] = a.msm_partition if n_gpus > 1 else None
         res["config"]["msm_jobs_in_flight"] = a.msm_async if not distributed else 1
+        res["config"]["msm_contexts"] = len(msm_engs)
     rc = 0
     if rank == 0:
         w = dict(WORK[wl])
@@ -489,7 +531,7 @@ def run(a):
             w["S"], w["M"] = 0, -(-253 // a.fb_window) * 7   # ceil(253/w) mixed additions
         if wl == "fixedbase" and a.fb_window == 6:
             w["S"], w["M"] = 0, 43 * 7
-        if main_ms:
+        if main_ms and len(msm_engs) == 1:
             kern_ms = sum(main_ms) / len(main_ms)
             tail = sum(tail_ms) / len(tail_ms)
         else:                                                       # workloads without the event hooks: whole pass
@@ -502,7 +544,7 @@ def run(a):
         res["roofline"] = {
             "bound": "valu_int32", "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TIMAD32/s",
             "frac": achieved / peak,
-            "frac_min": (n * work_main / (min(main_ms) * 1e-3) / peak) if main_ms else None,     # the fastest dispatch of the timed region
+            "frac_min": (n * work_main / (min(main_ms) * 1e-3) / peak) if main_ms and len(msm_engs) == 1 else None,     # the fastest dispatch of the timed region
             # multiply-adds actually issued by the signed 9x29-bit representation (153 per mul, 117 per square) / measured peak
             "mad_issue_frac": n * (153 * w["M"] + 117 * w["S"]) / (kern_ms * 1e-3) / peak,
             "traffic": traffic["bytes_per_launch"] if traffic else None,
@@ -606,6 +648,8 @@ def run(a):
         print(json.dumps(res))
         sys.stdout.flush()
     table.close()
+    for e in msm_engs[1:]:
+        e.close()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

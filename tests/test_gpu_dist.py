@@ -84,6 +84,16 @@ def test_bench_exits_3_when_verification_fails():
         assert res["verified"] is False and res["all_units_equal_second_pass"] is True
 
 
+def test_msm_several_contexts_in_bench():
+    """--msm-contexts 3 --msm-async 2: three contexts (streams + workspaces) on the one GPU, one host thread each, two jobs in flight
+    per context; the step's MSMs are dealt among them; same point, verified"""
+    res = run_bench(["--workload", "msm", "--log2n", "15", "--steps", "2", "--warmup", "1", "--passes", "11", "--msm-contexts", "3", "--msm-async", "2",
+                     "--no-cpu-baseline"], {})
+    assert res["verified"] is True and res["all_units_equal_second_pass"] is True
+    assert res["config"]["msm_contexts"] == 3 and res["config"]["msm_jobs_in_flight"] == 2
+    assert res["msm_result"] == oracle_msm(1 << 15)
+
+
 def test_msm_async_pipeline_in_bench():
     """--msm-async 3: three MSMs in flight on one context; same point, verified"""
     res = run_bench(["--workload", "msm", "--log2n", "15", "--steps", "2", "--warmup", "1", "--passes", "7", "--msm-async", "3", "--no-cpu-baseline"], {})

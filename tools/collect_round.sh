@@ -7,12 +7,13 @@ for f in gpurun_out/profiles_$TAG/*; do
   b=$(basename $f)
   case $b in ${TAG}_*_kernel_stats.txt|${TAG}_*_pmc.txt|${TAG}_*_bench.json|traffic.json|${TAG}_kernel_resources.txt|${TAG}_instr_mix.txt) cp $f profiles/;; esac
 done
-for f in default dec1 dec3 msm20 msm22 msm17 msm20_async2 msm17_async2 msm10 fb16 fb6; do cp gpurun_out/${TAG}_bench_$f.json profiles/${TAG}_bench_$f.json; done
+for f in default dec1 dec3 msm20 msm22 msm17 msm20_async2 msm17_async2 msm17_ctx2 msm17_ctx4 msm20_ctx2 msm10 fb16 fb6; do cp gpurun_out/${TAG}_bench_$f.json profiles/${TAG}_bench_$f.json; done
 BID=$(python3 -c "import json; print(json.load(open('profiles/traffic.json'))['build_id'])")
 HDR="# commit $(cat profiles/BUILD_COMMIT) | build_id $BID | MI355X gfx950"
 cp gpurun_out/${TAG}_msm17_kernel_stats.txt profiles/${TAG}_msm17_kernel_stats.txt
 (echo "$HDR"; echo "# command: python tools/latency.py   (median wall time per C-ABI call, device-resident inputs)"; grep -v amdgpu gpurun_out/${TAG}_latency.txt) > profiles/${TAG}_latency.txt
 (echo "$HDR"; echo "# command: python tools/composite_bench.py 22"; grep -v amdgpu gpurun_out/${TAG}_fixedbase_composite.txt) > profiles/${TAG}_fixedbase_composite.txt
+(echo "$HDR"; echo "# command: python experiments/misc/msm_concurrency.py <log2n> <iters> for 2^17, 2^20, 2^10 terms   (K contexts = K streams + K workspace sets on ONE GPU, one host thread each; sync = jj_msm per call, async2 = two jobs in flight per context; best of 3)"; grep -v amdgpu gpurun_out/${TAG}_msm_concurrency.txt) > profiles/${TAG}_msm_concurrency.txt
 (echo "$HDR"; echo "# command: python experiments/misc/msm_partition_cost.py 20 8"; grep -v amdgpu gpurun_out/${TAG}_msm_partition_cost.txt) > profiles/${TAG}_msm_partition_cost.txt
 (echo "$HDR"; echo "# command: python tests/config1_cpu.py   (BASELINE.json configs[0] on the CPU port of the reference algorithm, host of the GPU box)"; cat gpurun_out/${TAG}_config1_cpu.txt) > profiles/${TAG}_config1_cpu.txt
 (echo "$HDR"; echo "# command: python tests/soak.py 240 3000   (randomised differential soak of every entry point against the C oracle; last rounds and verdict)"; grep -v amdgpu gpurun_out/${TAG}_soak.txt | tail -6) > profiles/${TAG}_soak.txt

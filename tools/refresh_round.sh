@@ -15,12 +15,16 @@ python bench.py --workload msm --no-cpu-baseline > gpurun_out/${TAG}_bench_msm20
 python bench.py --workload msm --log2n 17 --no-cpu-baseline > gpurun_out/${TAG}_bench_msm17.json 2>/dev/null
 python bench.py --workload msm --msm-async 2 --no-cpu-baseline > gpurun_out/${TAG}_bench_msm20_async2.json 2>/dev/null   # two jobs in flight (jj_msm_begin / _finish)
 python bench.py --workload msm --log2n 17 --msm-async 2 --no-cpu-baseline > gpurun_out/${TAG}_bench_msm17_async2.json 2>/dev/null
+python bench.py --workload msm --log2n 17 --msm-contexts 2 --msm-async 2 --no-cpu-baseline > gpurun_out/${TAG}_bench_msm17_ctx2.json 2>/dev/null   # two contexts x two jobs in flight: sustained throughput
+python bench.py --workload msm --log2n 17 --msm-contexts 4 --msm-async 2 --no-cpu-baseline > gpurun_out/${TAG}_bench_msm17_ctx4.json 2>/dev/null
+python bench.py --workload msm --msm-contexts 2 --msm-async 2 --no-cpu-baseline > gpurun_out/${TAG}_bench_msm20_ctx2.json 2>/dev/null
 python bench.py --workload msm --log2n 10 --no-cpu-baseline > gpurun_out/${TAG}_bench_msm10.json 2>/dev/null           # small-batch path
 python bench.py --workload fixedbase --fb-window 16 --no-cpu-baseline > gpurun_out/${TAG}_bench_fb16.json 2>/dev/null
 python bench.py --workload fixedbase --fb-window 6 --no-cpu-baseline > gpurun_out/${TAG}_bench_fb6.json 2>/dev/null      # round 2's kernel: signed 6-bit windows
 bash tools/msm_profile.sh $TAG 17 > gpurun_out/${TAG}_msm17_profile.log 2>&1                                             # gpurun_out/<tag>_msm17_kernel_stats.txt
 python tools/latency.py > gpurun_out/${TAG}_latency.txt 2>&1
 python tools/composite_bench.py 22 > gpurun_out/${TAG}_fixedbase_composite.txt 2>&1
+(python experiments/misc/msm_concurrency.py 17 60; python experiments/misc/msm_concurrency.py 20 30; python experiments/misc/msm_concurrency.py 10 200) > gpurun_out/${TAG}_msm_concurrency.txt 2>&1
 python experiments/misc/msm_partition_cost.py 20 8 > gpurun_out/${TAG}_msm_partition_cost.txt 2>&1
 (python tests/config1_cpu.py; lscpu | grep -E "^CPU\(s\)|Model name") > gpurun_out/${TAG}_config1_cpu.txt 2>&1
 timeout 600 python tests/soak.py 240 3000 > gpurun_out/${TAG}_soak.txt 2>&1 || echo "SOAK FAILED" >> gpurun_out/${TAG}_soak.txt
