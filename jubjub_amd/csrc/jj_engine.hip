@@ -37,6 +37,17 @@ struct jj_table {
 };
 
 struct jj_ctx;
+// One MSM pipeline of a context: its own workspaces, and for lanes >= 1 its own streams.  Lane 0 runs on the context's launch
+// stream (jj_msm, host-array jobs); device-pointer jobs of jj_msm_begin alternate over the lanes, so that the dependent chains at
+// the end of one MSM (a few hundred wavefronts) overlap the sort and accumulation of the next -- what several contexts on one
+// device give (profiles/r3_msm_concurrency.txt), without the caller having to run several.
+struct MsmLane {
+  hipStream_t stream = nullptr, aux = nullptr;      // lane 0: filled from the context at every use; other lanes: owned
+  hipEvent_t fork_ev = nullptr, join_ev = nullptr, ready_ev = nullptr;
+  DevBuf buf[8], ctl, bigpart, seg, rec;             // kprime, niels, offsets, idx, buckets, heads/records, -, tile counts | counters + lists | big-bucket partials | segments | record
+  bool owned = false;
+};
+constexpr int MSM_LANES_MAX = 4;
 struct jj_msm_job {
   jj_ctx* c = nullptr;
   hipEvent_t ev = nullptr;
@@ -77,7 +88,9 @@ struct jj_ctx {
   size_t pipe_chunk = (size_t)1 << 18;   // elements per pipeline chunk (JJ_PIPE_CHUNK_LOG2)
   // MSM jobs (jj_msm_begin / jj_msm_finish): free list of page-locked record buffers + events
   std::vector<jj_msm_job*> job_pool;
-  DevBuf msm_rec;                // the record of partial window sums a pass leaves on the device
+  MsmLane lanes[MSM_LANES_MAX];
+  int msm_lanes = 2;             // lanes that device-pointer jobs of jj_msm_begin alternate over (JJ_MSM_LANES, 1..4; memory per lane in use)
+  unsigned next_lane = 0;
   uint8_t host_out[8][64];       // results on their way to a device pointer (ring: the copies are asynchronous)
   int host_out_next = 0;
   int msm_small_blk = 4;         // small-batch path: at most this many 64-quad workgroups per window (JJ_MSM_SMALL_BLK, 1..64; 4 x 64 windows = one per CU)
@@ -127,7 +140,7 @@ static void prof_mark(jj_ctx* c, int which) {
 static int switch_stream(jj_ctx* c, hipStream_t s);
 static int ensure(jj_ctx* c, DevBuf& b, size_t bytes) {
   if (bytes <= b.cap) return JJ_OK;
-  if (b.p) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+  if (b.p) { HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, hipFree(b.p)); b.p = nullptr; b.cap = 0; }   // growth only; the buffer may be in use on any of the context's streams
   size_t want = std::max(bytes, (size_t)4096);
   hipError_t e = hipMalloc(&b.p, want);
   if (e != hipSuccess) { c->err = std::string("hipMalloc failed: ") + hipGetErrorString(e); b.p = nullptr; return JJ_ERR_NOMEM; }
@@ -337,6 +350,7 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
   c->stream = c->own_stream;
   if (const char* e = getenv("JJ_PIPE_CHUNK_LOG2")) { int v = atoi(e); if (v >= 8 && v <= 24) c->pipe_chunk = (size_t)1 << v; }
   if (const char* e = getenv("JJ_MSM_WINDOWS")) c->msm_windows = atoi(e);
+  if (const char* e = getenv("JJ_MSM_LANES")) { int v = atoi(e); if (v >= 1 && v <= MSM_LANES_MAX) c->msm_lanes = v; }
   if (const char* e = getenv("JJ_MSM_SMALL_BLK")) { int v = atoi(e); if (v >= 1 && v <= MSM_TREE_QUADS) c->msm_small_blk = v; }
   if (const char* e = getenv("JJ_MSM_SMALL_MAX")) { int v = atoi(e); if (v >= 0 && v <= (1 << 20)) c->msm_small_max = v; }
   if (const char* e = getenv("JJ_MSM_ACCUM")) c->msm_segments = strcmp(e, "chunks") == 0 ? 0 : strcmp(e, "segments") == 0 ? 1 : -1;
@@ -378,8 +392,17 @@ JJ_API int jj_ctx_destroy(jj_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   DevBuf* all[] = {&c->in[0], &c->in[1], &c->in[2], &c->in[3], &c->out[0], &c->out[1], &c->okb, &c->ws_ext, &c->msm_seg, &c->ws_scratch, &c->ws_tables,
                    &c->ws_tmp[0], &c->ws_tmp[1], &c->ws_tmp[2], &c->ws_tmp[3], &c->msm[0], &c->msm[1], &c->msm[2], &c->msm[3],
-                   &c->msm[4], &c->msm[5], &c->msm[6], &c->msm[7], &c->sqrt_tabs, &c->cursor, &c->msm_rec};
+                   &c->msm[4], &c->msm[5], &c->msm[6], &c->msm[7], &c->sqrt_tabs, &c->cursor};
   for (jj_msm_job* j : c->job_pool) { if (j->host) (void)hipHostFree(j->host); (void)hipEventDestroy(j->ev); delete j; }
+  for (MsmLane& L : c->lanes) {
+    if (L.owned) { (void)hipStreamSynchronize(L.stream); (void)hipStreamSynchronize(L.aux); }
+    DevBuf* lb[] = {&L.buf[0], &L.buf[1], &L.buf[2], &L.buf[3], &L.buf[4], &L.buf[5], &L.buf[6], &L.buf[7], &L.ctl, &L.bigpart, &L.seg, &L.rec};
+    for (DevBuf* b : lb) if (b->p) (void)hipFree(b->p);
+    if (L.owned) {
+      (void)hipEventDestroy(L.fork_ev); (void)hipEventDestroy(L.join_ev); (void)hipEventDestroy(L.ready_ev);
+      (void)hipStreamDestroy(L.aux); (void)hipStreamDestroy(L.stream);
+    }
+  }
   for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
   if (c->pipe.ready) {
     for (int i = 0; i < 2; i++) {
@@ -1078,23 +1101,23 @@ static int msm_windows_for(jj_ctx* c, size_t n) {
 }
 // counters (MSM_COUNTER_WORDS words, cleared by the first kernel of a pass) | big-bucket work list | workgroup partial sums
 constexpr size_t MSM_BIG_OFF = 512, MSM_PART_OFF = MSM_BIG_OFF + sizeof(BigBucket) * FIXUP_BIG_MAX;
-static int msm_ensure_ctl(jj_ctx* c) { return ensure(c, c->ws_tmp[1], MSM_PART_OFF + (size_t)64 * MSM_TREE_QUADS * MSM_PART_WORDS * 4); }
-static int msm_enqueue_small(jj_ctx* c, size_t n, const void* ds, const void* dp, int part_w0, int part_stride, void* rec_dev) {
+static int msm_ensure_ctl(jj_ctx* c, MsmLane& L) { return ensure(c, L.ctl, MSM_PART_OFF + (size_t)64 * MSM_TREE_QUADS * MSM_PART_WORDS * 4); }
+static int msm_enqueue_small(jj_ctx* c, MsmLane& L, size_t n, const void* ds, const void* dp, int part_w0, int part_stride, void* rec_dev) {
   MsmParams mp;
   msm_layout(mp, SM_W, part_w0, part_stride);
   int rc;
-  if ((rc = ensure(c, c->msm[0], n * 32))) return rc;
-  if ((rc = ensure(c, c->msm[1], n * (size_t)(SM_SLOTS * ENIELS_WORDS) * 4))) return rc;
-  if ((rc = msm_ensure_ctl(c))) return rc;
-  u32* counters = (u32*)c->ws_tmp[1].p; u32* part = (u32*)((uint8_t*)c->ws_tmp[1].p + MSM_PART_OFF);
+  if ((rc = ensure(c, L.buf[0], n * 32))) return rc;
+  if ((rc = ensure(c, L.buf[1], n * (size_t)(SM_SLOTS * ENIELS_WORDS) * 4))) return rc;
+  if ((rc = msm_ensure_ctl(c, L))) return rc;
+  u32* counters = (u32*)L.ctl.p; u32* part = (u32*)((uint8_t*)L.ctl.p + MSM_PART_OFF);
   // workgroups of 64 quads per window: about 4 terms per quad, at most msm_small_blk (4 x 64 windows = one workgroup per CU)
   const u32 nblk = (u32)std::min<size_t>(c->msm_small_blk, std::max<size_t>(1, (n + 255) / 256));
-  hipLaunchKernelGGL(k_msm_small_tables, dim3(blocks_for(4 * n)), dim3(256), 0, c->stream, n, ds, dp, mp, (u32*)c->msm[1].p, (u32*)c->msm[0].p, counters);
-  hipLaunchKernelGGL(k_msm_small_sum, dim3(nblk, mp.Ws), dim3(4 * MSM_TREE_QUADS), 0, c->stream, n, mp, nblk, (const u32*)c->msm[1].p, (const u32*)c->msm[0].p, part, counters, (u32*)rec_dev);
+  hipLaunchKernelGGL(k_msm_small_tables, dim3(blocks_for(4 * n)), dim3(256), 0, L.stream, n, ds, dp, mp, (u32*)L.buf[1].p, (u32*)L.buf[0].p, counters);
+  hipLaunchKernelGGL(k_msm_small_sum, dim3(nblk, mp.Ws), dim3(4 * MSM_TREE_QUADS), 0, L.stream, n, mp, nblk, (const u32*)L.buf[1].p, (const u32*)L.buf[0].p, part, counters, (u32*)rec_dev);
   return JJ_OK;
 }
 
-static int msm_enqueue_pippenger(jj_ctx* c, size_t n, const void* ds, const void* dp, int part_w0, int part_stride, void* rec_dev) {
+static int msm_enqueue_pippenger(jj_ctx* c, MsmLane& ln, size_t n, const void* ds, const void* dp, int part_w0, int part_stride, void* rec_dev) {
   MsmParams mp;
   msm_layout(mp, msm_windows_for(c, n), part_w0, part_stride);
   const u32 B = mp.B, Ws = (u32)mp.Ws;
@@ -1108,7 +1131,7 @@ static int msm_enqueue_pippenger(jj_ctx* c, size_t n, const void* ds, const void
   const u32 K = B / L, nblk = std::min<u32>(MSM_TREE_QUADS, (K + MSM_TREE_QUADS - 1) / MSM_TREE_QUADS);      // workgroups of 64 quads per window
   int jbits = 0; while ((1u << jbits) < B) jbits++;
   int rc;
-  DevBuf &kprime = c->msm[0], &niels = c->msm[1], &offb = c->msm[2], &idx = c->msm[3], &buckets = c->msm[4], &ra = c->msm[5], &tcnt = c->msm[7];
+  DevBuf &kprime = ln.buf[0], &niels = ln.buf[1], &offb = ln.buf[2], &idx = ln.buf[3], &buckets = ln.buf[4], &ra = ln.buf[5], &tcnt = ln.buf[7];
   u32 chunk = MSM_CHUNK_MIN;                           // 16 entries per lane up to 2^19 terms, 32 at 2^20, then proportional to n (measured)
   while (chunk < 256 && ((size_t)chunk << 15) < n) chunk <<= 1;
   if (n < ((size_t)1 << 15)) chunk = 8;               // small inputs (only reached with the small-batch path switched off): more lanes, shorter chains
@@ -1137,23 +1160,23 @@ static int msm_enqueue_pippenger(jj_ctx* c, size_t n, const void* ds, const void
   if ((rc = ensure(c, buckets, (size_t)EXT_AOS_WORDS * 4 * nb))) return rc;
   // ra: first the two-pass sort's records (4 + 1 bytes per entry), then the chunk heads / segment heads
   if ((rc = ensure(c, ra, std::max<size_t>((size_t)EXT_AOS_WORDS * 4 * std::max<size_t>((size_t)Ws * nchunk, (n * (size_t)Ws) / 8 + 1), n * (size_t)Ws * 5 + 64)))) return rc;
-  if ((rc = msm_ensure_ctl(c))) return rc;                                                              // counters, big-bucket work list, workgroup partial sums
-  if ((rc = ensure(c, c->ws_tmp[0], (size_t)5 * NL * 4 * FIXUP_BIG_MAX * FIXUP_BIG_QUADS))) return rc;   // their partial sums
-  if (use_segments && (rc = ensure(c, c->msm_seg, hdr_words * 4 + 16 + nb * sizeof(MergeItem) + max_segs * sizeof(Seg)))) return rc;   // bh [stiles][P+1] | count [P+1] | offset [P+2] | merge list | segments
-  hipStream_t st = c->stream;
+  if ((rc = msm_ensure_ctl(c, ln))) return rc;                                                           // counters, big-bucket work list, workgroup partial sums
+  if ((rc = ensure(c, ln.bigpart, (size_t)5 * NL * 4 * FIXUP_BIG_MAX * FIXUP_BIG_QUADS))) return rc;      // the big buckets' partial sums
+  if (use_segments && (rc = ensure(c, ln.seg, hdr_words * 4 + 16 + nb * sizeof(MergeItem) + max_segs * sizeof(Seg)))) return rc;   // bh [stiles][P+1] | count [P+1] | offset [P+2] | merge list | segments
+  hipStream_t st = ln.stream;
   u32* off = (u32*)offb.p;
-  u32* counters = (u32*)c->ws_tmp[1].p;                   // cleared by the sort's plan kernel
-  BigBucket* big = (BigBucket*)((uint8_t*)c->ws_tmp[1].p + MSM_BIG_OFF);
-  u32* part = (u32*)((uint8_t*)c->ws_tmp[1].p + MSM_PART_OFF);
+  u32* counters = (u32*)ln.ctl.p;                          // cleared by the sort's plan kernel
+  BigBucket* big = (BigBucket*)((uint8_t*)ln.ctl.p + MSM_BIG_OFF);
+  u32* part = (u32*)((uint8_t*)ln.ctl.p + MSM_PART_OFF);
   // Large inputs: the point half of the conversion (bandwidth- and multiplier-bound, 55 us at 2^20 terms) runs on the second
   // stream beside the sort (LDS-bound) and is joined before the accumulation; the two extra events cost ~10 us, more than the
   // overlap returns below 2^18 terms.  JJ_MSM_FORK=0/1 overrides.
   const bool fork = c->msm_fork < 0 ? n >= ((size_t)1 << 18) : c->msm_fork != 0;
   if (fork) {
-    HIPCHK(c, hipEventRecord(c->fork_ev, st));
-    HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->fork_ev, 0));
-    hipLaunchKernelGGL(k_msm_convert, dim3(blocks_for(n)), dim3(256), 0, c->aux_stream, n, ds, dp, mp, (u32*)kprime.p, (u32*)niels.p, 2);
-    HIPCHK(c, hipEventRecord(c->join_ev, c->aux_stream));
+    HIPCHK(c, hipEventRecord(ln.fork_ev, st));
+    HIPCHK(c, hipStreamWaitEvent(ln.aux, ln.fork_ev, 0));
+    hipLaunchKernelGGL(k_msm_convert, dim3(blocks_for(n)), dim3(256), 0, ln.aux, n, ds, dp, mp, (u32*)kprime.p, (u32*)niels.p, 2);
+    HIPCHK(c, hipEventRecord(ln.join_ev, ln.aux));
     hipLaunchKernelGGL(k_msm_convert, dim3(blocks_for(n)), dim3(256), 0, st, n, ds, dp, mp, (u32*)kprime.p, (u32*)niels.p, 1);
   } else {
     hipLaunchKernelGGL(k_msm_convert, dim3(blocks_for(n)), dim3(256), 0, st, n, ds, dp, mp, (u32*)kprime.p, (u32*)niels.p, 3);
@@ -1171,19 +1194,19 @@ static int msm_enqueue_pippenger(jj_ctx* c, size_t n, const void* ds, const void
     hipLaunchKernelGGL(k_msm_scatter, dim3(ntiles * 8 * ((Ws + 7) / 8)), dim3(MSM_SORT_THREADS), B * 4, st, n, tile, ntiles, mp, (const u32*)kprime.p, (const u32*)tcnt.p, (u32*)idx.p);
   }
   const ExtAoS head{(u32*)ra.p}, bk{(u32*)buckets.p};
-  SoA partial = soa_of(c->ws_tmp[0], (size_t)FIXUP_BIG_MAX * FIXUP_BIG_QUADS);
+  SoA partial = soa_of(ln.bigpart, (size_t)FIXUP_BIG_MAX * FIXUP_BIG_QUADS);
   if (use_segments) {
-    u32* bh = (u32*)c->msm_seg.p; u32* soff = bh + bh_words + (P + 1);
+    u32* bh = (u32*)ln.seg.p; u32* soff = bh + bh_words + (P + 1);
     MergeItem* merge = (MergeItem*)(((uintptr_t)(bh + hdr_words) + 15) & ~(uintptr_t)15);
     Seg* seg = (Seg*)(merge + nb);
     hipLaunchKernelGGL(k_seg_hist, dim3(stiles), dim3(256), 0, st, nb, B, per_tile, P, (const u32*)off, bk, bh);
     hipLaunchKernelGGL(k_seg_plan, dim3(1), dim3(1024), (bh_words + P + 2) * 4, st, stiles, P, bh, soff + (P + 1));
     hipLaunchKernelGGL(k_seg_scatter, dim3(stiles), dim3(256), 0, st, nb, B, per_tile, P, (const u32*)off, (const u32*)bh, seg, counters, merge, big);
-    if (fork) HIPCHK(c, hipStreamWaitEvent(st, c->join_ev, 0));
+    if (fork) HIPCHK(c, hipStreamWaitEvent(st, ln.join_ev, 0));
     hipLaunchKernelGGL(k_msm_accumulate_seg, dim3(blocks_for(max_segs)), dim3(256), 0, st, (const u32*)(soff + (P + 1)), (const Seg*)seg, (const u32*)idx.p, (const u32*)niels.p, bk, head);
     hipLaunchKernelGGL(k_msm_merge, dim3(blocks_for(4 * std::min(nb, max_segs))), dim3(256), 0, st, (const u32*)counters, (const MergeItem*)merge, bk, head);
   } else {
-    if (fork) HIPCHK(c, hipStreamWaitEvent(st, c->join_ev, 0));
+    if (fork) HIPCHK(c, hipStreamWaitEvent(st, ln.join_ev, 0));
     hipLaunchKernelGGL(k_msm_accumulate, dim3(blocks_for(nchunk), Ws), dim3(256), 0, st, n, B, chunk, nchunk, (const u32*)off, (const u32*)idx.p, (const u32*)niels.p, bk, head);
     hipLaunchKernelGGL(k_msm_fixup, dim3(blocks_for(4 * nb)), dim3(256), 0, st, n, B, Ws, chunk, nchunk, (const u32*)off, bk, head, counters, big);
   }
@@ -1193,10 +1216,28 @@ static int msm_enqueue_pippenger(jj_ctx* c, size_t n, const void* ds, const void
   return JJ_OK;
 }
 // one pass (at most 2^24 terms: 32-bit sort indices), record left at rec_dev
-static int msm_enqueue(jj_ctx* c, size_t n, const void* ds, const void* dp, int part_w0, int part_stride, void* rec_dev, size_t* rec_bytes) {
+static int msm_enqueue(jj_ctx* c, MsmLane& L, size_t n, const void* ds, const void* dp, int part_w0, int part_stride, void* rec_dev, size_t* rec_bytes) {
   const bool small = n <= (size_t)c->msm_small_max;
   *rec_bytes = jjhost::rec_bytes(small ? SM_W : msm_windows_for(c, n));
-  return small ? msm_enqueue_small(c, n, ds, dp, part_w0, part_stride, rec_dev) : msm_enqueue_pippenger(c, n, ds, dp, part_w0, part_stride, rec_dev);
+  return small ? msm_enqueue_small(c, L, n, ds, dp, part_w0, part_stride, rec_dev) : msm_enqueue_pippenger(c, L, n, ds, dp, part_w0, part_stride, rec_dev);
+}
+// lane k of the context, ready for use: lane 0 follows the context's launch stream; the others own two streams, created on first
+// use, and start their work after everything already queued on the launch stream (the inputs may have been produced there)
+static int msm_lane(jj_ctx* c, int k, MsmLane** out) {
+  MsmLane& L = c->lanes[k];
+  if (k == 0) { L.stream = c->stream; L.aux = c->aux_stream; L.fork_ev = c->fork_ev; L.join_ev = c->join_ev; *out = &L; return JJ_OK; }
+  if (!L.owned) {
+    HIPCHK(c, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+    HIPCHK(c, hipStreamCreateWithFlags(&L.aux, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&L.fork_ev, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&L.join_ev, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&L.ready_ev, hipEventDisableTiming));
+    L.owned = true;
+  }
+  HIPCHK(c, hipEventRecord(L.ready_ev, c->stream));
+  HIPCHK(c, hipStreamWaitEvent(L.stream, L.ready_ev, 0));
+  *out = &L;
+  return JJ_OK;
 }
 
 // ---- asynchronous jobs: jj_msm_begin queues every pass of one MSM and the copy of its records into the job's own page-locked
@@ -1228,28 +1269,33 @@ static void msm_job_put(jj_ctx* c, jj_msm_job* j) {
   (void)hipEventDestroy(j->ev);
   delete j;
 }
-static int msm_begin_locked(jj_ctx* c, size_t n, const void* scalars, const void* points, int part_w0, int part_stride, jj_msm_job** out) {
+// spread: device-pointer jobs alternate over the context's lanes (jj_msm_begin); otherwise lane 0 (jj_msm; host arrays are staged
+// through buffers the launch stream owns)
+static int msm_begin_locked(jj_ctx* c, size_t n, const void* scalars, const void* points, int part_w0, int part_stride, bool spread, jj_msm_job** out) {
   const size_t PASS = (size_t)1 << c->msm_pass_log2;
   const size_t npass = n ? (n + PASS - 1) / PASS : 0;
   jj_msm_job* j;
   int rc = msm_job_get(c, npass, &j); if (rc) return rc;
+  int k = 0;
+  if (spread && n && c->msm_lanes > 1 && is_device_ptr(scalars) && is_device_ptr(points)) k = (int)(c->next_lane++ % (unsigned)c->msm_lanes);
+  MsmLane* L = nullptr;
+  if ((rc = msm_lane(c, k, &L))) { msm_job_put(c, j); return rc; }
+  auto fail = [&](int code) { (void)hipStreamSynchronize(L->stream); (void)hipGetLastError(); msm_job_put(c, j); return code; };   // record copies may be on their way into the job's buffer
   if (n) {
     const void *ds, *dp;
-    if ((rc = stage_in(c, 0, scalars, 32 * n, &ds)) || (rc = stage_in(c, 1, points, 64 * n, &dp)) || (rc = ensure(c, c->msm_rec, jjhost::REC_MAX_BYTES))) { msm_job_put(c, j); return rc; }
+    if ((rc = stage_in(c, 0, scalars, 32 * n, &ds)) || (rc = stage_in(c, 1, points, 64 * n, &dp)) || (rc = ensure(c, L->rec, jjhost::REC_MAX_BYTES))) return fail(rc);
     for (size_t lo = 0; lo < n; lo += PASS) {
       const size_t cnt = std::min(PASS, n - lo);
       size_t used = 0;
-      // a failure after earlier passes were queued: their record copies may still be on their way into the job's buffer, so the
-      // stream is drained before the buffer goes back to the free list
-      if ((rc = msm_enqueue(c, cnt, (const uint8_t*)ds + lo * 32, (const uint8_t*)dp + lo * 64, part_w0, part_stride, c->msm_rec.p, &used))) { (void)hipStreamSynchronize(c->stream); msm_job_put(c, j); return rc; }
-      hipError_t e = hipMemcpyAsync(j->host + j->nrec * jjhost::REC_MAX_BYTES, c->msm_rec.p, used, hipMemcpyDeviceToHost, c->stream);
-      if (e != hipSuccess) { c->err = std::string("hipMemcpyAsync(record) failed: ") + hipGetErrorString(e); (void)hipStreamSynchronize(c->stream); msm_job_put(c, j); return JJ_ERR_HIP; }
+      if ((rc = msm_enqueue(c, *L, cnt, (const uint8_t*)ds + lo * 32, (const uint8_t*)dp + lo * 64, part_w0, part_stride, L->rec.p, &used))) return fail(rc);
+      hipError_t e = hipMemcpyAsync(j->host + j->nrec * jjhost::REC_MAX_BYTES, L->rec.p, used, hipMemcpyDeviceToHost, L->stream);
+      if (e != hipSuccess) { c->err = std::string("hipMemcpyAsync(record) failed: ") + hipGetErrorString(e); return fail(JJ_ERR_HIP); }
       j->nrec++;
     }
   }
-  hipError_t e = hipEventRecord(j->ev, c->stream);
+  hipError_t e = hipEventRecord(j->ev, L->stream);
   if (e == hipSuccess) e = hipGetLastError();
-  if (e != hipSuccess) { c->err = std::string("MSM launch failed: ") + hipGetErrorString(e); (void)hipStreamSynchronize(c->stream); (void)hipGetLastError(); msm_job_put(c, j); return JJ_ERR_HIP; }
+  if (e != hipSuccess) { c->err = std::string("MSM launch failed: ") + hipGetErrorString(e); return fail(JJ_ERR_HIP); }
   *out = j;
   return JJ_OK;
 }
@@ -1257,7 +1303,7 @@ JJ_API int jj_msm_begin(jj_ctx* c, size_t n, const void* scalars, const void* po
   if (!c || !job) return JJ_ERR_INVALID;
   *job = nullptr;
   JJ_ENTER(c);
-  return msm_begin_locked(c, n, scalars, points, 0, 1, job);
+  return msm_begin_locked(c, n, scalars, points, 0, 1, true, job);
 }
 // waits for the job's records, host tail, result to out64 (host pointer: written before the call returns; device pointer: a
 // 64-byte copy queued on the context's stream).  The job is released in every case.
@@ -1287,7 +1333,7 @@ JJ_API int jj_msm(jj_ctx* c, size_t n, const void* scalars, const void* points, 
   {
     JJ_ENTER(c);
     prof_mark(c, 0);
-    const int rc = msm_begin_locked(c, n, scalars, points, 0, 1, &j);
+    const int rc = msm_begin_locked(c, n, scalars, points, 0, 1, false, &j);
     if (rc) return rc;
   }
   const int rc = jj_msm_finish(j, out64);
@@ -1317,7 +1363,9 @@ JJ_API int jj_msm_partial(jj_ctx* c, size_t n, const void* scalars, const void* 
     if ((rc = stage_in(c, 0, scalars, 32 * n, &ds))) return rc;
     if ((rc = stage_in(c, 1, points, 64 * n, &dp))) return rc;
     size_t used = 0;
-    if ((rc = msm_enqueue(c, n, ds, dp, part_index, part_count, o.dev, &used))) return rc;
+    MsmLane* L = nullptr;
+    if ((rc = msm_lane(c, 0, &L))) return rc;
+    if ((rc = msm_enqueue(c, *L, n, ds, dp, part_index, part_count, o.dev, &used))) return rc;
   }
   bool sync = false;
   if ((rc = finish_out(c, o, &sync))) return rc;

@@ -504,6 +504,37 @@ def test_msm_async_jobs_interleaved(eng):
             assert (g == want[k % len(sizes)]).all(), ("device", depth, k)
 
 
+@pytest.mark.parametrize("lanes", ["1", "3", "4"])
+def test_msm_jobs_over_several_lanes(monkeypatch, lanes):
+    """JJ_MSM_LANES: device-pointer jobs of jj_msm_begin alternate over the context's MSM lanes (own streams and workspaces; default 2),
+    so the dependent chains of one MSM overlap the sort / accumulation of the next: mixed sizes (small-batch path, one-pass and
+    two-pass Pippenger, multi-pass), more jobs in flight than lanes, workspaces that grow while other lanes are busy, results
+    written to device memory, and the synchronous jj_msm in between (lane 0)."""
+    import torch
+
+    from jubjub_amd import Engine
+
+    monkeypatch.setenv("JJ_MSM_LANES", lanes)
+    monkeypatch.setenv("JJ_MSM_PASS_LOG2", "16")
+    e2 = Engine(0)
+    dev = torch.device("cuda", 0)
+    sizes = (700, 40000, 5, 20000, 70000, 300, 100000, 17000, 33000)
+    data = [(rand_scalars(1200 + n, n, full_width=True), rand_points(1201 + n, n)) for n in sizes]
+    want = [O.msm(S, P) for S, P in data]
+    dd = [(torch.from_numpy(S).to(dev), torch.from_numpy(P).to(dev)) for S, P in data]
+    pending, got = [], []
+    for k, (S, P) in enumerate(dd + dd):
+        pending.append(e2.msm_begin(S, P))
+        if k % 5 == 2:
+            assert (e2.msm(*dd[k % len(dd)]).cpu().numpy() == want[k % len(dd)]).all()      # a synchronous MSM between the jobs
+        if len(pending) == 5:
+            got.append(e2.msm_finish(pending.pop(0)))
+    got += [e2.msm_finish(j) for j in pending]
+    for k, g in enumerate(got):
+        assert (g == want[k % len(sizes)]).all(), (lanes, k)
+    e2.close()
+
+
 @pytest.mark.parametrize("G", [2, 3, 8])
 def test_msm_partial_records_term_and_window_partition(eng, G):
     """jj_msm_partial + jj_msm_combine: the MSM cut G ways by terms (every part: all windows of its own terms) and by windows (every
