@@ -7,7 +7,7 @@ for f in gpurun_out/profiles_$TAG/*; do
   b=$(basename $f)
   case $b in ${TAG}_*_kernel_stats.txt|${TAG}_*_pmc.txt|${TAG}_*_bench.json|traffic.json|${TAG}_kernel_resources.txt|${TAG}_instr_mix.txt) cp $f profiles/;; esac
 done
-for f in default dec1 dec3 msm20 msm22 msm17 msm20_async2 msm17_async2 msm17_ctx2 msm17_ctx4 msm20_ctx2 msm10 fb16 fb6; do cp gpurun_out/${TAG}_bench_$f.json profiles/${TAG}_bench_$f.json; done
+for f in default dec1 dec3 msm20 msm22 msm17 msm20_async2 msm17_async2 msm17_async4 msm20_async4 msm17_ctx2 msm17_ctx4 msm20_ctx2 msm10 fb16 fb6; do cp gpurun_out/${TAG}_bench_$f.json profiles/${TAG}_bench_$f.json; done
 BID=$(python3 -c "import json; print(json.load(open('profiles/traffic.json'))['build_id'])")
 HDR="# commit $(cat profiles/BUILD_COMMIT) | build_id $BID | MI355X gfx950"
 cp gpurun_out/${TAG}_msm17_kernel_stats.txt profiles/${TAG}_msm17_kernel_stats.txt

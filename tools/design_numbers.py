@@ -25,7 +25,7 @@ def pmc(wl):
             "bytes": g(r"=>\s+(\d+) B per unit")}
 
 
-for name in ("varbase_bench", "fixedbase_bench", "msm_bench", "decompress_bench", "bench_default", "bench_dec1", "bench_dec3", "bench_msm20", "bench_msm17", "bench_msm22", "bench_msm20_async2", "bench_msm17_async2", "bench_msm17_ctx2", "bench_msm17_ctx4", "bench_msm20_ctx2", "bench_msm10", "bench_fb16", "bench_fb6"):
+for name in ("varbase_bench", "fixedbase_bench", "msm_bench", "decompress_bench", "bench_default", "bench_dec1", "bench_dec3", "bench_msm20", "bench_msm17", "bench_msm22", "bench_msm20_async2", "bench_msm17_async2", "bench_msm17_async4", "bench_msm20_async4", "bench_msm17_ctx2", "bench_msm17_ctx4", "bench_msm20_ctx2", "bench_msm10", "bench_fb16", "bench_fb6"):
     d = line(name)
     if not d:
         continue

@@ -13,8 +13,10 @@ python bench.py --workload decompress --decompress-flags 3 --no-cpu-baseline > g
 python bench.py --workload msm --log2n 22 --no-cpu-baseline --no-verify > gpurun_out/${TAG}_bench_msm22.json 2>/dev/null
 python bench.py --workload msm --no-cpu-baseline > gpurun_out/${TAG}_bench_msm20.json 2>/dev/null      # without the profiler's per-dispatch overhead
 python bench.py --workload msm --log2n 17 --no-cpu-baseline > gpurun_out/${TAG}_bench_msm17.json 2>/dev/null
-python bench.py --workload msm --msm-async 2 --no-cpu-baseline > gpurun_out/${TAG}_bench_msm20_async2.json 2>/dev/null   # two jobs in flight (jj_msm_begin / _finish)
+python bench.py --workload msm --msm-async 2 --no-cpu-baseline > gpurun_out/${TAG}_bench_msm20_async2.json 2>/dev/null   # two jobs in flight over the context's two lanes (jj_msm_begin / _finish)
 python bench.py --workload msm --log2n 17 --msm-async 2 --no-cpu-baseline > gpurun_out/${TAG}_bench_msm17_async2.json 2>/dev/null
+python bench.py --workload msm --log2n 17 --msm-async 4 --no-cpu-baseline > gpurun_out/${TAG}_bench_msm17_async4.json 2>/dev/null
+python bench.py --workload msm --msm-async 4 --no-cpu-baseline > gpurun_out/${TAG}_bench_msm20_async4.json 2>/dev/null
 python bench.py --workload msm --log2n 17 --msm-contexts 2 --msm-async 2 --no-cpu-baseline > gpurun_out/${TAG}_bench_msm17_ctx2.json 2>/dev/null   # two contexts x two jobs in flight: sustained throughput
 python bench.py --workload msm --log2n 17 --msm-contexts 4 --msm-async 2 --no-cpu-baseline > gpurun_out/${TAG}_bench_msm17_ctx4.json 2>/dev/null
 python bench.py --workload msm --msm-contexts 2 --msm-async 2 --no-cpu-baseline > gpurun_out/${TAG}_bench_msm20_ctx2.json 2>/dev/null
