@@ -1,7 +1,9 @@
 /* Minimal C caller of the drop-in boundary (include/jubjub_hip.h):
  *   cc -Iinclude examples/scalar_mul.c -Ljubjub_amd/lib -ljubjub_hip -Wl,-rpath,$PWD/jubjub_amd/lib -o scalar_mul
- * Computes [k](8G) for k = 1..16 with the var-base ladder and with a fixed-base table, compresses the results and
- * prints them: they are the 16 encodings of the reference's test_serialization_consistency (src/lib.rs:1811-1876). */
+ * Computes [k](8G) for k = 1..16 with the var-base ladder, the constant-time ladder and a fixed-base table, compresses the
+ * results and prints them: they are the 16 encodings of the reference's test_serialization_consistency (src/lib.rs:1811-1876).
+ * Then sum_k k * (8G) three ways: jj_msm, jj_msm_begin / jj_msm_finish, and jj_msm_partial (two window parts) + jj_msm_combine;
+ * all must equal [136](8G) from the fixed-base table. */
 #include <stdio.h>
 #include <string.h>
 
@@ -29,13 +31,28 @@ int main(void) {
   jj_table* table = NULL;
   if ((rc = jj_fixedbase_table_create(ctx, g8, 0, &table))) goto fail;     /* AffineNielsPoint * Fr with a device-resident table */
   if ((rc = jj_fixedbase_mul_compressed(ctx, table, N, scalars, enc2))) goto fail;
+  uint8_t out_ct[N][64], enc3[N][32];
+  if ((rc = jj_varbase_mul_ct(ctx, N, scalars, points, out_ct))) goto fail; /* the same products, no scalar-dependent address or branch */
+  if ((rc = jj_compress(ctx, N, out_ct, enc3))) goto fail;
+  /* sum_k k * (8G) = [1 + 2 + ... + 16](8G) = [136](8G) */
+  uint8_t k136[32] = {136}, want[64], sum1[64], sum2[64], sum3[64];
+  static uint8_t recs[2][JJ_MSM_PARTIAL_BYTES];
+  jj_msm_job* job = NULL;
+  if ((rc = jj_fixedbase_mul(ctx, table, 1, k136, want))) goto fail;
+  if ((rc = jj_msm(ctx, N, scalars, points, sum1))) goto fail;             /* iter.map(|(p, k)| p * k).sum() */
+  if ((rc = jj_msm_begin(ctx, N, scalars, points, &job))) goto fail;       /* the same in two halves */
+  if ((rc = jj_msm_finish(job, sum2))) goto fail;
+  for (int g = 0; g < 2; g++) if ((rc = jj_msm_partial(ctx, N, scalars, points, g, 2, recs[g]))) goto fail;   /* ... and in two window parts */
+  if ((rc = jj_msm_combine(2, recs, sum3))) goto fail;
   jj_fixedbase_table_destroy(ctx, table);
 
   for (int i = 0; i < N; i++) {
     printf("%2d*(8G) = ", i + 1);
     for (int b = 0; b < 32; b++) printf("%02x", enc[i][b]);
-    printf("%s\n", memcmp(enc[i], enc2[i], 32) ? "  MISMATCH between var-base and fixed-base" : "");
+    printf("%s\n", (memcmp(enc[i], enc2[i], 32) || memcmp(enc[i], enc3[i], 32)) ? "  MISMATCH between the ladders and the fixed-base table" : "");
   }
+  printf("sum_k k*(8G): msm %s, begin/finish %s, partial+combine %s\n", memcmp(sum1, want, 64) ? "MISMATCH" : "ok", memcmp(sum2, want, 64) ? "MISMATCH" : "ok",
+         memcmp(sum3, want, 64) ? "MISMATCH" : "ok");
   jj_ctx_destroy(ctx);
   return 0;
 fail:

@@ -74,5 +74,6 @@ def test_c_example_runs(tmp_path):
     assert r.returncode == 0, r.stderr
     g = json.load(open(os.path.join(GOLDEN_DIR, "reference_vectors.json")))
     want = [bytes(e).hex() for e in g["serialization_16"]["encodings"]]
-    got = [line.split("= ")[1].strip() for line in r.stdout.splitlines() if "*(8G)" in line]
+    got = [line.split("= ")[1].strip() for line in r.stdout.splitlines() if "*(8G) =" in line]
     assert got == want
+    assert "msm ok, begin/finish ok, partial+combine ok" in r.stdout, r.stdout
