@@ -67,14 +67,14 @@ struct jj_ctx {
   int cus = 0, clock_khz = 0, wave = 64;
   std::string err;
   // staging for host-pointer arguments (inputs 0..3, outputs 0..1) and kernel workspaces
-  DevBuf in[4], out[2], okb, ws_ext, msm_seg, ws_scratch, ws_tables, ws_tmp[4], msm[8], sqrt_tabs, cursor;
+  DevBuf in[4], out[2], okb, ws_ext, ws_scratch, ws_tables, ws_tmp[4], sqrt_tabs, cursor;      // (the workspaces of the MSM live in its lanes)
   SqrtTables sqrt_tables{nullptr, nullptr};
   int msm_segments = -1;         // bucket accumulation: 1 = length-sorted segments, 0 = fixed chunks + fix-up, -1 = segments from 2^18 terms
                                  // (2-4 % faster there, slower below: more launches) (JJ_MSM_ACCUM=segments|chunks)
   int msm_seg_len = 0;           // segment length override (JJ_MSM_SEG_LEN; 0 = n / 2^14 clamped to [32, 1024])
   int msm_chunk = 0;             // accumulation chunk override (JJ_MSM_CHUNK; 0 = scale with n)
-  int msm_reduce_chunk = 0;      // bucket-reduce chunk length (0 = from the bucket count, see msm_pippenger; JJ_MSM_REDUCE_CHUNK, a power of two)
-  int msm_two_pass = -1;         // counting sort in two passes (coarse bin, then low 8 bits): -1 = when the window has >= 13 bits; JJ_MSM_SORT=1pass|2pass
+  int msm_reduce_chunk = 0;      // bucket-reduce chunk length (0 = from the bucket count, see msm_enqueue_pippenger; JJ_MSM_REDUCE_CHUNK, a power of two)
+  int msm_two_pass = -1;         // counting sort in two passes (coarse bin, then low 8 bits): always above 4096 buckets per window, never below; at exactly 4096: 0 = one pass, else two (JJ_MSM_SORT=1pass|2pass)
   int msm_fork = -1;             // point half of the MSM conversion on the second stream: -1 = from 2^18 terms, 0 / 1 = never / always (JJ_MSM_FORK)
   int msm_pass_log2 = 24;        // terms per Pippenger pass (JJ_MSM_PASS_LOG2 overrides; for tests)
   // optional per-call kernel timing (HIP events on the launch stream): e0 | main kernel | e1 | normalise tail | e2
@@ -390,9 +390,8 @@ JJ_API int jj_ctx_destroy(jj_ctx* c) {
   if (!c) return JJ_ERR_INVALID;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  DevBuf* all[] = {&c->in[0], &c->in[1], &c->in[2], &c->in[3], &c->out[0], &c->out[1], &c->okb, &c->ws_ext, &c->msm_seg, &c->ws_scratch, &c->ws_tables,
-                   &c->ws_tmp[0], &c->ws_tmp[1], &c->ws_tmp[2], &c->ws_tmp[3], &c->msm[0], &c->msm[1], &c->msm[2], &c->msm[3],
-                   &c->msm[4], &c->msm[5], &c->msm[6], &c->msm[7], &c->sqrt_tabs, &c->cursor};
+  DevBuf* all[] = {&c->in[0], &c->in[1], &c->in[2], &c->in[3], &c->out[0], &c->out[1], &c->okb, &c->ws_ext, &c->ws_scratch, &c->ws_tables,
+                   &c->ws_tmp[0], &c->ws_tmp[1], &c->ws_tmp[2], &c->ws_tmp[3], &c->sqrt_tabs, &c->cursor};
   for (jj_msm_job* j : c->job_pool) { if (j->host) (void)hipHostFree(j->host); (void)hipEventDestroy(j->ev); delete j; }
   for (MsmLane& L : c->lanes) {
     if (L.owned) { (void)hipStreamSynchronize(L.stream); (void)hipStreamSynchronize(L.aux); }
