@@ -398,6 +398,8 @@ static JJ_DEV Ext varbase_windowed(const Affine& P, u32 (&k)[8], u32* slot) {
     if (i > 0) {
       // two doublings per trip so that the results can alternate between two register sets (a rolled loop copies 36
       // registers back per doubling)
+      // (writing the five doublings out straight -- no loop, no register copies -- is 6.6 % SLOWER: 8 k instructions per window no
+      // longer fit the instruction cache; profiles/r3_varbase_traffic_probe.txt)
       #pragma unroll 1
       for (int d = 0; d < (VB_W - 1) / 2; d++) acc = Curve::dbl(Curve::dbl(acc));
       if constexpr ((VB_W - 1) % 2) acc = Curve::dbl(acc);
