@@ -287,24 +287,25 @@ static JJ_DEV u32 block_exclusive_scan_1024(u32 v, u32* part, u32* total) {
   __syncthreads();
   return r;
 }
-constexpr int MSM_PLAN_PER = 4;      // buckets per thread of the plan kernel: B <= 4096
+constexpr int MSM_PLAN_PER = 4;      // at most this many buckets per thread of the plan kernel: B <= 4096
 __global__ void __launch_bounds__(1024) k_msm_plan(size_t n, u32 B, u32 ntiles, u32* tcount, u32* off, u32* counters) {
   __shared__ u32 part[17];
   const u32 s = blockIdx.x;
   if (s == 0 && threadIdx.x < MSM_COUNTER_WORDS) counters[threadIdx.x] = 0;
   u32* tc = tcount + (size_t)s * ntiles * B;
-  const u32 b0 = threadIdx.x * MSM_PLAN_PER;
+  const u32 per = (B + 1023u) / 1024u;                       // consecutive buckets per thread: all 1024 threads work when B >= 1024
+  const u32 b0 = threadIdx.x * per;
   u32 tot[MSM_PLAN_PER], sum = 0;
   _Pragma("unroll") for (int j = 0; j < MSM_PLAN_PER; j++) {
     tot[j] = 0;
-    if (b0 + j < B) for (u32 t = 0; t < ntiles; t++) tot[j] += tc[(size_t)t * B + b0 + j];
+    if ((u32)j < per && b0 + j < B) for (u32 t = 0; t < ntiles; t++) tot[j] += tc[(size_t)t * B + b0 + j];
     sum += tot[j];
   }
   u32 total;
   u32 run = (u32)(s * n) + block_exclusive_scan_1024(sum, part, &total);
   u32* o = off + (size_t)s * (B + 1);
   _Pragma("unroll") for (int j = 0; j < MSM_PLAN_PER; j++) {
-    if (b0 + j >= B) break;
+    if ((u32)j >= per || b0 + j >= B) break;
     o[b0 + j] = run;
     u32 r2 = run;
     for (u32 t = 0; t < ntiles; t++) { u32* p = tc + (size_t)t * B + b0 + j; const u32 c = *p; *p = r2; r2 += c; }
