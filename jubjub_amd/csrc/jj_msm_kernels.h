@@ -551,39 +551,58 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(size_t n, u32 B, u32 chu
 }
 // buckets[b] (+)= heads of the chunks that continue bucket b; empty buckets become the identity.
 // A bucket with more than FIXUP_SERIAL_MAX heads (heavily skewed digit distribution: repeated scalars) is appended to a work
-// list instead and reduced by a whole workgroup in k_msm_fixup_big; if the list is full the quad falls back to the serial loop
-// (slow but correct).  One quad of lanes per bucket; the next head is fetched while the current one is added.
+// list instead and reduced by a whole workgroup in k_msm_fixup_big; if the list is full the pair falls back to the serial loop
+// (slow but correct).
 constexpr u32 FIXUP_SERIAL_MAX = 32;
 constexpr u32 FIXUP_BIG_MAX = 2048;       // work-list capacity
 constexpr u32 FIXUP_BIG_QUADS = 64;       // quads (of 4 lanes) per big bucket
 struct BigBucket { u32 bucket, t_first, t_last, pad; };
+// TWO LANES per bucket, each running whole-lane additions (reference src/lib.rs:992-999) over every other head (the next head is
+// fetched while the current one is added), then one more addition folds the odd lane's sum into the even lane's.  A wave on its
+// own issues at nearly the SIMD's full rate (experiments/lone_wave), so what counts is instructions per wave and waves per SIMD:
+// ~5 + 1 whole-lane additions of ~2100 instructions in 736 waves (2^17 terms) against ~8 four-round quad additions of ~1200 in
+// 1472 waves for one quad per bucket (round 2 .. early round 3: 67 us against 52 us).
+static JJ_DEV Ext pair_partner(const Ext& e) {      // the point held by the other lane of the pair (lane ^ 1)
+  Ext r;
+  _Pragma("unroll") for (int l = 0; l < NL; l++) {
+    r.u.l[l] = (u32)__builtin_amdgcn_mov_dpp((int)e.u.l[l], 0xB1, 0xf, 0xf, false);
+    r.v.l[l] = (u32)__builtin_amdgcn_mov_dpp((int)e.v.l[l], 0xB1, 0xf, 0xf, false);
+    r.z.l[l] = (u32)__builtin_amdgcn_mov_dpp((int)e.z.l[l], 0xB1, 0xf, 0xf, false);
+    r.t1.l[l] = (u32)__builtin_amdgcn_mov_dpp((int)e.t1.l[l], 0xB1, 0xf, 0xf, false);
+    r.t2.l[l] = (u32)__builtin_amdgcn_mov_dpp((int)e.t2.l[l], 0xB1, 0xf, 0xf, false);
+  }
+  return r;
+}
 __global__ void __launch_bounds__(256) k_msm_fixup(size_t n, u32 B, u32 Ws, u32 chunk, u32 nchunk, const u32* off, ExtAoS buckets, ExtAoS head, u32* counters, BigBucket* big) {
-  const size_t g = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
-  const u32 role = threadIdx.x & 3u;
+  const size_t g = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
+  const u32 half = threadIdx.x & 1u;
   if (g >= (size_t)Ws * B) return;
   const u32 s = (u32)(g / B), j = (u32)(g % B);
   const u32* o = off + (size_t)s * (B + 1);
   const u32 base = (u32)(s * n), lo = o[j] - base, hi = o[j + 1] - base;
-  if (lo == hi) { if (role == 0) aos_put_ext(buckets, g, Curve::identity()); return; }
+  if (lo == hi) { if (half == 0) aos_put_ext(buckets, g, Curve::identity()); return; }
   const size_t t_first = (size_t)s * nchunk + lo / chunk + 1, t_last = (size_t)s * nchunk + (hi - 1) / chunk;
   if (t_first > t_last) return;
   if (t_last - t_first + 1 > FIXUP_SERIAL_MAX) {
-    u32 slot = role == 0 ? atomicAdd(&counters[2], 1u) : 0u;
-    slot = (u32)__shfl((int)slot, (int)(threadIdx.x & 60u), 64);          // the quad leader's slot
+    u32 slot = half == 0 ? atomicAdd(&counters[2], 1u) : 0u;
+    slot = (u32)__shfl((int)slot, (int)(threadIdx.x & 62u), 64);          // the even lane's slot
     if (slot < FIXUP_BIG_MAX) {
-      if (role == 0) { big[slot].bucket = (u32)g; big[slot].t_first = (u32)t_first; big[slot].t_last = (u32)t_last; big[slot].pad = 0; }
+      if (half == 0) { big[slot].bucket = (u32)g; big[slot].t_first = (u32)t_first; big[slot].t_last = (u32)t_last; big[slot].pad = 0; }
       return;
     }
   }
-  Ext acc = aos_ext(buckets, g);   // the bucket's own first run (written by the chunk that contains its first entry)
-  Ext nx = aos_ext(head, t_first);
+  // even lane: the bucket's own first run + heads t_first, t_first + 2, ...; odd lane: heads t_first + 1, t_first + 3, ...
+  Ext acc = half == 0 ? aos_ext(buckets, g) : Curve::identity();
+  size_t t = t_first + half;
+  Ext nx = aos_ext(head, t <= t_last ? t : t_last);
   #pragma unroll 1
-  for (size_t t = t_first; t <= t_last; t++) {
+  for (; t <= t_last; t += 2) {
     const Ext cur = nx;
-    if (t < t_last) nx = aos_ext(head, t + 1);
-    acc = quad_add_ext(acc, cur, role);
+    if (t + 2 <= t_last) nx = aos_ext(head, t + 2);
+    acc = Curve::add(acc, Curve::to_niels(cur));
   }
-  if (role == 0) aos_put_ext(buckets, g, acc);
+  acc = Curve::add(acc, Curve::to_niels(pair_partner(acc)));
+  if (half == 0) aos_put_ext(buckets, g, acc);
 }
 // ---- Segment-sorted accumulation (large inputs).  Every non-empty bucket is cut into segments of at most P entries, the
 // segments are counting-sorted by length (longest first), and each lane adds up one segment: lanes of a wave run the
