@@ -1279,16 +1279,16 @@ static int msm_begin_locked(jj_ctx* c, size_t n, const void* scalars, const void
   if (spread && n && c->msm_lanes > 1 && is_device_ptr(scalars) && is_device_ptr(points)) k = (int)(c->next_lane++ % (unsigned)c->msm_lanes);
   MsmLane* L = nullptr;
   if ((rc = msm_lane(c, k, &L))) { msm_job_put(c, j); return rc; }
-  auto fail = [&](int code) { (void)hipStreamSynchronize(L->stream); (void)hipGetLastError(); msm_job_put(c, j); return code; };   // record copies may be on their way into the job's buffer
+  auto fail = [&](int code) { (void)hipStreamSynchronize(L->stream); (void)hipGetLastError(); msm_job_put(c, j); return code; };   // kernels may still be writing into the job's buffer
   if (n) {
     const void *ds, *dp;
-    if ((rc = stage_in(c, 0, scalars, 32 * n, &ds)) || (rc = stage_in(c, 1, points, 64 * n, &dp)) || (rc = ensure(c, L->rec, jjhost::REC_MAX_BYTES))) return fail(rc);
+    if ((rc = stage_in(c, 0, scalars, 32 * n, &ds)) || (rc = stage_in(c, 1, points, 64 * n, &dp))) return fail(rc);
     for (size_t lo = 0; lo < n; lo += PASS) {
       const size_t cnt = std::min(PASS, n - lo);
       size_t used = 0;
-      if ((rc = msm_enqueue(c, *L, cnt, (const uint8_t*)ds + lo * 32, (const uint8_t*)dp + lo * 64, part_w0, part_stride, L->rec.p, &used))) return fail(rc);
-      hipError_t e = hipMemcpyAsync(j->host + j->nrec * jjhost::REC_MAX_BYTES, L->rec.p, used, hipMemcpyDeviceToHost, L->stream);
-      if (e != hipSuccess) { c->err = std::string("hipMemcpyAsync(record) failed: ") + hipGetErrorString(e); return fail(JJ_ERR_HIP); }
+      // the kernels that finish a window write its point straight into the job's page-locked buffer (device-visible host memory):
+      // no copy operation between the last kernel and the host tail
+      if ((rc = msm_enqueue(c, *L, cnt, (const uint8_t*)ds + lo * 32, (const uint8_t*)dp + lo * 64, part_w0, part_stride, j->host + j->nrec * jjhost::REC_MAX_BYTES, &used))) return fail(rc);
       j->nrec++;
     }
   }

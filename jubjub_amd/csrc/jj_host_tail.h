@@ -1,8 +1,8 @@
 // Host-side finish of an MSM: the device leaves a RECORD of window sums (jj_msm_kernels.h: 64-byte header, then one 128-byte
 // point per window: U, V, Z, T = T1 T2, already in the 4 x 64-bit Montgomery form used here); the window sums of several records
 // (passes, devices, ranks) are added window by window, the windows are combined by Horner (252 dependent point doublings in all)
-// and the result is converted to affine.  That chain has no parallelism a GPU could use -- a lone wavefront issues one
-// multiply-add per ~9 cycles, 1.5 us per doubling -- while a host core does the same doubling in ~0.15 us.
+// and the result is converted to affine.  That chain has no parallelism a GPU could use -- a quad of lanes needs two rounds of
+// ~300 instructions, 1.4 us, per doubling -- while a host core does the same doubling in ~0.15 us.
 //
 // Plain 4 x 64-bit Montgomery arithmetic (radix 2^256) modulo q; every constant is derived at start-up from q and
 // d = -10240/10241, nothing is tabulated.  Point formulas: the same completed-point formulas as jj_curve.h

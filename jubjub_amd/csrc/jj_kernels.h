@@ -978,8 +978,8 @@ static JJ_DEV Ext soa_ext(const SoA& s, size_t i) { Ext e; e.u = s.get(0, i); e.
 static JJ_DEV void soa_put_ext(const SoA& s, size_t i, const Ext& e) {
   s.put(0, i, e.u); s.put(1, i, e.v); s.put(2, i, e.z); s.put(3, i, Fq::carry(e.t1)); s.put(4, i, Fq::carry(e.t2));
 }
-// Latency-bound tails (bucket reduce, folds, big-bucket fix-up) are serial chains of point operations, and a lone
-// wave issues only one VALU instruction per ~9 cycles, so each point operation is spread over the four lanes of a quad: lane r squares {U, V, Z, U-V}[r], the four
+// The tails (bucket reduce, folds, big-bucket fix-up) are serial chains of point operations bound by the instructions one wave
+// has to issue (experiments/lone_wave), so each point operation is spread over the four lanes of a quad: lane r squares {U, V, Z, U-V}[r], the four
 // squares are broadcast inside the quad with DPP quad_perm moves, every lane forms the completed point, and lane r
 // multiplies one of (cu*ct, cv*cz, cz*ct).  Same formulas as Curve::dbl (reference src/lib.rs:739-828), ~2.4x fewer
 // instructions on the critical path.
