@@ -1203,7 +1203,7 @@ static int msm_enqueue_pippenger(jj_ctx* c, MsmLane& ln, size_t n, const void* d
     hipLaunchKernelGGL(k_seg_scatter, dim3(stiles), dim3(256), 0, st, nb, B, per_tile, P, (const u32*)off, (const u32*)bh, seg, counters, merge, big);
     if (fork) HIPCHK(c, hipStreamWaitEvent(st, ln.join_ev, 0));
     hipLaunchKernelGGL(k_msm_accumulate_seg, dim3(blocks_for(max_segs)), dim3(256), 0, st, (const u32*)(soff + (P + 1)), (const Seg*)seg, (const u32*)idx.p, (const u32*)niels.p, bk, head);
-    hipLaunchKernelGGL(k_msm_merge, dim3(blocks_for(4 * std::min(nb, max_segs))), dim3(256), 0, st, (const u32*)counters, (const MergeItem*)merge, bk, head);
+    hipLaunchKernelGGL(k_msm_merge, dim3(std::min<unsigned>(blocks_for(4 * std::min(nb, max_segs)), 4u * c->cus)), dim3(256), 0, st, (const u32*)counters, (const MergeItem*)merge, bk, head);
   } else {
     if (fork) HIPCHK(c, hipStreamWaitEvent(st, ln.join_ev, 0));
     hipLaunchKernelGGL(k_msm_accumulate, dim3(blocks_for(nchunk), Ws), dim3(256), 0, st, n, B, chunk, nchunk, (const u32*)off, (const u32*)idx.p, (const u32*)niels.p, bk, head);

@@ -709,14 +709,16 @@ __global__ void __launch_bounds__(256, JJ_MSM_ACC_MINBLOCKS) k_msm_accumulate_se
 }
 // buckets with a few extra segments: one quad of lanes folds them in
 __global__ void __launch_bounds__(256) k_msm_merge(const u32* counters, const MergeItem* merge, ExtAoS buckets, ExtAoS head) {
-  const size_t m = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
-  const u32 role = threadIdx.x & 3u;
-  if (m >= counters[1]) return;
-  const MergeItem it = merge[m];
-  Ext acc = aos_ext(buckets, it.bucket);
+  const u32 role = threadIdx.x & 3u, cnt = counters[1];
+  // grid-stride over the list: it is short (or empty) unless scalars repeat, and the launch is sized for that
   #pragma unroll 1
-  for (u32 j = 0; j < it.k; j++) acc = quad_add_ext(acc, aos_ext(head, (size_t)it.h0 + j), role);
-  if (role == 0) aos_put_ext(buckets, it.bucket, acc);
+  for (size_t m = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2; m < cnt; m += (size_t)gridDim.x * (blockDim.x >> 2)) {
+    const MergeItem it = merge[m];
+    Ext acc = aos_ext(buckets, it.bucket);
+    #pragma unroll 1
+    for (u32 j = 0; j < it.k; j++) acc = quad_add_ext(acc, aos_ext(head, (size_t)it.h0 + j), role);
+    if (role == 0) aos_put_ext(buckets, it.bucket, acc);
+  }
 }
 // Big buckets, one launch: every workgroup folds a strided share of the listed buckets' heads into FIXUP_BIG_QUADS partials each
 // (written to `partial[item][quad]`); the LAST workgroup to finish (a device-side counter) folds the partials of every item
