@@ -367,8 +367,7 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
   {
     const struct { const void* fn; int bytes; } lds_needs[] = {
       {reinterpret_cast<const void*>(k_fixedbase<true>), FB_LDS_BYTES}, {reinterpret_cast<const void*>(k_fixedbase<false>), FB_LDS_BYTES},
-      {reinterpret_cast<const void*>(k_fixedbase_comb<true>), FBC_LDS_BYTES}, {reinterpret_cast<const void*>(k_fixedbase_comb<false>), FBC_LDS_BYTES},
-      {reinterpret_cast<const void*>(k_seg_plan), 80 * 1024}};
+      {reinterpret_cast<const void*>(k_fixedbase_comb<true>), FBC_LDS_BYTES}, {reinterpret_cast<const void*>(k_fixedbase_comb<false>), FBC_LDS_BYTES}};
     for (const auto& a : lds_needs)
       if (hipFuncSetAttribute(a.fn, hipFuncAttributeMaxDynamicSharedMemorySize, a.bytes) != hipSuccess) return fail(JJ_ERR_HIP);   // the kernels could not launch later
   }
@@ -1147,7 +1146,7 @@ static int msm_enqueue_pippenger(jj_ctx* c, MsmLane& ln, size_t n, const void* d
   // segments of at most P entries, sorted by length; P bounds the serial depth of one lane (~ n / 2^14 additions)
   u32 P = (u32)std::min<size_t>(SEG_PMAX, std::max<size_t>(32, n >> 14));
   if (c->msm_seg_len >= 8 && c->msm_seg_len <= SEG_PMAX) P = (u32)c->msm_seg_len;
-  const u32 stiles = (u32)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(256, 15000 / (P + 1)), (nb + 255) / 256));   // the plan kernel keeps the tiles x (P+1) matrix in LDS
+  const u32 stiles = (u32)std::max<size_t>(1, std::min<size_t>(4096, (nb + 255) / 256));          // tiles of the two segment passes: 256 buckets each, more above 2^20 buckets
   const u32 per_tile = (u32)((nb + stiles - 1) / stiles);
   const size_t max_segs = nb + (n * (size_t)Ws) / P + 1;
   const size_t bh_words = (size_t)stiles * (P + 1), hdr_words = bh_words + 2 * (P + 2) + 16;
@@ -1199,8 +1198,8 @@ static int msm_enqueue_pippenger(jj_ctx* c, MsmLane& ln, size_t n, const void* d
     MergeItem* merge = (MergeItem*)(((uintptr_t)(bh + hdr_words) + 15) & ~(uintptr_t)15);
     Seg* seg = (Seg*)(merge + nb);
     hipLaunchKernelGGL(k_seg_hist, dim3(stiles), dim3(256), 0, st, nb, B, per_tile, P, (const u32*)off, bk, bh);
-    hipLaunchKernelGGL(k_seg_plan, dim3(1), dim3(1024), (bh_words + P + 2) * 4, st, stiles, P, bh, soff + (P + 1));
-    hipLaunchKernelGGL(k_seg_scatter, dim3(stiles), dim3(256), 0, st, nb, B, per_tile, P, (const u32*)off, (const u32*)bh, seg, counters, merge, big);
+    hipLaunchKernelGGL(k_seg_plan, dim3(P + 1), dim3(256), 0, st, stiles, bh, soff);
+    hipLaunchKernelGGL(k_seg_scatter, dim3(stiles), dim3(256), 0, st, nb, B, per_tile, P, (const u32*)off, (const u32*)bh, (const u32*)soff, soff + (P + 1), seg, counters, merge, big);
     if (fork) HIPCHK(c, hipStreamWaitEvent(st, ln.join_ev, 0));
     hipLaunchKernelGGL(k_msm_accumulate_seg, dim3(blocks_for(max_segs)), dim3(256), 0, st, (const u32*)(soff + (P + 1)), (const Seg*)seg, (const u32*)idx.p, (const u32*)niels.p, bk, head);
     hipLaunchKernelGGL(k_msm_merge, dim3(std::min<unsigned>(blocks_for(4 * std::min(nb, max_segs)), 4u * c->cus)), dim3(256), 0, st, (const u32*)counters, (const MergeItem*)merge, bk, head);

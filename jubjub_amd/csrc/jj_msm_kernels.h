@@ -621,7 +621,8 @@ static JJ_DEV void seg_bucket(const u32* off, u32 B, size_t g, u32& lo, u32& c) 
   const u32* o = off + s * (B + 1);
   lo = o[j]; c = o[j + 1] - lo;
 }
-// pass 1: per-block histogram of segment lengths, key = P - len (longer first); empty buckets become the identity
+// pass 1: per-tile histogram of segment lengths, key = P - len (longer first), stored key-major (bh[key * tiles + tile]: the plan
+// scans one key's row); empty buckets become the identity
 __global__ void __launch_bounds__(256) k_seg_hist(size_t nb, u32 B, u32 per_tile, u32 P, const u32* off, ExtAoS buckets, u32* bh) {
   __shared__ u32 hist[SEG_PMAX + 1];
   for (u32 k = threadIdx.x; k <= P; k += 256) hist[k] = 0;
@@ -637,30 +638,46 @@ __global__ void __launch_bounds__(256) k_seg_hist(size_t nb, u32 B, u32 per_tile
     if (rem) atomicAdd(&hist[P - rem], 1u);
   }
   __syncthreads();
-  for (u32 k = threadIdx.x; k <= P; k += 256) bh[(size_t)blockIdx.x * (P + 1) + k] = hist[k];
+  for (u32 k = threadIdx.x; k <= P; k += 256) bh[(size_t)k * gridDim.x + blockIdx.x] = hist[k];
 }
-// between the passes, one workgroup: per-key totals over the blocks, exclusive scan over the keys, and each block's
-// first slot per key written back into bh (the whole matrix, tiles x (P+1) <= 16384 words, sits in LDS)
-__global__ void __launch_bounds__(1024) k_seg_plan(u32 tiles, u32 P, u32* bh, u32* total_out) {
-  extern __shared__ u32 msm_lds[];
-  u32* m = msm_lds;                       // [tiles][P+1]
-  u32* offk = msm_lds + (size_t)tiles * (P + 1);   // [P+2]
-  const u32 K = P + 1;
-  for (u32 i = threadIdx.x; i < tiles * K; i += 1024) m[i] = bh[i];
+// exclusive scan over `cnt` words of `v` by one 256-thread workgroup (in place); returns the total
+static JJ_DEV u32 block_scan_excl(u32* v, u32 cnt, u32* sc /* [256] shared */) {
+  const u32 tid = threadIdx.x, per = (cnt + 255) / 256, t0 = tid * per;
+  u32 mine = 0;
+  for (u32 t = t0; t < t0 + per && t < cnt; t++) mine += v[t];
+  sc[tid] = mine;
   __syncthreads();
-  for (u32 k = threadIdx.x; k < K; k += 1024) { u32 sm = 0; for (u32 t = 0; t < tiles; t++) sm += m[t * K + k]; offk[k] = sm; }
+  for (u32 d = 1; d < 256; d <<= 1) {
+    const u32 x = tid >= d ? sc[tid - d] : 0u;
+    __syncthreads();
+    sc[tid] += x;
+    __syncthreads();
+  }
+  u32 run = sc[tid] - mine;
+  for (u32 t = t0; t < t0 + per && t < cnt; t++) { const u32 c = v[t]; v[t] = run; run += c; }
+  const u32 total = sc[255];
   __syncthreads();
-  if (threadIdx.x == 0) { u32 run = 0; for (u32 k = 0; k < K; k++) { const u32 c = offk[k]; offk[k] = run; run += c; } *total_out = run; }
-  __syncthreads();
-  for (u32 k = threadIdx.x; k < K; k += 1024) { u32 run = offk[k]; for (u32 t = 0; t < tiles; t++) { const u32 c = m[t * K + k]; m[t * K + k] = run; run += c; } }
-  __syncthreads();
-  for (u32 i = threadIdx.x; i < tiles * K; i += 1024) bh[i] = m[i];
+  return total;
 }
-// pass 2: bh now holds each block's first slot per key; every segment takes the next slot of its key
-__global__ void __launch_bounds__(256) k_seg_scatter(size_t nb, u32 B, u32 per_tile, u32 P, const u32* off, const u32* bh, Seg* seg,
+// between the passes, one workgroup per key: the key's row becomes each tile's first slot within the key, the key's total goes to
+// tot[key].  (Round 2's plan was a single workgroup holding the whole matrix in LDS, which also capped the tiles of the two passes
+// at ~230.)  The keys' first slots -- an exclusive scan over at most 1025 totals -- are formed by every workgroup of pass 2 itself.
+__global__ void __launch_bounds__(256) k_seg_plan(u32 tiles, u32* bh, u32* tot /* [P + 1] */) {
+  __shared__ u32 sc[256];
+  const u32 total = block_scan_excl(bh + (size_t)blockIdx.x * tiles, tiles, sc);
+  if (threadIdx.x == 0) tot[blockIdx.x] = total;
+}
+// pass 2: every segment takes the next slot of its key: the key's first slot (scan of the totals) + the tile's first slot within the
+// key + a running count
+__global__ void __launch_bounds__(256) k_seg_scatter(size_t nb, u32 B, u32 per_tile, u32 P, const u32* off, const u32* bh, const u32* tot, u32* total_out, Seg* seg,
                                                       u32* counters /* [0] heads, [1] merge items, [2] big buckets */, MergeItem* merge, BigBucket* big) {
   __shared__ u32 cur[SEG_PMAX + 1];
-  for (u32 k = threadIdx.x; k <= P; k += 256) cur[k] = bh[(size_t)blockIdx.x * (P + 1) + k];
+  __shared__ u32 sc[256];
+  for (u32 k = threadIdx.x; k <= P; k += 256) cur[k] = tot[k];
+  __syncthreads();
+  const u32 all = block_scan_excl(cur, P + 1, sc);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *total_out = all;                   // number of segments, read by the accumulation
+  for (u32 k = threadIdx.x; k <= P; k += 256) cur[k] += bh[(size_t)k * gridDim.x + blockIdx.x];
   __syncthreads();
   const size_t base = (size_t)blockIdx.x * per_tile;
   for (u32 j = threadIdx.x; j < per_tile; j += 256) {

@@ -414,6 +414,17 @@ def test_msm_skewed_buckets(eng):
     assert to_pt(eng.msm(Z, P)) == J.AFFINE_IDENTITY
 
 
+def test_msm_big_bucket_list_overflow(eng):
+    """128 distinct scalars repeated over 2^17 terms: every non-empty bucket holds 1024 entries = 64 chunk heads, and there are about
+    128 x 23 of them -- more than the big-bucket work list holds (2048), so the fix-up's pairs of lanes also run their serial
+    fallback, next to a full work list for the workgroup-per-bucket kernel."""
+    n = 1 << 17
+    base = rand_scalars(71, 128, full_width=True)
+    S = np.ascontiguousarray(base[np.arange(n) % 128])
+    P = rand_points(72, n)
+    assert (eng.msm(S, P) == O.msm(S, P)).all()
+
+
 @pytest.mark.parametrize("window", [16, 17, 19, 20, 21, 23, 28, 32])
 @pytest.mark.parametrize("sort", ["2pass", "1pass"])
 def test_msm_window_counts_both_sorts(monkeypatch, window, sort):
