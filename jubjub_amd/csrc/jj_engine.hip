@@ -42,8 +42,8 @@ struct jj_ctx;
 // the end of one MSM (a few hundred wavefronts) overlap the sort and accumulation of the next -- what several contexts on one
 // device give (profiles/r3_msm_concurrency.txt), without the caller having to run several.
 struct MsmLane {
-  hipStream_t stream = nullptr, aux = nullptr;      // lane 0: filled from the context at every use; other lanes: owned
-  hipEvent_t fork_ev = nullptr, join_ev = nullptr, ready_ev = nullptr;
+  hipStream_t stream = nullptr;                     // lane 0: the context's launch stream, filled in at every use; other lanes: owned
+  hipEvent_t ready_ev = nullptr;
   DevBuf buf[8], ctl, bigpart, seg, rec;             // kprime, niels, offsets, idx, buckets, heads/records, -, tile counts | counters + lists | big-bucket partials | segments | record
   bool owned = false;
 };
@@ -60,8 +60,6 @@ struct jj_ctx {
   std::recursive_mutex mu;       // every entry point locks its context: calls from several host threads are serialised
   int device = 0;
   hipStream_t own_stream = nullptr;
-  hipStream_t aux_stream = nullptr;   // second stream of the MSM: the point conversion runs beside the sort
-  hipEvent_t fork_ev = nullptr, join_ev = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t order_ev = nullptr;   // orders a newly selected launch stream after the work queued on the previous one
   int cus = 0, clock_khz = 0, wave = 64;
@@ -75,7 +73,6 @@ struct jj_ctx {
   int msm_chunk = 0;             // accumulation chunk override (JJ_MSM_CHUNK; 0 = scale with n)
   int msm_reduce_chunk = 0;      // bucket-reduce chunk length (0 = from the bucket count, see msm_enqueue_pippenger; JJ_MSM_REDUCE_CHUNK, a power of two)
   int msm_two_pass = -1;         // counting sort in two passes (coarse bin, then low 8 bits): always above 4096 buckets per window, never below; at exactly 4096: 0 = one pass, else two (JJ_MSM_SORT=1pass|2pass)
-  int msm_fork = -1;             // point half of the MSM conversion on the second stream: -1 = from 2^18 terms, 0 / 1 = never / always (JJ_MSM_FORK)
   int msm_pass_log2 = 24;        // terms per Pippenger pass (JJ_MSM_PASS_LOG2 overrides; for tests)
   // optional per-call kernel timing (HIP events on the launch stream): e0 | main kernel | e1 | normalise tail | e2
   // pipelined host-buffer path: copy streams + two device slots (caller buffers are page-locked in place)
@@ -336,17 +333,12 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
     (void)hipGetLastError();
     if (c->sqrt_tabs.p) (void)hipFree(c->sqrt_tabs.p);
     if (c->order_ev) (void)hipEventDestroy(c->order_ev);
-    if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
-    if (c->join_ev) (void)hipEventDestroy(c->join_ev);
-    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return code;
   };
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(JJ_ERR_HIP);
   if (hipEventCreateWithFlags(&c->order_ev, hipEventDisableTiming) != hipSuccess) return fail(JJ_ERR_HIP);
-  if (hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess) return fail(JJ_ERR_HIP);
-  if (hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming) != hipSuccess) return fail(JJ_ERR_HIP);
   c->stream = c->own_stream;
   if (const char* e = getenv("JJ_PIPE_CHUNK_LOG2")) { int v = atoi(e); if (v >= 8 && v <= 24) c->pipe_chunk = (size_t)1 << v; }
   if (const char* e = getenv("JJ_MSM_WINDOWS")) c->msm_windows = atoi(e);
@@ -358,7 +350,6 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
   if (const char* e = getenv("JJ_MSM_CHUNK")) { int v = atoi(e); if (v >= 8 && v <= 1024) c->msm_chunk = v; }
   if (const char* e = getenv("JJ_MSM_REDUCE_CHUNK")) { int v = atoi(e); if (v >= 2 && v <= 256 && (v & (v - 1)) == 0) c->msm_reduce_chunk = v; }
   if (const char* e = getenv("JJ_MSM_SORT")) c->msm_two_pass = !strcmp(e, "2pass") ? 1 : (!strcmp(e, "1pass") ? 0 : -1);
-  if (const char* e = getenv("JJ_MSM_FORK")) c->msm_fork = atoi(e) != 0 ? 1 : 0;
   if (const char* e = getenv("JJ_MSM_PASS_LOG2")) { int v = atoi(e); if (v >= 10 && v <= 24) c->msm_pass_log2 = v; }
   if (const char* e = getenv("JJ_VB_QUAD_MAX")) { int v = atoi(e); if (v >= 0 && v <= (1 << 20)) c->vb_quad_max = v; }
   if (const char* e = getenv("JJ_FB_GATHER_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) c->fb_gather_blocks_per_cu = v; }
@@ -393,12 +384,12 @@ JJ_API int jj_ctx_destroy(jj_ctx* c) {
                    &c->ws_tmp[0], &c->ws_tmp[1], &c->ws_tmp[2], &c->ws_tmp[3], &c->sqrt_tabs, &c->cursor};
   for (jj_msm_job* j : c->job_pool) { if (j->host) (void)hipHostFree(j->host); (void)hipEventDestroy(j->ev); delete j; }
   for (MsmLane& L : c->lanes) {
-    if (L.owned) { (void)hipStreamSynchronize(L.stream); (void)hipStreamSynchronize(L.aux); }
+    if (L.owned) (void)hipStreamSynchronize(L.stream);
     DevBuf* lb[] = {&L.buf[0], &L.buf[1], &L.buf[2], &L.buf[3], &L.buf[4], &L.buf[5], &L.buf[6], &L.buf[7], &L.ctl, &L.bigpart, &L.seg, &L.rec};
     for (DevBuf* b : lb) if (b->p) (void)hipFree(b->p);
     if (L.owned) {
-      (void)hipEventDestroy(L.fork_ev); (void)hipEventDestroy(L.join_ev); (void)hipEventDestroy(L.ready_ev);
-      (void)hipStreamDestroy(L.aux); (void)hipStreamDestroy(L.stream);
+      (void)hipEventDestroy(L.ready_ev);
+      (void)hipStreamDestroy(L.stream);
     }
   }
   for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
@@ -412,9 +403,6 @@ JJ_API int jj_ctx_destroy(jj_ctx* c) {
   }
   for (auto& r : c->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); (void)hipEventDestroy(r.e2); }
   if (c->order_ev) (void)hipEventDestroy(c->order_ev);
-  if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
-  if (c->join_ev) (void)hipEventDestroy(c->join_ev);
-  if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
   return JJ_OK;
@@ -1166,19 +1154,10 @@ static int msm_enqueue_pippenger(jj_ctx* c, MsmLane& ln, size_t n, const void* d
   u32* counters = (u32*)ln.ctl.p;                          // cleared by the sort's plan kernel
   BigBucket* big = (BigBucket*)((uint8_t*)ln.ctl.p + MSM_BIG_OFF);
   u32* part = (u32*)((uint8_t*)ln.ctl.p + MSM_PART_OFF);
-  // Large inputs: the point half of the conversion (bandwidth- and multiplier-bound, 55 us at 2^20 terms) runs on the second
-  // stream beside the sort (LDS-bound) and is joined before the accumulation; the two extra events cost ~10 us, more than the
-  // overlap returns below 2^18 terms.  JJ_MSM_FORK=0/1 overrides.
-  const bool fork = c->msm_fork < 0 ? n >= ((size_t)1 << 18) : c->msm_fork != 0;
-  if (fork) {
-    HIPCHK(c, hipEventRecord(ln.fork_ev, st));
-    HIPCHK(c, hipStreamWaitEvent(ln.aux, ln.fork_ev, 0));
-    hipLaunchKernelGGL(k_msm_convert, dim3(blocks_for(n)), dim3(256), 0, ln.aux, n, ds, dp, mp, (u32*)kprime.p, (u32*)niels.p, 2);
-    HIPCHK(c, hipEventRecord(ln.join_ev, ln.aux));
-    hipLaunchKernelGGL(k_msm_convert, dim3(blocks_for(n)), dim3(256), 0, st, n, ds, dp, mp, (u32*)kprime.p, (u32*)niels.p, 1);
-  } else {
-    hipLaunchKernelGGL(k_msm_convert, dim3(blocks_for(n)), dim3(256), 0, st, n, ds, dp, mp, (u32*)kprime.p, (u32*)niels.p, 3);
-  }
+  // One conversion launch for scalars and points.  (Rounds 2-3 ran the point half on a second stream beside the sort from 2^18
+  // terms; with the entries staged through LDS the conversion is short enough that the fork, its two events and the contention
+  // with the sort's first kernel cost more than the overlap returns: 2^18 terms 0.565 -> 0.556 ms, 2^20 1.262 -> 1.254 ms.)
+  hipLaunchKernelGGL(k_msm_convert, dim3(blocks_for(n)), dim3(256), 0, st, n, ds, dp, mp, (u32*)kprime.p, (u32*)niels.p, 3);
   if (two_pass) {
     u32* tc = (u32*)tcnt.p; u32* tcs = tc + (size_t)Ws * pm;
     u32* rec = (u32*)ra.p; uint8_t* lo8 = (uint8_t*)ra.p + n * (size_t)Ws * 4;     // the head buffer is free until the accumulation
@@ -1200,11 +1179,9 @@ static int msm_enqueue_pippenger(jj_ctx* c, MsmLane& ln, size_t n, const void* d
     hipLaunchKernelGGL(k_seg_hist, dim3(stiles), dim3(256), 0, st, nb, B, per_tile, P, (const u32*)off, bk, bh);
     hipLaunchKernelGGL(k_seg_plan, dim3(P + 1), dim3(256), 0, st, stiles, bh, soff);
     hipLaunchKernelGGL(k_seg_scatter, dim3(stiles), dim3(256), 0, st, nb, B, per_tile, P, (const u32*)off, (const u32*)bh, (const u32*)soff, soff + (P + 1), seg, counters, merge, big);
-    if (fork) HIPCHK(c, hipStreamWaitEvent(st, ln.join_ev, 0));
     hipLaunchKernelGGL(k_msm_accumulate_seg, dim3(blocks_for(max_segs)), dim3(256), 0, st, (const u32*)(soff + (P + 1)), (const Seg*)seg, (const u32*)idx.p, (const u32*)niels.p, bk, head);
     hipLaunchKernelGGL(k_msm_merge, dim3(std::min<unsigned>(blocks_for(4 * std::min(nb, max_segs)), 4u * c->cus)), dim3(256), 0, st, (const u32*)counters, (const MergeItem*)merge, bk, head);
   } else {
-    if (fork) HIPCHK(c, hipStreamWaitEvent(st, ln.join_ev, 0));
     hipLaunchKernelGGL(k_msm_accumulate, dim3(blocks_for(nchunk), Ws), dim3(256), 0, st, n, B, chunk, nchunk, (const u32*)off, (const u32*)idx.p, (const u32*)niels.p, bk, head);
     hipLaunchKernelGGL(k_msm_fixup, dim3(blocks_for(2 * nb)), dim3(256), 0, st, n, B, Ws, chunk, nchunk, (const u32*)off, bk, head, counters, big);
   }
@@ -1223,12 +1200,9 @@ static int msm_enqueue(jj_ctx* c, MsmLane& L, size_t n, const void* ds, const vo
 // use, and start their work after everything already queued on the launch stream (the inputs may have been produced there)
 static int msm_lane(jj_ctx* c, int k, MsmLane** out) {
   MsmLane& L = c->lanes[k];
-  if (k == 0) { L.stream = c->stream; L.aux = c->aux_stream; L.fork_ev = c->fork_ev; L.join_ev = c->join_ev; *out = &L; return JJ_OK; }
+  if (k == 0) { L.stream = c->stream; *out = &L; return JJ_OK; }
   if (!L.owned) {
     HIPCHK(c, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
-    HIPCHK(c, hipStreamCreateWithFlags(&L.aux, hipStreamNonBlocking));
-    HIPCHK(c, hipEventCreateWithFlags(&L.fork_ev, hipEventDisableTiming));
-    HIPCHK(c, hipEventCreateWithFlags(&L.join_ev, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&L.ready_ev, hipEventDisableTiming));
     L.owned = true;
   }

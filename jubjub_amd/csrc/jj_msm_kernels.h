@@ -222,22 +222,36 @@ __global__ void __launch_bounds__(4 * MSM_TREE_QUADS) k_msm_small_sum(size_t n, 
 // recode scalars (k' word-major) and convert points to affine-Niels AoS (27 words in a 128-byte record)
 // what: 1 = scalars, 2 = points, 3 = both (the two halves are independent: the sort needs only the scalars, so the host may run
 // the point half on a second stream beside it)
+// The 128-byte entries leave through LDS: a lane's own entry is eight 16-byte pieces, and stored lane by lane every store
+// instruction would touch 64 different lines with 16 bytes each; staged per wave, consecutive lanes store consecutive pieces (1 KB
+// per instruction, whole lines).
 __global__ void __launch_bounds__(256) k_msm_convert(size_t n, const void* scalars, const void* points, MsmParams mp, u32* kprime, u32* niels, int what) {
+  constexpr int PIECES = GNIELS_WORDS / 4, ROW = PIECES + 1;       // 16-byte pieces per entry; row stride padded against bank conflicts
+  __shared__ uint4 stage[4][64 * ROW];
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  if (what & 1) {
+  if ((what & 1) && i < n) {
     u32 k[8];
     load8(k, scalars, i);
     msm_recode(k, mp);
     _Pragma("unroll") for (int j = 0; j < 8; j++) kprime[(size_t)j * n + i] = k[j];
   }
   if (!(what & 2)) return;
-  const ANiels t = Curve::to_niels(load_affine(points, i));
-  u32 wv[ANIELS_WORDS];
-  _Pragma("unroll") for (int l = 0; l < NL; l++) { wv[l] = t.vpu.l[l]; wv[NL + l] = t.vmu.l[l]; wv[2 * NL + l] = t.t2d.l[l]; }
-  wv[27] = 0;
-  uint4* e = reinterpret_cast<uint4*>(niels + i * GNIELS_WORDS);
-  _Pragma("unroll") for (int v = 0; v < ANIELS_WORDS / 4; v++) e[v] = make_uint4(wv[4 * v], wv[4 * v + 1], wv[4 * v + 2], wv[4 * v + 3]);
+  const u32 lane = threadIdx.x & 63u;
+  uint4* my = stage[threadIdx.x >> 6];
+  if (i < n) {
+    const ANiels t = Curve::to_niels(load_affine(points, i));
+    u32 wv[GNIELS_WORDS];
+    _Pragma("unroll") for (int l = 0; l < NL; l++) { wv[l] = t.vpu.l[l]; wv[NL + l] = t.vmu.l[l]; wv[2 * NL + l] = t.t2d.l[l]; }
+    _Pragma("unroll") for (int l = ANIELS_WORDS - 1; l < GNIELS_WORDS; l++) wv[l] = 0;
+    _Pragma("unroll") for (int v = 0; v < PIECES; v++) my[lane * ROW + v] = make_uint4(wv[4 * v], wv[4 * v + 1], wv[4 * v + 2], wv[4 * v + 3]);
+  }
+  __syncthreads();
+  const size_t r0 = (size_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u);          // first entry of this wave
+  uint4* out = reinterpret_cast<uint4*>(niels + r0 * GNIELS_WORDS);
+  _Pragma("unroll") for (int cpc = 0; cpc < PIECES; cpc++) {
+    const u32 q = (u32)cpc * 64u + lane, rec = q / PIECES, piece = q % PIECES;
+    if (r0 + rec < n) out[q] = my[rec * ROW + piece];
+  }
 }
 
 // ================================================================================================ Pippenger: counting sort

@@ -458,19 +458,17 @@ def test_msm_window_counts_both_sorts(monkeypatch, window, sort):
     e2.close()
 
 
-@pytest.mark.parametrize("fork", ["1", "0"])
-def test_msm_point_conversion_on_second_stream(monkeypatch, fork):
-    """JJ_MSM_FORK: the point half of the MSM's conversion kernel on the context's second stream beside the sort (default from 2^18
-    terms), forced on / off for small inputs; back-to-back calls reuse the workspaces the forked kernel writes."""
+def test_msm_back_to_back_sizes(monkeypatch):
+    """Pippenger calls of changing sizes back to back on one context: every call reuses (and regrows) the workspaces of the one
+    before it, including the LDS-staged conversion's ragged last workgroup (n not a multiple of 64)."""
     from jubjub_amd import Engine
 
-    monkeypatch.setenv("JJ_MSM_FORK", fork)
     monkeypatch.setenv("JJ_MSM_SMALL_MAX", "0")
     e2 = Engine(0)
-    for n in (1, 300, 5000, 40000, 2000, 40001):
+    for n in (1, 300, 5000, 40000, 2000, 40001, 63, 65):
         S = rand_scalars(712 + n, n, full_width=True)
         P = rand_points(713 + n, n)
-        assert (e2.msm(S, P) == O.msm(S, P)).all(), (fork, n)
+        assert (e2.msm(S, P) == O.msm(S, P)).all(), n
     e2.close()
 
 

@@ -16,10 +16,10 @@ db = sqlite3.connect(glob.glob(os.path.join(d, "**", "*results.db"), recursive=T
 cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
 q = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else "0")
 rows = db.execute("select name, start, end, %s from kernels order by start" % q).fetchall()
-# the last MSM: from the last k_msm_convert / k_msm_small_tables back to the end
-first = max(i for i, r in enumerate(rows) if ("k_msm_convert" in r[0] or "k_msm_small_tables" in r[0]) and (i == 0 or not ("k_msm_convert" in rows[i - 1][0])))
-sel = rows[first:]
-sel = [r for r in sel if "jj::" in r[0]]
+# the last MSM: the kernels after the second-to-last record-writing kernel (reduce_fold / small_sum) up to the last one
+rows = [r for r in rows if "jj::" in r[0] and "k_peak_mad" not in r[0]]
+ends = [i for i, r in enumerate(rows) if "k_msm_reduce_fold" in r[0] or "k_msm_small_sum" in r[0]]
+sel = rows[ends[-2] + 1: ends[-1] + 1]
 t0 = sel[0][1]
 print("# 2^%s-term MSM, last call of the run: kernel, queue, start us, duration us, gap to the previous END on any queue us" % lg)
 prev_end = t0
