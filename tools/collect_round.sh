@@ -12,6 +12,7 @@ BID=$(python3 -c "import json; print(json.load(open('profiles/traffic.json'))['b
 HDR="# commit $(cat profiles/BUILD_COMMIT) | build_id $BID | MI355X gfx950"
 cp gpurun_out/${TAG}_msm17_kernel_stats.txt profiles/${TAG}_msm17_kernel_stats.txt
 (echo "$HDR"; echo "# command: python tools/latency.py   (median wall time per C-ABI call, device-resident inputs)"; grep -v amdgpu gpurun_out/${TAG}_latency.txt) > profiles/${TAG}_latency.txt
+(echo "$HDR"; echo "# command: bash tools/msm_timeline.sh 20 | 17 | 10   (rocprofv3 --kernel-trace of a short bench run; the kernels of the last MSM call)"; grep -v amdgpu gpurun_out/${TAG}_msm_timeline.txt) > profiles/${TAG}_msm_timeline.txt
 (echo "$HDR"; echo "# command: python tools/composite_bench.py 22"; grep -v amdgpu gpurun_out/${TAG}_fixedbase_composite.txt) > profiles/${TAG}_fixedbase_composite.txt
 (echo "$HDR"; echo "# command: python experiments/misc/msm_concurrency.py <log2n> <iters> for 2^17, 2^20, 2^10 terms   (K contexts = K streams + K workspace sets on ONE GPU, one host thread each; sync = jj_msm per call, async2 = two jobs in flight per context; best of 3)"; grep -v amdgpu gpurun_out/${TAG}_msm_concurrency.txt) > profiles/${TAG}_msm_concurrency.txt
 (echo "$HDR"; echo "# command: python experiments/misc/msm_partition_cost.py 20 8"; grep -v amdgpu gpurun_out/${TAG}_msm_partition_cost.txt) > profiles/${TAG}_msm_partition_cost.txt

@@ -25,6 +25,7 @@ python bench.py --workload fixedbase --fb-window 16 --no-cpu-baseline > gpurun_o
 python bench.py --workload fixedbase --fb-window 6 --no-cpu-baseline > gpurun_out/${TAG}_bench_fb6.json 2>/dev/null      # round 2's kernel: signed 6-bit windows
 bash tools/msm_profile.sh $TAG 17 > gpurun_out/${TAG}_msm17_profile.log 2>&1                                             # gpurun_out/<tag>_msm17_kernel_stats.txt
 python tools/latency.py > gpurun_out/${TAG}_latency.txt 2>&1
+(bash tools/msm_timeline.sh 20; bash tools/msm_timeline.sh 17; bash tools/msm_timeline.sh 10) > gpurun_out/${TAG}_msm_timeline.txt 2>&1            # start / end of every kernel of one call
 python tools/composite_bench.py 22 > gpurun_out/${TAG}_fixedbase_composite.txt 2>&1
 (python experiments/misc/msm_concurrency.py 17 60; python experiments/misc/msm_concurrency.py 20 30; python experiments/misc/msm_concurrency.py 10 200) > gpurun_out/${TAG}_msm_concurrency.txt 2>&1
 python experiments/misc/msm_partition_cost.py 20 8 > gpurun_out/${TAG}_msm_partition_cost.txt 2>&1
