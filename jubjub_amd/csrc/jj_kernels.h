@@ -254,18 +254,18 @@ __global__ void __launch_bounds__(256) k_normalize(size_t n, size_t T, SoA ext, 
     const u32 zz = Fq::is_zero_product(z) ? ~0u : 0u;
     acc = Fq::select(Fq::mul(acc, z), acc, zz);
   }
-  Fe inv = Fq::invert(acc);
+  // the running inverse is kept in PLAIN form (one product by the plain one per chunk): times a Montgomery-form prefix or Z it stays
+  // plain, so 1/Z comes out plain and U/Z, V/Z go straight to plain integers (one product per coordinate, none for the conversion),
+  // then two conditional additions of q
+  Fe inv = Fq::mul(Fq::invert(acc), Fq::plain_one());
   #pragma unroll 1
   for (int j = CHUNK - 1; j >= 0; j--) {
     const size_t i = t + (size_t)j * T;
     if (i >= n) continue;
     const Fe z = ext.get(2, i);
     const u32 zz = Fq::is_zero_product(z) ? ~0u : 0u;
-    const Fe zinv = Fq::select(Fq::mul(inv, scratch.get(0, i)), Fq::zero(), zz);
+    const Fe zp = Fq::select(Fq::mul(inv, scratch.get(0, i)), Fq::zero(), zz);
     inv = Fq::select(Fq::mul(inv, z), inv, zz);
-    // U/Z and V/Z straight to plain integers: multiply by the PLAIN form of 1/Z (one product for both coordinates instead
-    // of one per coordinate in to_words), then two conditional additions of q
-    const Fe zp = Fq::mul(zinv, Fq::plain_one());
     u32 wu[8], wv[8];
     Fq::pack(wu, Fq::canon_plain_product(Fq::mul(ext.get(0, i), zp)));
     Fq::pack(wv, Fq::canon_plain_product(Fq::mul(ext.get(1, i), zp)));
