@@ -69,7 +69,7 @@ struct jj_ctx {
   SqrtTables sqrt_tables{nullptr, nullptr};
   int msm_segments = -1;         // bucket accumulation: 1 = length-sorted segments, 0 = fixed chunks + fix-up, -1 = segments from 2^18 terms
                                  // (2-4 % faster there, slower below: more launches) (JJ_MSM_ACCUM=segments|chunks)
-  int msm_seg_len = 0;           // segment length override (JJ_MSM_SEG_LEN; 0 = n / 2^14 clamped to [32, 1024])
+  int msm_seg_len = 0;           // segment length override (JJ_MSM_SEG_LEN; 0 = twice the mean bucket of the widest windows, clamped to [32, 1024])
   int msm_chunk = 0;             // accumulation chunk override (JJ_MSM_CHUNK; 0 = scale with n)
   int msm_reduce_chunk = 0;      // bucket-reduce chunk length (0 = from the bucket count, see msm_enqueue_pippenger; JJ_MSM_REDUCE_CHUNK, a power of two)
   int msm_two_pass = -1;         // counting sort in two passes (coarse bin, then low 8 bits): always above 4096 buckets per window, never below; at exactly 4096: 0 = one pass, else two (JJ_MSM_SORT=1pass|2pass)
@@ -1080,10 +1080,11 @@ static void msm_layout(MsmParams& mp, int W, int w0, int wstride) {
 // any W is as good as its entry count n W and its bucket count ~ W 2^(253/W - 1) make it
 static int msm_windows_for(jj_ctx* c, size_t n) {
   if (c->msm_windows >= 8 && c->msm_windows <= 36) return c->msm_windows;
-  // measured (experiments/misc/msm_sweep*.sh, profiles/r3_msm_window_sweep.txt): 16 windows (13 of 16 bits, 3 of 15) from 2^18 terms;
-  // below, 23 windows of 11 bits: wider windows cut the additions but their buckets (4096+ per window) make the latency-bound
-  // fix-up and reduce chains longer than the additions they save
-  return n >= ((size_t)1 << 18) ? 16 : 23;
+  // measured (experiments/misc/msm_sweep*.sh, profiles/r3_msm_window_sweep.txt, r3_msm_reduce_grid.txt): 16 windows (13 of 16 bits, 3 of
+  // 15) from 2^20 terms; 17 windows (15 of 15 bits, 2 of 14: half the buckets, so the bucket reduce is 145 us instead of 210, for
+  // 6 % more additions) from 2^18; below, 23 windows of 11 bits: wider windows cut the additions but their buckets (4096+ per
+  // window) make the fix-up and reduce chains longer than the additions they save
+  return n >= ((size_t)1 << 20) ? 16 : n >= ((size_t)1 << 18) ? 17 : 23;
 }
 // counters (MSM_COUNTER_WORDS words, cleared by the first kernel of a pass) | big-bucket work list | workgroup partial sums
 constexpr size_t MSM_BIG_OFF = 512, MSM_PART_OFF = MSM_BIG_OFF + sizeof(BigBucket) * FIXUP_BIG_MAX;
@@ -1108,13 +1109,17 @@ static int msm_enqueue_pippenger(jj_ctx* c, MsmLane& ln, size_t n, const void* d
   msm_layout(mp, msm_windows_for(c, n), part_w0, part_stride);
   const u32 B = mp.B, Ws = (u32)mp.Ws;
   const size_t nb = (size_t)Ws * B;
-  // buckets per reduce chunk (serial depth 2L + ~2c): the reduce is latency-bound, so short chunks (more quads in flight) win
-  // as long as the per-chunk double-and-add by the chunk's first index stays small against the 2L additions -- measured:
-  // 32 for the 2^19 buckets of 16-bit windows, 4-8 below.  JJ_MSM_REDUCE_CHUNK overrides; never more than one window.
-  const u32 L_auto = nb >= ((size_t)1 << 18) ? 32u : (nb >= ((size_t)1 << 16) ? 8u : 4u);
+  // buckets per reduce chunk: a quad walks L buckets (2 L additions), then ~2 c operations multiply by the chunk's first index, and
+  // every workgroup of 64 quads is one wave per SIMD of a CU.  The chains are bound by the instructions a wave issues, and a
+  // second workgroup on a CU slows both by ~1.6x, so: the smallest L (at least 4) for which the workgroups that have chunks fit
+  // one per CU.  JJ_MSM_REDUCE_CHUNK overrides; never more than one window.
+  auto reduce_blocks = [&](u32 l) { const u32 nk = std::min<u32>(MSM_TREE_QUADS, (B / l + MSM_TREE_QUADS - 1) / MSM_TREE_QUADS); u32 t = 0; for (u32 s = 0; s < Ws; s++) t += msm_reduce_blocks(mp, (int)s, l, nk); return t; };
+  u32 L_auto = 4;
+  while (L_auto < B && reduce_blocks(L_auto) > (u32)c->cus) L_auto <<= 1;
   const u32 L = std::min<u32>(c->msm_reduce_chunk ? (u32)c->msm_reduce_chunk : L_auto, B);
   if (B % L || (L & (L - 1))) { c->err = "inconsistent MSM tuning override (JJ_MSM_REDUCE_CHUNK must be a power of two dividing the bucket count)"; return JJ_ERR_INVALID; }
-  const u32 K = B / L, nblk = std::min<u32>(MSM_TREE_QUADS, (K + MSM_TREE_QUADS - 1) / MSM_TREE_QUADS);      // workgroups of 64 quads per window
+  const u32 K = B / L, nblk = std::min<u32>(MSM_TREE_QUADS, (K + MSM_TREE_QUADS - 1) / MSM_TREE_QUADS);      // workgroups of 64 quads per window, at most
+  const u32 reduce_grid = reduce_blocks(L);
   int jbits = 0; while ((1u << jbits) < B) jbits++;
   int rc;
   DevBuf &kprime = ln.buf[0], &niels = ln.buf[1], &offb = ln.buf[2], &idx = ln.buf[3], &buckets = ln.buf[4], &ra = ln.buf[5], &tcnt = ln.buf[7];
@@ -1131,8 +1136,8 @@ static int msm_enqueue_pippenger(jj_ctx* c, MsmLane& ln, size_t n, const void* d
   const u32 ntiles = (u32)std::max<size_t>(1, std::min<size_t>((size_t)(c->cus + Ws - 1) / Ws, (n + 4095) / 4096));
   const size_t tile = (n + ntiles - 1) / ntiles;
   const bool use_segments = c->msm_segments == 1 || (c->msm_segments < 0 && n >= ((size_t)1 << 18));
-  // segments of at most P entries, sorted by length; P bounds the serial depth of one lane (~ n / 2^14 additions)
-  u32 P = (u32)std::min<size_t>(SEG_PMAX, std::max<size_t>(32, n >> 14));
+  // segments of at most P entries, sorted by length; P bounds the serial depth of one lane: twice the mean bucket of the widest windows
+  u32 P = (u32)std::min<size_t>(SEG_PMAX, std::max<size_t>(32, 2 * n / B));
   if (c->msm_seg_len >= 8 && c->msm_seg_len <= SEG_PMAX) P = (u32)c->msm_seg_len;
   const u32 stiles = (u32)std::max<size_t>(1, std::min<size_t>(4096, (nb + 255) / 256));          // tiles of the two segment passes: 256 buckets each, more above 2^20 buckets
   const u32 per_tile = (u32)((nb + stiles - 1) / stiles);
@@ -1186,8 +1191,8 @@ static int msm_enqueue_pippenger(jj_ctx* c, MsmLane& ln, size_t n, const void* d
     hipLaunchKernelGGL(k_msm_fixup, dim3(blocks_for(2 * nb)), dim3(256), 0, st, n, B, Ws, chunk, nchunk, (const u32*)off, bk, head, counters, big);
   }
   hipLaunchKernelGGL(k_msm_fixup_big, dim3(256), dim3(256), 0, st, counters, (const BigBucket*)big, bk, head, partial);
-  if (K > MSM_TREE_QUADS * nblk) hipLaunchKernelGGL(k_msm_reduce_fold<true>, dim3(nblk, Ws), dim3(4 * MSM_TREE_QUADS), 0, st, n, mp, L, nblk, jbits, bk, part, counters, (u32*)rec_dev);
-  else hipLaunchKernelGGL(k_msm_reduce_fold<false>, dim3(nblk, Ws), dim3(4 * MSM_TREE_QUADS), 0, st, n, mp, L, nblk, jbits, bk, part, counters, (u32*)rec_dev);
+  if (K > MSM_TREE_QUADS * nblk) hipLaunchKernelGGL(k_msm_reduce_fold<true>, dim3(reduce_grid), dim3(4 * MSM_TREE_QUADS), 0, st, n, mp, L, nblk, jbits, bk, part, counters, (u32*)rec_dev);
+  else hipLaunchKernelGGL(k_msm_reduce_fold<false>, dim3(reduce_grid), dim3(4 * MSM_TREE_QUADS), 0, st, n, mp, L, nblk, jbits, bk, part, counters, (u32*)rec_dev);
   return JJ_OK;
 }
 // one pass (at most 2^24 terms: 32-bit sort indices), record left at rec_dev

@@ -128,12 +128,13 @@ static JJ_DEV void quad_tree_sum(u32* st, u32 quad, u32 role, u32 live, Ext& acc
 // one to arrive (counter MSM_COUNTERS + s, cleared by the first kernel of the pass) folds all of them and writes the window's point.
 constexpr int MSM_COUNTERS = 8;                       // [0] heads, [1] merge items, [2] big buckets, [3] big-bucket blocks done; then one arrival counter per slot
 constexpr int MSM_COUNTER_WORDS = MSM_COUNTERS + 64;
-static JJ_DEV void msm_finish_window(u32* st, u32 quad, u32 role, u32 nblk, u32 blk, u32 s, int w, Ext& acc, Fe& T, u32* part, u32* counters, u32* rec) {
+// (nblk workgroups of this window; `stride` part slots per window, the same for every window of the pass)
+static JJ_DEV void msm_finish_window(u32* st, u32 quad, u32 role, u32 nblk, u32 stride, u32 blk, u32 s, int w, Ext& acc, Fe& T, u32* part, u32* counters, u32* rec) {
   __shared__ u32 last_s;
   if (nblk > 1) {
     if (quad == 0 && role == 0) {
       const Fe t1 = Fq::carry(acc.t1), t2 = Fq::carry(acc.t2);
-      u32* p = part + ((size_t)s * nblk + blk) * MSM_PART_WORDS;
+      u32* p = part + ((size_t)s * stride + blk) * MSM_PART_WORDS;
       _Pragma("unroll") for (int l = 0; l < NL; l++) { p[l] = acc.u.l[l]; p[NL + l] = acc.v.l[l]; p[2 * NL + l] = acc.z.l[l]; p[3 * NL + l] = t1.l[l]; p[4 * NL + l] = t2.l[l]; p[5 * NL + l] = T.l[l]; }
     }
     __threadfence();
@@ -143,7 +144,7 @@ static JJ_DEV void msm_finish_window(u32* st, u32 quad, u32 role, u32 nblk, u32 
     if (!last_s) return;
     __threadfence();
     if (quad < nblk) {
-      const u32* p = part + ((size_t)s * nblk + quad) * MSM_PART_WORDS;
+      const u32* p = part + ((size_t)s * stride + quad) * MSM_PART_WORDS;
       _Pragma("unroll") for (int l = 0; l < NL; l++) { acc.u.l[l] = p[l]; acc.v.l[l] = p[NL + l]; acc.z.l[l] = p[2 * NL + l]; acc.t1.l[l] = p[3 * NL + l]; acc.t2.l[l] = p[4 * NL + l]; T.l[l] = p[5 * NL + l]; }
     }
     quad_tree_sum(st, quad, role, nblk, acc, T);
@@ -215,7 +216,7 @@ __global__ void __launch_bounds__(4 * MSM_TREE_QUADS) k_msm_small_sum(size_t n, 
   const size_t base = (size_t)blk * MSM_TREE_QUADS;
   const u32 live = base >= n ? 0u : (n - base < MSM_TREE_QUADS ? (u32)(n - base) : (u32)MSM_TREE_QUADS);      // quads of this block that hold a term
   quad_tree_sum(st, quad, role, live, acc, T);                                            // identity when the block has no term
-  msm_finish_window(st, quad, role, nblk, blk, blockIdx.y, w, acc, T, part, counters, rec);
+  msm_finish_window(st, quad, role, nblk, nblk, blk, blockIdx.y, w, acc, T, part, counters, rec);
 }
 
 // ================================================================================================ Pippenger: conversion
@@ -829,13 +830,24 @@ static JJ_DEV Ext msm_reduce_chunk(const MsmParams& mp, u32 s, u32 k, u32 L, int
   Tout = Tt;
   return total;
 }
-// MULTI: a quad may own several chunks (only with tuning overrides that leave more than 64 * 64 chunks per window)
+// workgroups of 64 quads that window slot s needs: its chunks of L buckets, 64 to a workgroup, at most nblk
+static __host__ __device__ __forceinline__ u32 msm_reduce_blocks(const MsmParams& mp, int s, u32 L, u32 nblk) {
+  const int w = mp.w0 + s * mp.wstride, width = mp.c + (w < mp.r ? 1 : 0);
+  const u32 Kw = ((1u << (width - 1)) + L - 1) / L, need = (Kw + MSM_TREE_QUADS - 1) / MSM_TREE_QUADS;
+  return need < nblk ? need : nblk;
+}
+// MULTI: a quad may own several chunks (only with tuning overrides that leave more than 64 * 64 chunks per window).
+// The grid is ONE-dimensional and holds only workgroups that have chunks (a window one bit narrower than the widest needs half as
+// many): the dispatcher places every launched workgroup at once, so workgroups beyond one per CU would share a CU with another
+// chain from the start and both would run ~1.6x longer -- 272 launched for 256 that work cost 217 us instead of 130.
 template <bool MULTI>
 __global__ void __launch_bounds__(4 * MSM_TREE_QUADS) k_msm_reduce_fold(size_t n, MsmParams mp, u32 L, u32 nblk, int jbits, ExtAoS buckets, u32* part, u32* counters, u32* rec) {
   __shared__ __attribute__((aligned(16))) u32 st[MSM_TREE_QUADS * LDS_PT_WORDS];
-  const u32 role = threadIdx.x & 3u, quad = threadIdx.x >> 2, blk = blockIdx.x, s = blockIdx.y;
+  const u32 role = threadIdx.x & 3u, quad = threadIdx.x >> 2;
+  u32 blk = blockIdx.x, s = 0, nblk_s = msm_reduce_blocks(mp, 0, L, nblk);
+  while (blk >= nblk_s) { blk -= nblk_s; s++; nblk_s = msm_reduce_blocks(mp, (int)s, L, nblk); }      // the host launched exactly the sum
   const int w = msm_slot_window(mp, (int)s);
-  if (blk == 0 && s == 0 && threadIdx.x == 0) msm_write_header(rec, mp, n);
+  if (blockIdx.x == 0 && threadIdx.x == 0) msm_write_header(rec, mp, n);
   const u32 Bw = 1u << (msm_win_width(mp, w) - 1);
   const u32 Kw = (Bw + L - 1) / L;                              // chunks of this window that hold buckets
   const int lb = __ffs((int)L) - 1;
@@ -845,7 +857,7 @@ __global__ void __launch_bounds__(4 * MSM_TREE_QUADS) k_msm_reduce_fold(size_t n
   if (k0 < Kw) acc = msm_reduce_chunk(mp, s, k0, L, lb, jbits, buckets, role, Tacc);
   if constexpr (MULTI) {
     #pragma unroll 1
-    for (u32 k = k0 + MSM_TREE_QUADS * nblk; k < Kw; k += MSM_TREE_QUADS * nblk) {
+    for (u32 k = k0 + MSM_TREE_QUADS * nblk_s; k < Kw; k += MSM_TREE_QUADS * nblk_s) {
       Fe Tt, dummy;
       const Ext total = msm_reduce_chunk(mp, s, k, L, lb, jbits, buckets, role, Tt);
       acc = quad_add_ext_t(acc, Tacc, total, Tt, role, Tacc, Tt, Tt, dummy);
@@ -854,6 +866,5 @@ __global__ void __launch_bounds__(4 * MSM_TREE_QUADS) k_msm_reduce_fold(size_t n
   const u32 base = blk * MSM_TREE_QUADS;
   const u32 live = base >= Kw ? 0u : (Kw - base < (u32)MSM_TREE_QUADS ? Kw - base : (u32)MSM_TREE_QUADS);
   quad_tree_sum(st, quad, role, live, acc, Tacc);
-  msm_finish_window(st, quad, role, nblk, blk, s, w, acc, Tacc, part, counters, rec);
+  msm_finish_window(st, quad, role, nblk_s, nblk, blk, s, w, acc, Tacc, part, counters, rec);
 }
-

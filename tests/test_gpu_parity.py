@@ -428,7 +428,7 @@ def test_msm_big_bucket_list_overflow(eng):
 @pytest.mark.parametrize("window", [16, 17, 19, 20, 21, 23, 28, 32])
 @pytest.mark.parametrize("sort", ["2pass", "1pass"])
 def test_msm_window_counts_both_sorts(monkeypatch, window, sort):
-    """JJ_MSM_WINDOWS: W windows tiling the 253 scalar bits exactly (16: 13 windows of 16 bits + 3 of 15, the default from 2^18
+    """JJ_MSM_WINDOWS: W windows tiling the 253 scalar bits exactly (16: 13 windows of 16 bits + 3 of 15, the default from 2^20
     terms; 21: one of 13 bits + 20 of 12; 23: all 11 bits; ...) forced on small inputs, with the two-pass sort (coarse bin, then
     the low bits in LDS; always taken above 4096 buckets per window) and the single-pass one (JJ_MSM_SORT decides at exactly 4096):
     ragged sizes, a bin far larger than the LDS stage (equal scalars), zero digits, the largest top-window digit."""
