@@ -67,7 +67,7 @@ struct jj_ctx {
   // staging for host-pointer arguments (inputs 0..3, outputs 0..1) and kernel workspaces
   DevBuf in[4], out[2], okb, ws_ext, ws_scratch, ws_tables, ws_tmp[4], sqrt_tabs, cursor;      // (the workspaces of the MSM live in its lanes)
   SqrtTables sqrt_tables{nullptr, nullptr};
-  int msm_segments = -1;         // bucket accumulation: 1 = length-sorted segments, 0 = fixed chunks + fix-up, -1 = segments from 2^18 terms
+  int msm_segments = -1;         // bucket accumulation: 1 = length-sorted segments, 0 = fixed chunks + fix-up, -1 = segments from MSM_LARGE_MIN (147 456) terms
                                  // (2-4 % faster there, slower below: more launches) (JJ_MSM_ACCUM=segments|chunks)
   int msm_seg_len = 0;           // segment length override (JJ_MSM_SEG_LEN; 0 = twice the mean bucket of the widest windows, clamped to [32, 1024])
   int msm_chunk = 0;             // accumulation chunk override (JJ_MSM_CHUNK; 0 = scale with n)
@@ -1078,13 +1078,16 @@ static void msm_layout(MsmParams& mp, int W, int w0, int wstride) {
 }
 // number of windows for n terms (measured on MI355X; JJ_MSM_WINDOWS overrides): the windows tile the 253 scalar bits exactly, so
 // any W is as good as its entry count n W and its bucket count ~ W 2^(253/W - 1) make it
+// from this many terms the large-input configuration (17 / 16 windows, length-sorted segments) is faster than 23 windows + chunks + fix-up
+// (experiments/misc/msm_crossover.py: 131 072 terms 0.438 against 0.448 ms, 150 000 terms 0.485 against 0.459 ms, 235 000 terms 0.727 against 0.533 ms)
+constexpr size_t MSM_LARGE_MIN = (size_t)9 << 14;
 static int msm_windows_for(jj_ctx* c, size_t n) {
   if (c->msm_windows >= 8 && c->msm_windows <= 36) return c->msm_windows;
   // measured (experiments/misc/msm_sweep*.sh, profiles/r3_msm_window_sweep.txt, r3_msm_reduce_grid.txt): 16 windows (13 of 16 bits, 3 of
   // 15) from 2^20 terms; 17 windows (15 of 15 bits, 2 of 14: half the buckets, so the bucket reduce is 145 us instead of 210, for
-  // 6 % more additions) from 2^18; below, 23 windows of 11 bits: wider windows cut the additions but their buckets (4096+ per
+  // 6 % more additions) from MSM_LARGE_MIN terms; below, 23 windows of 11 bits: wider windows cut the additions but their buckets (4096+ per
   // window) make the fix-up and reduce chains longer than the additions they save
-  return n >= ((size_t)1 << 20) ? 16 : n >= ((size_t)1 << 18) ? 17 : 23;
+  return n >= ((size_t)1 << 20) ? 16 : n >= MSM_LARGE_MIN ? 17 : 23;
 }
 // counters (MSM_COUNTER_WORDS words, cleared by the first kernel of a pass) | big-bucket work list | workgroup partial sums
 constexpr size_t MSM_BIG_OFF = 512, MSM_PART_OFF = MSM_BIG_OFF + sizeof(BigBucket) * FIXUP_BIG_MAX;
@@ -1135,7 +1138,7 @@ static int msm_enqueue_pippenger(jj_ctx* c, MsmLane& ln, size_t n, const void* d
   // one-pass sort tiles: enough (tile, window) blocks to fill the GPU, each at least 4096 terms
   const u32 ntiles = (u32)std::max<size_t>(1, std::min<size_t>((size_t)(c->cus + Ws - 1) / Ws, (n + 4095) / 4096));
   const size_t tile = (n + ntiles - 1) / ntiles;
-  const bool use_segments = c->msm_segments == 1 || (c->msm_segments < 0 && n >= ((size_t)1 << 18));
+  const bool use_segments = c->msm_segments == 1 || (c->msm_segments < 0 && n >= MSM_LARGE_MIN);
   // segments of at most P entries, sorted by length; P bounds the serial depth of one lane: twice the mean bucket of the widest windows
   u32 P = (u32)std::min<size_t>(SEG_PMAX, std::max<size_t>(32, 2 * n / B));
   if (c->msm_seg_len >= 8 && c->msm_seg_len <= SEG_PMAX) P = (u32)c->msm_seg_len;
