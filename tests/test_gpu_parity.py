@@ -414,6 +414,15 @@ def test_msm_skewed_buckets(eng):
     assert to_pt(eng.msm(Z, P)) == J.AFFINE_IDENTITY
 
 
+def test_msm_around_the_large_input_switch(eng):
+    """Default configuration on both sides of the switch from 23 windows + chunks + fix-up to 17 windows + length-sorted segments
+    (147 456 terms), ragged sizes, against the oracle."""
+    for n in (147455, 147457):
+        S = rand_scalars(81 + n, n, full_width=True)
+        P = rand_points(82, n)
+        assert (eng.msm(S, P) == O.msm(S, P)).all(), n
+
+
 def test_msm_big_bucket_list_overflow(eng):
     """128 distinct scalars repeated over 2^17 terms: every non-empty bucket holds 1024 entries = 64 chunk heads, and there are about
     128 x 23 of them -- more than the big-bucket work list holds (2048), so the fix-up's pairs of lanes also run their serial
