@@ -378,7 +378,7 @@ def test_msm_small_batch_path_and_pippenger_on_the_same_inputs(monkeypatch, smal
 
 @pytest.mark.parametrize("mode", ["segments", "chunks"])
 def test_msm_both_accumulation_schemes(monkeypatch, mode):
-    """Bucket accumulation by length-sorted segments (default from 2^18 terms) and by fixed chunks + fix-up (below),
+    """Bucket accumulation by length-sorted segments (default from 147 456 terms) and by fixed chunks + fix-up (below),
     forced in turn on the same inputs, including skewed digit distributions and short segments."""
     from jubjub_amd import Engine
 
