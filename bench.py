@@ -22,6 +22,9 @@ line; under `python -m torch.distributed.run --nproc-per-node N ... bench.py --g
                    aggregate time per MSM, not the latency of one.
 --scaling strong : 2^log2n units IN TOTAL, cut into contiguous shards (BASELINE configs[3]: 2^20-term MSM over 8 GPUs;
                    configs[4]: 2^26 encodings over 8 GPUs with --log2n 26).
+--host-buffers   : pageable | pinned: the timed region is the C-ABI call on HOST arrays (H2D + kernels + D2H, pipelined by the
+                   library); `metric` says so, `pcie_inclusive` is true and `roofline.pcie` prices both directions against the link.
+                   This is never the headline value (that one has its inputs resident in HBM).
 Rank 0 prints ONE JSON line.
 
 Inputs come from the library's counter-based generators (jj_synth_scalars / jj_random_points: Group::random semantics,
@@ -53,6 +56,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+PCIE_PEAK_GBPS = 63.0    # host link: PCIe Gen5 x16, per direction (what the link measures on this pool: profiles/r4_pcie_probe.txt)
 SEED = 0x4A55424A5542
 POINT_SEED = SEED ^ 0x9E3779B97F4A7C15
 RAW_SEED = SEED ^ 0x5DEECE66D
@@ -130,6 +134,11 @@ def parse():
     ap.add_argument("--msm-async", type=int, default=1, help="N = 1 MSM workload: jobs in flight per context (1 = synchronous jj_msm calls)")
     ap.add_argument("--msm-contexts", type=int, default=1, help="N = 1 MSM workload: contexts (each with its own stream and workspaces) driven by as many host threads on the one GPU: "
                     "the latency-bound tails of one MSM overlap the sort / accumulation of another")
+    ap.add_argument("--host-buffers", default=None, choices=["pageable", "pinned"],
+                    help="time the C-ABI call on HOST arrays (the path a drop-in caller takes) instead of device-resident tensors: pinned = page-locked "
+                         "buffers from jj_host_alloc, pageable = plain numpy memory (page-locked in place by every call); inputs and result buffers are "
+                         "allocated once and reused; the JSON gains roofline.pcie; varbase / fixedbase / decompress, N = 1")
+    ap.add_argument("--compressed", action="store_true", help="varbase / fixedbase: 32-byte compressed results (jj_*_mul_compressed)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target wall time of each CPU baseline sample")
     return ap.parse_args()
@@ -242,6 +251,8 @@ def verify_sample(wl, a, lo, n, out, ok, msm_inputs):
     else:
         pts = np.stack([pt64(J.synth_point(lo + i, POINT_SEED)[0]) for i in idx])
         want = O.varbase_mul(scal, pts)
+    if a.compressed:
+        want = O.compress(want)
     if FAULT:
         want = want.copy(); want.reshape(-1)[0] ^= 1
     return bool((out[idx].cpu().numpy() == want).all()), len(idx)
@@ -396,13 +407,46 @@ def run(a):
                     enc[gidx - lo] = inj[k]
         points = None
 
-    def one_pass():
+    host = a.host_buffers
+    if host and (wl == "msm" or distributed):
+        if rank == 0:
+            print("bench.py: --host-buffers covers the varbase / fixedbase / decompress workloads on one GPU", file=sys.stderr)
+        return 2
+    out_w = 32 if (a.compressed and wl in ("varbase", "fixedbase")) else 64
+    if host:
+        # the caller's side of the boundary: inputs in host memory, result buffers allocated ONCE and reused by every pass
+        halloc = eng.host_alloc if host == "pinned" else (lambda shape: np.empty(shape, np.uint8))
+
+        def to_host(t):
+            h = halloc(tuple(t.shape))
+            h[...] = t.cpu().numpy()
+            return h
+
+        h_scalars = to_host(scalars) if wl in ("varbase", "fixedbase") else None
+        h_points = to_host(points) if wl == "varbase" else None
+        h_enc = to_host(enc) if wl == "decompress" else None
+        h_out = halloc((n, out_w))
+        h_ok = halloc((n,)) if wl == "decompress" else None
+        h_out[...] = 0                                            # touched once (a fresh pageable result buffer would be faulted in inside the first call)
+        if h_ok is not None:
+            h_ok[...] = 0
+
+    def one_pass_device():
         if wl == "varbase":
-            return eng.varbase_mul(scalars, points)
+            return eng.varbase_mul_compressed(scalars, points) if a.compressed else eng.varbase_mul(scalars, points)
         if wl == "fixedbase":
-            return eng.fixedbase_mul(table, scalars)
-        if wl == "decompress":
-            return eng.decompress(enc, a.decompress_flags)
+            return eng.fixedbase_mul_compressed(table, scalars) if a.compressed else eng.fixedbase_mul(table, scalars)
+        return eng.decompress(enc, a.decompress_flags)
+
+    def one_pass():
+        if host:
+            if wl == "varbase":
+                return (eng.varbase_mul_compressed if a.compressed else eng.varbase_mul)(h_scalars, h_points, out=h_out)
+            if wl == "fixedbase":
+                return (eng.fixedbase_mul_compressed if a.compressed else eng.fixedbase_mul)(table, h_scalars, out=h_out)
+            return eng.decompress(h_enc, a.decompress_flags, out=(h_out, h_ok))
+        if wl != "msm":
+            return one_pass_device()
         if not distributed:
             return eng.msm(scalars, points)
         # every rank: its record of window sums (8 KB, stays on the device), all_gather, ONE copy to the host, ONE host tail
@@ -489,11 +533,32 @@ def run(a):
 
     # a second, untimed pass over the same inputs on EVERY rank (the MSM's pass holds a collective): rank 0 compares all its units
     # with the timed output below
-    out2 = None if a.no_verify else one_pass()
+    dev_ref = None
+    if host:
+        # the timed output lives in host arrays: bring it back to the device for the checks below, and time the same entry point on
+        # device-resident tensors in this process (the ratio host / device-resident is what the pipelining is judged by)
+        out = torch.from_numpy(np.array(h_out)).to(dev)
+        if wl == "decompress":
+            out = (out, torch.from_numpy(np.array(h_ok)).to(dev))
+        one_pass_device(); torch.cuda.synchronize(dev)
+        eng.profile(True)
+        t1 = time.perf_counter()
+        for _ in range(2):
+            o_dev = one_pass_device()
+        torch.cuda.synchronize(dev)
+        ddt = (time.perf_counter() - t1) / 2
+        main_ms, tail_ms = eng.profile_read()
+        eng.profile(False)
+        dev_ref = {"value": n / ddt, "unit": UNIT[wl], "ms_per_pass": ddt * 1e3}
+        del o_dev
+        out2 = None if a.no_verify else one_pass_device()         # the independent second pass runs device-resident
+    else:
+        out2 = None if a.no_verify else one_pass()
     units_per_step = total * passes
     value = units_per_step * a.steps / dt
     res = {
-        "metric": "Jubjub scalar-muls/sec (%s)" % wl if wl in ("varbase", "fixedbase") else "Jubjub %s units/sec" % wl,
+        "metric": ("Jubjub scalar-muls/sec (%s)" % wl if wl in ("varbase", "fixedbase") else "Jubjub %s units/sec" % wl) +
+                  (" -- C ABI on HOST buffers (%s), PCIe-inclusive: not the headline value" % host if host else ""),
         "value": value, "unit": UNIT[wl],
         "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3,
@@ -508,6 +573,13 @@ def run(a):
                            ("; all_gather of one 8 KB record of window sums per rank (%s), one host tail" % a.backend if wl == "msm" else "; no data-path collective")},
         "rccl_world_size": dist.get_world_size() if distributed else 1,
     }
+    if host:
+        res["pcie_inclusive"] = True
+        res["config"]["host_buffers"] = ("page-locked (jj_host_alloc), reused by every pass" if host == "pinned" else
+                                         "pageable numpy memory, reused by every pass; every call page-locks them in place (hipHostRegister) and releases them")
+        res["config"]["result_bytes"] = out_w
+        res["device_resident"] = dev_ref
+        res["host_over_device_resident"] = value / dev_ref["value"]
     if wl == "msm":
         res["config"]["msm_partition"] = a.msm_partition if n_gpus > 1 else None
         res["config"]["msm_jobs_in_flight"] = a.msm_async if not distributed else 1
@@ -559,6 +631,22 @@ def run(a):
                     "frac": n * w["bytes"] / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "bytes_per_unit": w["bytes"]},
             "build_id": build_id(),
         }
+        if host:
+            in_b = {"varbase": 96, "fixedbase": 32, "decompress": 32}[wl]
+            out_b = out_w + (1 if wl == "decompress" else 0)
+            per_pass = dt / a.steps / passes
+            h2d, d2h = n * in_b / per_pass / 1e9, n * out_b / per_pass / 1e9
+            res["roofline"]["note"] = "kernel_ms / frac: the same entry point on device-resident tensors in this process (2 passes after the timed region)"
+            res["roofline"]["pcie"] = {
+                "bound": "pcie", "link": "PCIe Gen5 x16: 63 GB/s per direction (32 GT/s x 16 lanes, 128b/130b), full duplex",
+                "bytes_per_unit": {"h2d": in_b, "d2h": out_b}, "h2d_GBps": h2d, "d2h_GBps": d2h, "peak_GBps": PCIE_PEAK_GBPS,
+                "frac": max(h2d, d2h) / PCIE_PEAK_GBPS, "frac_h2d": h2d / PCIE_PEAK_GBPS, "frac_d2h": d2h / PCIE_PEAK_GBPS,
+                "link_bound_units_per_s": PCIE_PEAK_GBPS * 1e9 / max(in_b, out_b),
+                "kernel_bound_units_per_s": dev_ref["value"],
+                "ms_per_pass": per_pass * 1e3,
+                "bound_by": "kernels" if dev_ref["value"] < PCIE_PEAK_GBPS * 1e9 / max(in_b, out_b) else "link",
+                "frac_of_min_bound": value / min(dev_ref["value"], PCIE_PEAK_GBPS * 1e9 / max(in_b, out_b)),
+            }
         if wl == "msm":
             res["msm_result"] = bytes(host_bytes(out).reshape(64).tolist()).hex()     # the point every rank ends up with
         if not a.no_verify:
@@ -580,7 +668,7 @@ def run(a):
             res["all_units_equal_second_pass"] = same
             if not (okv and same):
                 rc = 3
-        if wl == "varbase" and not a.no_extras and n_gpus == 1:
+        if wl == "varbase" and not a.no_extras and n_gpus == 1 and not host:
             # the other half of BASELINE.json's metric at ITS config (2^24 fixed-base scalar-muls), same process, outside the timed region above
             fn = 1 << 24
             fs = eng.synth_scalars(fn, SEED, 0, device=dev)
@@ -621,7 +709,7 @@ def run(a):
                 res["fixed_base_wide_window"]["verified"], _ = verify_sample("fixedbase", a, 0, fn, fo, None, None)
             wt.close()
             del fs, fo
-        if wl == "varbase" and not a.no_extras and n_gpus == 1:
+        if wl == "varbase" and not a.no_extras and n_gpus == 1 and not host:
             # the constant-time ladder (jj_varbase_mul_ct: table {P, 2P} in registers, signed 2-bit windows, mask selects) on the same batch
             for _ in range(2):
                 co = eng.varbase_mul_ct(scalars, points)

@@ -68,6 +68,22 @@ int jj_ctx_profile_read(jj_ctx* ctx, int max, float* main_ms, float* tail_ms, in
  * accumulate) lane-operations per second. */
 int jj_peak_imad32(jj_ctx* ctx, double* out_per_sec);
 
+/* ---- host buffers ---------------------------------------------------------------------------------------------------------
+ * A drop-in caller (the Rust shim of INTEGRATION.md, examples/scalar_mul.c) hands HOST arrays to the entry points below.  Large
+ * batches (>= 2^19 units) of jj_varbase_mul(_compressed), jj_fixedbase_mul(_compressed) and jj_decompress are then cut into chunks
+ * that flow over two copy streams while the kernels of the neighbouring chunk run.  That needs PAGE-LOCKED memory:
+ *   - memory from jj_host_alloc, or memory registered once with jj_host_register, is used as it is (no per-call cost);
+ *   - any other (pageable) array is page-locked in place for the duration of the call and released before it returns: correct,
+ *     but it costs ~0.1 ms per MB each time (measured: profiles/r4_pcie_probe.txt), i.e. more than the copy itself.
+ * Keep batch buffers in jj_host_alloc memory (or register a long-lived Vec / malloc block once) and reuse them across calls.
+ * These four functions need no context and no HIP headers on the caller's side.  jj_host_alloc: page-locked, visible to every
+ * device of the node, *out = NULL for bytes = 0.  jj_host_register: p .. p + bytes must be mapped and stay mapped until
+ * jj_host_unregister(p); registering overlapping ranges twice fails with JJ_ERR_INVALID. */
+int jj_host_alloc(size_t bytes, void** out);
+int jj_host_free(void* p);
+int jj_host_register(void* p, size_t bytes);
+int jj_host_unregister(void* p);
+
 /* ---- fields: Fq (base, = bls12_381::Scalar, src/lib.rs:62) and Fr (scalar, src/fr.rs) ------------------------ */
 /* Elements are 32-byte little-endian integers; inputs are reduced mod p like from_raw (src/fr.rs:347-349),
  * outputs are canonical.  reference: add 638-647, sub 620-634, mul 592-616, neg 651-665, square 353-381,
@@ -75,7 +91,11 @@ int jj_peak_imad32(jj_ctx* ctx, double* out_per_sec);
  * jj_fq_sqrt returns the root that ff 0.13's sqrt_tonelli_shanks is RECALLED to return (that crate is not part of the reference
  * tree and no reference test stores a raw Fq root), so WHICH of the two roots comes back is parity-UNVERIFIED; that it is a root
  * (or ok = 0 for a non-residue) is checked.  Point decompression does not depend on it: the encoding's sign bit picks the root
- * (src/lib.rs:518-520), and that path is pinned by the reference's vectors. */
+ * (src/lib.rs:518-520), and that path is pinned by the reference's vectors.
+ * TIMING: jj_fq_sqrt / jj_fr_sqrt, jj_decompress and jj_random_points are VARIABLE-TIME in their input: the square root reads a
+ * discrete-log table at an address derived from the element's bits (jj_kernels.h sqrt_pohlig).  The dependency's Fq::sqrt
+ * (bls12_381, called at src/lib.rs:515) is constant-time; that does not matter for PUBLIC encodings (signature / note / proof
+ * bytes), which is what these entry points are for -- do not feed them secret field elements. */
 int jj_fq_add(jj_ctx*, size_t n, const void* a, const void* b, void* out);
 int jj_fq_sub(jj_ctx*, size_t n, const void* a, const void* b, void* out);
 int jj_fq_mul(jj_ctx*, size_t n, const void* a, const void* b, void* out);
@@ -211,6 +231,20 @@ int jj_msm_finish(jj_msm_job* job, void* out64);
 int jj_msm_partial(jj_ctx*, size_t n, const void* scalars32, const void* points64, int part_index, int part_count, void* record);
 int jj_msm_combine(size_t count, const void* records_host, void* out64_host);
 
+/* The same exchange behind ONE call, for callers that run one process per GPU (the context holds "streams, tables,
+ * RCCL comm"; 8(e)).  jj_ctx_set_comm lends the context an RCCL communicator that the CALLER created (ncclCommInitRank; the
+ * rendezvous that carries the ncclUniqueId between the processes belongs to the application -- examples/msm_rccl.cpp does it with a
+ * file, bench.py over torch.distributed) together with this process's rank.  all_gather_fn: address of the ncclAllGather of the
+ * RCCL library that made the communicator, or NULL (then looked up among the symbols of the process, then in librccl.so.1);
+ * libjubjub_hip.so itself does not link RCCL.  nccl_comm = NULL detaches.  The communicator must outlive its use here; the caller
+ * destroys it.
+ * jj_msm_allgather: every rank calls it with ITS terms (partition 0) or with ALL terms (partition 1: rank g reduces windows g, g + G,
+ * ... of the whole batch; same n on every rank): record of window sums (jj_msm_partial) -> ncclAllGather of JJ_MSM_PARTIAL_BYTES per
+ * rank on the context's stream -> one copy of the G records to the host -> one host tail (jj_msm_combine).  Every rank returns the
+ * same point; out64 may be a host or a device pointer.  A collective: all ranks must call it, in the same order. */
+int jj_ctx_set_comm(jj_ctx*, void* nccl_comm, int rank, int nranks, void* all_gather_fn);
+int jj_msm_allgather(jj_ctx*, size_t n, const void* scalars32, const void* points64, int partition, void* out64);
+
 /* ---- encodings ----------------------------------------------------------------------------------------- */
 #define JJ_DECOMPRESS_ZIP216          1u  /* reject the two non-canonical encodings (src/lib.rs:469-471, 522-531) */
 #define JJ_DECOMPRESS_TORSION_FREE    2u  /* additionally require [r]P = O  (SubgroupPoint::from_bytes, lib.rs:1427-1429) */
@@ -243,7 +277,8 @@ int jj_random_points(jj_ctx*, size_t n, uint64_t seed, uint64_t first_index, int
  * jj_multi_msm: every device reduces its own terms to a record of partial window sums (jj_msm_partial); the records of all
  * devices meet in one host tail on the calling thread (jj_msm_combine).  Array arguments are HOST pointers (a device pointer is JJ_ERR_INVALID).  A device may be listed
  * more than once.  Processes that keep their batches resident in HBM run one process per GPU instead and exchange the MSM
- * partial points with RCCL all_gather (jubjub_amd/dist.py).  A jj_ctx may be used from several host threads: its entry
+ * records with an RCCL all_gather: jj_ctx_set_comm + jj_msm_allgather above (C / C++ / Rust: examples/msm_rccl.cpp), or
+ * jubjub_amd/dist.py over torch.distributed.  A jj_ctx may be used from several host threads: its entry
  * points serialise on a per-context lock. */
 typedef struct jj_multi jj_multi;
 typedef struct jj_mtable jj_mtable;

@@ -42,6 +42,8 @@ _SIGS.update({
     "jj_msm": [_sz, _vp, _vp, _vp],
     "jj_msm_begin": [_sz, _vp, _vp, C.POINTER(_vp)],
     "jj_msm_partial": [_sz, _vp, _vp, C.c_int, C.c_int, _vp],
+    "jj_ctx_set_comm": [_vp, C.c_int, C.c_int, _vp],
+    "jj_msm_allgather": [_sz, _vp, _vp, C.c_int, _vp],
     "jj_decompress": [_sz, _vp, C.c_uint, _vp, _u8p],
     "jj_compress": [_sz, _vp, _vp],
     "jj_batch_normalize": [_sz, _vp, _vp],
@@ -69,7 +71,8 @@ _SIGS.update({
 
 EXPORTS = sorted(list(_SIGS) + ["jj_ctx_create", "jj_ctx_destroy", "jj_last_error", "jj_version", "jj_device_info", "jj_recommended_wnaf_for_num_scalars",
                                 "jj_fixedbase_table_create", "jj_fr_char_le_bits", "jj_multi_create", "jj_multi_ctx", "jj_multi_last_error",
-                                "jj_msm_fold_partials", "jj_msm_finish", "jj_msm_combine"])
+                                "jj_msm_fold_partials", "jj_msm_finish", "jj_msm_combine",
+                                "jj_host_alloc", "jj_host_free", "jj_host_register", "jj_host_unregister"])
 
 _lib = None
 
@@ -133,6 +136,14 @@ def load():
     lib.jj_msm_finish.argtypes = [_vp, _vp]
     lib.jj_msm_combine.restype = C.c_int
     lib.jj_msm_combine.argtypes = [C.c_size_t, _vp, _vp]
+    lib.jj_host_alloc.restype = C.c_int
+    lib.jj_host_alloc.argtypes = [C.c_size_t, C.POINTER(_vp)]
+    lib.jj_host_free.restype = C.c_int
+    lib.jj_host_free.argtypes = [_vp]
+    lib.jj_host_register.restype = C.c_int
+    lib.jj_host_register.argtypes = [_vp, C.c_size_t]
+    lib.jj_host_unregister.restype = C.c_int
+    lib.jj_host_unregister.argtypes = [_vp]
     lib.jj_fr_char_le_bits.restype = C.c_int
     lib.jj_fr_char_le_bits.argtypes = [C.POINTER(C.c_uint8)]
     lib.jj_device_info.restype = C.c_int

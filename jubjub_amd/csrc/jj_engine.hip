@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <mutex>
 #include <thread>
+#include <dlfcn.h>
 
 #include "../../include/jubjub_hip.h"
 #include "jj_kernels.h"
@@ -48,6 +49,9 @@ struct MsmLane {
   bool owned = false;
 };
 constexpr int MSM_LANES_MAX = 4;
+// window-count override (JJ_MSM_WINDOWS): fewer than 16 windows means windows of 17+ bits, i.e. more than 128 coarse bins of 256 buckets
+// per window -- beyond the LDS arrays of k_msm_part_hist / k_msm_part_scatter (and bucket arrays of hundreds of MB)
+constexpr int MSM_WINDOWS_MIN = 16, MSM_WINDOWS_MAX = 36;
 struct jj_msm_job {
   jj_ctx* c = nullptr;
   hipEvent_t ev = nullptr;
@@ -82,7 +86,7 @@ struct jj_ctx {
     DevBuf din[2], dout[2];
     bool ready = false;
   } pipe;
-  size_t pipe_chunk = (size_t)1 << 18;   // elements per pipeline chunk (JJ_PIPE_CHUNK_LOG2)
+  size_t pipe_chunk = 0;                 // elements per pipeline chunk: 0 = per entry point (pipe_chunk_for), else JJ_PIPE_CHUNK_LOG2
   // MSM jobs (jj_msm_begin / jj_msm_finish): free list of page-locked record buffers + events
   std::vector<jj_msm_job*> job_pool;
   MsmLane lanes[MSM_LANES_MAX];
@@ -91,7 +95,7 @@ struct jj_ctx {
   uint8_t host_out[8][64];       // results on their way to a device pointer (ring: the copies are asynchronous)
   int host_out_next = 0;
   int msm_small_blk = 4;         // small-batch path: at most this many 64-quad workgroups per window (JJ_MSM_SMALL_BLK, 1..64; 4 x 64 windows = one per CU)
-  int msm_windows = 0;           // number of windows W (0 = from n; JJ_MSM_WINDOWS, 8..36)
+  int msm_windows = 0;           // number of windows W (0 = from n; JJ_MSM_WINDOWS, 16..36: the two-pass sort holds at most 128 coarse bins per window, i.e. windows of at most 16 bits)
   int msm_small_max = 1 << 14;   // batches up to this size take the two-launch small-batch path (JJ_MSM_SMALL_MAX; 0 = never)
   bool torsion_ladder = false;   // subgroup test: false = Tate pairing (k_torsion_free), true = multiply by r (reference definition)
   bool fb_const_time = true;     // fixed-base window select: true = lane-staged + ds_bpermute shuffle, false = per-lane LDS gather
@@ -99,6 +103,10 @@ struct jj_ctx {
   int vb_quad_max = 32768;       // batches up to this size run one scalar-mul per quad of lanes (JJ_VB_QUAD_MAX; 0 = never)
   int fb_gather_blocks_per_cu = 3;   // wide-window fixed-base kernel: resident blocks of 256 per CU (JJ_FB_GATHER_BLOCKS_PER_CU)
   int vb_blocks_per_cu = 2;      // var-base ladder: resident blocks of 256 per CU (the ladder holds ~190 VGPRs: 2 waves per SIMD); JJ_VB_BLOCKS_PER_CU
+  // multi-rank MSM exchange (jj_ctx_set_comm / jj_msm_allgather): the caller's RCCL communicator, ncclAllGather of the library that made it
+  typedef int (*AllGatherFn)(const void*, void*, size_t, int, void*, hipStream_t);
+  void* comm = nullptr; int comm_rank = 0, comm_nranks = 1; AllGatherFn all_gather = nullptr;
+  DevBuf gather_dev; uint8_t* gather_host = nullptr; size_t gather_host_cap = 0;
   bool profile = false;
   struct Rec { hipEvent_t e0, e1, e2; };
   std::vector<Rec> recs;
@@ -233,9 +241,19 @@ static bool all_host(std::initializer_list<const void*> ptrs) { for (const void*
 
 // body(cn, dev_in[k], dev_out[k]) must enqueue the chunk's kernels on c->stream.
 // Returns JJ_OK, an error, or +1 when the buffers could not be page-locked (caller uses the staging path).
+// Chunk length of the host-buffer pipeline for a batch of n units (0: the batch is too small to be cut, it is staged whole).
+// `pref_log2` is what the entry point measured as its best chunk at its BASELINE size (profiles/r4_pcie_inclusive.txt: 2^20 for the
+// fixed-base and decoder kernels -- shorter chunks pay the shared inversion of their normalisation over too few points, longer ones
+// pay the unoverlapped first copy in and last copy out; 2^17 for the var-base ladder, whose kernel time dwarfs its copies); smaller
+// batches are cut in four, down to 2^16 units per chunk.
+static size_t pipe_chunk_for(const jj_ctx* c, size_t n, int pref_log2) {
+  if (c->pipe_chunk) return n >= 2 * c->pipe_chunk ? c->pipe_chunk : 0;
+  size_t ch = (size_t)1 << pref_log2;
+  while (ch > ((size_t)1 << 16) && n < 4 * ch) ch >>= 1;
+  return n >= 4 * ch ? ch : 0;
+}
 template <int NIN, int NOUT, class Body>
-static int run_pipelined(jj_ctx* c, size_t n, const HostIn (&in)[NIN], const HostOut (&out)[NOUT], Body body) {
-  const size_t CH = c->pipe_chunk;
+static int run_pipelined(jj_ctx* c, size_t n, size_t CH, const HostIn (&in)[NIN], const HostOut (&out)[NOUT], Body body) {
   size_t in_stride = 0, out_stride = 0;
   for (int k = 0; k < NIN; k++) in_stride += in[k].elem;
   for (int k = 0; k < NOUT; k++) out_stride += out[k].elem;
@@ -304,6 +322,39 @@ done:
   return rc;
 }
 
+// ---------------------------------------------------------------------------------------------------- host buffers
+// Page-locked host memory for callers that do not link HIP themselves (include/jubjub_hip.h).  The entry points recognise such
+// memory (is_pinned_host) and move it with asynchronous copies on the copy streams without registering anything per call.
+JJ_API int jj_host_alloc(size_t bytes, void** out) {
+  if (!out) return JJ_ERR_INVALID;
+  *out = nullptr;
+  if (bytes == 0) return JJ_OK;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); return JJ_ERR_NODEVICE; }
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return JJ_ERR_NOMEM; }
+  *out = p;
+  return JJ_OK;
+}
+JJ_API int jj_host_free(void* p) {
+  if (!p) return JJ_OK;
+  if (hipHostFree(p) != hipSuccess) { (void)hipGetLastError(); return JJ_ERR_INVALID; }
+  return JJ_OK;
+}
+JJ_API int jj_host_register(void* p, size_t bytes) {
+  if (!p || !bytes) return JJ_ERR_INVALID;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); return JJ_ERR_NODEVICE; }
+  const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterPortable);
+  if (e != hipSuccess) { (void)hipGetLastError(); return e == hipErrorOutOfMemory ? JJ_ERR_NOMEM : JJ_ERR_INVALID; }
+  return JJ_OK;
+}
+JJ_API int jj_host_unregister(void* p) {
+  if (!p) return JJ_ERR_INVALID;
+  if (hipHostUnregister(p) != hipSuccess) { (void)hipGetLastError(); return JJ_ERR_INVALID; }
+  return JJ_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------- context
 JJ_API int jj_version(void) { return JJ_VERSION; }
 // WnafGroup::recommended_wnaf_for_num_scalars (reference src/lib.rs:1320-1335): same thresholds, same result.
@@ -340,8 +391,8 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(JJ_ERR_HIP);
   if (hipEventCreateWithFlags(&c->order_ev, hipEventDisableTiming) != hipSuccess) return fail(JJ_ERR_HIP);
   c->stream = c->own_stream;
-  if (const char* e = getenv("JJ_PIPE_CHUNK_LOG2")) { int v = atoi(e); if (v >= 8 && v <= 24) c->pipe_chunk = (size_t)1 << v; }
-  if (const char* e = getenv("JJ_MSM_WINDOWS")) c->msm_windows = atoi(e);
+  if (const char* e = getenv("JJ_PIPE_CHUNK_LOG2")) { int v = atoi(e); if (v >= 8 && v <= 24) c->pipe_chunk = (size_t)1 << v; }   // overrides the per-entry-point chunk
+  if (const char* e = getenv("JJ_MSM_WINDOWS")) { int v = atoi(e); if (v >= MSM_WINDOWS_MIN && v <= MSM_WINDOWS_MAX) c->msm_windows = v; else fprintf(stderr, "libjubjub_hip: JJ_MSM_WINDOWS=%s ignored (valid: %d..%d)\n", e, MSM_WINDOWS_MIN, MSM_WINDOWS_MAX); }
   if (const char* e = getenv("JJ_MSM_LANES")) { int v = atoi(e); if (v >= 1 && v <= MSM_LANES_MAX) c->msm_lanes = v; }
   if (const char* e = getenv("JJ_MSM_SMALL_BLK")) { int v = atoi(e); if (v >= 1 && v <= MSM_TREE_QUADS) c->msm_small_blk = v; }
   if (const char* e = getenv("JJ_MSM_SMALL_MAX")) { int v = atoi(e); if (v >= 0 && v <= (1 << 20)) c->msm_small_max = v; }
@@ -393,6 +444,8 @@ JJ_API int jj_ctx_destroy(jj_ctx* c) {
     }
   }
   for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
+  if (c->gather_dev.p) (void)hipFree(c->gather_dev.p);
+  if (c->gather_host) (void)hipHostFree(c->gather_host);
   if (c->pipe.ready) {
     for (int i = 0; i < 2; i++) {
       (void)hipEventDestroy(c->pipe.ev_in[i]); (void)hipEventDestroy(c->pipe.ev_done[i]); (void)hipEventDestroy(c->pipe.ev_out[i]);
@@ -642,10 +695,10 @@ static int varbase_to_ext(jj_ctx* c, size_t n, const void* ds, const void* dp, S
 static int varbase_api(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out, int mode) {
   if (!c) return JJ_ERR_INVALID;
   JJ_ENTER(c);
-  if (n >= 2 * c->pipe_chunk && all_host({scalars, points, out})) {
+  if (const size_t ch = pipe_chunk_for(c, n, 17); ch && all_host({scalars, points, out})) {
     const HostIn in[2] = {{scalars, 32}, {points, 64}};
     const HostOut ho[1] = {{out, (size_t)(mode ? 32 : 64)}};
-    const int prc = run_pipelined(c, n, in, ho, [&](size_t cn, const void* const* di, void* const* dout) -> int {
+    const int prc = run_pipelined(c, n, ch, in, ho, [&](size_t cn, const void* const* di, void* const* dout) -> int {
       int rc2;
       if ((rc2 = ensure_ext(c, cn, 3))) return rc2;
       SoA ext = soa_of(c->ws_ext, cn);
@@ -890,8 +943,9 @@ JJ_API int jj_fixedbase_table_destroy(jj_ctx* c, jj_table* t) {
 static int fixedbase_launch(jj_ctx* c, const jj_table* t, size_t n, const void* ds, SoA ext, int chain = 0) {
   const unsigned blocks = (unsigned)std::min((size_t)c->cus, (n + 511) / 512);   // one 512-thread workgroup per CU (LDS-bound)
   if (t->window_bits == 7) {
-    if (c->fb_const_time) hipLaunchKernelGGL(k_fixedbase_comb<true>, dim3(blocks), dim3(512), FBC_LDS_BYTES, c->stream, n, ds, (const u32*)t->dev, ext, chain);
-    else hipLaunchKernelGGL(k_fixedbase_comb<false>, dim3(blocks), dim3(512), FBC_LDS_BYTES, c->stream, n, ds, (const u32*)t->dev, ext, chain);
+    const unsigned cblocks = (unsigned)std::min((size_t)c->cus, (n + FBC_THREADS - 1) / FBC_THREADS);
+    if (c->fb_const_time) hipLaunchKernelGGL(k_fixedbase_comb<true>, dim3(cblocks), dim3(FBC_THREADS), FBC_LDS_BYTES, c->stream, n, ds, (const u32*)t->dev, ext, chain);
+    else hipLaunchKernelGGL(k_fixedbase_comb<false>, dim3(cblocks), dim3(FBC_THREADS), FBC_LDS_BYTES, c->stream, n, ds, (const u32*)t->dev, ext, chain);
   } else if (t->window_bits != FB_W) {
     const unsigned gblocks = (unsigned)std::min((size_t)c->cus * c->fb_gather_blocks_per_cu, (n + 255) / 256);
     hipLaunchKernelGGL(k_fixedbase_gather, dim3(gblocks), dim3(256), 0, c->stream, n, ds, (const u32*)t->dev, t->fp, ext, chain);
@@ -903,10 +957,10 @@ static int fixedbase_api(jj_ctx* c, const jj_table* t, size_t n, const void* sca
   if (!c || !t) return JJ_ERR_INVALID;
   JJ_ENTER(c);
   if (t->device != c->device) { c->err = "fixed-base table belongs to another device"; return JJ_ERR_INVALID; }
-  if (n >= 2 * c->pipe_chunk && all_host({scalars, out})) {
+  if (const size_t ch = pipe_chunk_for(c, n, 20); ch && all_host({scalars, out})) {
     const HostIn in[1] = {{scalars, 32}};
     const HostOut ho[1] = {{out, (size_t)(mode ? 32 : 64)}};
-    const int prc = run_pipelined(c, n, in, ho, [&](size_t cn, const void* const* di, void* const* dout) -> int {
+    const int prc = run_pipelined(c, n, ch, in, ho, [&](size_t cn, const void* const* di, void* const* dout) -> int {
       int rc2;
       if ((rc2 = ensure_ext(c, cn, 3))) return rc2;
       SoA ext = soa_of(c->ws_ext, cn);
@@ -974,7 +1028,10 @@ JJ_API int jj_fixedbase_composite_create(jj_ctx* c, int nbases, const void* base
   if (slots > FB_NWIN) { c->err = "composite table: the bases need more than 42 six-bit windows (sum of ceil((bits + 2) / 6))"; delete t; return JJ_ERR_INVALID; }
   t->fx.nb = nbases;
   std::vector<uint8_t> bases((size_t)nbases * 64);
-  if (is_device_ptr(bases64)) { HIPCHK(c, hipMemcpy(bases.data(), bases64, bases.size(), hipMemcpyDeviceToHost)); } else memcpy(bases.data(), bases64, bases.size());
+  if (is_device_ptr(bases64)) {
+    const hipError_t e = hipMemcpy(bases.data(), bases64, bases.size(), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { c->err = std::string("hipMemcpy(bases) failed: ") + hipGetErrorString(e); delete t; return JJ_ERR_HIP; }
+  } else memcpy(bases.data(), bases64, bases.size());
   // Q_s = 64^(local window) B_b for every slot in use, then j Q_s for j = 0 .. 32; unused slots and the carry entry hold the identity
   int rc;
   std::vector<uint8_t> s1((size_t)slots * 32, 0), p1((size_t)slots * 64), q((size_t)slots * 64);
@@ -1082,7 +1139,7 @@ static void msm_layout(MsmParams& mp, int W, int w0, int wstride) {
 // (experiments/misc/msm_crossover.py: 131 072 terms 0.438 against 0.448 ms, 150 000 terms 0.485 against 0.459 ms, 235 000 terms 0.727 against 0.533 ms)
 constexpr size_t MSM_LARGE_MIN = (size_t)9 << 14;
 static int msm_windows_for(jj_ctx* c, size_t n) {
-  if (c->msm_windows >= 8 && c->msm_windows <= 36) return c->msm_windows;
+  if (c->msm_windows >= MSM_WINDOWS_MIN && c->msm_windows <= MSM_WINDOWS_MAX) return c->msm_windows;
   // measured (experiments/misc/msm_sweep*.sh, profiles/r3_msm_window_sweep.txt, r3_msm_reduce_grid.txt): 16 windows (13 of 16 bits, 3 of
   // 15) from 2^20 terms; 17 windows (15 of 15 bits, 2 of 14: half the buckets, so the bucket reduce is 145 us instead of 210, for
   // 6 % more additions) from MSM_LARGE_MIN terms; below, 23 windows of 11 bits: wider windows cut the additions but their buckets (4096+ per
@@ -1133,6 +1190,7 @@ static int msm_enqueue_pippenger(jj_ctx* c, MsmLane& ln, size_t n, const void* d
   const u32 nchunk = (u32)((n + chunk - 1) / chunk);
   const bool two_pass = B > 4096 || (B == 4096 && c->msm_two_pass != 0);      // the one-pass plan kernel covers 4096 buckets per window
   const u32 HB = B >> MSM_LO_BITS;
+  if (two_pass && HB > MSM_HB_MAX) { c->err = "MSM window layout has more coarse bins per window than the two-pass sort holds (JJ_MSM_WINDOWS must be 16..36)"; return JJ_ERR_INVALID; }
   const u32 ptiles = (u32)((n + MSM_P1_TILE - 1) / MSM_P1_TILE);        // the first pass of the two-pass sort orders a whole tile in LDS
   const size_t pm = (size_t)HB * ptiles;                               // runs per slot
   // one-pass sort tiles: enough (tile, window) blocks to fill the GPU, each at least 4096 terms
@@ -1236,10 +1294,11 @@ static int msm_job_get(jj_ctx* c, size_t nrec, jj_msm_job** out) {
   if (j->cap < want) {
     if (j->host) (void)hipHostFree(j->host);
     j->host = nullptr; j->cap = 0;
-    if (hipHostMalloc((void**)&j->host, want, hipHostMallocDefault) != hipSuccess) { (void)hipEventDestroy(j->ev); delete j; c->err = "hipHostMalloc failed"; return JJ_ERR_NOMEM; }
+    if (hipHostMalloc((void**)&j->host, want, hipHostMallocCoherent | hipHostMallocPortable) != hipSuccess) { (void)hipEventDestroy(j->ev); delete j; c->err = "hipHostMalloc failed"; return JJ_ERR_NOMEM; }
     j->cap = want;
   }
   j->nrec = 0;
+  for (size_t r = 0; r < std::max<size_t>(nrec, 1); r++) memset(j->host + r * jjhost::REC_MAX_BYTES, 0, jjhost::REC_HDR_BYTES);   // a stale header of a pooled buffer must never validate
   *out = j;
   return JJ_OK;
 }
@@ -1290,7 +1349,7 @@ JJ_API int jj_msm_begin(jj_ctx* c, size_t n, const void* scalars, const void* po
 JJ_API int jj_msm_finish(jj_msm_job* j, void* out64) {
   if (!j || !j->c) return JJ_ERR_INVALID;
   jj_ctx* c = j->c;
-  if (!out64) { std::lock_guard<std::recursive_mutex> lk(c->mu); msm_job_put(c, j); return JJ_ERR_INVALID; }
+  if (!out64) { (void)hipEventSynchronize(j->ev); std::lock_guard<std::recursive_mutex> lk(c->mu); msm_job_put(c, j); return JJ_ERR_INVALID; }   // the job's kernels may still be writing into its buffer
   hipError_t e = hipEventSynchronize(j->ev);                       // no context lock while waiting: other threads may queue work
   jjhost::Ext total = jjhost::identity();
   const bool ok = e == hipSuccess && jjhost::combine_records(j->host, j->nrec, jjhost::REC_MAX_BYTES, &total);
@@ -1326,15 +1385,19 @@ JJ_API int jj_msm(jj_ctx* c, size_t n, const void* scalars, const void* points, 
 //   part_index = g, part_count = G    windows g, g + G, ... of the n terms given (window partition: every rank passes ALL terms)
 JJ_API int jj_msm_partial(jj_ctx* c, size_t n, const void* scalars, const void* points, int part_index, int part_count, void* record) {
   if (!c || !record || part_count < 1 || part_index < 0 || part_index >= part_count) return JJ_ERR_INVALID;
-  if (n > ((size_t)1 << c->msm_pass_log2)) { c->err = "jj_msm_partial takes at most one pass of terms (2^24); cut larger inputs"; return JJ_ERR_INVALID; }
   JJ_ENTER(c);
+  if (n > ((size_t)1 << c->msm_pass_log2)) { c->err = "jj_msm_partial takes at most one pass of terms (2^24); cut larger inputs"; return JJ_ERR_INVALID; }
   int rc; OutRef o;
   if ((rc = stage_out(c, c->out[0], record, JJ_MSM_PARTIAL_BYTES, &o))) return rc;
   static_assert(JJ_MSM_PARTIAL_BYTES == jjhost::REC_MAX_BYTES, "record size");
   HIPCHK(c, hipMemsetAsync(o.dev, 0, JJ_MSM_PARTIAL_BYTES, c->stream));
-  if (n == 0) {
+  // the window count this call's layout has (as msm_enqueue picks it); a window partition over more parts than windows leaves
+  // the parts beyond the last window nothing to do (zero-sized grids would fail the launches and no header would be written)
+  const int layout_W = n <= (size_t)c->msm_small_max ? SM_W : msm_windows_for(c, n);
+  if (n == 0 || part_index >= layout_W) {
     // an empty shard: a valid record without windows
-    uint32_t hdr[MSM_REC_HDR_WORDS] = {MSM_REC_MAGIC, 2u, (uint32_t)SM_W, 1u};
+    uint32_t hdr[MSM_REC_HDR_WORDS] = {MSM_REC_MAGIC, 2u, (uint32_t)(n == 0 ? SM_W : layout_W), 1u};
+    hdr[6] = (uint32_t)n; hdr[7] = (uint32_t)((uint64_t)n >> 32);
     memcpy(c->host_out[c->host_out_next], hdr, 64);
     HIPCHK(c, hipMemcpyAsync(o.dev, c->host_out[c->host_out_next], 64, hipMemcpyHostToDevice, c->stream));
     c->host_out_next = (c->host_out_next + 1) % 8;
@@ -1358,6 +1421,61 @@ JJ_API int jj_msm_combine(size_t count, const void* records_host, void* out64_ho
   jjhost::Ext total = jjhost::identity();
   if (!jjhost::combine_records((const uint8_t*)records_host, count, JJ_MSM_PARTIAL_BYTES, &total)) return JJ_ERR_INVALID;
   jjhost::to_affine64((uint8_t*)out64_host, total);
+  return JJ_OK;
+}
+
+// ---- multi-rank MSM behind the C ABI ("context: streams, tables, RCCL comm"; 8(e)).  The communicator is the caller's
+// (its rendezvous -- who carries the ncclUniqueId to whom -- belongs to the application: examples/msm_rccl.cpp does it with a file,
+// bench.py over torch.distributed); the context borrows it.  libjubjub_hip.so does not link RCCL: ncclAllGather is taken from the
+// caller, or looked up in the process, or in librccl.so.1 -- it must be the ncclAllGather of the library that made the communicator.
+JJ_API int jj_ctx_set_comm(jj_ctx* c, void* nccl_comm, int rank, int nranks, void* all_gather_fn) {
+  if (!c) return JJ_ERR_INVALID;
+  JJ_ENTER(c);
+  if (!nccl_comm) { c->comm = nullptr; c->comm_rank = 0; c->comm_nranks = 1; c->all_gather = nullptr; return JJ_OK; }   // detach
+  if (nranks < 1 || nranks > 4096 || rank < 0 || rank >= nranks) { c->err = "jj_ctx_set_comm: bad rank / nranks"; return JJ_ERR_INVALID; }
+  void* fn = all_gather_fn;
+  if (!fn) fn = dlsym(RTLD_DEFAULT, "ncclAllGather");
+  if (!fn) { void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL); if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL); if (h) fn = dlsym(h, "ncclAllGather"); }
+  if (!fn) { c->err = "jj_ctx_set_comm: ncclAllGather not found (pass its address, or load librccl first)"; return JJ_ERR_INVALID; }
+  c->comm = nccl_comm; c->comm_rank = rank; c->comm_nranks = nranks; c->all_gather = (jj_ctx::AllGatherFn)fn;
+  return JJ_OK;
+}
+// One MSM over the terms (partition 0: each rank passes ITS terms) or the windows (partition 1: each rank passes ALL terms) of every
+// rank of the communicator: record of window sums on this device -> ncclAllGather of JJ_MSM_PARTIAL_BYTES per rank over xGMI -> ONE
+// copy of the gathered records to the host -> ONE host tail (jj_msm_combine) on every rank.  Every rank gets the same point.
+JJ_API int jj_msm_allgather(jj_ctx* c, size_t n, const void* scalars, const void* points, int partition, void* out64) {
+  if (!c || !out64 || (partition != 0 && partition != 1)) return JJ_ERR_INVALID;
+  {
+    JJ_ENTER(c);
+    if (!c->comm || !c->all_gather) { c->err = "jj_msm_allgather: no communicator (jj_ctx_set_comm)"; return JJ_ERR_INVALID; }
+  }
+  const int G = c->comm_nranks;
+  int rc;
+  {
+    JJ_ENTER(c);
+    if ((rc = ensure(c, c->gather_dev, (size_t)(G + 1) * JJ_MSM_PARTIAL_BYTES))) return rc;
+    if (c->gather_host_cap < (size_t)G * JJ_MSM_PARTIAL_BYTES) {
+      if (c->gather_host) (void)hipHostFree(c->gather_host);
+      c->gather_host = nullptr; c->gather_host_cap = 0;
+      if (hipHostMalloc((void**)&c->gather_host, (size_t)G * JJ_MSM_PARTIAL_BYTES, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); c->err = "hipHostMalloc failed"; return JJ_ERR_NOMEM; }
+      c->gather_host_cap = (size_t)G * JJ_MSM_PARTIAL_BYTES;
+    }
+  }
+  uint8_t* mine = (uint8_t*)c->gather_dev.p;                       // this rank's record, then the G gathered ones
+  uint8_t* all = mine + JJ_MSM_PARTIAL_BYTES;
+  if ((rc = jj_msm_partial(c, n, scalars, points, partition ? c->comm_rank : 0, partition ? G : 1, mine))) return rc;
+  JJ_ENTER(c);
+  const int nrc = c->all_gather(mine, all, JJ_MSM_PARTIAL_BYTES, /* ncclUint8 */ 1, c->comm, c->stream);
+  if (nrc != 0) { c->err = "ncclAllGather failed with ncclResult_t " + std::to_string(nrc); return JJ_ERR_HIP; }
+  HIPCHK(c, hipMemcpyAsync(c->gather_host, all, (size_t)G * JJ_MSM_PARTIAL_BYTES, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  jjhost::Ext total = jjhost::identity();
+  if (!jjhost::combine_records(c->gather_host, (size_t)G, JJ_MSM_PARTIAL_BYTES, &total)) { c->err = "a gathered MSM record is damaged (bad header)"; return JJ_ERR_HIP; }
+  if (is_device_ptr(out64)) {
+    jjhost::to_affine64(c->host_out[c->host_out_next], total);
+    HIPCHK(c, hipMemcpyAsync(out64, c->host_out[c->host_out_next], 64, hipMemcpyHostToDevice, c->stream));
+    c->host_out_next = (c->host_out_next + 1) % 8;
+  } else jjhost::to_affine64((uint8_t*)out64, total);
   return JJ_OK;
 }
 
@@ -1400,34 +1518,46 @@ JJ_API int jj_compress(jj_ctx* c, size_t n, const void* points, void* out32) {
   if ((rc = finish_out(c, o, &sync))) return rc;
   return finish(c, sync);
 }
+// the decoder and the flag kernels that follow it, on device pointers (n > 0), all on c->stream
+static int decompress_dev(jj_ctx* c, size_t n, const void* di, unsigned flags, void* dout, uint8_t* dok, bool prof) {
+  int rc;
+  if ((rc = ensure(c, c->ws_scratch, (size_t)NL * 4 * n))) return rc;
+  SoA scratch = soa_of(c->ws_scratch, n);
+  if (prof) prof_mark(c, 0);
+  const size_t lanes_wanted = (size_t)c->cus * 64 * 8;
+  if (n >= lanes_wanted * 32) { size_t T = (n + 31) / 32; hipLaunchKernelGGL((k_decompress<32>), dim3(blocks_for(T)), dim3(256), 0, c->stream, n, T, di, flags, scratch, c->sqrt_tables, dout, dok); }
+  else if (n >= lanes_wanted * 8) { size_t T = (n + 15) / 16; hipLaunchKernelGGL((k_decompress<16>), dim3(blocks_for(T)), dim3(256), 0, c->stream, n, T, di, flags, scratch, c->sqrt_tables, dout, dok); }
+  else if (n <= 16384) { hipLaunchKernelGGL((k_decompress<1>), dim3(blocks_for(n)), dim3(256), 0, c->stream, n, n, di, flags, scratch, c->sqrt_tables, dout, dok); }   // latency: no shared inversion
+  else { size_t T = (n + 3) / 4; hipLaunchKernelGGL((k_decompress<4>), dim3(blocks_for(T)), dim3(256), 0, c->stream, n, T, di, flags, scratch, c->sqrt_tables, dout, dok); }
+  if (prof) { prof_mark(c, 1); prof_mark(c, 2); }
+  // Invalid encodings were written as (0,0); the subgroup kernels below may compute garbage for them, the ok byte masks it.
+  if (flags & JJ_DECOMPRESS_TORSION_FREE) { if ((rc = torsion_free_dev(c, n, dout, dok, 1))) return rc; }
+  if (flags & (JJ_DECOMPRESS_NOT_SMALL_ORDER | JJ_DECOMPRESS_CLEAR_COFACTOR)) {
+    if ((rc = ensure_ext(c, n, 3))) return rc;
+    SoA ext = soa_of(c->ws_ext, n);
+    hipLaunchKernelGGL(k_small_order_cofactor, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, (const void*)dout, flags, ext, dok);
+    if (flags & JJ_DECOMPRESS_CLEAR_COFACTOR) { if ((rc = normalize_launch(c, n, ext, dout, 0))) return rc; }
+  }
+  if (flags & (JJ_DECOMPRESS_TORSION_FREE | JJ_DECOMPRESS_NOT_SMALL_ORDER | JJ_DECOMPRESS_CLEAR_COFACTOR))
+    hipLaunchKernelGGL(k_mask_outputs, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, dout, (const uint8_t*)dok);
+  return JJ_OK;
+}
 JJ_API int jj_decompress(jj_ctx* c, size_t n, const void* in32, unsigned flags, void* out64, uint8_t* ok) {
   if (!c || (!ok && n)) return JJ_ERR_INVALID;
   JJ_ENTER(c);
+  if (const size_t ch = pipe_chunk_for(c, n, 20); ch && all_host({in32, out64, ok})) {
+    const HostIn in[1] = {{in32, 32}};
+    const HostOut ho[2] = {{out64, 64}, {ok, 1}};
+    const int prc = run_pipelined(c, n, ch, in, ho, [&](size_t cn, const void* const* di, void* const* dout) -> int {
+      return decompress_dev(c, cn, di[0], flags, dout[0], (uint8_t*)dout[1], false);
+    });
+    if (prc <= 0) return prc;      // +1: buffers could not be page-locked -> plain staging below
+  }
   const void* di; int rc; OutRef o, ko;
   if ((rc = stage_in(c, 0, in32, 32 * n, &di))) return rc;
   if ((rc = stage_out(c, c->out[0], out64, 64 * n, &o))) return rc;
   if ((rc = stage_out(c, c->okb, ok, n, &ko))) return rc;
-  if (n) {
-    if ((rc = ensure(c, c->ws_scratch, (size_t)NL * 4 * n))) return rc;
-    SoA scratch = soa_of(c->ws_scratch, n);
-    prof_mark(c, 0);
-    const size_t lanes_wanted = (size_t)c->cus * 64 * 8;
-    if (n >= lanes_wanted * 32) { size_t T = (n + 31) / 32; hipLaunchKernelGGL((k_decompress<32>), dim3(blocks_for(T)), dim3(256), 0, c->stream, n, T, di, flags, scratch, c->sqrt_tables, o.dev, (uint8_t*)ko.dev); }
-    else if (n >= lanes_wanted * 8) { size_t T = (n + 15) / 16; hipLaunchKernelGGL((k_decompress<16>), dim3(blocks_for(T)), dim3(256), 0, c->stream, n, T, di, flags, scratch, c->sqrt_tables, o.dev, (uint8_t*)ko.dev); }
-    else if (n <= 16384) { hipLaunchKernelGGL((k_decompress<1>), dim3(blocks_for(n)), dim3(256), 0, c->stream, n, n, di, flags, scratch, c->sqrt_tables, o.dev, (uint8_t*)ko.dev); }   // latency: no shared inversion
-    else { size_t T = (n + 3) / 4; hipLaunchKernelGGL((k_decompress<4>), dim3(blocks_for(T)), dim3(256), 0, c->stream, n, T, di, flags, scratch, c->sqrt_tables, o.dev, (uint8_t*)ko.dev); }
-    prof_mark(c, 1); prof_mark(c, 2);
-    // Invalid encodings were written as (0,0); the subgroup kernels below may compute garbage for them, the ok byte masks it.
-    if (flags & JJ_DECOMPRESS_TORSION_FREE) { if ((rc = torsion_free_dev(c, n, o.dev, (uint8_t*)ko.dev, 1))) return rc; }
-    if (flags & (JJ_DECOMPRESS_NOT_SMALL_ORDER | JJ_DECOMPRESS_CLEAR_COFACTOR)) {
-      if ((rc = ensure_ext(c, n, 3))) return rc;
-      SoA ext = soa_of(c->ws_ext, n);
-      hipLaunchKernelGGL(k_small_order_cofactor, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, (const void*)o.dev, flags, ext, (uint8_t*)ko.dev);
-      if (flags & JJ_DECOMPRESS_CLEAR_COFACTOR) { if ((rc = normalize_launch(c, n, ext, o.dev, 0))) return rc; }
-    }
-    if (flags & (JJ_DECOMPRESS_TORSION_FREE | JJ_DECOMPRESS_NOT_SMALL_ORDER | JJ_DECOMPRESS_CLEAR_COFACTOR))
-      hipLaunchKernelGGL(k_mask_outputs, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, o.dev, (const uint8_t*)ko.dev);
-  }
+  if (n && (rc = decompress_dev(c, n, di, flags, o.dev, (uint8_t*)ko.dev, true))) return rc;
   bool sync = false;
   if ((rc = finish_out(c, o, &sync))) return rc;
   if ((rc = finish_out(c, ko, &sync))) return rc;

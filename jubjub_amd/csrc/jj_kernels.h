@@ -649,8 +649,12 @@ constexpr int FBC_TENT = 128;                                // entries per tabl
 constexpr int FBC_TABLES = FBC_BLOCKS + 2;                   // + T_0 - B, T_0 + B
 constexpr int FBC_ENTRIES = FBC_TABLES * FBC_TENT;
 constexpr int FBC_LDS_BYTES = FBC_ENTRIES * ANIELS_WORDS * 4;
+#ifndef JJ_FBC_THREADS
+#define JJ_FBC_THREADS 512
+#endif
+constexpr int FBC_THREADS = JJ_FBC_THREADS;                  // one workgroup per CU (the table fills the LDS): waves per SIMD = FBC_THREADS / 256
 template <bool CT>
-__global__ void __launch_bounds__(512) k_fixedbase_comb(size_t n, const void* scalars, const u32* table, SoA ext, int chain) {
+__global__ void __launch_bounds__(FBC_THREADS) k_fixedbase_comb(size_t n, const void* scalars, const u32* table, SoA ext, int chain) {
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
   {
     const uint4* src = reinterpret_cast<const uint4*>(table);
@@ -1138,7 +1142,6 @@ __global__ void __launch_bounds__(256) k_varbase_quad(size_t n, const void* scal
   }
 }
 
-// One workgroup per listed big bucket: FIXUP_BIG_QUADS quads each fold a strided share of the bucket's heads into a
 
 #include "jj_msm_kernels.h"
 

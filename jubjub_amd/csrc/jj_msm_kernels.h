@@ -367,13 +367,14 @@ __global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_scatter(size_t n, size
 //                        the whole sort: no scan over the buckets), orders the bin in LDS and copies it out coalesced
 // A bin larger than the LDS stage (skewed scalars) is scattered directly; its stores still stay within the one block.
 constexpr int MSM_LO_BITS = 8;
+constexpr u32 MSM_HB_MAX = 128;        // coarse bins per window the LDS arrays below are sized for (windows of at most 16 bits)
 #ifndef JJ_MSM_P2_THREADS
 #define JJ_MSM_P2_THREADS 512
 #endif
 constexpr int MSM_P2_THREADS = JJ_MSM_P2_THREADS;
 constexpr u32 MSM_P2_CAP = 12288;     // entries staged in LDS (48 KB): 1.5 x the mean bin of a 2^20-term, 16-bit-window pass
 __global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_part_hist(size_t n, size_t tile, MsmParams mp, const u32* kp, u32* tc) {
-  __shared__ u32 h[(MSM_SORT_THREADS / 64) * 128];          // one histogram per wave: fewer same-address collisions
+  __shared__ u32 h[(MSM_SORT_THREADS / 64) * MSM_HB_MAX];          // one histogram per wave: fewer same-address collisions
   const int w = msm_slot_window(mp, (int)blockIdx.y);
   const u32 HB = mp.B >> MSM_LO_BITS, wave = threadIdx.x >> 6;
   for (u32 b = threadIdx.x; b < (MSM_SORT_THREADS / 64) * HB; b += MSM_SORT_THREADS) h[b] = 0;
@@ -414,7 +415,7 @@ __global__ void __launch_bounds__(1024) k_msm_part_plan(size_t n, u32 m, const u
 constexpr u32 MSM_P1_TILE = 8192;
 constexpr int MSM_P1_PER = MSM_P1_TILE / MSM_SORT_THREADS;
 __global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_part_scatter(size_t n, size_t tile, MsmParams mp, const u32* kp, const u32* tcs, u32* rec, uint8_t* lo8) {
-  __shared__ u32 cnt[128], delta[128], live_s;
+  __shared__ u32 cnt[MSM_HB_MAX], delta[MSM_HB_MAX], live_s;
   __shared__ u32 st_rec[MSM_P1_TILE];
   __shared__ uint8_t st_lo[MSM_P1_TILE], st_bin[MSM_P1_TILE];
   const int w = msm_slot_window(mp, (int)blockIdx.y);

@@ -1,8 +1,10 @@
 """
 Multi-GPU host logic: one process per GPU (torch.distributed; backend "nccl" = RCCL on ROCm, "gloo" on CPU
-for tests).  The independent-batch workloads shard with NO data-path collective; MSM exchanges one 64-byte
-affine partial point per rank with all_gather (elliptic-curve addition is not an RCCL reduction operator) and
-every rank folds the partial points locally.
+for tests).  The independent-batch workloads shard with NO data-path collective; MSM all-gathers one record of partial
+window sums per rank (JJ_MSM_PARTIAL_BYTES = 8256 bytes; elliptic-curve addition is not an RCCL reduction operator),
+copies the gathered records to the host once and every rank runs one host tail over them (jj_msm_combine).
+C / C++ / Rust callers do the same exchange without Python: jj_ctx_set_comm + jj_msm_allgather (include/jubjub_hip.h,
+examples/msm_rccl.cpp).
 
 `engine` is any object with the Engine methods used here (varbase_mul, fixedbase_mul, decompress, msm,
 point_sum); production code passes jubjub_amd.Engine — the CPU tests pass an oracle-backed stand-in.
@@ -78,3 +80,72 @@ def msm_distributed(engine, scalars, points, group=None, presharded=False, parti
     dist.all_gather(gathered, t, group=group)                   # world x 8 KB; latency-bound, not bandwidth-bound
     stacked = torch.stack(gathered)
     return engine.msm_combine(stacked if is_torch else stacked.numpy())
+
+
+# ---------------------------------------------------------------------------------------------------------------- RCCL at the C level
+class RcclComm:
+    """An RCCL communicator of this process's own (ncclCommInitRank through ctypes), for the exchange that runs entirely behind the C
+    ABI (Engine.set_comm + Engine.msm_allgather = jj_ctx_set_comm + jj_msm_allgather).  torch.distributed keeps its communicator
+    private, so the ncclUniqueId of this one is created on rank 0 and carried to the other ranks by `broadcast` (a callable: bytes on
+    rank 0 / None elsewhere -> the 128 bytes on every rank; default: torch.distributed.broadcast_object_list).  The library used is
+    the RCCL the process already has (PyTorch's bundled librccl.so), else /opt/rocm's: its ncclAllGather goes to the context with
+    the communicator, because the two must come from the same library instance.
+    The current HIP device (torch.cuda.set_device) must be this rank's GPU when the communicator is created."""
+
+    def __init__(self, rank, world, broadcast=None, lib_path=None):
+        import ctypes as C
+
+        self.rank, self.world = int(rank), int(world)
+        self._lib = C.CDLL(lib_path or self._find_library())
+
+        class UniqueId(C.Structure):
+            _fields_ = [("internal", C.c_char * 128)]
+
+        self._lib.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
+        self._lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+        self._lib.ncclCommDestroy.argtypes = [C.c_void_p]
+        self._lib.ncclGetErrorString.restype = C.c_char_p
+        uid = UniqueId()
+        raw = None
+        if self.rank == 0:
+            self._ok(self._lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+            raw = C.string_at(C.addressof(uid), 128)
+        if self.world > 1:
+            raw = (broadcast or self._torch_broadcast)(raw)
+        C.memmove(C.addressof(uid), raw, 128)
+        h = C.c_void_p()
+        self._ok(self._lib.ncclCommInitRank(C.byref(h), self.world, uid, self.rank), "ncclCommInitRank")
+        self.handle = h.value
+        self.all_gather_addr = C.cast(self._lib.ncclAllGather, C.c_void_p).value
+
+    @staticmethod
+    def _find_library():
+        import importlib.util
+        import os
+
+        try:
+            spec = importlib.util.find_spec("torch")
+        except (ImportError, ValueError):
+            spec = None
+        if spec is not None and spec.submodule_search_locations:
+            cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "librccl.so")
+            if os.path.exists(cand):
+                return cand
+        return "librccl.so.1"
+
+    @staticmethod
+    def _torch_broadcast(raw):
+        import torch.distributed as dist
+
+        box = [raw]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    def _ok(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed: %s" % (what, self._lib.ncclGetErrorString(rc).decode()))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.ncclCommDestroy(self.handle)
+            self.handle = None

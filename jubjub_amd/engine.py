@@ -55,6 +55,21 @@ class _Arg:
             self.device = None
 
 
+class _HostBlock:
+    """owner of one jj_host_alloc block"""
+
+    def __init__(self, lib, ptr):
+        self._lib, self._ptr = lib, ptr
+
+    def __del__(self):
+        try:
+            if self._ptr:
+                self._lib.jj_host_free(C.c_void_p(self._ptr))
+                self._ptr = None
+        except Exception:
+            pass
+
+
 class FixedBaseTable:
     def __init__(self, engine, handle):
         self._engine = engine
@@ -117,6 +132,36 @@ class Engine:
         self._check(self._lib.jj_device_info(self._ctx, out))
         return {"cus": out[0], "clock_khz": out[1], "wavefront": out[2]}
 
+    # -------------------------------------------------------------- page-locked host arrays (jj_host_alloc / jj_host_register)
+    def host_alloc(self, shape):
+        """numpy uint8 array in page-locked host memory (jj_host_alloc): host batches in such arrays are pipelined over the copy
+        streams without any per-call registration.  Freed when the array (and every view of it) is gone."""
+        shape = tuple(shape) if isinstance(shape, (tuple, list)) else (int(shape),)
+        nbytes = int(np.prod(shape, dtype=np.int64))
+        if nbytes == 0:
+            return np.empty(shape, np.uint8)
+        p = C.c_void_p()
+        rc = self._lib.jj_host_alloc(C.c_size_t(nbytes), C.byref(p))
+        if rc:
+            raise JubjubError("jj_host_alloc(%d bytes) failed with %d" % (nbytes, rc))
+        buf = (C.c_uint8 * nbytes).from_address(p.value)
+        buf._jj_owner = _HostBlock(self._lib, p.value)   # numpy keeps `buf` alive through .base; the block is freed with it
+        return np.frombuffer(buf, dtype=np.uint8).reshape(shape)
+
+    def host_register(self, array):
+        """page-locks an existing numpy array once (jj_host_register); pair with host_unregister(array)"""
+        a = np.ascontiguousarray(array)
+        if a is not array and a.ctypes.data != array.ctypes.data:
+            raise ValueError("a contiguous array is required")
+        rc = self._lib.jj_host_register(C.c_void_p(a.ctypes.data), C.c_size_t(a.nbytes))
+        if rc:
+            raise JubjubError("jj_host_register failed with %d" % rc)
+
+    def host_unregister(self, array):
+        rc = self._lib.jj_host_unregister(C.c_void_p(array.ctypes.data))
+        if rc:
+            raise JubjubError("jj_host_unregister failed with %d" % rc)
+
     def profile(self, enable=True):
         self._check(self._lib.jj_ctx_profile(self._ctx, 1 if enable else 0))
 
@@ -151,7 +196,9 @@ class Engine:
         a = np.empty((n, width) if width > 1 else (n,), dtype=np.uint8)
         return a, (a.ctypes.data if a.size else None)
 
-    def _call(self, name, ins, in_widths, out_widths, extra_before=(), extra_mid=(), n_override=None):
+    def _call(self, name, ins, in_widths, out_widths, extra_before=(), extra_mid=(), n_override=None, out=None):
+        """`out`: caller-owned result array(s) (one per output, same kind as the inputs, exact byte size) instead of fresh ones —
+        e.g. page-locked buffers from host_alloc() that are reused across calls."""
         args = [_Arg(x, w) for x, w in zip(ins, in_widths)]
         n = args[0].n if n_override is None else n_override
         for a in args[1:]:
@@ -159,7 +206,17 @@ class Engine:
                 raise ValueError("length mismatch: %d vs %d" % (a.n, n))  # cf. the assert at reference src/lib.rs:841
         self._bind_stream(args)
         outs, optrs = [], []
-        for w in out_widths:
+        if out is not None:
+            given = list(out) if isinstance(out, (tuple, list)) else [out]
+            if len(given) != len(out_widths):
+                raise ValueError("%d output arrays expected" % len(out_widths))
+            for o, w in zip(given, out_widths):
+                oa = _Arg(o, w)
+                if oa.n != (n if n_override is None else 1) or oa.torch != args[0].torch or oa.keep is not o:
+                    raise ValueError("out: a contiguous uint8 array of %d x %d bytes of the inputs' kind expected" % (n, w))
+                outs.append(o)
+                optrs.append(oa.ptr)
+        for w in out_widths[len(outs):]:
             o, p = self._alloc(args[0], n if n_override is None else 1, w)
             outs.append(o)
             optrs.append(p)
@@ -236,8 +293,8 @@ class Engine:
         return out.reshape(64)
 
     # -------------------------------------------------------------- scalar multiplication
-    def varbase_mul(self, scalars, points):
-        return self._call("jj_varbase_mul", [scalars, points], [32, 64], [64])
+    def varbase_mul(self, scalars, points, out=None):
+        return self._call("jj_varbase_mul", [scalars, points], [32, 64], [64], out=out)
 
     def varbase_mul_ct(self, scalars, points):
         """constant-time ladder for secret scalars (jj_varbase_mul_ct): no scalar-dependent address or branch"""
@@ -253,11 +310,11 @@ class Engine:
         self._check(self._lib.jj_varbase_mul_scalar(self._ctx, C.c_size_t(p.n), a.ptr, p.ptr, optr))
         return out
 
-    def varbase_mul_compressed(self, scalars, points):
-        return self._call("jj_varbase_mul_compressed", [scalars, points], [32, 64], [32])
+    def varbase_mul_compressed(self, scalars, points, out=None):
+        return self._call("jj_varbase_mul_compressed", [scalars, points], [32, 64], [32], out=out)
 
-    def fixedbase_mul_compressed(self, table, scalars):
-        return self._call("jj_fixedbase_mul_compressed", [scalars], [32], [32], extra_before=(table._h,))
+    def fixedbase_mul_compressed(self, table, scalars, out=None):
+        return self._call("jj_fixedbase_mul_compressed", [scalars], [32], [32], extra_before=(table._h,), out=out)
 
     def varbase_mul_exact(self, scalars, points):
         return self._call("jj_varbase_mul_exact", [scalars, points], [32, 64], [160])
@@ -271,8 +328,8 @@ class Engine:
         self._check(self._lib.jj_fixedbase_table_create(self._ctx, a.ptr, int(window_bits), C.byref(h)))
         return FixedBaseTable(self, h)
 
-    def fixedbase_mul(self, table, scalars):
-        return self._call("jj_fixedbase_mul", [scalars], [32], [64], extra_before=(table._h,))
+    def fixedbase_mul(self, table, scalars, out=None):
+        return self._call("jj_fixedbase_mul", [scalars], [32], [64], extra_before=(table._h,), out=out)
 
     def fixedbase_multi_mul(self, tables, scalars):
         """out[i] = sum_j tables[j] * scalars[j][i]; scalars: (len(tables), n, 32) bytes, base-major."""
@@ -349,6 +406,27 @@ class Engine:
         self._check(self._lib.jj_msm_partial(self._ctx, C.c_size_t(a.n), a.ptr, p.ptr, C.c_int(part_index), C.c_int(part_count), optr))
         return out
 
+    def set_comm(self, comm):
+        """Lends the context an RCCL communicator (jj_ctx_set_comm): `comm` is a jubjub_amd.dist.RcclComm (or None to detach)."""
+        if comm is None:
+            self._check(self._lib.jj_ctx_set_comm(self._ctx, None, 0, 1, None))
+            self._comm = None
+            return
+        self._check(self._lib.jj_ctx_set_comm(self._ctx, C.c_void_p(comm.handle), C.c_int(comm.rank), C.c_int(comm.world), C.c_void_p(comm.all_gather_addr)))
+        self._comm = comm                                          # keep the communicator (and its library) alive
+
+    def msm_allgather(self, scalars, points, partition="terms"):
+        """One MSM over all ranks of the communicator lent with set_comm, entirely behind the C ABI (jj_msm_allgather): record of
+        window sums -> ncclAllGather over xGMI -> one copy to the host -> one host tail.  partition "terms": the arrays are THIS
+        rank's terms; "window": ALL terms on every rank.  Returns the 64-byte affine sum as a numpy array (host) on every rank."""
+        a, p = _Arg(scalars, 32), _Arg(points, 64)
+        if a.n != p.n:
+            raise ValueError("length mismatch: %d vs %d" % (a.n, p.n))
+        self._bind_stream([a, p])
+        out = np.empty((64,), np.uint8)
+        self._check(self._lib.jj_msm_allgather(self._ctx, C.c_size_t(a.n), a.ptr, p.ptr, C.c_int({"terms": 0, "window": 1}[partition]), out.ctypes.data))
+        return out
+
     def msm_combine(self, records):
         """Second half (jj_msm_combine, host only): any number of records (count x MSM_PARTIAL_BYTES bytes; numpy, or a torch
         tensor on any device: copied to the host once) -> the 64-byte affine sum as a numpy array."""
@@ -361,8 +439,8 @@ class Engine:
         return out
 
     # -------------------------------------------------------------- encodings
-    def decompress(self, enc, flags=FLAG_ZIP216):
-        return self._call("jj_decompress", [enc], [32], [64, 1], extra_mid=(C.c_uint(flags),))
+    def decompress(self, enc, flags=FLAG_ZIP216, out=None):
+        return self._call("jj_decompress", [enc], [32], [64, 1], extra_mid=(C.c_uint(flags),), out=out)
 
     def compress(self, points):
         return self._call("jj_compress", [points], [64], [32])

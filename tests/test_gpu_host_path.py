@@ -1,0 +1,217 @@
+"""
+The path a drop-in caller takes: HOST arrays handed to the C ABI (include/jubjub_hip.h "host buffers"): page-locked buffers from
+jj_host_alloc, buffers registered once with jj_host_register, and plain pageable memory, each through the chunked copy / compute
+pipeline (run_pipelined, jj_engine.hip) -- bit-exact against the device-resident path and the oracle.
+Also the C-level multi-rank MSM exchange (jj_ctx_set_comm + jj_msm_allgather, examples/msm_rccl.cpp) with one rank over RCCL.
+Boundary semantics: /root/reference/src/lib.rs:873-879 (ExtendedPoint * Fr), 1109-1115 (AffineNielsPoint * Fr), 469-627 (from_bytes).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle as O
+from oracle import jubjub_ref as J
+from util import pt64, rand_points, rand_scalars
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_PIPE = (1 << 19) + (1 << 18) + 77          # pipelined: cut into chunks of 2^17 units, the last one ragged
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from jubjub_amd import Engine
+
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def _inputs(n, seed):
+    s = rand_scalars(seed, n)
+    small = rand_points(seed + 1, 4096)
+    p = small[np.arange(n) % 4096]                      # 4096 distinct points repeated: the oracle side stays cheap
+    return s, np.ascontiguousarray(p)
+
+
+def _host(eng, kind, a):
+    """the array in the requested kind of host memory: 'pinned' (jj_host_alloc), 'registered' (jj_host_register), 'pageable'"""
+    if kind == "pinned":
+        h = eng.host_alloc(a.shape)
+        h[...] = a
+        return h
+    h = np.array(a, copy=True)
+    if kind == "registered":
+        eng.host_register(h)
+    return h
+
+
+@pytest.mark.parametrize("kind", ["pinned", "registered", "pageable"])
+def test_varbase_fixedbase_host_pipeline(eng, kind):
+    import torch
+
+    n = N_PIPE
+    s, p = _inputs(n, 901)
+    hs, hp = _host(eng, kind, s), _host(eng, kind, p)
+    out = _host(eng, kind, np.zeros((n, 64), np.uint8))
+    out32 = _host(eng, kind, np.zeros((n, 32), np.uint8))
+    try:
+        r = eng.varbase_mul(hs, hp, out=out)
+        assert r is out
+        dev = eng.varbase_mul(torch.from_numpy(s).cuda(), torch.from_numpy(p).cuda()).cpu().numpy()
+        assert (out == dev).all()
+        idx = np.concatenate([np.arange(0, n, 4099), [n - 1, (1 << 18) - 1, 1 << 18, (1 << 19) - 1, 1 << 19]])
+        assert (out[idx] == O.varbase_mul(s[idx], p[idx])).all()
+        eng.varbase_mul_compressed(hs, hp, out=out32)
+        assert (out32[idx] == O.compress(O.varbase_mul(s[idx], p[idx]))).all()
+        base = pt64(J.GENERATOR)
+        tab = eng.fixedbase_table(base)
+        eng.fixedbase_mul(tab, hs, out=out)
+        dev = eng.fixedbase_mul(tab, torch.from_numpy(s).cuda()).cpu().numpy()
+        assert (out == dev).all()
+        assert (out[idx] == O.fixedbase_mul(s[idx], base)).all()
+        eng.fixedbase_mul_compressed(tab, hs, out=out32)
+        assert (out32[idx] == O.compress(O.fixedbase_mul(s[idx], base))).all()
+        tab.close()
+    finally:
+        if kind == "registered":
+            for a in (hs, hp, out, out32):
+                eng.host_unregister(a)
+
+
+@pytest.mark.parametrize("kind", ["pinned", "pageable"])
+@pytest.mark.parametrize("flags", [1, 13])
+def test_decompress_host_pipeline(eng, kind, flags):
+    """jj_decompress on host arrays runs the chunked pipeline too (points + validity bytes come back per chunk)."""
+    import torch
+
+    n = N_PIPE
+    pts = rand_points(77, 4096)[np.arange(n) % 4096]
+    enc = O.compress(np.ascontiguousarray(pts))
+    rng = np.random.default_rng(5)
+    bad = rng.integers(0, n, size=n // 16)
+    enc[bad] = rng.integers(0, 256, size=(len(bad), 32), dtype=np.uint8)         # off-curve / non-canonical noise
+    he = _host(eng, kind, enc)
+    out = _host(eng, kind, np.zeros((n, 64), np.uint8))
+    ok = _host(eng, kind, np.zeros((n,), np.uint8))
+    eng.decompress(he, flags, out=(out, ok))
+    d_out, d_ok = eng.decompress(torch.from_numpy(enc).cuda(), flags)
+    assert (ok == d_ok.cpu().numpy()).all() and (out == d_out.cpu().numpy()).all()
+    idx = np.concatenate([np.arange(0, n, 1021), bad[:200], [n - 1, (1 << 18) - 1, 1 << 18]])
+    eo, ek = O.decompress(enc[idx], flags)
+    assert (ok[idx] == ek).all() and (out[idx] == eo).all()
+    assert 0 < int(ok.sum()) < n
+
+
+def test_host_alloc_api(eng):
+    lib = eng._lib
+    p = C.c_void_p()
+    assert lib.jj_host_alloc(0, C.byref(p)) == 0 and not p.value
+    assert lib.jj_host_alloc(1 << 20, C.byref(p)) == 0 and p.value
+    assert lib.jj_host_free(p) == 0
+    assert lib.jj_host_free(None) == 0
+    assert lib.jj_host_register(None, 16) != 0
+    a = np.zeros(1 << 20, np.uint8)
+    eng.host_register(a)
+    eng.host_unregister(a)
+    assert lib.jj_host_unregister(C.c_void_p(a.ctypes.data)) != 0            # not registered any more
+    h = eng.host_alloc((1000, 32))
+    v = h[10:20]
+    del h
+    v[...] = 7                                                               # a view keeps the block alive
+    assert int(v.sum()) == 7 * 320
+
+
+# ------------------------------------------------------------------------------------------------ C-level RCCL exchange
+def test_msm_allgather_one_rank_rccl(eng):
+    """jj_ctx_set_comm + jj_msm_allgather with a real RCCL communicator of one rank: both partitions equal jj_msm and the oracle."""
+    import torch
+
+    from jubjub_amd.dist import RcclComm
+
+    torch.cuda.set_device(0)
+    comm = RcclComm(0, 1)
+    try:
+        eng.set_comm(comm)
+        for n in (0, 1, 777, 40000):
+            s, p = rand_scalars(31 + n, n), rand_points(32 + n, n)
+            ds, dp = torch.from_numpy(s).cuda(), torch.from_numpy(p).cuda()
+            want = O.msm(s, p).reshape(64)
+            assert (eng.msm_allgather(ds, dp, "terms") == want).all(), n
+            assert (eng.msm_allgather(ds, dp, "window") == want).all(), n
+            assert (eng.msm_allgather(s, p, "terms") == want).all(), n         # host arrays are staged
+    finally:
+        eng.set_comm(None)
+        comm.close()
+    with pytest.raises(Exception):
+        eng.msm_allgather(s, p)                                                 # no communicator
+
+
+def test_msm_rccl_example_one_rank(tmp_path):
+    """examples/msm_rccl.cpp (one process per GPU, ncclUniqueId through a file) built against /opt/rocm's librccl and run with one
+    rank: its three ways agree and the point equals the oracle's MSM over the same synthetic terms."""
+    import torch
+
+    from jubjub_amd import Engine
+
+    lib = os.path.join(ROOT, "jubjub_amd", "lib")
+    exe = tmp_path / "msm_rccl"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "msm_rccl.cpp"),
+                           "-L", lib, "-ljubjub_hip", "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
+    n = 50000
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", JJ_ID_FILE=str(tmp_path / "id"))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([str(exe), str(n), "2"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "allgather == partial+ncclAllGather+combine: ok; term partition == window partition: ok" in r.stdout, r.stdout
+    got = [ln.split("result=")[1].strip() for ln in r.stdout.splitlines() if "result=" in ln][0]
+    e = Engine(0)
+    SEED = 0x4A55424A5542
+    s = e.synth_scalars(n, SEED, 0, device=torch.device("cuda", 0)).cpu().numpy()
+    p = e.random_points(n, SEED ^ 0x9E3779B97F4A7C15, 0, subgroup=False, device=torch.device("cuda", 0)).cpu().numpy()
+    e.close()
+    assert got == bytes(O.msm(s, p).reshape(64).tolist()).hex()
+
+
+# ------------------------------------------------------------------------------------------------ ADVICE r3 regressions
+def test_msm_windows_override_out_of_range_is_ignored(monkeypatch, capfd):
+    """JJ_MSM_WINDOWS below 16 would need more than 128 coarse bins per window in the two-pass sort (LDS overrun): the override is
+    ignored with a warning and the MSM is still right."""
+    from jubjub_amd import Engine
+
+    monkeypatch.setenv("JJ_MSM_WINDOWS", "12")
+    monkeypatch.setenv("JJ_MSM_SMALL_MAX", "0")
+    e = Engine(0)
+    n = 70000
+    s, p = rand_scalars(8, n), rand_points(9, n)
+    got = e.msm(s, p)
+    e.close()
+    assert (got == O.msm(s, p).reshape(64)).all()
+    assert "JJ_MSM_WINDOWS=12 ignored" in capfd.readouterr().err
+
+
+def test_msm_window_partition_with_more_parts_than_windows(eng):
+    """part_index >= W: an empty but valid record (no zero-sized launches); all the parts still combine to the MSM."""
+    n = 300                                       # small-batch path: W = 64 windows
+    s, p = rand_scalars(41, n), rand_points(42, n)
+    G = 70
+    recs = np.stack([eng.msm_partial(s, p, g, G) for g in range(G)])
+    assert (eng.msm_combine(recs) == O.msm(s, p).reshape(64)).all()
+    hdr = recs[G - 1][:32].view("<u4")
+    assert hdr[0] == 0x504D4A4A and hdr[4] == 0 and hdr[5] == 0          # no windows present
+
+
+def test_msm_finish_without_output_releases_the_job(eng):
+    import torch
+
+    n = 20000
+    s, p = torch.from_numpy(rand_scalars(51, n)).cuda(), torch.from_numpy(rand_points(52, n)).cuda()
+    lib = eng._lib
+    for _ in range(4):
+        h = C.c_void_p()
+        assert lib.jj_msm_begin(eng._ctx, C.c_size_t(n), C.c_void_p(s.data_ptr()), C.c_void_p(p.data_ptr()), C.byref(h)) == 0
+        assert lib.jj_msm_finish(h, None) != 0                              # invalid argument; the job is released after its kernels finished
+    assert (eng.msm(s, p).cpu().numpy() == O.msm(s.cpu().numpy(), p.cpu().numpy()).reshape(64)).all()
