@@ -56,6 +56,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+NOMINAL_PEAK_IMAD32 = 1024 * 16 * 2.4e9   # 1024 SIMDs x 16 lanes x 2.4 GHz boost clock: one 32x32+64 multiply-add per lane per 4-cycle wave64 issue
 PCIE_PEAK_GBPS = 63.0    # host link: PCIe Gen5 x16, per direction (what the link measures on this pool: profiles/r4_pcie_probe.txt)
 SEED = 0x4A55424A5542
 POINT_SEED = SEED ^ 0x9E3779B97F4A7C15
@@ -97,6 +98,7 @@ DEFAULT_LOG2N = {"varbase": 20, "fixedbase": 24, "msm": 20, "decompress": 23}
 UNIT = {"varbase": "scalar-muls/s", "fixedbase": "scalar-muls/s", "msm": "terms/s", "decompress": "points/s"}
 GEN_U = 0x62EDCBB8BF3787C88B0F03DDD60A8187CAF55D1B29BF81AFE4B3D35DF1A7ADFE   # generator (u, 11), reference src/lib.rs:1380-1396
 SAMPLE_STRIDE = 1 << 10
+BLOCK_LOG2 = 14          # besides the strided sample: one CONTIGUOUS block of 2^14 units (whole waves, whole workgroups) recomputed by the oracle
 # edge encodings injected into the decoder's input at fixed global indices: (index, kind)
 INJECT_FIRST, INJECT_STEP = 1000, 4096
 # JJ_BENCH_FAULT_INJECT=1 flips one bit of the CHECKER's expected values (never of the product's output): the run must then report
@@ -139,6 +141,9 @@ def parse():
                          "buffers from jj_host_alloc, pageable = plain numpy memory (page-locked in place by every call); inputs and result buffers are "
                          "allocated once and reused; the JSON gains roofline.pcie; varbase / fixedbase / decompress, N = 1")
     ap.add_argument("--compressed", action="store_true", help="varbase / fixedbase: 32-byte compressed results (jj_*_mul_compressed)")
+    ap.add_argument("--msm-exchange", default="c", choices=["c", "torch"],
+                    help="multi-rank MSM over the nccl backend: c = the whole exchange behind the C ABI (jj_ctx_set_comm + jj_msm_allgather on an RCCL "
+                         "communicator of this process's own); torch = jj_msm_partial + torch.distributed.all_gather + jj_msm_combine")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target wall time of each CPU baseline sample")
     return ap.parse_args()
@@ -218,8 +223,8 @@ def decoder_input_for(i, inj):
     return J.affine_to_bytes(J.synth_point(i, POINT_SEED)[0])
 
 
-def verify_sample(wl, a, lo, n, out, ok, msm_inputs):
-    """Recomputes every SAMPLE_STRIDE-th unit of rank 0's shard with the oracle, from the unit indices alone."""
+def verify_sample(wl, a, lo, n, out, ok, msm_inputs, idx=None):
+    """Recomputes every SAMPLE_STRIDE-th unit of rank 0's shard (or the units `idx`) with the oracle, from the unit indices alone."""
     import numpy as np
 
     from oracle import c_oracle as O
@@ -227,10 +232,12 @@ def verify_sample(wl, a, lo, n, out, ok, msm_inputs):
 
     b32 = lambda k: np.frombuffer(int(k).to_bytes(32, "little"), dtype=np.uint8)
     pt64 = lambda p: np.concatenate([b32(p[0]), b32(p[1])])
-    idx = list(range(0, n, SAMPLE_STRIDE))
+    strided = idx is None
+    idx = list(range(0, n, SAMPLE_STRIDE)) if strided else list(idx)
     if wl == "decompress":
         inj = injected_encodings()
-        idx = sorted(set(idx) | {i - lo for i in range(INJECT_FIRST, INJECT_FIRST + INJECT_STEP * len(inj), INJECT_STEP) if lo <= i < lo + n})
+        if strided:
+            idx = sorted(set(idx) | {i - lo for i in range(INJECT_FIRST, INJECT_FIRST + INJECT_STEP * len(inj), INJECT_STEP) if lo <= i < lo + n})
         enc = np.stack([np.frombuffer(decoder_input_for(lo + i, inj), dtype=np.uint8) for i in idx])
         eo, ek = O.decompress(enc, a.decompress_flags)
         if FAULT:
@@ -291,7 +298,11 @@ def cpu_baseline(workload, target_s):
 
     omp = ctypes.CDLL("libgomp.so.1")
     omp.omp_get_max_threads.restype = ctypes.c_int
-    all_threads = int(omp.omp_get_max_threads())
+    info = cpu_info()
+    # threads = the CPUs this process may actually use: the logical CPUs of its affinity mask, capped by the cgroup quota (a container
+    # that sees 256 logical CPUs but is throttled to 16 runs 16 threads, not 128 or 256)
+    effective = min(info["affinity"], int(-(-info["cgroup_cpu_quota"] // 1)) if info["cgroup_cpu_quota"] else info["affinity"])
+    all_threads = max(1, min(int(omp.omp_get_max_threads()), effective))
     base = np.frombuffer(J.GENERATOR[0].to_bytes(32, "little") + J.GENERATOR[1].to_bytes(32, "little"), dtype=np.uint8)
     rng = np.random.default_rng(2024)
 
@@ -320,16 +331,29 @@ def cpu_baseline(workload, target_s):
 
     one, n1, t1 = measure(1, min(target_s, 4.0))
     allc, na, ta = measure(all_threads, target_s)
+    res = {"value": allc, "unit": UNIT[workload], "cores": all_threads, "threads": all_threads, "effective_cpus": effective, "kind": "port",
+           "single_thread": {"value": one, "sample_units": n1, "seconds": t1},
+           "all_cores": {"value": allc, "threads": all_threads, "sample_units": na, "seconds": ta, "speedup_over_one_thread": allc / one},
+           "cpu": info,
+           "sample": "%d units (%d threads) / %d units (one thread) of the same synthetic workload, reference algorithm (exact 252-step ladder / "
+                     "per-point decode), oracle/jubjub_oracle.c -O3 + OpenMP" % (na, all_threads, n1),
+           "note": "threads = cores = the CPUs this process can really use: min(affinity mask, cgroup CPU quota), NOT the logical CPUs the box "
+                   "shows (`cpu.logical_cpus`); the rate is this container's, not the whole host's"}
+    if workload == "msm":
+        # the bucket method on the CPU beside the naive fold of ladders (the reference's own semantics, lib.rs:183-193)
+        workload = "msm_pippenger"
+        omp.omp_set_num_threads(all_threads)
+        n = 1 << 20
+        s = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+        s[:, 31] &= 0x0F
+        small = O.fixedbase_mul(s[:4096][::-1].copy(), base)
+        pts = np.ascontiguousarray(small[np.arange(n) % 4096])           # 2^20 terms over 4096 distinct points: the bucket method does not care
+        t0 = time.perf_counter(); O.msm_pippenger(s, pts, 13); tp = time.perf_counter() - t0
+        res["pippenger"] = {"value": n / tp, "unit": "terms/s", "threads": all_threads, "terms": n, "seconds": tp, "window_bits": 13,
+                            "note": "oracle/jubjub_oracle.c jjo_msm_pippenger: unsigned 13-bit windows, one bucket array per window, windows in parallel; "
+                                    "the reference itself has no MSM algorithm (its Sum is the fold measured as `value`)"}
     omp.omp_set_num_threads(all_threads)
-    info = cpu_info()
-    return {"value": allc, "unit": UNIT[workload], "cores": all_threads, "kind": "port",
-            "single_thread": {"value": one, "sample_units": n1, "seconds": t1},
-            "all_cores": {"value": allc, "threads": all_threads, "sample_units": na, "seconds": ta, "speedup_over_one_thread": allc / one},
-            "cpu": info,
-            "sample": "%d units (all cores) / %d units (one thread) of the same synthetic workload, reference algorithm (exact 252-step ladder / "
-                      "per-point decode), oracle/jubjub_oracle.c -O3 + OpenMP" % (na, n1),
-            "note": "OpenMP threads = omp_get_max_threads(); the speed-up over one thread is bounded by the physical cores / the container's CPU "
-                    "quota behind the logical CPUs listed in `cpu`"}
+    return res
 
 
 # ------------------------------------------------------------------------------------------------ one rank
@@ -407,6 +431,12 @@ def run(a):
                     enc[gidx - lo] = inj[k]
         points = None
 
+    rccl_comm = None
+    if wl == "msm" and distributed and a.backend == "nccl" and a.msm_exchange == "c":
+        from jubjub_amd.dist import RcclComm
+
+        rccl_comm = RcclComm(rank, world)          # this process's own communicator; the ncclUniqueId travels over torch.distributed
+        eng.set_comm(rccl_comm)
     host = a.host_buffers
     if host and (wl == "msm" or distributed):
         if rank == 0:
@@ -449,6 +479,9 @@ def run(a):
             return one_pass_device()
         if not distributed:
             return eng.msm(scalars, points)
+        if rccl_comm is not None:
+            # the whole exchange behind ONE C-ABI call: record -> ncclAllGather (RCCL over xGMI) -> one D2H -> one host tail
+            return eng.msm_allgather(scalars, points, "window" if by_window else "terms")
         # every rank: its record of window sums (8 KB, stays on the device), all_gather, ONE copy to the host, ONE host tail
         rec = eng.msm_partial(scalars, points, rank, world) if by_window else eng.msm_partial(scalars, points)
         if a.backend == "nccl":
@@ -517,19 +550,28 @@ def run(a):
 
     for _ in range(a.warmup):
         step()
+    peak_before = eng.peak_imad32_samples(5) if rank == 0 else None     # the roofline denominator, sampled on both sides of the timed region
     barrier()
     eng.profile(True)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = step()
+    t_own = time.perf_counter() - t0                                    # this rank's own loop, before it waits for the others
     barrier()
     dt = time.perf_counter() - t0
     main_ms, tail_ms = eng.profile_read()
     eng.profile(False)
+    peak_after = eng.peak_imad32_samples(5) if rank == 0 else None
+    rank_ms = [t_own / a.steps * 1e3]
     if distributed:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
+        tcpu = "cpu" if a.backend != "nccl" else dev
+        tmax = torch.tensor([dt], dtype=torch.float64, device=tcpu)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        mine = torch.tensor([t_own / a.steps * 1e3], dtype=torch.float64, device=tcpu)
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_ms = [float(t.item()) for t in every]
 
     # a second, untimed pass over the same inputs on EVERY rank (the MSM's pass holds a collective): rank 0 compares all its units
     # with the timed output below
@@ -570,8 +612,10 @@ def run(a):
             "units_per_step": units_per_step, "passes_per_step": passes, "ms_per_pass": dt / a.steps / passes * 1e3,
             "scalars": "jj_synth_scalars: canonical Fr from splitmix64(seed + 4 i + j)", "points": "jj_random_points: Group::random rejection sampling (full group, order 8r), affine 64 B",
             "parallelism": ("window partition: rank g owns windows g, g + G, ... of all terms" if by_window else "contiguous shards, one process per GPU") +
-                           ("; all_gather of one 8 KB record of window sums per rank (%s), one host tail" % a.backend if wl == "msm" else "; no data-path collective")},
+                           ("; all_gather of one 8 KB record of window sums per rank (%s%s), one host tail" % (a.backend, ", behind the C ABI: jj_msm_allgather on this process's own RCCL communicator" if rccl_comm is not None else "") if wl == "msm" else "; no data-path collective")},
         "rccl_world_size": dist.get_world_size() if distributed else 1,
+        # each rank's own time per step before the closing barrier (ms_per_step is the max over ranks, barrier included): stragglers show here
+        "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "per_rank": rank_ms},
     }
     if host:
         res["pcie_inclusive"] = True
@@ -608,7 +652,8 @@ def run(a):
             tail = sum(tail_ms) / len(tail_ms)
         else:                                                       # workloads without the event hooks: whole pass
             kern_ms, tail = dt / a.steps / passes * 1e3, 0.0
-        peak = eng.peak_imad32()
+        samples = sorted(peak_before + peak_after)
+        peak = samples[len(samples) // 2]                       # median of the 10 samples taken before and after the timed region
         work_main = imad32(w["S"], w["M"])
         achieved = n * work_main / (kern_ms * 1e-3)
         traffic, traffic_note = traffic_record(wl, log2n)
@@ -616,6 +661,12 @@ def run(a):
         res["roofline"] = {
             "bound": "valu_int32", "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TIMAD32/s",
             "frac": achieved / peak,
+            # the denominator: median of 5 + 5 single measurements (before / after the timed region) and their spread; frac_nominal uses the
+            # data-sheet ceiling instead (1024 SIMDs x 16 lanes x 2.4 GHz), which no sustained integer load reaches on this part
+            "peak_samples": {"before": [x / 1e12 for x in peak_before], "after": [x / 1e12 for x in peak_after], "median": peak / 1e12,
+                             "min": samples[0] / 1e12, "max": samples[-1] / 1e12, "spread": (samples[-1] - samples[0]) / peak},
+            "frac_at_peak_max": achieved / samples[-1], "frac_at_peak_min": achieved / samples[0],
+            "peak_nominal": NOMINAL_PEAK_IMAD32 / 1e12, "frac_nominal": achieved / NOMINAL_PEAK_IMAD32,
             "frac_min": (n * work_main / (min(main_ms) * 1e-3) / peak) if main_ms and len(msm_engs) == 1 else None,     # the fastest dispatch of the timed region
             # multiply-adds actually issued by the signed 9x29-bit representation (153 per mul, 117 per square) / measured peak
             "mad_issue_frac": n * (153 * w["M"] + 117 * w["S"]) / (kern_ms * 1e-3) / peak,
@@ -658,6 +709,14 @@ def run(a):
                 res["verified_note"] = "rank 0's shard vs the oracle (the all-rank sum is checked by tests/test_gpu_dist.py)"
             okv, cnt = verify_sample(wl, a, lo, n, o, k, (scalars, points))
             res["verified"], res["verified_units"] = okv, cnt
+            if wl != "msm":
+                # one CONTIGUOUS block of 2^14 units (256 whole waves) recomputed by the oracle as well: a defect tied to a lane, wave or
+                # workgroup position that a stride-1024 sample can step over shows here
+                bn = min(n, 1 << BLOCK_LOG2)
+                b0 = ((n // 2) // bn) * bn if n >= 2 * bn else 0
+                okb, cntb = verify_sample(wl, a, lo, n, o, k, None, idx=range(b0, b0 + bn))
+                res["verified_block"] = {"ok": okb, "first_unit": lo + b0, "units": cntb}
+                okv = okv and okb
             # every unit of the timed output against a fresh pass over the same inputs, compared on the device (the oracle sample
             # above checks one unit in 2^10; this ties all the others to a second, independent run)
             o2v, k2 = (out2 if isinstance(out2, tuple) else (out2, None))
@@ -735,6 +794,9 @@ def run(a):
             res["cpu_baseline"] = cpu_baseline(wl, a.cpu_seconds)
         print(json.dumps(res))
         sys.stdout.flush()
+    if rccl_comm is not None:
+        eng.set_comm(None)
+        rccl_comm.close()
     table.close()
     for e in msm_engs[1:]:
         e.close()

@@ -66,7 +66,10 @@ int jj_ctx_profile(jj_ctx* ctx, int enable);
 int jj_ctx_profile_read(jj_ctx* ctx, int max, float* main_ms, float* tail_ms, int* count);
 /* Integer-VALU roofline denominator, measured on this device: sustained v_mad_u64_u32 (32x32+64 -> 64 multiply-
  * accumulate) lane-operations per second. */
-int jj_peak_imad32(jj_ctx* ctx, double* out_per_sec);
+int jj_peak_imad32(jj_ctx* ctx, double* out_per_sec);                            /* median of five samples */
+/* `count` (1..64) single timed launches after one warm-up launch, in launch order: the sustained clock moves by a few percent within a
+ * session, so report median and spread (bench.py samples before and after its workload). */
+int jj_peak_imad32_samples(jj_ctx* ctx, int count, double* out_per_sec);
 
 /* ---- host buffers ---------------------------------------------------------------------------------------------------------
  * A drop-in caller (the Rust shim of INTEGRATION.md, examples/scalar_mul.c) hands HOST arrays to the entry points below.  Large

@@ -53,6 +53,7 @@ _SIGS.update({
     "jj_ctx_profile": [C.c_int],
     "jj_ctx_profile_read": [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)],
     "jj_peak_imad32": [C.POINTER(C.c_double)],
+    "jj_peak_imad32_samples": [C.c_int, C.POINTER(C.c_double)],
     "jj_fq_to_le_bits": [_sz, _vp, _vp],
     "jj_fr_to_le_bits": [_sz, _vp, _vp],
     "jj_synth_scalars": [_sz, C.c_uint64, C.c_uint64, _vp],

@@ -37,6 +37,7 @@ struct jj_table {
   jj_table() { memset(&fx, 0, sizeof fx); }
 };
 
+struct WorkSet { DevBuf ext, scratch, tables, cursor; };
 struct jj_ctx;
 // One MSM pipeline of a context: its own workspaces, and for lanes >= 1 its own streams.  Lane 0 runs on the context's launch
 // stream (jj_msm, host-array jobs); device-pointer jobs of jj_msm_begin alternate over the lanes, so that the dependent chains at
@@ -69,7 +70,12 @@ struct jj_ctx {
   int cus = 0, clock_khz = 0, wave = 64;
   std::string err;
   // staging for host-pointer arguments (inputs 0..3, outputs 0..1) and kernel workspaces
-  DevBuf in[4], out[2], okb, ws_ext, ws_scratch, ws_tables, ws_tmp[4], sqrt_tabs, cursor;      // (the workspaces of the MSM live in its lanes)
+  DevBuf in[4], out[2], okb, ws_tmp[4], sqrt_tabs;      // (the workspaces of the MSM live in its lanes)
+  // kernel workspaces of the batch entry points: extended SoA, normalisation scratch, var-base window tables, the waves' work cursor.
+  // Every launch helper goes through `ws`; the host-buffer pipeline points it at the set of the chunk's slot (its two slots run on
+  // their own compute streams, so that the kernels of neighbouring chunks overlap), everything else uses ws0.
+  WorkSet ws0;
+  WorkSet* ws = &ws0;
   SqrtTables sqrt_tables{nullptr, nullptr};
   int msm_segments = -1;         // bucket accumulation: 1 = length-sorted segments, 0 = fixed chunks + fix-up, -1 = segments from MSM_LARGE_MIN (147 456) terms
                                  // (2-4 % faster there, slower below: more launches) (JJ_MSM_ACCUM=segments|chunks)
@@ -81,11 +87,18 @@ struct jj_ctx {
   // optional per-call kernel timing (HIP events on the launch stream): e0 | main kernel | e1 | normalise tail | e2
   // pipelined host-buffer path: copy streams + two device slots (caller buffers are page-locked in place)
   struct Pipe {
-    hipStream_t h2d = nullptr, d2h = nullptr;
-    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+    hipStream_t h2d = nullptr, d2h = nullptr, cs[2] = {nullptr, nullptr};   // copy streams; one compute stream per slot
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr}, ev_start = nullptr;
     DevBuf din[2], dout[2];
+    WorkSet wset;                          // kernel workspaces of slot 1 (slot 0 uses the context's ws0)
     bool ready = false;
   } pipe;
+  int dec_c_mid = 8;                     // decoder, batches of 2^20 .. 2^21 - 1 encodings (the host pipeline's chunk): encodings per lane of the shared inversion.  8 = two waves
+                                         // per SIMD: 444 M/s against 431 with 16 (one wave per SIMD) and 396 with 4 (profiles/r4_pcie_inclusive.txt); JJ_DEC_C_MID = 8 | 16.
+                                         // (The normalisation kernel stays at 16 there: 8 and 4 measured slower, same file.)
+  bool pipe_two_streams = false;         // JJ_PIPE_STREAMS=2: the chunks of the two slots on two compute streams with their own workspaces.  Measured (profiles/
+                                         // r4_pcie_inclusive.txt): 1.7x SLOWER for the fixed-base and decoder pipelines (2^24 units 31.4 -> 53.6 ms) -- kernels of two
+                                         // streams that each fill the CUs time-share them instead of overlapping; kept as an experiment knob only
   size_t pipe_chunk = 0;                 // elements per pipeline chunk: 0 = per entry point (pipe_chunk_for), else JJ_PIPE_CHUNK_LOG2
   // MSM jobs (jj_msm_begin / jj_msm_finish): free list of page-locked record buffers + events
   std::vector<jj_msm_job*> job_pool;
@@ -213,7 +226,9 @@ static int pipe_prepare(jj_ctx* c, size_t in_bytes, size_t out_bytes) {
   if (!P.ready) {
     HIPCHK(c, hipStreamCreateWithFlags(&P.h2d, hipStreamNonBlocking));
     HIPCHK(c, hipStreamCreateWithFlags(&P.d2h, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&P.ev_start, hipEventDisableTiming));
     for (int i = 0; i < 2; i++) {
+      HIPCHK(c, hipStreamCreateWithFlags(&P.cs[i], hipStreamNonBlocking));
       HIPCHK(c, hipEventCreateWithFlags(&P.ev_in[i], hipEventDisableTiming));
       HIPCHK(c, hipEventCreateWithFlags(&P.ev_done[i], hipEventDisableTiming));
       HIPCHK(c, hipEventCreateWithFlags(&P.ev_out[i], hipEventDisableTiming));
@@ -277,10 +292,18 @@ static int run_pipelined(jj_ctx* c, size_t n, size_t CH, const HostIn (&in)[NIN]
   clock_gettime(CLOCK_MONOTONIC, &ts1);
   jj_ctx::Pipe& P = c->pipe;
   hipStream_t saved = c->stream;
-  if ((rc = switch_stream(c, c->own_stream))) { unlock(); return rc; }
+  // One compute stream for all chunks (default).  JJ_PIPE_STREAMS=2: the chunks of slot s run on compute stream cs[s] with the
+  // workspaces of slot s, meant to overlap the short normalisation of chunk k with the ladder of chunk k + 1 -- measured 1.7x slower
+  // (see pipe_two_streams).  The compute streams start after the work already queued on the context's launch stream.
+  const bool two = c->pipe_two_streams;
+  hipStream_t cs[2] = {two ? P.cs[0] : c->own_stream, two ? P.cs[1] : c->own_stream};
+  WorkSet* wsets[2] = {&c->ws0, two ? &P.wset : &c->ws0};
   const size_t nchunks = (n + CH - 1) / CH;
   rc = JJ_OK;
   #define PIPE_CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { c->err = std::string(#call) + " failed: " + hipGetErrorString(e_); rc = JJ_ERR_HIP; goto done; } } while (0)
+  PIPE_CHK(hipEventRecord(P.ev_start, saved));
+  PIPE_CHK(hipStreamWaitEvent(cs[0], P.ev_start, 0));
+  if (cs[1] != cs[0]) PIPE_CHK(hipStreamWaitEvent(cs[1], P.ev_start, 0));
   for (size_t k = 0; k < nchunks; k++) {
     const int s = (int)(k & 1); const size_t lo = k * CH, cn = std::min(CH, n - lo);
     const void* din[NIN]; void* dout[NOUT];
@@ -292,6 +315,7 @@ static int run_pipelined(jj_ctx* c, size_t n, size_t CH, const HostIn (&in)[NIN]
       off += CH * in[j].elem;
     }
     PIPE_CHK(hipEventRecord(P.ev_in[s], P.h2d));
+    c->stream = cs[s]; c->ws = wsets[s];
     PIPE_CHK(hipStreamWaitEvent(c->stream, P.ev_in[s], 0));
     if (k >= 2) PIPE_CHK(hipStreamWaitEvent(c->stream, P.ev_out[s], 0));         // slot's previous results have left dout[s]
     off = 0;
@@ -312,12 +336,14 @@ static int run_pipelined(jj_ctx* c, size_t n, size_t CH, const HostIn (&in)[NIN]
   clock_gettime(CLOCK_MONOTONIC, &ts3);
   if (dbg) {
     auto ms = [](const timespec& a, const timespec& b) { return (b.tv_sec - a.tv_sec) * 1e3 + (b.tv_nsec - a.tv_nsec) * 1e-6; };
-    fprintf(stderr, "[jj pipe] n=%zu chunks=%zu register %.2f ms, enqueue %.2f ms, drain %.2f ms\n", n, nchunks, ms(ts0, ts1), ms(ts1, ts2), ms(ts2, ts3));
+    fprintf(stderr, "[jj pipe] n=%zu chunk=%zu chunks=%zu compute streams=%d register %.2f ms, enqueue %.2f ms, drain %.2f ms\n", n, CH, nchunks, two ? 2 : 1, ms(ts0, ts1), ms(ts1, ts2), ms(ts2, ts3));
   }
 done:
   #undef PIPE_CHK
-  if (rc != JJ_OK) { (void)hipStreamSynchronize(P.h2d); (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(P.d2h); }
-  { const int rc2 = switch_stream(c, saved); if (rc == JJ_OK) rc = rc2; }
+  if (rc != JJ_OK) { (void)hipStreamSynchronize(P.h2d); (void)hipStreamSynchronize(cs[0]); (void)hipStreamSynchronize(cs[1]); (void)hipStreamSynchronize(P.d2h); }
+  // every chunk's kernels finished before its copy out did, and all copies were waited for (or, on error, every stream was drained):
+  // nothing of this call is in flight any more, the context returns to the stream and workspaces it came with
+  c->stream = saved; c->ws = &c->ws0;
   unlock();
   return rc;
 }
@@ -391,6 +417,8 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(JJ_ERR_HIP);
   if (hipEventCreateWithFlags(&c->order_ev, hipEventDisableTiming) != hipSuccess) return fail(JJ_ERR_HIP);
   c->stream = c->own_stream;
+  if (const char* e = getenv("JJ_DEC_C_MID")) { int v = atoi(e); if (v == 8 || v == 16) c->dec_c_mid = v; }
+  if (const char* e = getenv("JJ_PIPE_STREAMS")) c->pipe_two_streams = atoi(e) == 2;
   if (const char* e = getenv("JJ_PIPE_CHUNK_LOG2")) { int v = atoi(e); if (v >= 8 && v <= 24) c->pipe_chunk = (size_t)1 << v; }   // overrides the per-entry-point chunk
   if (const char* e = getenv("JJ_MSM_WINDOWS")) { int v = atoi(e); if (v >= MSM_WINDOWS_MIN && v <= MSM_WINDOWS_MAX) c->msm_windows = v; else fprintf(stderr, "libjubjub_hip: JJ_MSM_WINDOWS=%s ignored (valid: %d..%d)\n", e, MSM_WINDOWS_MIN, MSM_WINDOWS_MAX); }
   if (const char* e = getenv("JJ_MSM_LANES")) { int v = atoi(e); if (v >= 1 && v <= MSM_LANES_MAX) c->msm_lanes = v; }
@@ -431,8 +459,9 @@ JJ_API int jj_ctx_destroy(jj_ctx* c) {
   if (!c) return JJ_ERR_INVALID;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  DevBuf* all[] = {&c->in[0], &c->in[1], &c->in[2], &c->in[3], &c->out[0], &c->out[1], &c->okb, &c->ws_ext, &c->ws_scratch, &c->ws_tables,
-                   &c->ws_tmp[0], &c->ws_tmp[1], &c->ws_tmp[2], &c->ws_tmp[3], &c->sqrt_tabs, &c->cursor};
+  DevBuf* all[] = {&c->in[0], &c->in[1], &c->in[2], &c->in[3], &c->out[0], &c->out[1], &c->okb, &c->ws0.ext, &c->ws0.scratch, &c->ws0.tables,
+                   &c->ws_tmp[0], &c->ws_tmp[1], &c->ws_tmp[2], &c->ws_tmp[3], &c->sqrt_tabs, &c->ws0.cursor,
+                   &c->pipe.wset.ext, &c->pipe.wset.scratch, &c->pipe.wset.tables, &c->pipe.wset.cursor};
   for (jj_msm_job* j : c->job_pool) { if (j->host) (void)hipHostFree(j->host); (void)hipEventDestroy(j->ev); delete j; }
   for (MsmLane& L : c->lanes) {
     if (L.owned) (void)hipStreamSynchronize(L.stream);
@@ -452,7 +481,8 @@ JJ_API int jj_ctx_destroy(jj_ctx* c) {
       if (c->pipe.din[i].p) (void)hipFree(c->pipe.din[i].p);
       if (c->pipe.dout[i].p) (void)hipFree(c->pipe.dout[i].p);
     }
-    (void)hipStreamDestroy(c->pipe.h2d); (void)hipStreamDestroy(c->pipe.d2h);
+    (void)hipEventDestroy(c->pipe.ev_start);
+    (void)hipStreamDestroy(c->pipe.h2d); (void)hipStreamDestroy(c->pipe.d2h); (void)hipStreamDestroy(c->pipe.cs[0]); (void)hipStreamDestroy(c->pipe.cs[1]);
   }
   for (auto& r : c->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); (void)hipEventDestroy(r.e2); }
   if (c->order_ev) (void)hipEventDestroy(c->order_ev);
@@ -524,27 +554,36 @@ JJ_API int jj_ctx_profile_read(jj_ctx* c, int max, float* main_ms, float* tail_m
   return JJ_OK;
 }
 // Measured integer-VALU roofline denominator: sustained v_mad_u64_u32 lane-operations per second on this device.
-JJ_API int jj_peak_imad32(jj_ctx* c, double* out_per_sec) {
-  if (!c || !out_per_sec) return JJ_ERR_INVALID;
+// `count` timed launches after one warm-up launch, each ~1.5 ms of 8 independent multiply-add chains per lane on every SIMD; the
+// clock the part sustains moves by a few percent with temperature and with what ran just before, so callers report the median with
+// its spread (bench.py: before and after the workload) instead of one best value.
+JJ_API int jj_peak_imad32_samples(jj_ctx* c, int count, double* out_per_sec) {
+  if (!c || !out_per_sec || count < 1 || count > 64) return JJ_ERR_INVALID;
   JJ_ENTER(c);
   int rc = ensure(c, c->ws_tmp[0], (size_t)c->cus * 8 * 256 * 4); if (rc) return rc;
   const int iters = 4000, blocks = c->cus * 8;
   hipEvent_t e0, e1;
   HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
-  double best = 0;
-  for (int rep = 0; rep < 3; rep++) {
-    hipLaunchKernelGGL(k_peak_mad, dim3(blocks), dim3(256), 0, c->stream, (u32*)c->ws_tmp[0].p, rep == 0 ? 50 : iters, 12345u);
-    if (rep == 0) continue;
+  hipLaunchKernelGGL(k_peak_mad, dim3(blocks), dim3(256), 0, c->stream, (u32*)c->ws_tmp[0].p, iters, 12345u);     // warm-up: clocks ramp
+  for (int rep = 0; rep < count; rep++) {
     HIPCHK(c, hipEventRecord(e0, c->stream));
     hipLaunchKernelGGL(k_peak_mad, dim3(blocks), dim3(256), 0, c->stream, (u32*)c->ws_tmp[0].p, iters, 12345u);
     HIPCHK(c, hipEventRecord(e1, c->stream));
     HIPCHK(c, hipEventSynchronize(e1));
     float ms = 0; HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
     const double ops = (double)iters * 64.0 /* mads per iteration */ * 256.0 * blocks;
-    best = std::max(best, ops / (ms * 1e-3));
+    out_per_sec[rep] = ops / (ms * 1e-3);
   }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  *out_per_sec = best;
+  return JJ_OK;
+}
+// the median of five samples
+JJ_API int jj_peak_imad32(jj_ctx* c, double* out_per_sec) {
+  if (!c || !out_per_sec) return JJ_ERR_INVALID;
+  double v[5];
+  const int rc = jj_peak_imad32_samples(c, 5, v); if (rc) return rc;
+  std::sort(v, v + 5);
+  *out_per_sec = v[2];
   return JJ_OK;
 }
 
@@ -619,13 +658,13 @@ JJ_API int jj_fr_char_le_bits(uint8_t out256[256]) {
 
 // ---------------------------------------------------------------------------------------------------- normalisation
 static SoA soa_of(DevBuf& b, size_t n) { SoA s; s.base = (u32*)b.p; s.n = n; return s; }
-static int ensure_ext(jj_ctx* c, size_t n, int coords) { return ensure(c, c->ws_ext, (size_t)coords * NL * 4 * std::max(n, (size_t)1)); }
+static int ensure_ext(jj_ctx* c, size_t n, int coords) { return ensure(c, c->ws->ext, (size_t)coords * NL * 4 * std::max(n, (size_t)1)); }
 
 // ext SoA (coords 0..2) -> affine 64 B (mode 0) or compressed 32 B (mode 1) at device pointer dout
 static int normalize_launch(jj_ctx* c, size_t n, SoA ext, void* dout, int mode) {
   if (!n) return JJ_OK;
-  int rc = ensure(c, c->ws_scratch, (size_t)NL * 4 * n); if (rc) return rc;
-  SoA scratch = soa_of(c->ws_scratch, n);
+  int rc = ensure(c, c->ws->scratch, (size_t)NL * 4 * n); if (rc) return rc;
+  SoA scratch = soa_of(c->ws->scratch, n);
   // chunk length: amortise the ~330-multiplication inversion, but keep >= ~8 waves per CU in flight (and two rounds of them: a 64-point
   // chunk at 2^23 units loses more to the single-round tail than the shared inversion returns, measured on the decoder)
   const size_t lanes_wanted = (size_t)c->cus * 64 * 8;
@@ -648,7 +687,7 @@ static int point_op(jj_ctx* c, size_t n, const void* p, const void* q, void* out
   OutRef o;
   if ((rc = stage_out(c, c->out[0], out, out_elem * n, &o))) return rc;
   if ((rc = ensure_ext(c, n, 3))) return rc;
-  SoA ext = soa_of(c->ws_ext, n);
+  SoA ext = soa_of(c->ws->ext, n);
   if (n) {
     hipLaunchKernelGGL((k_point_op<OP>), dim3(blocks_for(n)), dim3(256), 0, c->stream, n, dp, dq, ext, o.dev);
     if (OP <= PT_COFACTOR && (rc = normalize_launch(c, n, ext, o.dev, 0))) return rc;
@@ -677,19 +716,19 @@ static void varbase_geometry(jj_ctx* c, size_t n, unsigned* blocks, size_t* thre
 }
 static int varbase_to_ext(jj_ctx* c, size_t n, const void* ds, const void* dp, SoA ext, bool five, bool shared_scalar = false) {
   if (n <= (size_t)c->vb_quad_max && !shared_scalar) {      // small batch: one scalar multiplication per quad of lanes (3x lower latency)
-    int rc = ensure(c, c->ws_tables, n * (size_t)(VB_SLOTS * ENIELS_WORDS) * 4); if (rc) return rc;
-    if (five) hipLaunchKernelGGL(k_varbase_quad<true>, dim3(blocks_for(4 * n)), dim3(256), 0, c->stream, n, ds, dp, (u32*)c->ws_tables.p, ext);
-    else hipLaunchKernelGGL(k_varbase_quad<false>, dim3(blocks_for(4 * n)), dim3(256), 0, c->stream, n, ds, dp, (u32*)c->ws_tables.p, ext);
+    int rc = ensure(c, c->ws->tables, n * (size_t)(VB_SLOTS * ENIELS_WORDS) * 4); if (rc) return rc;
+    if (five) hipLaunchKernelGGL(k_varbase_quad<true>, dim3(blocks_for(4 * n)), dim3(256), 0, c->stream, n, ds, dp, (u32*)c->ws->tables.p, ext);
+    else hipLaunchKernelGGL(k_varbase_quad<false>, dim3(blocks_for(4 * n)), dim3(256), 0, c->stream, n, ds, dp, (u32*)c->ws->tables.p, ext);
     return JJ_OK;
   }
   unsigned blocks; size_t threads;
   varbase_geometry(c, n, &blocks, &threads);
-  int rc = ensure(c, c->ws_tables, threads * (size_t)(VB_SLOTS * ENIELS_WORDS) * 4); if (rc) return rc;
-  if ((rc = ensure(c, c->cursor, 64))) return rc;
-  HIPCHK(c, hipMemsetAsync(c->cursor.p, 0, 8, c->stream));          // the waves' work cursor
-  if (shared_scalar) hipLaunchKernelGGL((k_varbase<false, true>), dim3(blocks), dim3(256), 0, c->stream, n, ds, dp, (u32*)c->ws_tables.p, ext, (unsigned long long*)c->cursor.p);
-  else if (five) hipLaunchKernelGGL((k_varbase<true, false>), dim3(blocks), dim3(256), 0, c->stream, n, ds, dp, (u32*)c->ws_tables.p, ext, (unsigned long long*)c->cursor.p);
-  else hipLaunchKernelGGL((k_varbase<false, false>), dim3(blocks), dim3(256), 0, c->stream, n, ds, dp, (u32*)c->ws_tables.p, ext, (unsigned long long*)c->cursor.p);
+  int rc = ensure(c, c->ws->tables, threads * (size_t)(VB_SLOTS * ENIELS_WORDS) * 4); if (rc) return rc;
+  if ((rc = ensure(c, c->ws->cursor, 64))) return rc;
+  HIPCHK(c, hipMemsetAsync(c->ws->cursor.p, 0, 8, c->stream));          // the waves' work cursor
+  if (shared_scalar) hipLaunchKernelGGL((k_varbase<false, true>), dim3(blocks), dim3(256), 0, c->stream, n, ds, dp, (u32*)c->ws->tables.p, ext, (unsigned long long*)c->ws->cursor.p);
+  else if (five) hipLaunchKernelGGL((k_varbase<true, false>), dim3(blocks), dim3(256), 0, c->stream, n, ds, dp, (u32*)c->ws->tables.p, ext, (unsigned long long*)c->ws->cursor.p);
+  else hipLaunchKernelGGL((k_varbase<false, false>), dim3(blocks), dim3(256), 0, c->stream, n, ds, dp, (u32*)c->ws->tables.p, ext, (unsigned long long*)c->ws->cursor.p);
   return JJ_OK;
 }
 static int varbase_api(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out, int mode) {
@@ -701,7 +740,7 @@ static int varbase_api(jj_ctx* c, size_t n, const void* scalars, const void* poi
     const int prc = run_pipelined(c, n, ch, in, ho, [&](size_t cn, const void* const* di, void* const* dout) -> int {
       int rc2;
       if ((rc2 = ensure_ext(c, cn, 3))) return rc2;
-      SoA ext = soa_of(c->ws_ext, cn);
+      SoA ext = soa_of(c->ws->ext, cn);
       if ((rc2 = varbase_to_ext(c, cn, di[0], di[1], ext, false))) return rc2;
       return normalize_launch(c, cn, ext, dout[0], mode);
     });
@@ -712,7 +751,7 @@ static int varbase_api(jj_ctx* c, size_t n, const void* scalars, const void* poi
   if ((rc = stage_in(c, 1, points, 64 * n, &dp))) return rc;
   if ((rc = stage_out(c, c->out[0], out, (mode ? 32 : 64) * n, &o))) return rc;
   if ((rc = ensure_ext(c, n, 3))) return rc;
-  SoA ext = soa_of(c->ws_ext, n);
+  SoA ext = soa_of(c->ws->ext, n);
   if (n) {
     prof_mark(c, 0);
     if ((rc = varbase_to_ext(c, n, ds, dp, ext, false))) return rc;
@@ -738,7 +777,7 @@ JJ_API int jj_varbase_mul_scalar(jj_ctx* c, size_t n, const void* scalar32, cons
   if ((rc = ensure(c, c->ws_tmp[1], 32))) return rc;
   HIPCHK(c, hipMemcpyAsync(c->ws_tmp[1].p, scalar32, 32, is_device_ptr(scalar32) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
   if ((rc = ensure_ext(c, n, 3))) return rc;
-  SoA ext = soa_of(c->ws_ext, n);
+  SoA ext = soa_of(c->ws->ext, n);
   if (n) {
     if (n <= (size_t)c->vb_quad_max) {
       if ((rc = ensure(c, c->ws_tmp[0], 32 * n))) return rc;
@@ -760,7 +799,7 @@ JJ_API int jj_varbase_mul_ct(jj_ctx* c, size_t n, const void* scalars, const voi
   if ((rc = stage_in(c, 1, points, 64 * n, &dp))) return rc;
   if ((rc = stage_out(c, c->out[0], out, 64 * n, &o))) return rc;
   if ((rc = ensure_ext(c, n, 3))) return rc;
-  SoA ext = soa_of(c->ws_ext, n);
+  SoA ext = soa_of(c->ws->ext, n);
   if (n) {
     prof_mark(c, 0);
     hipLaunchKernelGGL(k_varbase_ct, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, ds, dp, ext);
@@ -798,7 +837,7 @@ static int torsion_free_dev(jj_ctx* c, size_t n, const void* dpts, uint8_t* dok,
   HIPCHK(c, hipMemcpyAsync(c->ws_tmp[1].p, FR_MODULUS_BYTES, 32, hipMemcpyHostToDevice, c->stream));
   hipLaunchKernelGGL(k_fill_scalar, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, c->ws_tmp[0].p, (const uint8_t*)c->ws_tmp[1].p);
   if ((rc = ensure_ext(c, n, 3))) return rc;
-  SoA ext = soa_of(c->ws_ext, n);
+  SoA ext = soa_of(c->ws->ext, n);
   if ((rc = varbase_to_ext(c, n, c->ws_tmp[0].p, dpts, ext, false))) return rc;
   hipLaunchKernelGGL(k_is_identity_ext, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, ext, dok, combine);
   return JJ_OK;
@@ -814,7 +853,7 @@ static int torsion_pred(jj_ctx* c, size_t n, const void* p, uint8_t* out, bool p
     if (prime_order) {   // & !is_identity  (reference src/lib.rs:717-719)
       if ((rc = ensure(c, c->ws_tmp[2], n))) return rc;
       if ((rc = ensure_ext(c, n, 3))) return rc;
-      hipLaunchKernelGGL((k_point_op<PT_IS_IDENTITY>), dim3(blocks_for(n)), dim3(256), 0, c->stream, n, dp, (const void*)nullptr, soa_of(c->ws_ext, n), c->ws_tmp[2].p);
+      hipLaunchKernelGGL((k_point_op<PT_IS_IDENTITY>), dim3(blocks_for(n)), dim3(256), 0, c->stream, n, dp, (const void*)nullptr, soa_of(c->ws->ext, n), c->ws_tmp[2].p);
       hipLaunchKernelGGL(k_and_bytes, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, (uint8_t*)o.dev, (const uint8_t*)c->ws_tmp[2].p, 1);
     }
   }
@@ -963,7 +1002,7 @@ static int fixedbase_api(jj_ctx* c, const jj_table* t, size_t n, const void* sca
     const int prc = run_pipelined(c, n, ch, in, ho, [&](size_t cn, const void* const* di, void* const* dout) -> int {
       int rc2;
       if ((rc2 = ensure_ext(c, cn, 3))) return rc2;
-      SoA ext = soa_of(c->ws_ext, cn);
+      SoA ext = soa_of(c->ws->ext, cn);
       if ((rc2 = fixedbase_launch(c, t, cn, di[0], ext))) return rc2;
       return normalize_launch(c, cn, ext, dout[0], mode);
     });
@@ -973,7 +1012,7 @@ static int fixedbase_api(jj_ctx* c, const jj_table* t, size_t n, const void* sca
   if ((rc = stage_in(c, 0, scalars, 32 * n, &ds))) return rc;
   if ((rc = stage_out(c, c->out[0], out, (mode ? 32 : 64) * n, &o))) return rc;
   if ((rc = ensure_ext(c, n, 3))) return rc;
-  SoA ext = soa_of(c->ws_ext, n);
+  SoA ext = soa_of(c->ws->ext, n);
   if (n) {
     prof_mark(c, 0);
     if ((rc = fixedbase_launch(c, t, n, ds, ext))) return rc;
@@ -997,7 +1036,7 @@ JJ_API int jj_fixedbase_multi_mul(jj_ctx* c, const jj_table* const* tables, int 
   if ((rc = stage_in(c, 0, scalars, 32 * n * (size_t)nbases, &ds))) return rc;
   if ((rc = stage_out(c, c->out[0], out64, 64 * n, &o))) return rc;
   if ((rc = ensure_ext(c, n, 5))) return rc;
-  SoA ext = soa_of(c->ws_ext, n);
+  SoA ext = soa_of(c->ws->ext, n);
   if (n) {
     prof_mark(c, 0);
     for (int j = 0; j < nbases; j++) {
@@ -1064,7 +1103,7 @@ JJ_API int jj_fixedbase_composite_mul(jj_ctx* c, const jj_table* t, size_t n, co
   if ((rc = stage_out(c, c->out[0], out64, 64 * n, &o))) return rc;
   if ((rc = ensure_ext(c, n, 3))) return rc;
   if ((rc = ensure(c, c->ws_tmp[2], 32 * std::max<size_t>(n, 1)))) return rc;
-  SoA ext = soa_of(c->ws_ext, n);
+  SoA ext = soa_of(c->ws->ext, n);
   if (n) {
     prof_mark(c, 0);
     hipLaunchKernelGGL(k_pack_composite, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, ds, t->fx, c->ws_tmp[2].p);
@@ -1521,11 +1560,12 @@ JJ_API int jj_compress(jj_ctx* c, size_t n, const void* points, void* out32) {
 // the decoder and the flag kernels that follow it, on device pointers (n > 0), all on c->stream
 static int decompress_dev(jj_ctx* c, size_t n, const void* di, unsigned flags, void* dout, uint8_t* dok, bool prof) {
   int rc;
-  if ((rc = ensure(c, c->ws_scratch, (size_t)NL * 4 * n))) return rc;
-  SoA scratch = soa_of(c->ws_scratch, n);
+  if ((rc = ensure(c, c->ws->scratch, (size_t)NL * 4 * n))) return rc;
+  SoA scratch = soa_of(c->ws->scratch, n);
   if (prof) prof_mark(c, 0);
   const size_t lanes_wanted = (size_t)c->cus * 64 * 8;
   if (n >= lanes_wanted * 32) { size_t T = (n + 31) / 32; hipLaunchKernelGGL((k_decompress<32>), dim3(blocks_for(T)), dim3(256), 0, c->stream, n, T, di, flags, scratch, c->sqrt_tables, dout, dok); }
+  else if (n >= lanes_wanted * 8 && n < lanes_wanted * 16 && c->dec_c_mid == 8) { size_t T = (n + 7) / 8; hipLaunchKernelGGL((k_decompress<8>), dim3(blocks_for(T)), dim3(256), 0, c->stream, n, T, di, flags, scratch, c->sqrt_tables, dout, dok); }
   else if (n >= lanes_wanted * 8) { size_t T = (n + 15) / 16; hipLaunchKernelGGL((k_decompress<16>), dim3(blocks_for(T)), dim3(256), 0, c->stream, n, T, di, flags, scratch, c->sqrt_tables, dout, dok); }
   else if (n <= 16384) { hipLaunchKernelGGL((k_decompress<1>), dim3(blocks_for(n)), dim3(256), 0, c->stream, n, n, di, flags, scratch, c->sqrt_tables, dout, dok); }   // latency: no shared inversion
   else { size_t T = (n + 3) / 4; hipLaunchKernelGGL((k_decompress<4>), dim3(blocks_for(T)), dim3(256), 0, c->stream, n, T, di, flags, scratch, c->sqrt_tables, dout, dok); }
@@ -1534,7 +1574,7 @@ static int decompress_dev(jj_ctx* c, size_t n, const void* di, unsigned flags, v
   if (flags & JJ_DECOMPRESS_TORSION_FREE) { if ((rc = torsion_free_dev(c, n, dout, dok, 1))) return rc; }
   if (flags & (JJ_DECOMPRESS_NOT_SMALL_ORDER | JJ_DECOMPRESS_CLEAR_COFACTOR)) {
     if ((rc = ensure_ext(c, n, 3))) return rc;
-    SoA ext = soa_of(c->ws_ext, n);
+    SoA ext = soa_of(c->ws->ext, n);
     hipLaunchKernelGGL(k_small_order_cofactor, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, (const void*)dout, flags, ext, dok);
     if (flags & JJ_DECOMPRESS_CLEAR_COFACTOR) { if ((rc = normalize_launch(c, n, ext, dout, 0))) return rc; }
   }
@@ -1570,7 +1610,7 @@ JJ_API int jj_batch_normalize(jj_ctx* c, size_t n, const void* ext160, void* out
   if ((rc = stage_in(c, 0, ext160, 160 * n, &de))) return rc;
   if ((rc = stage_out(c, c->out[0], out64, 64 * n, &o))) return rc;
   if ((rc = ensure_ext(c, n, 3))) return rc;
-  SoA ext = soa_of(c->ws_ext, n);
+  SoA ext = soa_of(c->ws->ext, n);
   if (n) {
     hipLaunchKernelGGL(k_ext160_to_soa, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, de, ext);
     if ((rc = normalize_launch(c, n, ext, o.dev, 0))) return rc;

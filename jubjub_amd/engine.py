@@ -177,6 +177,12 @@ class Engine:
         self._check(self._lib.jj_peak_imad32(self._ctx, C.byref(out)))
         return out.value
 
+    def peak_imad32_samples(self, count=7):
+        """`count` single measurements of the integer multiply-add peak (jj_peak_imad32_samples), in launch order"""
+        out = (C.c_double * count)()
+        self._check(self._lib.jj_peak_imad32_samples(self._ctx, count, out))
+        return [out[i] for i in range(count)]
+
     def _bind_stream(self, args):
         """When any argument is a torch CUDA tensor, run on torch's current stream."""
         if any(a.torch for a in args):

@@ -190,6 +190,16 @@ def msm(scalars, points):
     return out
 
 
+def msm_pippenger(scalars, points, window_bits=13):
+    """the same sum by the bucket method (CPU baseline of the MSM workload; jjo_msm_pippenger)"""
+    s, p = _u8(scalars, 32), _u8(points, 64)
+    out = np.zeros(64, np.uint8)
+    rc = lib().jjo_msm_pippenger(C.c_size_t(s.shape[0]), _p(s), _p(p), C.c_int(window_bits), _p(out))
+    if rc:
+        raise RuntimeError("jjo_msm_pippenger failed: %d" % rc)
+    return out
+
+
 def point_sum(points):
     p = _u8(points, 64)
     out = np.zeros(64, np.uint8)

@@ -19,6 +19,7 @@
  * Build: gcc -O3 -march=native -fopenmp -shared -fPIC oracle/jubjub_oracle.c -o oracle/libjj_oracle.so
  */
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <stddef.h>
 
@@ -575,6 +576,48 @@ API int jjo_msm(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t
   }
   affine_t o = ext_to_affine(&total); store_affine(&o, out_affine);
   return 0;
+}
+/* The same sum by the bucket method (Pippenger), for the CPU baseline of the MSM workload ("CPU Pippenger at 2^20 beside
+ * the naive fold").  The reference has NO multi-scalar algorithm (its semantics are the fold above, lib.rs:183-193); this is the
+ * textbook method written with the reference's own point formulas only (mixed addition lib.rs:956-968, addition 883-920, doubling
+ * 739-828): unsigned c-bit windows of the low 252 scalar bits (the ladder ignores the top four, lib.rs:357-379), one bucket array per
+ * window, windows in parallel (OpenMP), running-sum bucket reduction, Horner over the windows.  Same group element as jjo_msm. */
+API int jjo_msm_pippenger(size_t n, const uint8_t *scalars, const uint8_t *points, int c, uint8_t *out_affine) {
+  if (c < 1 || c > 20) return -1;
+  const int W = (252 + c - 1) / c;
+  const size_t nb = ((size_t)1 << c) - 1;
+  aniels_t *pn = (aniels_t *)malloc((n ? n : 1) * sizeof(aniels_t));
+  ext_t *wsum = (ext_t *)malloc((size_t)W * sizeof(ext_t));
+  if (!pn || !wsum) { free(pn); free(wsum); return -2; }
+  #pragma omp parallel for schedule(static)
+  for (size_t i = 0; i < n; i++) { affine_t a = load_affine(points + 64 * i); pn[i] = affine_to_niels(&a); }
+  int fail = 0;
+  #pragma omp parallel for schedule(dynamic, 1)
+  for (int w = 0; w < W; w++) {
+    ext_t *bk = (ext_t *)malloc(nb * sizeof(ext_t));
+    if (!bk) { fail = 1; wsum[w] = ext_identity(); continue; }
+    for (size_t j = 0; j < nb; j++) bk[j] = ext_identity();
+    for (size_t i = 0; i < n; i++) {
+      unsigned d = 0;
+      for (int b = 0; b < c; b++) { const int bit = w * c + b; if (bit < 252) d |= (unsigned)ladder_bit(scalars + 32 * i, bit) << b; }
+      if (d) bk[d - 1] = ext_add_aniels(&bk[d - 1], &pn[i]);
+    }
+    ext_t running = ext_identity(), sum = ext_identity();
+    for (size_t j = nb; j-- > 0;) {
+      eniels_t bn = ext_to_niels(&bk[j]); running = ext_add_eniels(&running, &bn);
+      eniels_t rn = ext_to_niels(&running); sum = ext_add_eniels(&sum, &rn);
+    }
+    wsum[w] = sum;
+    free(bk);
+  }
+  ext_t total = ext_identity();
+  for (int w = W - 1; w >= 0; w--) {
+    for (int b = 0; b < c; b++) total = ext_double(&total);
+    eniels_t sn = ext_to_niels(&wsum[w]); total = ext_add_eniels(&total, &sn);
+  }
+  affine_t o = ext_to_affine(&total); store_affine(&o, out_affine);
+  free(pn); free(wsum);
+  return fail ? -2 : 0;
 }
 /* Sum of affine points (lib.rs:183-193) */
 API int jjo_sum(size_t n, const uint8_t *points, uint8_t *out_affine) {

@@ -84,6 +84,34 @@ def test_c_example_compiles(tmp_path):
     assert out.exists()
 
 
+def test_rccl_example_compiles(tmp_path):
+    """examples/msm_rccl.cpp (the C-level multi-rank MSM exchange) compiles against the header, RCCL and the library."""
+    import subprocess
+
+    out = tmp_path / "msm_rccl"
+    lib = os.path.join(ROOT, "jubjub_amd", "lib")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "msm_rccl.cpp"),
+                           "-L", lib, "-ljubjub_hip", "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-o", str(out)])
+    assert out.exists()
+
+
+def test_host_buffer_api_without_a_gpu():
+    """jj_host_alloc / jj_host_register need a device to page-lock for: without one they fail cleanly (no CPU fallback, no crash);
+    jj_host_free(NULL) is a no-op everywhere"""
+    import torch
+
+    from jubjub_amd import _lib
+
+    lib = _lib.load()
+    assert lib.jj_host_free(None) == 0
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by tests/test_gpu_host_path.py")
+    p = ctypes.c_void_p()
+    assert lib.jj_host_alloc(1 << 20, ctypes.byref(p)) == _lib.JJ_ERR_NODEVICE and not p.value
+    buf = ctypes.create_string_buffer(1 << 16)
+    assert lib.jj_host_register(buf, 1 << 16) == _lib.JJ_ERR_NODEVICE
+
+
 def test_msm_fold_partials_host_only():
     """jj_msm_fold_partials (the last step of an MSM cut across devices / ranks) is a host-only function: partial points incl. the
     identity, 8-torsion points and P, -P pairs against the oracle's fold (reference `Sum`, src/lib.rs:183-193)."""

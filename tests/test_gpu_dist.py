@@ -120,6 +120,44 @@ def test_one_rank_rccl_all_gather_leg():
     assert "all_gather" in res["config"]["parallelism"]
 
 
+@pytest.mark.parametrize("exchange", ["c", "torch"])
+def test_one_rank_rccl_msm_both_exchanges(exchange):
+    """--msm-exchange c: the whole exchange behind the C ABI (jj_msm_allgather on this process's own RCCL communicator, the default);
+    torch: jj_msm_partial + torch.distributed.all_gather + jj_msm_combine.  Pippenger size, one rank over RCCL."""
+    res = run_bench(["--gpus", "1", "--workload", "msm", "--log2n", "16", "--steps", "2", "--warmup", "1", "--passes", "2", "--no-cpu-baseline",
+                     "--msm-exchange", exchange], {"JJ_BENCH_FORCE_DIST": "1", "MASTER_PORT": str(free_port())})
+    assert res["verified"] is True and res["rccl_world_size"] == 1 and res["msm_result"] == oracle_msm(1 << 16)
+    assert ("jj_msm_allgather" in res["config"]["parallelism"]) == (exchange == "c")
+    assert len(res["rank_ms_per_step"]["per_rank"]) == 1
+
+
+@pytest.mark.parametrize("workload,extra", [("varbase", ["--log2n", "15", "--no-extras"]), ("fixedbase", ["--log2n", "16"]),
+                                            ("decompress", ["--log2n", "16"])])
+def test_one_rank_rccl_leg_every_workload(workload, extra):
+    """what the driver's multi-GPU run does for the independent-shard workloads -- init_process_group(nccl), barrier, the all_reduce(MAX)
+    of the step time, the all_gather of the per-rank times -- with the one rank a 1-GPU box can hold (JJ_BENCH_FORCE_DIST=1)"""
+    res = run_bench(["--gpus", "1", "--workload", workload, "--steps", "2", "--warmup", "1", "--no-cpu-baseline"] + extra,
+                    {"JJ_BENCH_FORCE_DIST": "1", "MASTER_PORT": str(free_port())})
+    assert res["n_gpus"] == 1 and res["rccl_world_size"] == 1 and res["verified"] is True and res["all_units_equal_second_pass"] is True
+    assert res["verified_block"]["ok"] is True and res["verified_block"]["units"] == 1 << 14
+    r = res["rank_ms_per_step"]
+    assert r["min"] <= r["max"] <= res["ms_per_step"] * 1.001
+    pk = res["roofline"]["peak_samples"]
+    assert len(pk["before"]) == 5 and len(pk["after"]) == 5 and pk["min"] <= pk["median"] <= pk["max"]
+    assert 0 < res["roofline"]["frac_nominal"] < res["roofline"]["frac_at_peak_min"] * 1.2
+
+
+@pytest.mark.parametrize("kind", ["pinned", "pageable"])
+def test_bench_host_buffers_line(kind):
+    """--host-buffers: the timed region is the C-ABI call on host arrays; the line carries roofline.pcie and is verified"""
+    res = run_bench(["--workload", "fixedbase", "--log2n", "20", "--host-buffers", kind, "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], {})
+    assert res["pcie_inclusive"] is True and "HOST buffers" in res["metric"]
+    assert res["verified"] is True and res["all_units_equal_second_pass"] is True and res["verified_block"]["ok"] is True
+    pc = res["roofline"]["pcie"]
+    assert pc["bytes_per_unit"] == {"h2d": 32, "d2h": 64} and 0 < pc["frac"] < 1 and pc["peak_GBps"] == 63.0
+    assert 0.2 < res["host_over_device_resident"] < 1.1
+
+
 def test_too_many_gpus_is_refused_not_mislabelled():
     """--gpus 8 on a box with fewer devices must fail loudly instead of reporting a 1-GPU run"""
     import torch

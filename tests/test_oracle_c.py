@@ -201,6 +201,19 @@ def test_batch_normalize_and_msm():
     assert to_pt(O.point_sum(arr64(pts))) == J.ext_to_affine(J.ext_sum([J.affine_to_extended(p) for p in pts]))
     # empty inputs
     assert to_pt(O.msm(np.zeros((0, 32), np.uint8), np.zeros((0, 64), np.uint8))) == J.AFFINE_IDENTITY
+    # the bucket method (the CPU baseline of the MSM workload) gives the same group element as the fold of ladders, for every window
+    # width, with full-width scalars (top four bits ignored like the ladder), torsion points and the identity among the terms
+    import util
+
+    n = 700
+    S = util.rand_scalars(77, n, full_width=True)
+    P = util.rand_points(78, n)
+    P[:8] = util.arr64([J.AFFINE_IDENTITY] * 8)
+    S[8:12] = 0
+    want = O.msm(S, P)
+    for c in (1, 3, 8, 13):
+        assert (O.msm_pippenger(S, P, c) == want).all(), c
+    assert to_pt(O.msm_pippenger(S[:0], P[:0], 13)) == J.AFFINE_IDENTITY
 
 
 def test_decompress_flags_vs_python():
