@@ -54,6 +54,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before the first HIP call of this process: see jubjub_amd/_lib.py
 
 HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 NOMINAL_PEAK_IMAD32 = 1024 * 16 * 2.4e9   # 1024 SIMDs x 16 lanes x 2.4 GHz boost clock: one 32x32+64 multiply-add per lane per 4-cycle wave64 issue

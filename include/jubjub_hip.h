@@ -221,6 +221,13 @@ int jj_msm(jj_ctx*, size_t n, const void* scalars32, const void* points64, void*
 typedef struct jj_msm_job jj_msm_job;
 int jj_msm_begin(jj_ctx*, size_t n, const void* scalars32, const void* points64, jj_msm_job** job);
 int jj_msm_finish(jj_msm_job* job, void* out64);
+/* Opt-in device-side finish: the same sum with NO host hop.  The record of window sums stays on the device, one quad of lanes runs
+ * the Horner chain (252 dependent doublings) and the inversion there and writes the affine point to out64_dev (DEVICE memory, 16-byte
+ * aligned); the call only queues work on the context's stream and returns.  The finish is a ~0.5 ms chain on four lanes against ~0.05 ms
+ * on a host core (profiles/r4_msm_dev_finish.txt): use it when the sum feeds the next kernel and the host thread must not wait on the
+ * stream (jj_msm does: D2H of the record + host tail + H2D of the point); use jj_msm / jj_msm_begin for latency and throughput.
+ * At most 2^24 terms per call; inputs may be host arrays (staged) or device arrays. */
+int jj_msm_dev(jj_ctx*, size_t n, const void* scalars32, const void* points64, void* out64_dev);
 /* MSM cut across devices or ranks.  jj_msm_partial leaves the RECORD of partial window sums instead of the
  * point: JJ_MSM_PARTIAL_BYTES bytes (64-byte header: magic, version, number of windows W, 1, bit mask of the windows
  * present, n; then one 128-byte point per window: U, V, Z and T = T1 T2, each the 256-bit little-endian integer of

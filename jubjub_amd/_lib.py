@@ -3,6 +3,11 @@ there is no CPU fallback in the product path."""
 import ctypes as C
 import os
 
+# HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue serialise; a context's
+# copy / compute pipeline beside PyTorch's streams needs more (jj_engine.hip jj_default_hw_queues has the measurements).  Read when the
+# HIP runtime initialises, so it is set at import time, before torch or this library makes the first HIP call; a user's value wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("JJ_LIB_PATH") or os.path.join(HERE, "lib", "libjubjub_hip.so")   # JJ_LIB_PATH: A/B builds of the same library
 
@@ -40,6 +45,7 @@ _SIGS.update({
     "jj_fixedbase_composite_create": [C.c_int, _vp, C.POINTER(C.c_int), C.POINTER(_vp)],
     "jj_fixedbase_composite_mul": [_vp, _sz, _vp, _vp],
     "jj_msm": [_sz, _vp, _vp, _vp],
+    "jj_msm_dev": [_sz, _vp, _vp, _vp],
     "jj_msm_begin": [_sz, _vp, _vp, C.POINTER(_vp)],
     "jj_msm_partial": [_sz, _vp, _vp, C.c_int, C.c_int, _vp],
     "jj_ctx_set_comm": [_vp, C.c_int, C.c_int, _vp],

@@ -30,11 +30,12 @@ struct CurveT {
   // completed point (u:z, v:t) -> extended; lib.rs:1052-1060.
   static JJ_DEV Ext into_extended(const Fe& cu, const Fe& cv, const Fe& cz, const Fe& ct) {
     Ext p;
-    p.u = F::mul(cu, ct);
-    p.v = F::mul(cv, cz);
-    p.z = F::mul(cz, ct);
-    p.t1 = cu;
-    p.t2 = cv;
+    const Fe ou = F::opaque(cu), ov = F::opaque(cv), oz = F::opaque(cz), ot = F::opaque(ct);   // each enters two products: hidden once
+    p.u = F::mul_hidden(ou, ot);
+    p.v = F::mul_hidden(ov, oz);
+    p.z = F::mul_hidden(oz, ot);
+    p.t1 = ou;
+    p.t2 = ov;
     return p;
   }
 
@@ -44,10 +45,11 @@ struct CurveT {
   // instructions per doubling instead of 4S + 3M and 115.  Same completed point (2UV, VV+UU, VV-UU, 2ZZ-(VV-UU)), so
   // T1, T2 and the projective coordinates equal the reference's.
   static JJ_DEV Ext dbl(const Ext& p) {
-    const Fe uu = F::sqr(p.u);
+    const Fe ou = F::opaque(p.u);             // U enters the square and the product: hidden once (see Field::opaque)
+    const Fe uu = F::sqr_hidden(ou);
     const Fe vv = F::sqr(p.v);
     const Fe zz2 = F::sqr2(p.z);
-    const Fe cu = F::mul(p.u, F::dbl(p.v));   // 2UV   (= T1)
+    const Fe cu = F::mul_hidden(ou, F::opaque(F::dbl(p.v)));   // 2UV   (= T1)
     const Fe vpu = F::add(vv, uu);            // VV + UU
     const Fe vmu = F::sub(vv, uu);            // VV - UU
     const Fe ct = F::sub(zz2, vmu);           // 2Z^2 - (VV-UU), lazy: limbs in (-2^29, 2^30)

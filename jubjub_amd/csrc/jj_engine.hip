@@ -88,7 +88,7 @@ struct jj_ctx {
   // pipelined host-buffer path: copy streams + two device slots (caller buffers are page-locked in place)
   struct Pipe {
     hipStream_t h2d = nullptr, d2h = nullptr, cs[2] = {nullptr, nullptr};   // copy streams; one compute stream per slot
-    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr}, ev_start = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr}, ev_start = nullptr, ev_tail = nullptr;
     DevBuf din[2], dout[2];
     WorkSet wset;                          // kernel workspaces of slot 1 (slot 0 uses the context's ws0)
     bool ready = false;
@@ -96,9 +96,17 @@ struct jj_ctx {
   int dec_c_mid = 8;                     // decoder, batches of 2^20 .. 2^21 - 1 encodings (the host pipeline's chunk): encodings per lane of the shared inversion.  8 = two waves
                                          // per SIMD: 444 M/s against 431 with 16 (one wave per SIMD) and 396 with 4 (profiles/r4_pcie_inclusive.txt); JJ_DEC_C_MID = 8 | 16.
                                          // (The normalisation kernel stays at 16 there: 8 and 4 measured slower, same file.)
-  bool pipe_two_streams = false;         // JJ_PIPE_STREAMS=2: the chunks of the two slots on two compute streams with their own workspaces.  Measured (profiles/
-                                         // r4_pcie_inclusive.txt): 1.7x SLOWER for the fixed-base and decoder pipelines (2^24 units 31.4 -> 53.6 ms) -- kernels of two
-                                         // streams that each fill the CUs time-share them instead of overlapping; kept as an experiment knob only
+  int pipe_mode = 1;                     // compute streams of the host-buffer pipeline (JJ_PIPE_STREAMS):
+                                         //   1  all kernels of all chunks on one stream;
+                                         //   2  the chunks of the two slots on two streams (own workspaces): 1.7x SLOWER for the fixed-base and decoder pipelines
+                                         //      (2^24 units 31.4 -> 53.6 ms: two kernels that each fill the CUs time-share them), experiment knob only;
+                                         //   3  the first kernel of every chunk (ladder / comb / decoder) on one stream, the kernels that follow it (normalisation,
+                                         //      flag kernels) on a second one, so that the latency-bound tail of chunk k runs beside the main kernel of chunk k + 1:
+                                         //      equal to mode 1 within noise (fixed-base 514-524 against 530 M/s, var-base 0.91 against 0.89-0.90 of device-resident).
+                                         //   Modes 2 and 3 need GPU_MAX_HW_QUEUES >= 8: with HIP's default of 4 hardware queues per process the fifth stream in use
+                                         //   shares a queue with another one and the copies serialise behind the kernels (1.7x slower, profiles/r4_pcie_inclusive.txt).
+  hipStream_t pipe_tail = nullptr;       // mode 3, inside a pipelined call: the stream pipe_to_tail() moves the chunk's remaining launches to
+  hipEvent_t pipe_tail_ev = nullptr;
   size_t pipe_chunk = 0;                 // elements per pipeline chunk: 0 = per entry point (pipe_chunk_for), else JJ_PIPE_CHUNK_LOG2
   // MSM jobs (jj_msm_begin / jj_msm_finish): free list of page-locked record buffers + events
   std::vector<jj_msm_job*> job_pool;
@@ -227,8 +235,9 @@ static int pipe_prepare(jj_ctx* c, size_t in_bytes, size_t out_bytes) {
     HIPCHK(c, hipStreamCreateWithFlags(&P.h2d, hipStreamNonBlocking));
     HIPCHK(c, hipStreamCreateWithFlags(&P.d2h, hipStreamNonBlocking));
     HIPCHK(c, hipEventCreateWithFlags(&P.ev_start, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&P.ev_tail, hipEventDisableTiming));
     for (int i = 0; i < 2; i++) {
-      HIPCHK(c, hipStreamCreateWithFlags(&P.cs[i], hipStreamNonBlocking));
+      if (c->pipe_mode != 1) HIPCHK(c, hipStreamCreateWithFlags(&P.cs[i], hipStreamNonBlocking));   // (a process's streams share a few hardware queues: none is created unless used)
       HIPCHK(c, hipEventCreateWithFlags(&P.ev_in[i], hipEventDisableTiming));
       HIPCHK(c, hipEventCreateWithFlags(&P.ev_done[i], hipEventDisableTiming));
       HIPCHK(c, hipEventCreateWithFlags(&P.ev_out[i], hipEventDisableTiming));
@@ -259,13 +268,22 @@ static bool all_host(std::initializer_list<const void*> ptrs) { for (const void*
 // Chunk length of the host-buffer pipeline for a batch of n units (0: the batch is too small to be cut, it is staged whole).
 // `pref_log2` is what the entry point measured as its best chunk at its BASELINE size (profiles/r4_pcie_inclusive.txt: 2^20 for the
 // fixed-base and decoder kernels -- shorter chunks pay the shared inversion of their normalisation over too few points, longer ones
-// pay the unoverlapped first copy in and last copy out; 2^17 for the var-base ladder, whose kernel time dwarfs its copies); smaller
+// pay the unoverlapped first copy in and last copy out; 2^18 for the var-base ladder, whose kernel time dwarfs its copies); smaller
 // batches are cut in four, down to 2^16 units per chunk.
 static size_t pipe_chunk_for(const jj_ctx* c, size_t n, int pref_log2) {
   if (c->pipe_chunk) return n >= 2 * c->pipe_chunk ? c->pipe_chunk : 0;
   size_t ch = (size_t)1 << pref_log2;
   while (ch > ((size_t)1 << 16) && n < 4 * ch) ch >>= 1;
   return n >= 4 * ch ? ch : 0;
+}
+// Inside a pipelined call in stream mode 3: the launches that follow go to the tail stream, ordered after what the chunk has queued on
+// its main stream so far.  A no-op everywhere else.
+static int pipe_to_tail(jj_ctx* c) {
+  if (!c->pipe_tail || c->stream == c->pipe_tail) return JJ_OK;
+  HIPCHK(c, hipEventRecord(c->pipe_tail_ev, c->stream));
+  HIPCHK(c, hipStreamWaitEvent(c->pipe_tail, c->pipe_tail_ev, 0));
+  c->stream = c->pipe_tail;
+  return JJ_OK;
 }
 template <int NIN, int NOUT, class Body>
 static int run_pipelined(jj_ctx* c, size_t n, size_t CH, const HostIn (&in)[NIN], const HostOut (&out)[NOUT], Body body) {
@@ -295,15 +313,19 @@ static int run_pipelined(jj_ctx* c, size_t n, size_t CH, const HostIn (&in)[NIN]
   // One compute stream for all chunks (default).  JJ_PIPE_STREAMS=2: the chunks of slot s run on compute stream cs[s] with the
   // workspaces of slot s, meant to overlap the short normalisation of chunk k with the ladder of chunk k + 1 -- measured 1.7x slower
   // (see pipe_two_streams).  The compute streams start after the work already queued on the context's launch stream.
-  const bool two = c->pipe_two_streams;
-  hipStream_t cs[2] = {two ? P.cs[0] : c->own_stream, two ? P.cs[1] : c->own_stream};
-  WorkSet* wsets[2] = {&c->ws0, two ? &P.wset : &c->ws0};
+  const int mode = c->pipe_mode;
+  const bool two = mode == 2;
+  hipStream_t cs[2] = {mode == 1 ? c->own_stream : P.cs[0], two ? P.cs[1] : (mode == 1 ? c->own_stream : P.cs[0])};     // main stream of slot 0 / 1
+  WorkSet* wsets[2] = {&c->ws0, mode == 1 ? &c->ws0 : &P.wset};
+  c->pipe_tail = mode == 3 ? P.cs[1] : nullptr;
+  c->pipe_tail_ev = P.ev_tail;
   const size_t nchunks = (n + CH - 1) / CH;
   rc = JJ_OK;
   #define PIPE_CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { c->err = std::string(#call) + " failed: " + hipGetErrorString(e_); rc = JJ_ERR_HIP; goto done; } } while (0)
   PIPE_CHK(hipEventRecord(P.ev_start, saved));
   PIPE_CHK(hipStreamWaitEvent(cs[0], P.ev_start, 0));
   if (cs[1] != cs[0]) PIPE_CHK(hipStreamWaitEvent(cs[1], P.ev_start, 0));
+  if (mode == 3) PIPE_CHK(hipStreamWaitEvent(P.cs[1], P.ev_start, 0));
   for (size_t k = 0; k < nchunks; k++) {
     const int s = (int)(k & 1); const size_t lo = k * CH, cn = std::min(CH, n - lo);
     const void* din[NIN]; void* dout[NOUT];
@@ -336,17 +358,26 @@ static int run_pipelined(jj_ctx* c, size_t n, size_t CH, const HostIn (&in)[NIN]
   clock_gettime(CLOCK_MONOTONIC, &ts3);
   if (dbg) {
     auto ms = [](const timespec& a, const timespec& b) { return (b.tv_sec - a.tv_sec) * 1e3 + (b.tv_nsec - a.tv_nsec) * 1e-6; };
-    fprintf(stderr, "[jj pipe] n=%zu chunk=%zu chunks=%zu compute streams=%d register %.2f ms, enqueue %.2f ms, drain %.2f ms\n", n, CH, nchunks, two ? 2 : 1, ms(ts0, ts1), ms(ts1, ts2), ms(ts2, ts3));
+    fprintf(stderr, "[jj pipe] n=%zu chunk=%zu chunks=%zu stream mode=%d register %.2f ms, enqueue %.2f ms, drain %.2f ms\n", n, CH, nchunks, mode, ms(ts0, ts1), ms(ts1, ts2), ms(ts2, ts3));
   }
 done:
   #undef PIPE_CHK
-  if (rc != JJ_OK) { (void)hipStreamSynchronize(P.h2d); (void)hipStreamSynchronize(cs[0]); (void)hipStreamSynchronize(cs[1]); (void)hipStreamSynchronize(P.d2h); }
+  if (rc != JJ_OK) { (void)hipStreamSynchronize(P.h2d); (void)hipStreamSynchronize(cs[0]); (void)hipStreamSynchronize(cs[1]); if (P.cs[1]) (void)hipStreamSynchronize(P.cs[1]); (void)hipStreamSynchronize(P.d2h); }
+  c->pipe_tail = nullptr;
   // every chunk's kernels finished before its copy out did, and all copies were waited for (or, on error, every stream was drained):
   // nothing of this call is in flight any more, the context returns to the stream and workspaces it came with
   c->stream = saved; c->ws = &c->ws0;
   unlock();
   return rc;
 }
+
+// HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  A context uses three streams in its host-
+// buffer pipeline (compute, copy in, copy out) and one more per extra MSM lane; beside PyTorch's or the caller's own streams that
+// exceeds four, and two streams that share a hardware queue serialise -- measured: jj_multi_* with a second context in the process
+// 268 -> 523 M fixed-base scalar-muls/s, a fourth pipeline stream 316 -> 520 M/s (profiles/r4_pcie_inclusive.txt).  The runtime reads
+// the variable when it initialises (first HIP call), so setting it here works whenever this library is loaded before that; a value
+// the user has set is left alone.
+__attribute__((constructor)) static void jj_default_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
 // ---------------------------------------------------------------------------------------------------- host buffers
 // Page-locked host memory for callers that do not link HIP themselves (include/jubjub_hip.h).  The entry points recognise such
@@ -418,7 +449,7 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
   if (hipEventCreateWithFlags(&c->order_ev, hipEventDisableTiming) != hipSuccess) return fail(JJ_ERR_HIP);
   c->stream = c->own_stream;
   if (const char* e = getenv("JJ_DEC_C_MID")) { int v = atoi(e); if (v == 8 || v == 16) c->dec_c_mid = v; }
-  if (const char* e = getenv("JJ_PIPE_STREAMS")) c->pipe_two_streams = atoi(e) == 2;
+  if (const char* e = getenv("JJ_PIPE_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= 3) c->pipe_mode = v; }
   if (const char* e = getenv("JJ_PIPE_CHUNK_LOG2")) { int v = atoi(e); if (v >= 8 && v <= 24) c->pipe_chunk = (size_t)1 << v; }   // overrides the per-entry-point chunk
   if (const char* e = getenv("JJ_MSM_WINDOWS")) { int v = atoi(e); if (v >= MSM_WINDOWS_MIN && v <= MSM_WINDOWS_MAX) c->msm_windows = v; else fprintf(stderr, "libjubjub_hip: JJ_MSM_WINDOWS=%s ignored (valid: %d..%d)\n", e, MSM_WINDOWS_MIN, MSM_WINDOWS_MAX); }
   if (const char* e = getenv("JJ_MSM_LANES")) { int v = atoi(e); if (v >= 1 && v <= MSM_LANES_MAX) c->msm_lanes = v; }
@@ -481,8 +512,8 @@ JJ_API int jj_ctx_destroy(jj_ctx* c) {
       if (c->pipe.din[i].p) (void)hipFree(c->pipe.din[i].p);
       if (c->pipe.dout[i].p) (void)hipFree(c->pipe.dout[i].p);
     }
-    (void)hipEventDestroy(c->pipe.ev_start);
-    (void)hipStreamDestroy(c->pipe.h2d); (void)hipStreamDestroy(c->pipe.d2h); (void)hipStreamDestroy(c->pipe.cs[0]); (void)hipStreamDestroy(c->pipe.cs[1]);
+    (void)hipEventDestroy(c->pipe.ev_start); (void)hipEventDestroy(c->pipe.ev_tail);
+    (void)hipStreamDestroy(c->pipe.h2d); (void)hipStreamDestroy(c->pipe.d2h); if (c->pipe.cs[0]) (void)hipStreamDestroy(c->pipe.cs[0]); if (c->pipe.cs[1]) (void)hipStreamDestroy(c->pipe.cs[1]);
   }
   for (auto& r : c->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); (void)hipEventDestroy(r.e2); }
   if (c->order_ev) (void)hipEventDestroy(c->order_ev);
@@ -734,7 +765,7 @@ static int varbase_to_ext(jj_ctx* c, size_t n, const void* ds, const void* dp, S
 static int varbase_api(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out, int mode) {
   if (!c) return JJ_ERR_INVALID;
   JJ_ENTER(c);
-  if (const size_t ch = pipe_chunk_for(c, n, 17); ch && all_host({scalars, points, out})) {
+  if (const size_t ch = pipe_chunk_for(c, n, 18); ch && all_host({scalars, points, out})) {
     const HostIn in[2] = {{scalars, 32}, {points, 64}};
     const HostOut ho[1] = {{out, (size_t)(mode ? 32 : 64)}};
     const int prc = run_pipelined(c, n, ch, in, ho, [&](size_t cn, const void* const* di, void* const* dout) -> int {
@@ -742,6 +773,7 @@ static int varbase_api(jj_ctx* c, size_t n, const void* scalars, const void* poi
       if ((rc2 = ensure_ext(c, cn, 3))) return rc2;
       SoA ext = soa_of(c->ws->ext, cn);
       if ((rc2 = varbase_to_ext(c, cn, di[0], di[1], ext, false))) return rc2;
+      if ((rc2 = pipe_to_tail(c))) return rc2;
       return normalize_launch(c, cn, ext, dout[0], mode);
     });
     if (prc <= 0) return prc;      // +1: buffers could not be page-locked -> plain staging below
@@ -1004,6 +1036,7 @@ static int fixedbase_api(jj_ctx* c, const jj_table* t, size_t n, const void* sca
       if ((rc2 = ensure_ext(c, cn, 3))) return rc2;
       SoA ext = soa_of(c->ws->ext, cn);
       if ((rc2 = fixedbase_launch(c, t, cn, di[0], ext))) return rc2;
+      if ((rc2 = pipe_to_tail(c))) return rc2;
       return normalize_launch(c, cn, ext, dout[0], mode);
     });
     if (prc <= 0) return prc;
@@ -1418,6 +1451,26 @@ JJ_API int jj_msm(jj_ctx* c, size_t n, const void* scalars, const void* points, 
   { JJ_ENTER(c); prof_mark(c, 1); prof_mark(c, 2); }
   return rc;
 }
+// Opt-in device-side finish: the record stays on the device, one quad runs the Horner chain and the inversion there, the affine sum
+// is written to DEVICE memory; nothing is copied to the host and no host thread waits (fully asynchronous on the context's stream).
+JJ_API int jj_msm_dev(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out64_dev) {
+  if (!c || !out64_dev) return JJ_ERR_INVALID;
+  JJ_ENTER(c);
+  if (!is_device_ptr(out64_dev) || ((uintptr_t)out64_dev & 15u)) { c->err = "jj_msm_dev writes its result to (16-byte aligned) device memory; use jj_msm for a host result"; return JJ_ERR_INVALID; }
+  if (n > ((size_t)1 << c->msm_pass_log2)) { c->err = "jj_msm_dev takes at most one pass of terms (2^24); use jj_msm, or add the sums of the parts with jj_point_add"; return JJ_ERR_INVALID; }
+  if (n == 0) { HIPCHK(c, hipMemcpyAsync(out64_dev, AFFINE_IDENTITY_BYTES, 64, hipMemcpyHostToDevice, c->stream)); return JJ_OK; }
+  int rc;
+  const void *ds, *dp;
+  if ((rc = stage_in(c, 0, scalars, 32 * n, &ds))) return rc;
+  if ((rc = stage_in(c, 1, points, 64 * n, &dp))) return rc;
+  MsmLane* L = nullptr;
+  if ((rc = msm_lane(c, 0, &L))) return rc;
+  if ((rc = ensure(c, L->rec, JJ_MSM_PARTIAL_BYTES))) return rc;
+  size_t used = 0;
+  if ((rc = msm_enqueue(c, *L, n, ds, dp, 0, 1, L->rec.p, &used))) return rc;
+  hipLaunchKernelGGL(k_msm_finish_dev, dim3(1), dim3(64), 0, c->stream, (const u32*)L->rec.p, out64_dev);
+  return finish(c, false);
+}
 // First half of an MSM that is cut across devices or ranks: the record of partial window sums, left where the
 // caller wants it (device memory: ready for an all_gather over RCCL; host memory: the call waits for the copy).
 //   part_index / part_count = 0 / 1   all windows of the n terms given (term partition: every rank passes its own terms)
@@ -1570,6 +1623,7 @@ static int decompress_dev(jj_ctx* c, size_t n, const void* di, unsigned flags, v
   else if (n <= 16384) { hipLaunchKernelGGL((k_decompress<1>), dim3(blocks_for(n)), dim3(256), 0, c->stream, n, n, di, flags, scratch, c->sqrt_tables, dout, dok); }   // latency: no shared inversion
   else { size_t T = (n + 3) / 4; hipLaunchKernelGGL((k_decompress<4>), dim3(blocks_for(T)), dim3(256), 0, c->stream, n, T, di, flags, scratch, c->sqrt_tables, dout, dok); }
   if (prof) { prof_mark(c, 1); prof_mark(c, 2); }
+  if ((rc = pipe_to_tail(c))) return rc;                      // (host-buffer pipeline, stream mode 3: the flag kernels run beside the next chunk's decoder)
   // Invalid encodings were written as (0,0); the subgroup kernels below may compute garbage for them, the ok byte masks it.
   if (flags & JJ_DECOMPRESS_TORSION_FREE) { if ((rc = torsion_free_dev(c, n, dout, dok, 1))) return rc; }
   if (flags & (JJ_DECOMPRESS_NOT_SMALL_ORDER | JJ_DECOMPRESS_CLEAR_COFACTOR)) {

@@ -104,7 +104,7 @@ static __device__ __forceinline__ u32 jj_opaque_asm(u32 x) { asm("" : "+v"(x)); 
 #define JJ_OPAQUE(x) ((u32)__builtin_annotation((u32)(x), "jj"))
 #endif
 #endif
-  template <bool SQUARE, bool DOUBLE>
+  template <bool SQUARE, bool DOUBLE, bool OPQ = true>
   static JJ_DEV Fe mul_fips(const Fe& a_in, const Fe& b_in) {
     i32 m[NL];
     i32 b2[NL], b4[NL];
@@ -113,7 +113,10 @@ static __device__ __forceinline__ u32 jj_opaque_asm(u32 x) { asm("" : "+v"(x)); 
     // selection cannot re-derive the range (values carried around a loop, selects), a signed x unsigned 64-bit product
     // is expanded into two v_mad_u64_u32 and two moves instead of one v_mad_i64_i32.
     Fe a, b;
-    _Pragma("unroll") for (int i = 0; i < NL; i++) { a.l[i] = JJ_OPAQUE(a_in.l[i]); b.l[i] = SQUARE ? a.l[i] : JJ_OPAQUE(b_in.l[i]); }
+    _Pragma("unroll") for (int i = 0; i < NL; i++) {
+      if constexpr (OPQ) { a.l[i] = JJ_OPAQUE(a_in.l[i]); b.l[i] = SQUARE ? a.l[i] : JJ_OPAQUE(b_in.l[i]); }
+      else { a.l[i] = a_in.l[i]; b.l[i] = SQUARE ? a.l[i] : b_in.l[i]; }
+    }
     if constexpr (SQUARE) {
       _Pragma("unroll") for (int i = 0; i < NL; i++) b2[i] = (i32)(a.l[i] << 1);
       if constexpr (DOUBLE) { _Pragma("unroll") for (int i = 0; i < NL; i++) b4[i] = (i32)(a.l[i] << 2); }
@@ -164,6 +167,12 @@ static __device__ __forceinline__ u32 jj_opaque_asm(u32 x) { asm("" : "+v"(x)); 
     return r;
   }
   static JJ_DEV Fe mul(const Fe& a, const Fe& b) { return mul_fips<false, false>(a, b); }
+  // A value that enters SEVERAL products is hidden once (opaque) and then multiplied as it is (mul_hidden): the "+v" constraint of the
+  // empty asm ties input and output to one register, so hiding a value that has another use left costs a v_mov per limb
+  // (36 per point operation when the four completed coordinates were hidden once per product).
+  static JJ_DEV Fe opaque(const Fe& a) { Fe r; _Pragma("unroll") for (int i = 0; i < NL; i++) r.l[i] = JJ_OPAQUE(a.l[i]); return r; }
+  static JJ_DEV Fe mul_hidden(const Fe& a, const Fe& b) { return mul_fips<false, false, false>(a, b); }
+  static JJ_DEV Fe sqr_hidden(const Fe& a) { return mul_fips<true, false, false>(a, a); }
   // r = a*a/R mod p.  reference Fr::square src/fr.rs:353-381 (same cross-term doubling idea).
   static JJ_DEV Fe sqr(const Fe& a) { return mul_fips<true, false>(a, a); }
   // r = 2*a*a/R mod p in one product (the doubling's 2Z^2)

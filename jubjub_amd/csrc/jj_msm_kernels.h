@@ -869,3 +869,45 @@ __global__ void __launch_bounds__(4 * MSM_TREE_QUADS) k_msm_reduce_fold(size_t n
   quad_tree_sum(st, quad, role, live, acc, Tacc);
   msm_finish_window(st, quad, role, nblk_s, nblk, blk, s, w, acc, Tacc, part, counters, rec);
 }
+
+// ================================================================================================ device-side finish (opt-in)
+// jj_msm_dev: the host tail's work -- Horner over the windows of ONE record (252 dependent doublings + one addition per window),
+// one inversion, canonical (u, v) -- on one quad of lanes, so that the sum never leaves the device and no host thread waits.
+// Same formulas as jj_host_tail.h WindowSums::finish.  A chain: ~2 x 252 multiplication rounds + the inversion's ~330 products on
+// a single lane of a single wave, ~0.5 ms -- ten times the host tail (profiles/r4_msm_dev_finish.txt): for pipelines that must
+// not synchronise with the host, not for latency.
+__global__ void __launch_bounds__(64) k_msm_finish_dev(const u32* rec, void* out64) {
+  const u32 role = threadIdx.x & 3u;
+  if (threadIdx.x >= 4) return;                                  // one quad; the other lanes of the wave leave
+  const int W = (int)rec[2];
+  const u64 mask = (u64)rec[4] | ((u64)rec[5] << 32);
+  const int c = 253 / W, r = 253 % W;
+  Ext acc = Curve::identity();
+  Fe T = Fq::zero();
+  bool any = false;
+  #pragma unroll 1
+  for (int w = W - 1; w >= 0; w--) {
+    if (any) {
+      const int width = c + (w < r ? 1 : 0);
+      #pragma unroll 1
+      for (int i = 0; i < width; i++) acc = quad_dbl_t(acc, role, T);
+    }
+    if ((mask >> w) & 1ull) {
+      // the window's point: U, V, Z, T as value * 2^256 mod q (plain canonical words) -> Montgomery form
+      const u32* src = rec + MSM_REC_HDR_WORDS + (size_t)w * MSM_REC_PT_WORDS;
+      u32 wd[8];
+      Ext p; Fe Tp;
+      load8(wd, src, 0); p.u = Fq::mul(Fq::unpack(wd), Fq::konst(FqP::FROM_HOST));
+      load8(wd, src, 1); p.v = Fq::mul(Fq::unpack(wd), Fq::konst(FqP::FROM_HOST));
+      load8(wd, src, 2); p.z = Fq::mul(Fq::unpack(wd), Fq::konst(FqP::FROM_HOST));
+      load8(wd, src, 3); Tp = Fq::mul(Fq::unpack(wd), Fq::konst(FqP::FROM_HOST));
+      p.t1 = p.u; p.t2 = p.v;                                     // unused by the T-carrying quad operations
+      if (any) { Fe dummy; acc = quad_add_ext_t(acc, T, p, Tp, role, T, Tp, Tp, dummy); }
+      else { acc = p; T = Tp; any = true; }
+    }
+  }
+  if (role == 0) {
+    const Fe zi = Fq::invert(acc.z);
+    store_affine(out64, 0, Fq::mul(acc.u, zi), Fq::mul(acc.v, zi));
+  }
+}

@@ -379,6 +379,20 @@ class Engine:
     def msm(self, scalars, points):
         return self._sum_like("jj_msm", [scalars, points], [32, 64])
 
+    def msm_dev(self, scalars, points, out=None):
+        """The same sum finished ON THE DEVICE (jj_msm_dev): no host hop, nothing waits; returns a torch uint8 tensor of 64 bytes on
+        the inputs' device (torch inputs), queued on torch's current stream."""
+        import torch
+
+        a, p = _Arg(scalars, 32), _Arg(points, 64)
+        if a.n != p.n:
+            raise ValueError("length mismatch: %d vs %d" % (a.n, p.n))
+        if out is None:
+            out = torch.empty(64, dtype=torch.uint8, device=a.device if a.torch else torch.device("cuda", self.device))
+        self._bind_stream([a, p, _Arg(out, 64)])
+        self._check(self._lib.jj_msm_dev(self._ctx, C.c_size_t(a.n), a.ptr, p.ptr, out.data_ptr()))
+        return out
+
     def msm_begin(self, scalars, points):
         """Queues one MSM (jj_msm_begin) and returns a job; msm_finish(job) waits for it and runs the host tail.  Several jobs
         may be in flight: the host tail of one overlaps the kernels of the next.  The inputs are kept alive by the job."""
@@ -549,12 +563,21 @@ class MultiEngine:
         a = np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, width)
         return a, (a.ctypes.data if a.size else None)
 
-    def varbase_mul(self, scalars, points):
+    @staticmethod
+    def _out(out, shape):
+        """a caller-owned result array (e.g. page-locked, reused across calls) or a fresh one"""
+        if out is None:
+            return np.empty(shape, np.uint8)
+        if out.dtype != np.uint8 or not out.flags["C_CONTIGUOUS"] or out.size != int(np.prod(shape)):
+            raise ValueError("out: a contiguous uint8 array of shape %r expected" % (shape,))
+        return out
+
+    def varbase_mul(self, scalars, points, out=None):
         s, sp = self._np(scalars, 32)
         p, pp = self._np(points, 64)
         if len(s) != len(p):
             raise ValueError("length mismatch")
-        out = np.empty((len(s), 64), np.uint8)
+        out = self._out(out, (len(s), 64))
         self._check(self._lib.jj_multi_varbase_mul(self._h, C.c_size_t(len(s)), sp, pp, out.ctypes.data if len(s) else None))
         return out
 
@@ -565,15 +588,15 @@ class MultiEngine:
         self._tables.append(t)
         return t
 
-    def fixedbase_mul(self, table, scalars):
+    def fixedbase_mul(self, table, scalars, out=None):
         s, sp = self._np(scalars, 32)
-        out = np.empty((len(s), 64), np.uint8)
+        out = self._out(out, (len(s), 64))
         self._check(self._lib.jj_multi_fixedbase_mul(self._h, table, C.c_size_t(len(s)), sp, out.ctypes.data if len(s) else None))
         return out
 
-    def decompress(self, enc, flags=FLAG_ZIP216):
+    def decompress(self, enc, flags=FLAG_ZIP216, out=None):
         e, ep = self._np(enc, 32)
-        out, ok = np.empty((len(e), 64), np.uint8), np.empty((len(e),), np.uint8)
+        out, ok = (self._out(out[0], (len(e), 64)), self._out(out[1], (len(e),))) if out is not None else (np.empty((len(e), 64), np.uint8), np.empty((len(e),), np.uint8))
         self._check(self._lib.jj_multi_decompress(self._h, C.c_size_t(len(e)), ep, C.c_uint(flags), out.ctypes.data if len(e) else None,
                                                   ok.ctypes.data if len(e) else None))
         return out, ok

@@ -215,3 +215,30 @@ def test_msm_finish_without_output_releases_the_job(eng):
         assert lib.jj_msm_begin(eng._ctx, C.c_size_t(n), C.c_void_p(s.data_ptr()), C.c_void_p(p.data_ptr()), C.byref(h)) == 0
         assert lib.jj_msm_finish(h, None) != 0                              # invalid argument; the job is released after its kernels finished
     assert (eng.msm(s, p).cpu().numpy() == O.msm(s.cpu().numpy(), p.cpu().numpy()).reshape(64)).all()
+
+
+# ------------------------------------------------------------------------------------------------ device-side MSM finish
+@pytest.mark.parametrize("n", [0, 1, 2, 300, 20000, 200000])
+def test_msm_dev_finish(eng, golden, n):
+    """jj_msm_dev: Horner over the record's windows + one inversion on a quad of lanes, result left in device memory -- equal to
+    jj_msm (host tail) and the oracle, for the small-batch layout (64 windows) and both Pippenger layouts (23 / 17 windows), with
+    8-torsion points, the identity and edge scalars among the terms."""
+    import torch
+
+    from util import EDGE_SCALARS, arr32, torsion_points
+
+    s, p = rand_scalars(61 + n, n, full_width=True), rand_points(62 + n, n)
+    if n >= 300:
+        t = torsion_points(golden)
+        p[:8] = t
+        s[8:8 + len(EDGE_SCALARS)] = arr32([k % (1 << 256) for k in EDGE_SCALARS])
+    ds, dp = torch.from_numpy(s).cuda(), torch.from_numpy(p).cuda()
+    got = eng.msm_dev(ds, dp)
+    assert got.is_cuda and got.shape == (64,)
+    want = O.msm(s, p).reshape(64)
+    assert (got.cpu().numpy() == want).all()
+    assert (eng.msm(ds, dp).cpu().numpy() == want).all()
+    out = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    assert eng.msm_dev(s, p, out=out) is out and (out.cpu().numpy() == want).all()       # host inputs are staged, the result still stays on the device
+    with pytest.raises(Exception):
+        eng._check(eng._lib.jj_msm_dev(eng._ctx, C.c_size_t(n), C.c_void_p(ds.data_ptr()), C.c_void_p(dp.data_ptr()), np.zeros(64, np.uint8).ctypes.data))   # host result pointer

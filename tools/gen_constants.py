@@ -70,6 +70,7 @@ def field_block(name, p, extra=""):
     s += arr("R2", limbs((MONT * MONT) % p))  # to-Montgomery multiplier
     s += arr("R2_256", limbs(((1 << 256) * MONT * MONT) % p))  # converts hi half of a 512-bit value: x*2^256 -> Montgomery
     s += arr("HOST_R", limbs((1 << 256) % p))   # 2^256 mod p as a PLAIN integer: mul(a, HOST_R) = value(a) * 2^256, the 4 x 64-bit Montgomery form of the host tail
+    s += arr("FROM_HOST", limbs(pow(2, 2 * LB * NL - 256, p)))   # 2^266 mod p as a PLAIN integer: mul(x, FROM_HOST) with x = value * 2^256 (the host tail's form) = value * 2^261 (Montgomery)
     s += arr("NEGP_DIGITS", signed_digits(-p))   # -p as the digits a Montgomery product emits (limbs 0..7 in [0, 2^29), signed top limb)
     s += arr("PM2", words32(p - 2, 8))  # exponent for inversion
     s += "  static constexpr int PBITS = %d;\n" % p.bit_length()

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Runs ON THE GPU BOX: the host-pointer (drop-in) path of the C ABI priced against the host link.
+#   gpurun -- 'bash tools/pcie_inclusive.sh r4'  ->  gpurun_out/<tag>_pcie_probe.txt, <tag>_pcie_inclusive.txt, <tag>_bench_host_*.json
+TAG=${1:-r4}
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+[ -x tools/pcie_probe ] || /opt/rocm/bin/hipcc -O2 -o tools/pcie_probe tools/pcie_probe.cpp -lpthread
+./tools/pcie_probe > gpurun_out/${TAG}_pcie_probe.txt 2>&1
+OUT=gpurun_out/${TAG}_pcie_inclusive.txt
+: > $OUT
+line() {  # name, bench args...
+  local name=$1; shift
+  python bench.py "$@" --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_bench_host_$name.json 2>/dev/null
+  python - "$name" gpurun_out/${TAG}_bench_host_$name.json >> $OUT <<'PY'
+import json, sys
+d = json.load(open(sys.argv[2])); p = d["roofline"]["pcie"]
+print("%-28s %7.1f M units/s  (device-resident %6.1f M/s, ratio %.3f)  %6.2f ms/pass  H2D %5.1f GB/s  D2H %5.1f GB/s  link frac %.3f  bound by %-7s  verified %s / block %s / second pass %s" % (
+    sys.argv[1], d["value"] / 1e6, d["device_resident"]["value"] / 1e6, d["host_over_device_resident"], p["ms_per_pass"], p["h2d_GBps"], p["d2h_GBps"], p["frac"],
+    p["bound_by"], d.get("verified"), d.get("verified_block", {}).get("ok"), d.get("all_units_equal_second_pass")))
+PY
+}
+for hb in pinned pageable; do
+  line varbase_$hb --workload varbase --host-buffers $hb
+  line fixedbase_$hb --workload fixedbase --host-buffers $hb
+  line fixedbase_compressed_$hb --workload fixedbase --host-buffers $hb --compressed
+  line decompress_$hb --workload decompress --host-buffers $hb
+done
+cat $OUT
