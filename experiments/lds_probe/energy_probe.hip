@@ -7,6 +7,7 @@
 #include <stdint.h>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
+// MODE 6: + one v_mov_b32 per mad; 7: + one v_bfi_b32 per mad
 // MODE 0: mads only; 1: + one v_add_u32 per mad; 2: + one 64-bit add (v_lshl_add_u64) per mad; 3: + one v_and_b32 + one v_ashrrev_i64 per mad (the
 // Montgomery column step); 4: + two v_add_u32 per mad; 5: mads replaced by v_mul_u32_u24-class 24-bit multiply-adds (v_mad_u32_u24)
 template <int MODE>
@@ -25,6 +26,8 @@ __global__ void __launch_bounds__(512) k(uint32_t* out, int iters, uint32_t seed
         if (MODE == 4) y[q] += x[(q + 3) & 7];
         if (MODE == 2) acc[(q + 1) & 7] += acc[q];
         if (MODE == 3) { x[q] = (uint32_t)acc[q] & 0x1fffffffu; acc[q] >>= 29; }
+        if (MODE == 6) { uint32_t t; asm volatile("v_mov_b32 %0, %1" : "=v"(t) : "v"(y[q])); y[(q + 1) & 7] = t; }
+        if (MODE == 7) { x[q] = (x[q] & y[(q + 1) & 7]) | (y[q] & ~y[(q + 1) & 7]); }
       }
     }
   }
@@ -54,6 +57,8 @@ int main() {
   run<4>("+ 2 v_add_u32 per multiply-add", &base);
   run<2>("+ 1 v_lshl_add_u64 per multiply-add", &base);
   run<3>("+ v_and_b32 + v_ashrrev_i64 per multiply-add", &base);
+  run<6>("+ 1 v_mov_b32 per multiply-add", &base);
+  run<7>("+ 1 v_bfi_b32 per multiply-add", &base);
   run<5>("24-bit multiply-adds instead (v_mad_u32_u24)", &base);
   run<0>("multiply-adds only again", &base);
   return 0;

@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX (through gpurun): the whole evidence set of a round at one build.
 #   gpurun -- 'bash tools/refresh_round.sh r3'     then locally: bash tools/collect_round.sh r3
 set -e
-TAG=${1:-r3}
+TAG=${1:-r4}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -10,7 +10,7 @@ python tools/profile_round.py --tag $TAG > gpurun_out/${TAG}_profile.log 2>&1
 python bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err
 python bench.py --workload decompress --decompress-flags 1 --no-cpu-baseline > gpurun_out/${TAG}_bench_dec1.json 2>/dev/null
 python bench.py --workload decompress --decompress-flags 3 --no-cpu-baseline > gpurun_out/${TAG}_bench_dec3.json 2>/dev/null
-python bench.py --workload msm --log2n 22 --no-cpu-baseline --no-verify > gpurun_out/${TAG}_bench_msm22.json 2>/dev/null
+python bench.py --workload msm --log2n 22 --no-cpu-baseline > gpurun_out/${TAG}_bench_msm22.json 2>/dev/null
 python bench.py --workload msm --no-cpu-baseline > gpurun_out/${TAG}_bench_msm20.json 2>/dev/null      # without the profiler's per-dispatch overhead
 python bench.py --workload msm --log2n 17 --no-cpu-baseline > gpurun_out/${TAG}_bench_msm17.json 2>/dev/null
 python bench.py --workload msm --msm-async 2 --no-cpu-baseline > gpurun_out/${TAG}_bench_msm20_async2.json 2>/dev/null   # two jobs in flight over the context's two lanes (jj_msm_begin / _finish)
@@ -30,5 +30,15 @@ python tools/composite_bench.py 22 > gpurun_out/${TAG}_fixedbase_composite.txt 2
 (python experiments/misc/msm_concurrency.py 17 60; python experiments/misc/msm_concurrency.py 20 30; python experiments/misc/msm_concurrency.py 10 200) > gpurun_out/${TAG}_msm_concurrency.txt 2>&1
 python experiments/misc/msm_partition_cost.py 20 8 > gpurun_out/${TAG}_msm_partition_cost.txt 2>&1
 (python tests/config1_cpu.py; lscpu | grep -E "^CPU\(s\)|Model name") > gpurun_out/${TAG}_config1_cpu.txt 2>&1
+# round 4: the host-pointer (drop-in) path priced against the host link, jj_multi_* on one GPU listed once / twice, the device-side MSM finish,
+# the LDS counters of the fixed-base select, the LDS / energy probes
+bash tools/pcie_inclusive.sh $TAG > /dev/null 2>&1
+python tools/multi_bench.py > gpurun_out/${TAG}_multi_bench.txt 2>&1
+python tools/msm_dev_finish.py > gpurun_out/${TAG}_msm_dev_finish.txt 2>&1
+bash tools/fixedbase_select_pmc.sh > gpurun_out/${TAG}_fixedbase_select_pmc.txt 2>&1
+[ -x experiments/lds_probe/probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o experiments/lds_probe/probe experiments/lds_probe/probe.hip
+[ -x experiments/lds_probe/energy_probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o experiments/lds_probe/energy_probe experiments/lds_probe/energy_probe.hip
+(./experiments/lds_probe/energy_probe; ./experiments/lds_probe/probe) > gpurun_out/${TAG}_issue_energy_probe.txt 2>&1
+python bench.py --workload msm --msm-exchange c --no-cpu-baseline > gpurun_out/${TAG}_bench_msm20_rccl1.json 2>/dev/null </dev/null
 timeout 600 python tests/soak.py 240 3000 > gpurun_out/${TAG}_soak.txt 2>&1 || echo "SOAK FAILED" >> gpurun_out/${TAG}_soak.txt
 tail -1 gpurun_out/${TAG}_profile.log
