@@ -137,10 +137,12 @@ def parse():
     ap.add_argument("--msm-async", type=int, default=1, help="N = 1 MSM workload: jobs in flight per context (1 = synchronous jj_msm calls)")
     ap.add_argument("--msm-contexts", type=int, default=1, help="N = 1 MSM workload: contexts (each with its own stream and workspaces) driven by as many host threads on the one GPU: "
                     "the latency-bound tails of one MSM overlap the sort / accumulation of another")
-    ap.add_argument("--host-buffers", default=None, choices=["pageable", "pinned"],
+    ap.add_argument("--host-buffers", default=None, choices=["pageable", "pinned", "fresh"],
                     help="time the C-ABI call on HOST arrays (the path a drop-in caller takes) instead of device-resident tensors: pinned = page-locked "
                          "buffers from jj_host_alloc, pageable = plain numpy memory (page-locked in place by every call); inputs and result buffers are "
-                         "allocated once and reused; the JSON gains roofline.pcie; varbase / fixedbase / decompress, N = 1")
+                         "allocated once and reused; fresh = pageable inputs and a NEWLY ALLOCATED pageable result array on every call (what a caller that "
+                         "returns a new Vec per call does: the pages of the result are faulted in inside the call); the JSON gains roofline.pcie; "
+                         "varbase / fixedbase / decompress, N = 1")
     ap.add_argument("--compressed", action="store_true", help="varbase / fixedbase: 32-byte compressed results (jj_*_mul_compressed)")
     ap.add_argument("--msm-exchange", default="c", choices=["c", "torch"],
                     help="multi-rank MSM over the nccl backend: c = the whole exchange behind the C ABI (jj_ctx_set_comm + jj_msm_allgather on an RCCL "
@@ -471,7 +473,16 @@ def run(a):
             return eng.fixedbase_mul_compressed(table, scalars) if a.compressed else eng.fixedbase_mul(table, scalars)
         return eng.decompress(enc, a.decompress_flags)
 
+    alloc_s = [0.0]                                                # fresh mode: time spent freeing the previous result array and allocating the next one
+
     def one_pass():
+        nonlocal h_out, h_ok
+        if host == "fresh":
+            ta = time.perf_counter()
+            h_out = None; h_ok = None                              # drop the previous result first, like a caller that consumed it
+            h_out = np.empty((n, out_w), np.uint8)
+            h_ok = np.empty((n,), np.uint8) if wl == "decompress" else None
+            alloc_s[0] += time.perf_counter() - ta
         if host:
             if wl == "varbase":
                 return (eng.varbase_mul_compressed if a.compressed else eng.varbase_mul)(h_scalars, h_points, out=h_out)
@@ -556,10 +567,12 @@ def run(a):
     peak_before = eng.peak_imad32_samples(5) if rank == 0 else None     # the roofline denominator, sampled on both sides of the timed region
     barrier()
     eng.profile(True)
+    alloc_s[0] = 0.0
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = step()
     t_own = time.perf_counter() - t0                                    # this rank's own loop, before it waits for the others
+    alloc_in_timed = alloc_s[0]
     barrier()
     dt = time.perf_counter() - t0
     main_ms, tail_ms = eng.profile_read()
@@ -622,8 +635,9 @@ def run(a):
     }
     if host:
         res["pcie_inclusive"] = True
-        res["config"]["host_buffers"] = ("page-locked (jj_host_alloc), reused by every pass" if host == "pinned" else
-                                         "pageable numpy memory, reused by every pass; every call page-locks them in place (hipHostRegister) and releases them")
+        res["config"]["host_buffers"] = {"pinned": "page-locked (jj_host_alloc), reused by every pass",
+                                         "pageable": "pageable numpy memory, reused by every pass; every call page-locks them in place (hipHostRegister) and releases them",
+                                         "fresh": "pageable numpy memory; the RESULT array is newly allocated (np.empty) for every call: its pages are faulted in and page-locked inside the call"}[host]
         res["config"]["result_bytes"] = out_w
         res["device_resident"] = dev_ref
         res["host_over_device_resident"] = value / dev_ref["value"]
@@ -698,6 +712,11 @@ def run(a):
                 "link_bound_units_per_s": PCIE_PEAK_GBPS * 1e9 / max(in_b, out_b),
                 "kernel_bound_units_per_s": dev_ref["value"],
                 "ms_per_pass": per_pass * 1e3,
+                # fresh mode: what the CALLER spends per pass releasing the previous result array and allocating the next one (munmap / mmap of
+                # the result's pages: any implementation that returns a new array per call pays it), and the time inside the C-ABI call alone
+                "caller_alloc_free_ms_per_pass": alloc_in_timed / a.steps / passes * 1e3 if host == "fresh" else None,
+                "call_ms_per_pass": (dt - alloc_in_timed) / a.steps / passes * 1e3,
+                "units_per_s_inside_the_call": units_per_step * a.steps / (dt - alloc_in_timed),
                 "bound_by": "kernels" if dev_ref["value"] < PCIE_PEAK_GBPS * 1e9 / max(in_b, out_b) else "link",
                 "frac_of_min_bound": value / min(dev_ref["value"], PCIE_PEAK_GBPS * 1e9 / max(in_b, out_b)),
             }

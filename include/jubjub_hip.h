@@ -75,10 +75,14 @@ int jj_peak_imad32_samples(jj_ctx* ctx, int count, double* out_per_sec);
  * A drop-in caller (the Rust shim of INTEGRATION.md, examples/scalar_mul.c) hands HOST arrays to the entry points below.  Large
  * batches (>= 2^19 units) of jj_varbase_mul(_compressed), jj_fixedbase_mul(_compressed) and jj_decompress are then cut into chunks
  * that flow over two copy streams while the kernels of the neighbouring chunk run.  That needs PAGE-LOCKED memory:
- *   - memory from jj_host_alloc, or memory registered once with jj_host_register, is used as it is (no per-call cost);
- *   - any other (pageable) array is page-locked in place for the duration of the call and released before it returns: correct,
- *     but it costs ~0.1 ms per MB each time (measured: profiles/r4_pcie_probe.txt), i.e. more than the copy itself.
- * Keep batch buffers in jj_host_alloc memory (or register a long-lived Vec / malloc block once) and reuse them across calls.
+ *   - memory from jj_host_alloc, or memory registered once with jj_host_register, is used as it is: the copies run straight
+ *     from and to it (2^24 fixed-base units: 0.90 of the device-resident rate, profiles/r4_pcie_inclusive.txt);
+ *   - any other (pageable) array passes through page-locked staging buffers of the context, copied by a few host threads (default
+ *     8, JJ_PIPE_COPY_THREADS) beside the GPU's work: within 2-3 % of the page-locked rates, nothing of the caller's is registered,
+ *     and a result array the caller has only just allocated costs no more than its page faults.  JJ_PIPE_PAGEABLE=register selects
+ *     round 3's way instead (the arrays are page-locked in place for the call: no CPU copies, but a freshly allocated 1 GB result
+ *     array then costs ~65 ms of serial page faults and pinning inside the call).
+ * Page-locked buffers that are reused across calls are the fastest arrangement and cost the host no copy threads.
  * These four functions need no context and no HIP headers on the caller's side.  jj_host_alloc: page-locked, visible to every
  * device of the node, *out = NULL for bytes = 0.  jj_host_register: p .. p + bytes must be mapped and stay mapped until
  * jj_host_unregister(p); registering overlapping ranges twice fails with JJ_ERR_INVALID. */

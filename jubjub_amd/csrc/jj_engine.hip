@@ -12,6 +12,9 @@
 #include <algorithm>
 #include <mutex>
 #include <thread>
+#include <condition_variable>
+#include <atomic>
+#include <functional>
 #include <dlfcn.h>
 
 #include "../../include/jubjub_hip.h"
@@ -38,6 +41,60 @@ struct jj_table {
 };
 
 struct WorkSet { DevBuf ext, scratch, tables, cursor; };
+// A few host threads that copy between a caller's pageable array and the context's page-locked staging buffers while the GPU works on the
+// neighbouring chunk (the host-buffer pipeline's bounce path).  One job at a time: copy(dst, src, bytes) cuts the range into page-aligned
+// slices, the pool's threads and the caller each take slices until none is left.
+class HostCopyPool {
+ public:
+  explicit HostCopyPool(int nthreads) {
+    for (int t = 0; t < nthreads; t++) th_.emplace_back([this]() { worker(); });
+  }
+  ~HostCopyPool() {
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; gen_++; }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  void copy(void* dst, const void* src, size_t bytes) {
+    if (bytes < ((size_t)4 << 20) || th_.empty()) { memcpy(dst, src, bytes); return; }
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      dst_ = (uint8_t*)dst; src_ = (const uint8_t*)src; bytes_ = bytes;
+      slice_ = std::max<size_t>((size_t)1 << 20, ((bytes / (4 * (th_.size() + 1))) + 4095) & ~(size_t)4095);
+      next_.store(0); pending_ = (int)th_.size(); gen_++;
+    }
+    cv_.notify_all();
+    run_slices();
+    std::unique_lock<std::mutex> lk(mu_);
+    done_cv_.wait(lk, [this]() { return pending_ == 0; });
+  }
+ private:
+  void run_slices() {
+    for (;;) {
+      const size_t lo = next_.fetch_add(slice_);
+      if (lo >= bytes_) return;
+      memcpy(dst_ + lo, src_ + lo, std::min(slice_, bytes_ - lo));
+    }
+  }
+  void worker() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&]() { return gen_ != seen; });
+        seen = gen_;
+        if (stop_) return;
+      }
+      run_slices();
+      { std::lock_guard<std::mutex> lk(mu_); if (--pending_ == 0) done_cv_.notify_one(); }
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex mu_;
+  std::condition_variable cv_, done_cv_;
+  uint8_t* dst_ = nullptr; const uint8_t* src_ = nullptr; size_t bytes_ = 0, slice_ = 1;
+  std::atomic<size_t> next_{0};
+  int pending_ = 0; uint64_t gen_ = 0; bool stop_ = false;
+};
 struct jj_ctx;
 // One MSM pipeline of a context: its own workspaces, and for lanes >= 1 its own streams.  Lane 0 runs on the context's launch
 // stream (jj_msm, host-array jobs); device-pointer jobs of jj_msm_begin alternate over the lanes, so that the dependent chains at
@@ -96,6 +153,18 @@ struct jj_ctx {
   int dec_c_mid = 8;                     // decoder, batches of 2^20 .. 2^21 - 1 encodings (the host pipeline's chunk): encodings per lane of the shared inversion.  8 = two waves
                                          // per SIMD: 444 M/s against 431 with 16 (one wave per SIMD) and 396 with 4 (profiles/r4_pcie_inclusive.txt); JJ_DEC_C_MID = 8 | 16.
                                          // (The normalisation kernel stays at 16 there: 8 and 4 measured slower, same file.)
+  // Pageable caller memory: bounce (default) = the chunks pass through page-locked staging buffers of the context, copied by a few host
+  // threads beside the GPU's work -- no registration of the caller's memory, so a result array the caller has just allocated costs only its
+  // page faults, spread over the copy threads (2^24 fixed-base units into a new 1 GB array: 99 ms with in-place page-locking, of which the
+  // kernel's serial page faults and pinning are 68 ms); register = page-lock the caller's arrays in place for the call (no CPU copies; as
+  // fast when the same arrays come back call after call, the runtime caches the pinning).  JJ_PIPE_PAGEABLE=bounce|register
+  bool pipe_bounce = true;
+  int pipe_copy_threads = 0;             // threads of the bounce path's copy pool (JJ_PIPE_COPY_THREADS; 0 = min(8, hardware threads / 2))
+  HostCopyPool* copy_pool = nullptr;
+  uint8_t* stage_in[3] = {nullptr, nullptr, nullptr}; uint8_t* stage_out[3] = {nullptr, nullptr, nullptr}; size_t stage_in_cap = 0, stage_out_cap = 0;   // three slots: the host runs two chunks ahead of its copies out
+  hipEvent_t ev_stage[3] = {nullptr, nullptr, nullptr};     // chunk k's copy out of the device has reached stage_out[k % 3]
+  bool pipe_ramp = true;                 // host-buffer pipeline: first and last chunk a quarter of the others (JJ_PIPE_RAMP=0: uniform)
+  bool pipe_prefault = true;             // pageable result arrays are touched by several threads before they are page-locked (JJ_PIPE_PREFAULT=0: off)
   int pipe_mode = 1;                     // compute streams of the host-buffer pipeline (JJ_PIPE_STREAMS):
                                          //   1  all kernels of all chunks on one stream;
                                          //   2  the chunks of the two slots on two streams (own workspaces): 1.7x SLOWER for the fixed-base and decoder pipelines
@@ -263,6 +332,25 @@ static bool is_pinned_host(const void* p, size_t bytes) {
 }
 static bool all_host(std::initializer_list<const void*> ptrs) { for (const void* p : ptrs) if (!p || is_device_ptr(p)) return false; return true; }
 
+// A result array the caller has just allocated (calloc / vec![0; n] / np.empty) has no pages yet: page-locking it makes the kernel fault
+// every page in, one after the other, inside hipHostRegister -- 12 ms per 100 MB on the box measured (profiles/r4_pcie_probe.txt: 123 ms
+// for the 1 GB result of a 2^24-unit fixed-base call, four times the call's own 31 ms).  Touching one byte per page from several
+// threads first (read and write back the same value: the array's contents, if any, stay) spreads the faults over the cores.
+static void prefault_parallel(void* p, size_t bytes) {
+  if (bytes < ((size_t)32 << 20)) return;
+  const unsigned hw = std::thread::hardware_concurrency();
+  const int T = (int)std::min<size_t>(std::min<unsigned>(hw ? hw : 4, 16), bytes >> 24);
+  if (T < 2) return;
+  std::vector<std::thread> th;
+  const size_t per = ((bytes / T) + 4095) & ~(size_t)4095;
+  for (int t = 0; t < T; t++)
+    th.emplace_back([=]() {
+      volatile uint8_t* q = (volatile uint8_t*)p;
+      const size_t lo = (size_t)t * per, hi = std::min(bytes, lo + per);
+      for (size_t o = lo; o < hi; o += 4096) q[o] = q[o];
+    });
+  for (auto& x : th) x.join();
+}
 // body(cn, dev_in[k], dev_out[k]) must enqueue the chunk's kernels on c->stream.
 // Returns JJ_OK, an error, or +1 when the buffers could not be page-locked (caller uses the staging path).
 // Chunk length of the host-buffer pipeline for a batch of n units (0: the batch is too small to be cut, it is staged whole).
@@ -285,41 +373,101 @@ static int pipe_to_tail(jj_ctx* c) {
   c->stream = c->pipe_tail;
   return JJ_OK;
 }
+// page-locked staging of the bounce path: three slots each way, grown on demand
+static int stage_ensure(jj_ctx* c, size_t in_bytes, size_t out_bytes) {
+  auto grow = [&](uint8_t* (&buf)[3], size_t& cap, size_t want) -> int {
+    if (want <= cap) return JJ_OK;
+    for (int i = 0; i < 3; i++) {
+      if (buf[i]) (void)hipHostFree(buf[i]);
+      buf[i] = nullptr;
+      if (hipHostMalloc((void**)&buf[i], want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); cap = 0; c->err = "hipHostMalloc(staging) failed"; return JJ_ERR_NOMEM; }
+    }
+    cap = want;
+    return JJ_OK;
+  };
+  int rc;
+  if ((rc = grow(c->stage_in, c->stage_in_cap, in_bytes))) return rc;
+  if ((rc = grow(c->stage_out, c->stage_out_cap, out_bytes))) return rc;
+  for (int i = 0; i < 3; i++) if (!c->ev_stage[i]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_stage[i], hipEventDisableTiming));
+  if (!c->copy_pool) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int T = c->pipe_copy_threads ? c->pipe_copy_threads : (int)std::min<unsigned>(8, std::max<unsigned>(2, hw / 2));
+    c->copy_pool = new HostCopyPool(T - 1);          // the calling thread copies too
+  }
+  return JJ_OK;
+}
 template <int NIN, int NOUT, class Body>
 static int run_pipelined(jj_ctx* c, size_t n, size_t CH, const HostIn (&in)[NIN], const HostOut (&out)[NOUT], Body body) {
   size_t in_stride = 0, out_stride = 0;
   for (int k = 0; k < NIN; k++) in_stride += in[k].elem;
   for (int k = 0; k < NOUT; k++) out_stride += out[k].elem;
   int rc = pipe_prepare(c, in_stride * CH, out_stride * CH); if (rc) return rc;
-  // page-lock the caller's buffers in place
   const bool dbg = getenv("JJ_PIPE_DEBUG") != nullptr;
   timespec ts0, ts1, ts2, ts3; clock_gettime(CLOCK_MONOTONIC, &ts0);
-  // memory that is page-locked already (hipHostMalloc, or registered by the caller -- jj_multi_* registers the whole batch once
-  // before it cuts it into per-device shards, whose boundaries are not page-aligned) is used as it is
+  // Memory that is page-locked already (jj_host_alloc / hipHostMalloc, or registered by the caller -- jj_multi_* registers the whole
+  // batch once before it cuts it into per-device shards, whose boundaries are not page-aligned) is copied from and to as it is.
+  // Pageable arrays go through the context's staging buffers (bounce, the default) or are page-locked in place for this call.
+  bool pin_in[NIN], pin_out[NOUT], any_bounce = false;
   void* locked[NIN + NOUT]; int nlocked = 0; bool ok = true;
-  for (int k = 0; k < NIN && ok; k++) {
-    if (is_pinned_host(in[k].p, n * in[k].elem)) continue;
-    if (hipHostRegister(const_cast<void*>(in[k].p), n * in[k].elem, hipHostRegisterDefault) == hipSuccess) locked[nlocked++] = const_cast<void*>(in[k].p); else ok = false;
-  }
-  for (int k = 0; k < NOUT && ok; k++) {
-    if (is_pinned_host(out[k].p, n * out[k].elem)) continue;
-    if (hipHostRegister(out[k].p, n * out[k].elem, hipHostRegisterDefault) == hipSuccess) locked[nlocked++] = out[k].p; else ok = false;
+  for (int k = 0; k < NIN; k++) pin_in[k] = is_pinned_host(in[k].p, n * in[k].elem);
+  for (int k = 0; k < NOUT; k++) pin_out[k] = is_pinned_host(out[k].p, n * out[k].elem);
+  if (c->pipe_bounce) {
+    for (int k = 0; k < NIN; k++) any_bounce |= !pin_in[k];
+    for (int k = 0; k < NOUT; k++) any_bounce |= !pin_out[k];
+    if (any_bounce && (rc = stage_ensure(c, in_stride * CH, out_stride * CH))) return rc;
+  } else {
+    for (int k = 0; k < NIN && ok; k++) {
+      if (pin_in[k]) continue;
+      if (hipHostRegister(const_cast<void*>(in[k].p), n * in[k].elem, hipHostRegisterDefault) == hipSuccess) { locked[nlocked++] = const_cast<void*>(in[k].p); pin_in[k] = true; } else ok = false;
+    }
+    for (int k = 0; k < NOUT && ok; k++) {
+      if (pin_out[k]) continue;
+      if (c->pipe_prefault) prefault_parallel(out[k].p, n * out[k].elem);
+      if (hipHostRegister(out[k].p, n * out[k].elem, hipHostRegisterDefault) == hipSuccess) { locked[nlocked++] = out[k].p; pin_out[k] = true; } else ok = false;
+    }
   }
   auto unlock = [&]() { for (int k = 0; k < nlocked; k++) (void)hipHostUnregister(locked[k]); };
   if (!ok) { (void)hipGetLastError(); unlock(); return 1; }
   clock_gettime(CLOCK_MONOTONIC, &ts1);
   jj_ctx::Pipe& P = c->pipe;
   hipStream_t saved = c->stream;
-  // One compute stream for all chunks (default).  JJ_PIPE_STREAMS=2: the chunks of slot s run on compute stream cs[s] with the
-  // workspaces of slot s, meant to overlap the short normalisation of chunk k with the ladder of chunk k + 1 -- measured 1.7x slower
-  // (see pipe_two_streams).  The compute streams start after the work already queued on the context's launch stream.
+  // One compute stream for all chunks (default); modes 2 and 3: see jj_ctx::pipe_mode.  The compute streams start after the work
+  // already queued on the context's launch stream.
   const int mode = c->pipe_mode;
   const bool two = mode == 2;
   hipStream_t cs[2] = {mode == 1 ? c->own_stream : P.cs[0], two ? P.cs[1] : (mode == 1 ? c->own_stream : P.cs[0])};     // main stream of slot 0 / 1
   WorkSet* wsets[2] = {&c->ws0, mode == 1 ? &c->ws0 : &P.wset};
   c->pipe_tail = mode == 3 ? P.cs[1] : nullptr;
   c->pipe_tail_ev = P.ev_tail;
-  const size_t nchunks = (n + CH - 1) / CH;
+  // Chunk schedule: chunks of CH units, except that the first and the last one are a quarter of that when the batch has at least four
+  // chunks -- the copy in of the first chunk and the copy out of the last one are the two transfers nothing overlaps
+  // (2^24 fixed-base units, chunks of 2^20: 0.6 ms + 1.3 ms of 31.5 ms; JJ_PIPE_RAMP=0: uniform chunks).
+  std::vector<size_t> bounds;       // chunk k = [bounds[k], bounds[k + 1])
+  {
+    const size_t edge = (c->pipe_ramp && n >= 4 * CH && CH >= ((size_t)1 << 18)) ? CH / 4 : 0;
+    size_t lo = 0;
+    bounds.push_back(0);
+    if (edge) { lo = edge; bounds.push_back(lo); }
+    while (n - lo > CH + edge) { lo += CH; bounds.push_back(lo); }
+    if (edge && n - lo > edge) { lo = n - edge; bounds.push_back(lo); }
+    bounds.push_back(n);
+  }
+  const size_t nchunks = bounds.size() - 1;
+  // bounce path: the host stages chunk k in and queues it, THEN moves the results of chunk k - 2 from their staging slot to the caller's array
+  // (waiting for that chunk's copy out of the device): it stays two chunks ahead of the GPU, which therefore never waits for a host copy.
+  // Staging slots rotate over three (a chunk's slot is free again when the chunk three before it has been copied out, which happened one
+  // iteration earlier), device slots over two as in the page-locked case.
+  auto copy_out = [&](size_t k) -> hipError_t {
+    const int g = (int)(k % 3); const size_t lo = bounds[k], cn = bounds[k + 1] - lo;
+    const hipError_t e = hipEventSynchronize(c->ev_stage[g]);
+    if (e != hipSuccess) return e;
+    size_t off = 0;
+    for (int j = 0; j < NOUT; j++) {
+      if (!pin_out[j]) c->copy_pool->copy((uint8_t*)out[j].p + lo * out[j].elem, c->stage_out[g] + off, cn * out[j].elem);
+      off += CH * out[j].elem;
+    }
+    return hipSuccess;
+  };
   rc = JJ_OK;
   #define PIPE_CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { c->err = std::string(#call) + " failed: " + hipGetErrorString(e_); rc = JJ_ERR_HIP; goto done; } } while (0)
   PIPE_CHK(hipEventRecord(P.ev_start, saved));
@@ -327,13 +475,16 @@ static int run_pipelined(jj_ctx* c, size_t n, size_t CH, const HostIn (&in)[NIN]
   if (cs[1] != cs[0]) PIPE_CHK(hipStreamWaitEvent(cs[1], P.ev_start, 0));
   if (mode == 3) PIPE_CHK(hipStreamWaitEvent(P.cs[1], P.ev_start, 0));
   for (size_t k = 0; k < nchunks; k++) {
-    const int s = (int)(k & 1); const size_t lo = k * CH, cn = std::min(CH, n - lo);
+    const int s = (int)(k & 1); const size_t lo = bounds[k], cn = bounds[k + 1] - lo;
+    const int g = (int)(k % 3);
     const void* din[NIN]; void* dout[NOUT];
     size_t off = 0;
     if (k >= 2) PIPE_CHK(hipStreamWaitEvent(P.h2d, P.ev_done[s], 0));            // slot's previous kernels have consumed din[s]
     for (int j = 0; j < NIN; j++) {
       din[j] = (uint8_t*)P.din[s].p + off;
-      PIPE_CHK(hipMemcpyAsync((uint8_t*)P.din[s].p + off, (const uint8_t*)in[j].p + lo * in[j].elem, cn * in[j].elem, hipMemcpyHostToDevice, P.h2d));
+      const uint8_t* src = (const uint8_t*)in[j].p + lo * in[j].elem;
+      if (!pin_in[j]) { c->copy_pool->copy(c->stage_in[g] + off, src, cn * in[j].elem); src = c->stage_in[g] + off; }      // (its last reader, the copy in of chunk k - 3, finished before that chunk's results were waited for)
+      PIPE_CHK(hipMemcpyAsync((uint8_t*)P.din[s].p + off, src, cn * in[j].elem, hipMemcpyHostToDevice, P.h2d));
       off += CH * in[j].elem;
     }
     PIPE_CHK(hipEventRecord(P.ev_in[s], P.h2d));
@@ -347,18 +498,22 @@ static int run_pipelined(jj_ctx* c, size_t n, size_t CH, const HostIn (&in)[NIN]
     PIPE_CHK(hipStreamWaitEvent(P.d2h, P.ev_done[s], 0));
     off = 0;
     for (int j = 0; j < NOUT; j++) {
-      PIPE_CHK(hipMemcpyAsync((uint8_t*)out[j].p + lo * out[j].elem, (uint8_t*)P.dout[s].p + off, cn * out[j].elem, hipMemcpyDeviceToHost, P.d2h));
+      uint8_t* dst = pin_out[j] ? (uint8_t*)out[j].p + lo * out[j].elem : c->stage_out[g] + off;
+      PIPE_CHK(hipMemcpyAsync(dst, (uint8_t*)P.dout[s].p + off, cn * out[j].elem, hipMemcpyDeviceToHost, P.d2h));
       off += CH * out[j].elem;
     }
     PIPE_CHK(hipEventRecord(P.ev_out[s], P.d2h));
+    if (any_bounce) { PIPE_CHK(hipEventRecord(c->ev_stage[g], P.d2h)); if (k >= 2) PIPE_CHK(copy_out(k - 2)); }
   }
   clock_gettime(CLOCK_MONOTONIC, &ts2);
+  if (any_bounce) { if (nchunks >= 2) PIPE_CHK(copy_out(nchunks - 2)); PIPE_CHK(copy_out(nchunks - 1)); }
   PIPE_CHK(hipStreamSynchronize(P.d2h));
   PIPE_CHK(hipGetLastError());
   clock_gettime(CLOCK_MONOTONIC, &ts3);
   if (dbg) {
     auto ms = [](const timespec& a, const timespec& b) { return (b.tv_sec - a.tv_sec) * 1e3 + (b.tv_nsec - a.tv_nsec) * 1e-6; };
-    fprintf(stderr, "[jj pipe] n=%zu chunk=%zu chunks=%zu stream mode=%d register %.2f ms, enqueue %.2f ms, drain %.2f ms\n", n, CH, nchunks, mode, ms(ts0, ts1), ms(ts1, ts2), ms(ts2, ts3));
+    fprintf(stderr, "[jj pipe] n=%zu chunk=%zu chunks=%zu stream mode=%d %s: prepare %.2f ms, loop %.2f ms, drain %.2f ms\n", n, CH, nchunks, mode,
+            any_bounce ? "bounce" : (nlocked ? "registered in place" : "page-locked"), ms(ts0, ts1), ms(ts1, ts2), ms(ts2, ts3));
   }
 done:
   #undef PIPE_CHK
@@ -449,6 +604,10 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
   if (hipEventCreateWithFlags(&c->order_ev, hipEventDisableTiming) != hipSuccess) return fail(JJ_ERR_HIP);
   c->stream = c->own_stream;
   if (const char* e = getenv("JJ_DEC_C_MID")) { int v = atoi(e); if (v == 8 || v == 16) c->dec_c_mid = v; }
+  if (const char* e = getenv("JJ_PIPE_PAGEABLE")) c->pipe_bounce = strcmp(e, "register") != 0;
+  if (const char* e = getenv("JJ_PIPE_COPY_THREADS")) { int v = atoi(e); if (v >= 0 && v <= 64) c->pipe_copy_threads = v; }
+  if (const char* e = getenv("JJ_PIPE_RAMP")) c->pipe_ramp = atoi(e) != 0;
+  if (const char* e = getenv("JJ_PIPE_PREFAULT")) c->pipe_prefault = atoi(e) != 0;
   if (const char* e = getenv("JJ_PIPE_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= 3) c->pipe_mode = v; }
   if (const char* e = getenv("JJ_PIPE_CHUNK_LOG2")) { int v = atoi(e); if (v >= 8 && v <= 24) c->pipe_chunk = (size_t)1 << v; }   // overrides the per-entry-point chunk
   if (const char* e = getenv("JJ_MSM_WINDOWS")) { int v = atoi(e); if (v >= MSM_WINDOWS_MIN && v <= MSM_WINDOWS_MAX) c->msm_windows = v; else fprintf(stderr, "libjubjub_hip: JJ_MSM_WINDOWS=%s ignored (valid: %d..%d)\n", e, MSM_WINDOWS_MIN, MSM_WINDOWS_MAX); }
@@ -504,6 +663,8 @@ JJ_API int jj_ctx_destroy(jj_ctx* c) {
     }
   }
   for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
+  delete c->copy_pool;
+  for (int i = 0; i < 3; i++) { if (c->stage_in[i]) (void)hipHostFree(c->stage_in[i]); if (c->stage_out[i]) (void)hipHostFree(c->stage_out[i]); if (c->ev_stage[i]) (void)hipEventDestroy(c->ev_stage[i]); }
   if (c->gather_dev.p) (void)hipFree(c->gather_dev.p);
   if (c->gather_host) (void)hipHostFree(c->gather_host);
   if (c->pipe.ready) {

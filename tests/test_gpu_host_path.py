@@ -106,6 +106,40 @@ def test_decompress_host_pipeline(eng, kind, flags):
     assert 0 < int(ok.sum()) < n
 
 
+def test_pageable_arrays_page_locked_in_place(monkeypatch):
+    """JJ_PIPE_PAGEABLE=register: pageable arrays are page-locked in place for the call instead of passing through the staging buffers
+    (round 3's way, kept as an option); with uniform chunks and a freshly allocated result array"""
+    import torch
+
+    from jubjub_amd import Engine
+
+    monkeypatch.setenv("JJ_PIPE_PAGEABLE", "register")
+    monkeypatch.setenv("JJ_PIPE_RAMP", "0")
+    e = Engine(0)
+    n = N_PIPE
+    s, p = _inputs(n, 77)
+    out = e.varbase_mul(s, p)                                   # a new numpy result array
+    dev = e.varbase_mul(torch.from_numpy(s).cuda(), torch.from_numpy(p).cuda()).cpu().numpy()
+    assert (out == dev).all()
+    e.close()
+
+
+def test_host_pipeline_chunk_schedule_edges(eng):
+    """batches just around the sizes where the chunk schedule changes shape (4 chunks, the short first / last chunk, a ragged tail),
+    pageable (bounce path: three staging slots) and page-locked"""
+    import torch
+
+    base = pt64(J.GENERATOR)
+    tab = eng.fixedbase_table(base)
+    for n in ((1 << 18) - 1, 1 << 18, (1 << 18) + 1, (1 << 20) + 4097, (1 << 22) + 3):
+        s = rand_scalars(1000 + (n & 0xffff), n)
+        want = eng.fixedbase_mul(tab, torch.from_numpy(s).cuda()).cpu().numpy()
+        assert (eng.fixedbase_mul(tab, s) == want).all(), n                                   # pageable in, fresh pageable out
+        hs, ho = _host(eng, "pinned", s), eng.host_alloc((n, 64))
+        assert (eng.fixedbase_mul(tab, hs, out=ho) == want).all(), n
+    tab.close()
+
+
 def test_host_alloc_api(eng):
     lib = eng._lib
     p = C.c_void_p()

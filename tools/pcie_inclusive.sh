@@ -14,9 +14,13 @@ line() {  # name, bench args...
   python - "$name" gpurun_out/${TAG}_bench_host_$name.json >> $OUT <<'PY'
 import json, sys
 d = json.load(open(sys.argv[2])); p = d["roofline"]["pcie"]
-print("%-28s %7.1f M units/s  (device-resident %6.1f M/s, ratio %.3f)  %6.2f ms/pass  H2D %5.1f GB/s  D2H %5.1f GB/s  link frac %.3f  bound by %-7s  verified %s / block %s / second pass %s" % (
+extra = ""
+if p.get("caller_alloc_free_ms_per_pass") is not None:
+    extra = "  [inside the call: %.2f ms = %.1f M units/s; caller's free + alloc of the result array: %.2f ms per pass]" % (
+        p["call_ms_per_pass"], p["units_per_s_inside_the_call"] / 1e6, p["caller_alloc_free_ms_per_pass"])
+print("%-36s %7.1f M units/s  (device-resident %6.1f M/s, ratio %.3f)  %6.2f ms/pass  H2D %5.1f GB/s  D2H %5.1f GB/s  link frac %.3f  bound by %-7s  verified %s / block %s / second pass %s%s" % (
     sys.argv[1], d["value"] / 1e6, d["device_resident"]["value"] / 1e6, d["host_over_device_resident"], p["ms_per_pass"], p["h2d_GBps"], p["d2h_GBps"], p["frac"],
-    p["bound_by"], d.get("verified"), d.get("verified_block", {}).get("ok"), d.get("all_units_equal_second_pass")))
+    p["bound_by"], d.get("verified"), d.get("verified_block", {}).get("ok"), d.get("all_units_equal_second_pass"), extra))
 PY
 }
 for hb in pinned pageable; do
@@ -25,4 +29,16 @@ for hb in pinned pageable; do
   line fixedbase_compressed_$hb --workload fixedbase --host-buffers $hb --compressed
   line decompress_$hb --workload decompress --host-buffers $hb
 done
+# pageable arrays page-locked in place for the call (round 3's way) instead of the bounce path through the context's staging buffers
+JJ_PIPE_PAGEABLE=register line fixedbase_pageable_register --workload fixedbase --host-buffers pageable
+JJ_PIPE_PAGEABLE=register line decompress_pageable_register --workload decompress --host-buffers pageable
+# a caller that allocates a NEW result array per call (vec![0u8; 64 * n]): bounce (default) and in-place page-locking with / without the pre-fault
+line fixedbase_fresh --workload fixedbase --host-buffers fresh
+JJ_PIPE_PAGEABLE=register line fixedbase_fresh_register --workload fixedbase --host-buffers fresh
+JJ_PIPE_PAGEABLE=register JJ_PIPE_PREFAULT=0 line fixedbase_fresh_register_noprefault --workload fixedbase --host-buffers fresh
+line decompress_fresh --workload decompress --host-buffers fresh
+line varbase_fresh --workload varbase --host-buffers fresh
+# uniform chunks (no short first / last chunk)
+JJ_PIPE_RAMP=0 line fixedbase_pinned_uniform_chunks --workload fixedbase --host-buffers pinned
+JJ_PIPE_RAMP=0 line decompress_pinned_uniform_chunks --workload decompress --host-buffers pinned
 cat $OUT
