@@ -251,8 +251,12 @@ static bool is_device_ptr(const void* p) {
   return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
 }
 
+static bool is_pinned_host(const void* p, size_t bytes);
+static int host_to_dev_bounced(jj_ctx* c, void* dev, const void* host, size_t bytes);
+static int dev_to_host_bounced(jj_ctx* c, void* host, const void* dev, size_t bytes);
+constexpr size_t BOUNCE_MIN_BYTES = (size_t)16 << 20;     // smaller pageable arrays are copied by the runtime's own staging
 // Resolves an input pointer: device pointers pass through (must be 16-byte aligned), host data is copied into a
-// staging buffer.
+// staging buffer (large pageable arrays through the page-locked staging slots, see host_to_dev_bounced).
 static int stage_in(jj_ctx* c, int slot, const void* p, size_t bytes, const void** dev) {
   if (bytes == 0) { *dev = nullptr; return JJ_OK; }
   if (!p) { c->err = "null input pointer"; return JJ_ERR_INVALID; }
@@ -261,7 +265,8 @@ static int stage_in(jj_ctx* c, int slot, const void* p, size_t bytes, const void
     *dev = p; return JJ_OK;
   }
   int rc = ensure(c, c->in[slot], bytes); if (rc) return rc;
-  if (bytes) HIPCHK(c, hipMemcpyAsync(c->in[slot].p, p, bytes, hipMemcpyHostToDevice, c->stream));
+  if (c->pipe_bounce && bytes >= BOUNCE_MIN_BYTES && !is_pinned_host(p, bytes)) { if ((rc = host_to_dev_bounced(c, c->in[slot].p, p, bytes))) return rc; }
+  else HIPCHK(c, hipMemcpyAsync(c->in[slot].p, p, bytes, hipMemcpyHostToDevice, c->stream));
   *dev = c->in[slot].p; return JJ_OK;
 }
 struct OutRef { void* user; void* dev; size_t bytes; bool host; };
@@ -278,7 +283,8 @@ static int stage_out(jj_ctx* c, DevBuf& buf, void* p, size_t bytes, OutRef* o) {
 }
 static int finish_out(jj_ctx* c, const OutRef& o, bool* need_sync) {
   if (o.host) {
-    if (o.bytes) HIPCHK(c, hipMemcpyAsync(o.user, o.dev, o.bytes, hipMemcpyDeviceToHost, c->stream));
+    if (c->pipe_bounce && o.bytes >= BOUNCE_MIN_BYTES && !is_pinned_host(o.user, o.bytes)) { const int rc = dev_to_host_bounced(c, o.user, o.dev, o.bytes); if (rc) return rc; }
+    else if (o.bytes) HIPCHK(c, hipMemcpyAsync(o.user, o.dev, o.bytes, hipMemcpyDeviceToHost, c->stream));
     *need_sync = true;
   }
   return JJ_OK;
@@ -394,6 +400,42 @@ static int stage_ensure(jj_ctx* c, size_t in_bytes, size_t out_bytes) {
     const int T = c->pipe_copy_threads ? c->pipe_copy_threads : (int)std::min<unsigned>(8, std::max<unsigned>(2, hw / 2));
     c->copy_pool = new HostCopyPool(T - 1);          // the calling thread copies too
   }
+  return JJ_OK;
+}
+// A large pageable array of an entry point that is not pipelined (the inputs of an MSM, the operands of a batched field or point
+// operation): hipMemcpyAsync from pageable memory goes through the runtime's own single-threaded staging (3 - 30 GB/s measured,
+// profiles/r4_pcie_probe.txt); here the copy pool fills page-locked staging slots while the previous slot's DMA runs.
+static int host_to_dev_bounced(jj_ctx* c, void* dev, const void* host, size_t bytes) {
+  int rc = stage_ensure(c, std::max(BOUNCE_MIN_BYTES, c->stage_in_cap), c->stage_out_cap); if (rc) return rc;
+  const size_t CHB = BOUNCE_MIN_BYTES;
+  size_t k = 0;
+  for (size_t lo = 0; lo < bytes; lo += CHB, k++) {
+    const int g = (int)(k % 3); const size_t cn = std::min(CHB, bytes - lo);
+    if (k >= 3) HIPCHK(c, hipEventSynchronize(c->ev_stage[g]));          // the slot's previous DMA has read it
+    c->copy_pool->copy(c->stage_in[g], (const uint8_t*)host + lo, cn);
+    HIPCHK(c, hipMemcpyAsync((uint8_t*)dev + lo, c->stage_in[g], cn, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_stage[g], c->stream));
+  }
+  for (size_t j = (k > 3 ? k - 3 : 0); j < k; j++) HIPCHK(c, hipEventSynchronize(c->ev_stage[j % 3]));   // the slots are free for the next user
+  return JJ_OK;
+}
+static int dev_to_host_bounced(jj_ctx* c, void* host, const void* dev, size_t bytes) {
+  int rc = stage_ensure(c, c->stage_in_cap, std::max(BOUNCE_MIN_BYTES, c->stage_out_cap)); if (rc) return rc;
+  const size_t CHB = BOUNCE_MIN_BYTES;
+  const size_t nch = (bytes + CHB - 1) / CHB;
+  auto drain = [&](size_t k) -> hipError_t {
+    const hipError_t e = hipEventSynchronize(c->ev_stage[k % 3]);
+    if (e != hipSuccess) return e;
+    c->copy_pool->copy((uint8_t*)host + k * CHB, c->stage_out[k % 3], std::min(CHB, bytes - k * CHB));
+    return hipSuccess;
+  };
+  for (size_t k = 0; k < nch; k++) {
+    HIPCHK(c, hipMemcpyAsync(c->stage_out[k % 3], (const uint8_t*)dev + k * CHB, std::min(CHB, bytes - k * CHB), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_stage[k % 3], c->stream));
+    if (k >= 2) HIPCHK(c, drain(k - 2));
+  }
+  if (nch >= 2) HIPCHK(c, drain(nch - 2));
+  HIPCHK(c, drain(nch - 1));
   return JJ_OK;
 }
 template <int NIN, int NOUT, class Body>

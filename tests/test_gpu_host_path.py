@@ -276,3 +276,18 @@ def test_msm_dev_finish(eng, golden, n):
     assert eng.msm_dev(s, p, out=out) is out and (out.cpu().numpy() == want).all()       # host inputs are staged, the result still stays on the device
     with pytest.raises(Exception):
         eng._check(eng._lib.jj_msm_dev(eng._ctx, C.c_size_t(n), C.c_void_p(ds.data_ptr()), C.c_void_p(dp.data_ptr()), np.zeros(64, np.uint8).ctypes.data))   # host result pointer
+
+
+def test_large_pageable_arrays_of_unpipelined_entry_points(eng):
+    """entry points outside the chunked pipeline (MSM inputs, batched field and point operations) move pageable arrays of 16 MB and more
+    through the page-locked staging slots (host_to_dev_bounced / dev_to_host_bounced): 2^20 + 5 units, several slots' worth each way"""
+    n = (1 << 20) + 5
+    s = rand_scalars(4242, n)
+    small = rand_points(4243, 2048)
+    p = np.ascontiguousarray(small[np.arange(n) % 2048])
+    assert (eng.msm(s, p) == O.msm_pippenger(s, p, 13).reshape(64)).all()
+    got = eng.field_binary("fq", "mul", s, s[::-1].copy())                    # 2 x 33.5 MB in, 33.5 MB out
+    idx = np.concatenate([np.arange(0, n, 997), [n - 1, (1 << 19) - 1, 1 << 19]])
+    assert (got[idx] == O.field_op(O.FQ, "mul", s[idx], s[::-1][idx])[0]).all()
+    dbl = eng.point_double(p)                                                  # 67 MB in, 67 MB out
+    assert (dbl[idx] == O.point_op("double", p[idx])).all()
