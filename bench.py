@@ -473,22 +473,24 @@ def run(a):
             return eng.fixedbase_mul_compressed(table, scalars) if a.compressed else eng.fixedbase_mul(table, scalars)
         return eng.decompress(enc, a.decompress_flags)
 
-    alloc_s = [0.0]                                                # fresh mode: time spent freeing the previous result array and allocating the next one
+    call_s = [0.0]                                                 # host-buffer modes: time spent inside the C-ABI calls themselves
 
     def one_pass():
         nonlocal h_out, h_ok
         if host == "fresh":
-            ta = time.perf_counter()
-            h_out = None; h_ok = None                              # drop the previous result first, like a caller that consumed it
+            h_out = None; h_ok = None                              # (the previous result array itself is released when the caller drops it: `out = step()`)
             h_out = np.empty((n, out_w), np.uint8)
             h_ok = np.empty((n,), np.uint8) if wl == "decompress" else None
-            alloc_s[0] += time.perf_counter() - ta
         if host:
+            tc = time.perf_counter()
             if wl == "varbase":
-                return (eng.varbase_mul_compressed if a.compressed else eng.varbase_mul)(h_scalars, h_points, out=h_out)
-            if wl == "fixedbase":
-                return (eng.fixedbase_mul_compressed if a.compressed else eng.fixedbase_mul)(table, h_scalars, out=h_out)
-            return eng.decompress(h_enc, a.decompress_flags, out=(h_out, h_ok))
+                r = (eng.varbase_mul_compressed if a.compressed else eng.varbase_mul)(h_scalars, h_points, out=h_out)
+            elif wl == "fixedbase":
+                r = (eng.fixedbase_mul_compressed if a.compressed else eng.fixedbase_mul)(table, h_scalars, out=h_out)
+            else:
+                r = eng.decompress(h_enc, a.decompress_flags, out=(h_out, h_ok))
+            call_s[0] += time.perf_counter() - tc
+            return r
         if wl != "msm":
             return one_pass_device()
         if not distributed:
@@ -567,12 +569,13 @@ def run(a):
     peak_before = eng.peak_imad32_samples(5) if rank == 0 else None     # the roofline denominator, sampled on both sides of the timed region
     barrier()
     eng.profile(True)
-    alloc_s[0] = 0.0
+    call_s[0] = 0.0
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = step()
-    t_own = time.perf_counter() - t0                                    # this rank's own loop, before it waits for the others
-    alloc_in_timed = alloc_s[0]
+    torch.cuda.synchronize(dev)
+    t_own = time.perf_counter() - t0                                    # this rank's own work done (device drained), before it waits for the others
+    call_in_timed = call_s[0]
     barrier()
     dt = time.perf_counter() - t0
     main_ms, tail_ms = eng.profile_read()
@@ -712,11 +715,11 @@ def run(a):
                 "link_bound_units_per_s": PCIE_PEAK_GBPS * 1e9 / max(in_b, out_b),
                 "kernel_bound_units_per_s": dev_ref["value"],
                 "ms_per_pass": per_pass * 1e3,
-                # fresh mode: what the CALLER spends per pass releasing the previous result array and allocating the next one (munmap / mmap of
-                # the result's pages: any implementation that returns a new array per call pays it), and the time inside the C-ABI call alone
-                "caller_alloc_free_ms_per_pass": alloc_in_timed / a.steps / passes * 1e3 if host == "fresh" else None,
-                "call_ms_per_pass": (dt - alloc_in_timed) / a.steps / passes * 1e3,
-                "units_per_s_inside_the_call": units_per_step * a.steps / (dt - alloc_in_timed),
+                # the time inside the C-ABI calls alone, and (fresh mode) what the CALLER spends per pass allocating the next result array and
+                # releasing the previous one (mmap / munmap of 1 GB of touched pages: any implementation that returns a new array per call pays it)
+                "call_ms_per_pass": call_in_timed / a.steps / passes * 1e3,
+                "units_per_s_inside_the_call": units_per_step * a.steps / call_in_timed,
+                "caller_alloc_free_ms_per_pass": (dt - call_in_timed) / a.steps / passes * 1e3 if host == "fresh" else None,
                 "bound_by": "kernels" if dev_ref["value"] < PCIE_PEAK_GBPS * 1e9 / max(in_b, out_b) else "link",
                 "frac_of_min_bound": value / min(dev_ref["value"], PCIE_PEAK_GBPS * 1e9 / max(in_b, out_b)),
             }

@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Randomised soak of the host-pointer path (include/jubjub_hip.h "host buffers"): random batch sizes around the pipeline's chunk
+boundaries, every array independently page-locked (jj_host_alloc) or pageable, random chunk lengths, bounce / in-place page-locking,
+uniform / ramped chunk schedules -- against the device-resident entry points (bit-exact, all units) and an oracle sample.
+Usage: python tests/soak_host.py [seconds] [seed]   (needs an MI355X)"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+
+from jubjub_amd import Engine  # noqa: E402
+from oracle import c_oracle as O  # noqa: E402
+from oracle import jubjub_ref as J  # noqa: E402
+from util import pt64  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+SEED0 = int(sys.argv[2]) if len(sys.argv) > 2 else 4000
+base = pt64(J.GENERATOR)
+small = O.fixedbase_mul(np.random.default_rng(1).integers(0, 256, size=(4096, 32), dtype=np.uint8) & np.array([255] * 31 + [15], np.uint8), base)
+ref = Engine(0)
+t_end, rnd, units = time.time() + budget, 0, 0
+while time.time() < t_end:
+    rng = np.random.default_rng(SEED0 + rnd)
+    env = {}
+    if rng.integers(0, 2):
+        env["JJ_PIPE_CHUNK_LOG2"] = str(int(rng.integers(14, 20)))
+    if rng.integers(0, 3) == 0:
+        env["JJ_PIPE_PAGEABLE"] = "register"
+    if rng.integers(0, 3) == 0:
+        env["JJ_PIPE_RAMP"] = "0"
+    if rng.integers(0, 2):
+        env["JJ_PIPE_COPY_THREADS"] = str(int(rng.integers(1, 9)))
+    os.environ.update(env)
+    eng = Engine(0)
+    for k in env:
+        del os.environ[k]
+    n = int(rng.choice([(1 << 18) + int(rng.integers(-3, 4)), int(rng.integers(1 << 16, 1 << 21)), (1 << 20) + int(rng.integers(-70000, 70000))]))
+
+    def host(a):
+        if rng.integers(0, 2):
+            h = eng.host_alloc(a.shape); h[...] = a
+            return h
+        return np.array(a, copy=True)
+
+    S = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    P = np.ascontiguousarray(small[rng.integers(0, 4096, size=n)])
+    idx = np.concatenate([rng.integers(0, n, size=300), [0, n - 1]])
+    dS, dP = torch.from_numpy(S).cuda(), torch.from_numpy(P).cuda()
+    hS, hP = host(S), host(P)
+    out = host(np.zeros((n, 64), np.uint8)) if rng.integers(0, 2) else None            # None: a fresh pageable result array
+    got = eng.varbase_mul(hS, hP, out=out)
+    assert (got == ref.varbase_mul(dS, dP).cpu().numpy()).all(), ("varbase", rnd, env, n)
+    assert (got[idx] == O.varbase_mul(S[idx], P[idx])).all(), ("varbase oracle", rnd)
+    tab, rtab = eng.fixedbase_table(base), ref.fixedbase_table(base)
+    out32 = host(np.zeros((n, 32), np.uint8)) if rng.integers(0, 2) else None
+    got = eng.fixedbase_mul_compressed(tab, hS, out=out32)
+    assert (got == ref.fixedbase_mul_compressed(rtab, dS).cpu().numpy()).all(), ("fixedbase compressed", rnd, env, n)
+    assert (got[idx] == O.compress(O.fixedbase_mul(S[idx], base))).all(), ("fixedbase oracle", rnd)
+    enc = O.compress(P)
+    bad = rng.integers(0, n, size=n // 20)
+    enc[bad] = rng.integers(0, 256, size=(len(bad), 32), dtype=np.uint8)
+    flags = int(rng.choice([1, 5, 13, 15]))
+    o1, k1 = eng.decompress(host(enc), flags, out=(host(np.zeros((n, 64), np.uint8)), host(np.zeros((n,), np.uint8))) if rng.integers(0, 2) else None)
+    o2, k2 = ref.decompress(torch.from_numpy(enc).cuda(), flags)
+    assert (k1 == k2.cpu().numpy()).all() and (o1 == o2.cpu().numpy()).all(), ("decompress", rnd, env, n, flags)
+    eo, ek = O.decompress(enc[idx], flags)
+    assert (k1[idx] == ek).all() and (o1[idx] == eo).all(), ("decompress oracle", rnd)
+    assert (eng.msm(hS, hP) == ref.msm(dS, dP).cpu().numpy()).all(), ("msm from host arrays", rnd, env, n)
+    tab.close(); rtab.close(); eng.close()
+    units += n; rnd += 1
+    print("round %d ok: n=%d %s (%d units so far, %.0f s left)" % (rnd, n, env, units, t_end - time.time()), flush=True)
+print("HOST SOAK PASSED: %d rounds, %d units per entry point, all bit-exact vs the device-resident path and the oracle sample" % (rnd, units))
