@@ -7,7 +7,7 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 template <int MODE>   // 0: bpermute only; 1: ds_read_b128 only; 2: mads only; 3: 54 bpermute + 14 reads per 1400 mads (the comb's mix); 4: the mix without LDS
-__global__ void __launch_bounds__(512) k(uint32_t* out, int iters) {
+__global__ void __launch_bounds__(768) k(uint32_t* out, int iters) {
   __shared__ uint4 lds[2048];
   const int lane = threadIdx.x & 63;
   for (int i = threadIdx.x; i < 2048; i += blockDim.x) lds[i] = make_uint4(i, i + 1, i + 2, i + 3);
@@ -42,7 +42,7 @@ template <int MODE> static int run(const char* name, int threads, int iters, dou
   uint32_t* out; CK(hipMalloc(&out, (size_t)blocks * threads * 4));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(threads), 0, 0, out, 10);
-  CK(hipEventRecord(e0)); hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(threads), 0, 0, out, iters); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  CK(hipEventRecord(e0)); hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(threads), 0, 0, out, iters); CK(hipGetLastError()); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   const double clk = 2.2e9 * ms * 1e-3;   // nominal cycles
   const int waves = threads / 64;

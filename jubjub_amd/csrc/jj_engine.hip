@@ -1215,7 +1215,7 @@ JJ_API int jj_fixedbase_table_destroy(jj_ctx* c, jj_table* t) {
   return JJ_OK;
 }
 static int fixedbase_launch(jj_ctx* c, const jj_table* t, size_t n, const void* ds, SoA ext, int chain = 0) {
-  const unsigned blocks = (unsigned)std::min((size_t)c->cus, (n + 511) / 512);   // one 512-thread workgroup per CU (LDS-bound)
+  // one workgroup per CU (the table fills the LDS)
   if (t->window_bits == 7) {
     const unsigned cblocks = (unsigned)std::min((size_t)c->cus, (n + FBC_THREADS - 1) / FBC_THREADS);
     if (c->fb_const_time) hipLaunchKernelGGL(k_fixedbase_comb<true>, dim3(cblocks), dim3(FBC_THREADS), FBC_LDS_BYTES, c->stream, n, ds, (const u32*)t->dev, ext, chain);
@@ -1223,8 +1223,11 @@ static int fixedbase_launch(jj_ctx* c, const jj_table* t, size_t n, const void* 
   } else if (t->window_bits != FB_W) {
     const unsigned gblocks = (unsigned)std::min((size_t)c->cus * c->fb_gather_blocks_per_cu, (n + 255) / 256);
     hipLaunchKernelGGL(k_fixedbase_gather, dim3(gblocks), dim3(256), 0, c->stream, n, ds, (const u32*)t->dev, t->fp, ext, chain);
-  } else if (c->fb_const_time) hipLaunchKernelGGL(k_fixedbase<true>, dim3(blocks), dim3(512), FB_LDS_BYTES, c->stream, n, ds, (const u32*)t->dev, ext, chain);
-  else hipLaunchKernelGGL(k_fixedbase<false>, dim3(blocks), dim3(512), FB_LDS_BYTES, c->stream, n, ds, (const u32*)t->dev, ext, chain);
+  } else {
+    const unsigned wblocks = (unsigned)std::min((size_t)c->cus, (n + FB_THREADS - 1) / FB_THREADS);
+    if (c->fb_const_time) hipLaunchKernelGGL(k_fixedbase<true>, dim3(wblocks), dim3(FB_THREADS), FB_LDS_BYTES, c->stream, n, ds, (const u32*)t->dev, ext, chain);
+    else hipLaunchKernelGGL(k_fixedbase<false>, dim3(wblocks), dim3(FB_THREADS), FB_LDS_BYTES, c->stream, n, ds, (const u32*)t->dev, ext, chain);
+  }
   return JJ_OK;
 }
 static int fixedbase_api(jj_ctx* c, const jj_table* t, size_t n, const void* scalars, void* out, int mode) {

@@ -554,8 +554,15 @@ static JJ_DEV u32 window6(const u32 (&k)[8], int i) {
 // is applied with bit masks.  CT = false reads the entry directly at a per-lane LDS address.
 static JJ_DEV Ext soa_ext(const SoA& s, size_t i);
 // chain: bit 0 = start from the point already in `ext` (sums over several fixed bases), bit 1 = also write t1, t2
+#ifndef JJ_FB_THREADS
+#define JJ_FB_THREADS 512
+#endif
+#ifndef JJ_FB_SINGLE_BUFFER
+#define JJ_FB_SINGLE_BUFFER 0
+#endif
+constexpr int FB_THREADS = JJ_FB_THREADS;
 template <bool CT>
-__global__ void __launch_bounds__(512) k_fixedbase(size_t n, const void* scalars, const u32* table, SoA ext, int chain) {
+__global__ void __launch_bounds__(FB_THREADS) k_fixedbase(size_t n, const void* scalars, const u32* table, SoA ext, int chain) {
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
   {
     const uint4* src = reinterpret_cast<const uint4*>(table);
@@ -616,6 +623,15 @@ __global__ void __launch_bounds__(512) k_fixedbase(size_t n, const void* scalars
     // the wait for the shuffles sits behind a whole addition
     static_assert(FB_NWIN % 2 == 0, "the window loop is unrolled by two");
     u32 j, neg0, neg1;
+#if JJ_FB_SINGLE_BUFFER
+    #pragma unroll 1
+    for (int i = FB_NWIN - 1; i >= 0; i--) {                  // one entry register set (see JJ_FBC_SINGLE_BUFFER)
+      next_digit(j, neg0);
+      const ANiels e = fetch(i, j);
+      acc = Curve::add_signed<true>(acc, e, neg0);
+    }
+    (void)neg1;
+#else
     next_digit(j, neg0);
     ANiels e0 = fetch(FB_NWIN - 1, j), e1;
     #pragma unroll 1
@@ -626,6 +642,7 @@ __global__ void __launch_bounds__(512) k_fixedbase(size_t n, const void* scalars
       if (i > 1) { next_digit(j, neg0); e0 = fetch(i - 2, j); }
       acc = Curve::add_signed<true>(acc, e1, neg1);
     }
+#endif
     if (live) {
       ext.put(0, idx, acc.u); ext.put(1, idx, acc.v); ext.put(2, idx, acc.z);
       if (chain & 2) { ext.put(3, idx, Fq::carry(acc.t1)); ext.put(4, idx, Fq::carry(acc.t2)); }
@@ -649,8 +666,16 @@ constexpr int FBC_TENT = 128;                                // entries per tabl
 constexpr int FBC_TABLES = FBC_BLOCKS + 2;                   // + T_0 - B, T_0 + B
 constexpr int FBC_ENTRIES = FBC_TABLES * FBC_TENT;
 constexpr int FBC_LDS_BYTES = FBC_ENTRIES * ANIELS_WORDS * 4;
+// Workgroup size and entry buffering of the comb kernel.  Round 3: 512 threads (two waves per SIMD) and two entry register sets (the entry
+// of step t + 1 shuffled in before the addition of step t: 174 VGPRs).  Round 4 (profiles/r4_fixedbase_select_pmc.txt, LDS probe): the
+// shuffles' LDS time is not hidden at two waves per SIMD (+14 % in the probe, +4 % at three), so: 768 threads, and ONE entry register
+// set (145 VGPRs: three waves per SIMD fit without a spill; the other waves cover the shuffle latency instead of the software prefetch).
+// Same box: 604-612 -> 620-625 M/s (512 threads + one set: 611-618; 1024 threads: 128 VGPRs, 30 spilled, 601-605).
 #ifndef JJ_FBC_THREADS
-#define JJ_FBC_THREADS 512
+#define JJ_FBC_THREADS 768
+#endif
+#ifndef JJ_FBC_SINGLE_BUFFER
+#define JJ_FBC_SINGLE_BUFFER 1
 #endif
 constexpr int FBC_THREADS = JJ_FBC_THREADS;                  // one workgroup per CU (the table fills the LDS): waves per SIMD = FBC_THREADS / 256
 template <bool CT>
@@ -734,6 +759,18 @@ __global__ void __launch_bounds__(FBC_THREADS) k_fixedbase_comb(size_t n, const 
     };
     Ext acc = Curve::identity();
     u32 j, neg0, neg1;
+#if JJ_FBC_SINGLE_BUFFER
+    // one entry register set: the entry of a step is fetched right before its addition and the other waves of the SIMD cover the shuffles'
+    // latency (three waves per SIMD with 768-thread workgroups need the 27 registers the second set takes)
+    #pragma unroll 1
+    for (int t = 0; t < 32; t++) {
+      next_digit(j, neg0);
+      const ANiels e = (t == 31) ? fetch_last(j, neg0) : fetch(FBC_BLOCKS - 1 - (t & 7), j);
+      acc = Curve::add_signed<true>(acc, e, neg0);
+      if (((t + 1) & 7) == 0 && t + 1 < 32) acc = Curve::dbl(acc);
+    }
+    (void)neg1;
+#else
     ANiels e0, e1;
     next_digit(j, neg0);
     e0 = fetch(FBC_BLOCKS - 1, j);
@@ -748,6 +785,7 @@ __global__ void __launch_bounds__(FBC_THREADS) k_fixedbase_comb(size_t n, const 
       acc = Curve::add_signed<true>(acc, e1, neg1);
       if (((t + 2) & 7) == 0 && t + 2 < 32) acc = Curve::dbl(acc);
     }
+#endif
     // sums over several bases (chain): the previous sum is added after the comb -- the doublings between the phases must not touch it
     if ((chain & 1) && live) acc = Curve::add<true>(acc, Curve::to_niels<false>(soa_ext(ext, idx)));
     if (live) {
