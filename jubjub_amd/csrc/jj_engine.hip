@@ -364,11 +364,16 @@ static void prefault_parallel(void* p, size_t bytes) {
 // fixed-base and decoder kernels -- shorter chunks pay the shared inversion of their normalisation over too few points, longer ones
 // pay the unoverlapped first copy in and last copy out; 2^18 for the var-base ladder, whose kernel time dwarfs its copies); smaller
 // batches are cut in four, down to 2^16 units per chunk.
-static size_t pipe_chunk_for(const jj_ctx* c, size_t n, int pref_log2) {
+// `quantum`: the kernel's lane count when every lane takes ceil(chunk / lanes) units in a grid-stride loop (the fixed-base kernels: one
+// workgroup per CU): a chunk that is not a multiple of it leaves most lanes idle during the last round -- 2^20 units over 196 608 lanes are
+// 5.33 per lane, i.e. the time of 6 (-11 %) -- so the chunk and the short first / last chunk are rounded to multiples of it.
+static size_t pipe_chunk_for(const jj_ctx* c, size_t n, int pref_log2, size_t quantum = 0) {
   if (c->pipe_chunk) return n >= 2 * c->pipe_chunk ? c->pipe_chunk : 0;
   size_t ch = (size_t)1 << pref_log2;
   while (ch > ((size_t)1 << 16) && n < 4 * ch) ch >>= 1;
-  return n >= 4 * ch ? ch : 0;
+  if (n < 4 * ch) return 0;
+  if (quantum && ch >= 2 * quantum) ch = ((ch + quantum / 2) / quantum) * quantum;
+  return ch;
 }
 // Inside a pipelined call in stream mode 3: the launches that follow go to the tail stream, ordered after what the chunk has queued on
 // its main stream so far.  A no-op everywhere else.
@@ -439,7 +444,7 @@ static int dev_to_host_bounced(jj_ctx* c, void* host, const void* dev, size_t by
   return JJ_OK;
 }
 template <int NIN, int NOUT, class Body>
-static int run_pipelined(jj_ctx* c, size_t n, size_t CH, const HostIn (&in)[NIN], const HostOut (&out)[NOUT], Body body) {
+static int run_pipelined(jj_ctx* c, size_t n, size_t CH, const HostIn (&in)[NIN], const HostOut (&out)[NOUT], Body body, size_t quantum = 0) {
   size_t in_stride = 0, out_stride = 0;
   for (int k = 0; k < NIN; k++) in_stride += in[k].elem;
   for (int k = 0; k < NOUT; k++) out_stride += out[k].elem;
@@ -486,7 +491,8 @@ static int run_pipelined(jj_ctx* c, size_t n, size_t CH, const HostIn (&in)[NIN]
   // (2^24 fixed-base units, chunks of 2^20: 0.6 ms + 1.3 ms of 31.5 ms; JJ_PIPE_RAMP=0: uniform chunks).
   std::vector<size_t> bounds;       // chunk k = [bounds[k], bounds[k + 1])
   {
-    const size_t edge = (c->pipe_ramp && n >= 4 * CH && CH >= ((size_t)1 << 18)) ? CH / 4 : 0;
+    size_t edge = (c->pipe_ramp && n >= 4 * CH && CH >= ((size_t)1 << 18)) ? CH / 4 : 0;
+    if (edge && quantum && CH % quantum == 0) edge = std::max(quantum, (edge / quantum) * quantum);      // whole rounds of the kernel's lanes
     size_t lo = 0;
     bounds.push_back(0);
     if (edge) { lo = edge; bounds.push_back(lo); }
@@ -1234,7 +1240,9 @@ static int fixedbase_api(jj_ctx* c, const jj_table* t, size_t n, const void* sca
   if (!c || !t) return JJ_ERR_INVALID;
   JJ_ENTER(c);
   if (t->device != c->device) { c->err = "fixed-base table belongs to another device"; return JJ_ERR_INVALID; }
-  if (const size_t ch = pipe_chunk_for(c, n, 20); ch && all_host({scalars, out})) {
+  // lanes of the table's kernel: one workgroup per CU for the LDS tables, fb_gather_blocks_per_cu blocks of 256 for the gathered ones
+  const size_t fb_lanes = t->window_bits == 7 ? (size_t)c->cus * FBC_THREADS : t->window_bits == FB_W ? (size_t)c->cus * FB_THREADS : (size_t)c->cus * c->fb_gather_blocks_per_cu * 256;
+  if (const size_t ch = pipe_chunk_for(c, n, 20, fb_lanes); ch && all_host({scalars, out})) {
     const HostIn in[1] = {{scalars, 32}};
     const HostOut ho[1] = {{out, (size_t)(mode ? 32 : 64)}};
     const int prc = run_pipelined(c, n, ch, in, ho, [&](size_t cn, const void* const* di, void* const* dout) -> int {
@@ -1244,7 +1252,7 @@ static int fixedbase_api(jj_ctx* c, const jj_table* t, size_t n, const void* sca
       if ((rc2 = fixedbase_launch(c, t, cn, di[0], ext))) return rc2;
       if ((rc2 = pipe_to_tail(c))) return rc2;
       return normalize_launch(c, cn, ext, dout[0], mode);
-    });
+    }, fb_lanes);
     if (prc <= 0) return prc;
   }
   const void* ds; int rc; OutRef o;
