@@ -1123,6 +1123,18 @@ static JJ_DEV Ext quad_add_ext_t(const Ext& p, const Fe& Tp, const Ext& q, const
   sout = quad_bcast<1>(r2);
   return quad_add_finish(a, b, c, Fq::add(zz, zz), role, Tout);
 }
+// The same with TWO side products (lanes 1 and 2 of the second round, which only lane 0 needs): sout1 = sa1 * sb1, sout2 = sa2 * sb2.
+static JJ_DEV Ext quad_add_ext_t2(const Ext& p, const Fe& Tp, const Ext& q, const Fe& Tq, u32 role, Fe& Tout,
+                                  const Fe& sa1, const Fe& sb1, Fe& sout1, const Fe& sa2, const Fe& sb2, Fe& sout2) {
+  const Fe r1 = Fq::mul(role_select4(Fq::sub(p.v, p.u), Fq::add(p.v, p.u), Tp, p.z, role),
+                        role_select4(Fq::sub(q.v, q.u), Fq::carry(Fq::add(q.v, q.u)), Tq, q.z, role));
+  const Fe a = quad_bcast<0>(r1), b = quad_bcast<1>(r1), tt = quad_bcast<2>(r1), zz = quad_bcast<3>(r1);
+  const Fe r2 = Fq::mul(role_select4(tt, sa1, sa2, tt, role), role_select4(Fq::konst(FqP::D2), sb1, sb2, Fq::konst(FqP::D2), role));
+  const Fe c = quad_bcast<0>(r2);
+  sout1 = quad_bcast<1>(r2);
+  sout2 = quad_bcast<2>(r2);
+  return quad_add_finish(a, b, c, Fq::add(zz, zz), role, Tout);
+}
 // Small batches: one scalar multiplication per quad of lanes.  Same signed-window ladder and table as
 // varbase_windowed, but every point operation is two multiplication rounds on four lanes (12 rounds per 5-bit window
 // instead of 43 dependent products), which is what matters when the batch cannot fill the SIMDs anyway.

@@ -797,32 +797,46 @@ __global__ void __launch_bounds__(256) k_msm_fixup_big(u32* counters, const BigB
 static JJ_DEV Ext msm_reduce_chunk(const MsmParams& mp, u32 s, u32 k, u32 L, int lb, int jbits, const ExtAoS& buckets, u32 role, Fe& Tout) {
   const size_t first = (size_t)s * mp.B + (size_t)k * L;       // bucket index of the pass
   const u32 j0 = k * L;                                        // index inside the window
-  // every point travels with T = t1*t2; T of the next bucket is the side product of the current addition
+  // Every accumulator travels with T = t1*t2.  `running += bucket` is a TWO-round addition: the bucket enters in extended-Niels form
+  // (V - U, V + U, 2Z, 2d T), whose 2d T is prepared two buckets ahead by the idle lanes of `total += running` (a three-round addition
+  // between two accumulators: only lane 0 needs its middle round): bucket j - 2's t1*t2 on lane 1, 2d times bucket j - 1's on lane 2.
+  // Five multiplication rounds per bucket instead of six (round 3).
   Ext running = Curve::identity(), total = Curve::identity();
   Fe Tr = Fq::zero(), Tt = Fq::zero(), dummy;
   Ext bk = aos_ext(buckets, first + L - 1);
-  Fe Tb = Fq::mul(bk.t1, bk.t2);                       // stored t1, t2 are carried
+  Ext bn = aos_ext(buckets, first + (L > 1 ? L - 2 : 0));
+  // prologue, two rounds: lane 0: t1*t2 of the first bucket, lane 1: of the second; then lane 0: 2d * (the first)
+  const Fe pr = Fq::mul(role_select4(bk.t1, bn.t1, bk.t1, bk.t1, role), role_select4(bk.t2, bn.t2, bk.t2, bk.t2, role));   // stored t1, t2 are carried
+  Fe Tnext = quad_bcast<1>(pr);                                // t1*t2 of bucket j - 1
+  Fe T2d = Fq::mul(quad_bcast<0>(pr), Fq::konst(FqP::D2));     // 2d t1*t2 of bucket j
   #pragma unroll 1
   for (int j = (int)L - 1; j >= 0; j--) {
-    const Ext nx = aos_ext(buckets, first + (j > 0 ? j - 1 : 0));
-    Fe Tn;
-    running = quad_add_ext_t(running, Tr, bk, Tb, role, Tr, nx.t1, nx.t2, Tn);
-    total = quad_add_ext_t(total, Tt, running, Tr, role, Tt, Tr, Tr, dummy);
-    bk = nx; Tb = Tn;
+    const Ext nn = aos_ext(buckets, first + (j > 1 ? j - 2 : 0));
+    ENiels en;
+    en.vpu = Fq::carry(Fq::add(bk.v, bk.u)); en.vmu = Fq::sub(bk.v, bk.u); en.z2 = Fq::add(bk.z, bk.z); en.t2d = T2d;
+    running = quad_add_eniels(running, Tr, en, 0u, role, Tr);
+    Fe Tnn, T2dn;
+    total = quad_add_ext_t2(total, Tt, running, Tr, role, Tt, nn.t1, nn.t2, Tnn, Tnext, Fq::konst(FqP::D2), T2dn);
+    bk = bn; bn = nn; T2d = T2dn; Tnext = Tnn;
   }
   // total += j0 * running   (j0 < B = 2^jbits).  j0 is a multiple of the chunk length L = 2^lb: double-and-add over the
-  // jbits - lb significant bits, then lb plain doublings (no additions for bits that are zero by construction)
+  // jbits - lb significant bits, then lb plain doublings (no additions for bits that are zero by construction).  `running` enters
+  // the additions in extended-Niels form too (one product for its 2d T, once): two rounds per addition instead of three.
   if (j0) {
+    ENiels rn;
+    rn.vpu = Fq::carry(Fq::add(running.v, running.u)); rn.vmu = Fq::sub(running.v, running.u); rn.z2 = Fq::add(running.z, running.z);
+    rn.t2d = Fq::mul(Tr, Fq::konst(FqP::D2));
+    const ENiels idn = Curve::eniels_identity();
     Ext m = Curve::identity();
     Fe Tm = Fq::zero();
     #pragma unroll 1
     for (int bit = jbits - 1; bit >= lb; bit--) {
       m = quad_dbl_t(m, role, Tm);
-      Ext sel = Curve::identity();
       const u32 mask = ((j0 >> bit) & 1u) ? ~0u : 0u;
-      sel.u = Fq::select(sel.u, running.u, mask); sel.v = Fq::select(sel.v, running.v, mask); sel.z = Fq::select(sel.z, running.z, mask);
-      const Fe Ts = Fq::select(Fq::zero(), Tr, mask);
-      m = quad_add_ext_t(m, Tm, sel, Ts, role, Tm, Tr, Tr, dummy);
+      ENiels sel;
+      sel.vpu = Fq::select(idn.vpu, rn.vpu, mask); sel.vmu = Fq::select(idn.vmu, rn.vmu, mask);
+      sel.z2 = Fq::select(idn.z2, rn.z2, mask); sel.t2d = Fq::select(idn.t2d, rn.t2d, mask);
+      m = quad_add_eniels(m, Tm, sel, 0u, role, Tm);
     }
     #pragma unroll 1
     for (int bit = 0; bit < lb; bit++) m = quad_dbl_t(m, role, Tm);
