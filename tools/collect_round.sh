@@ -19,11 +19,12 @@ cp gpurun_out/${TAG}_msm17_kernel_stats.txt profiles/${TAG}_msm17_kernel_stats.t
 (echo "$HDR"; echo "# command: python tests/config1_cpu.py   (BASELINE.json configs[0] on the CPU port of the reference algorithm, host of the GPU box)"; cat gpurun_out/${TAG}_config1_cpu.txt) > profiles/${TAG}_config1_cpu.txt
 (echo "$HDR"; echo "# command: python tests/soak.py 240 3000   (randomised differential soak of every entry point against the C oracle; last rounds and verdict)"; grep -v amdgpu gpurun_out/${TAG}_soak.txt | tail -6) > profiles/${TAG}_soak.txt
 # round 4 additions
-for f in gpurun_out/${TAG}_bench_host_*.json gpurun_out/${TAG}_bench_msm20_rccl1.json; do [ -s "$f" ] && cp $f profiles/; done
+for f in gpurun_out/${TAG}_bench_host_*.json gpurun_out/${TAG}_bench_msm20_rccl1.json gpurun_out/${TAG}_bench_msm20_cpu.json; do [ -s "$f" ] && cp $f profiles/; done
 (echo "$HDR"; echo "# command: ./tools/pcie_probe   (tools/pcie_probe.cpp: what the host link of the box gives; the host-pointer path is priced against it)"; cat gpurun_out/${TAG}_pcie_probe.txt) > profiles/${TAG}_pcie_probe.txt
 (echo "$HDR"; echo "# command: bash tools/pcie_inclusive.sh $TAG   (bench.py --host-buffers pinned|pageable at config sizes: the C-ABI call on HOST arrays is the timed region; full lines in ${TAG}_bench_host_*.json)"; cat gpurun_out/${TAG}_pcie_inclusive.txt) > profiles/${TAG}_pcie_inclusive.txt
 (echo "$HDR"; echo "# command: python tools/multi_bench.py   (jj_multi_* with page-locked host buffers on ONE GPU listed once and twice, beside the single-context entry points)"; grep -v amdgpu gpurun_out/${TAG}_multi_bench.txt) > profiles/${TAG}_multi_bench.txt
 (echo "$HDR"; echo "# command: python tools/msm_dev_finish.py"; grep -v amdgpu gpurun_out/${TAG}_msm_dev_finish.txt) > profiles/${TAG}_msm_dev_finish.txt
 (echo "$HDR"; grep -v amdgpu gpurun_out/${TAG}_fixedbase_select_pmc.txt) > profiles/${TAG}_fixedbase_select_pmc.txt
 (echo "$HDR"; echo "# command: ./experiments/lds_probe/energy_probe ; ./experiments/lds_probe/probe"; cat gpurun_out/${TAG}_issue_energy_probe.txt) > profiles/${TAG}_issue_energy_probe.txt
+(echo "$HDR"; echo "# command: python tests/soak_host.py 120"; grep -v amdgpu gpurun_out/${TAG}_soak_host.txt | tail -4) > profiles/${TAG}_soak_host.txt
 python3 tools/design_numbers.py $TAG

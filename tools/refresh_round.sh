@@ -39,6 +39,8 @@ bash tools/fixedbase_select_pmc.sh > gpurun_out/${TAG}_fixedbase_select_pmc.txt 
 [ -x experiments/lds_probe/probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o experiments/lds_probe/probe experiments/lds_probe/probe.hip
 [ -x experiments/lds_probe/energy_probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o experiments/lds_probe/energy_probe experiments/lds_probe/energy_probe.hip
 (./experiments/lds_probe/energy_probe; ./experiments/lds_probe/probe) > gpurun_out/${TAG}_issue_energy_probe.txt 2>&1
-python bench.py --workload msm --msm-exchange c --no-cpu-baseline > gpurun_out/${TAG}_bench_msm20_rccl1.json 2>/dev/null </dev/null
+JJ_BENCH_FORCE_DIST=1 python bench.py --gpus 1 --workload msm --msm-exchange c --no-cpu-baseline > gpurun_out/${TAG}_bench_msm20_rccl1.json 2>/dev/null </dev/null   # one rank over RCCL, the exchange behind the C ABI
+python bench.py --workload msm > gpurun_out/${TAG}_bench_msm20_cpu.json 2>/dev/null                                                   # with the CPU baseline: naive fold + bucket method
+timeout 300 python tests/soak_host.py 120 > gpurun_out/${TAG}_soak_host.txt 2>&1 || echo "HOST SOAK FAILED" >> gpurun_out/${TAG}_soak_host.txt
 timeout 600 python tests/soak.py 240 3000 > gpurun_out/${TAG}_soak.txt 2>&1 || echo "SOAK FAILED" >> gpurun_out/${TAG}_soak.txt
 tail -1 gpurun_out/${TAG}_profile.log
