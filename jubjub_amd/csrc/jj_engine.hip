@@ -361,9 +361,10 @@ static void prefault_parallel(void* p, size_t bytes) {
 // Returns JJ_OK, an error, or +1 when the buffers could not be page-locked (caller uses the staging path).
 // Chunk length of the host-buffer pipeline for a batch of n units (0: the batch is too small to be cut, it is staged whole).
 // `pref_log2` is what the entry point measured as its best chunk at its BASELINE size (profiles/r4_pcie_inclusive.txt: 2^20 for the
-// fixed-base and decoder kernels -- shorter chunks pay the shared inversion of their normalisation over too few points, longer ones
-// pay the unoverlapped first copy in and last copy out; 2^18 for the var-base ladder, whose kernel time dwarfs its copies); smaller
-// batches are cut in four, down to 2^16 units per chunk.
+// fixed-base kernels, 2^21 for the decoder -- shorter chunks pay the shared inversion of their normalisation over too few points and
+// leave the decoder one wave per SIMD, longer ones pay the unoverlapped first copy in and last copy out, which the short first / last
+// chunk only softens; 2^18 for the var-base ladder, whose kernel time dwarfs its copies); smaller batches are cut in four, down to
+// 2^16 units per chunk.
 // `quantum`: the kernel's lane count when every lane takes ceil(chunk / lanes) units in a grid-stride loop (the fixed-base kernels: one
 // workgroup per CU): a chunk that is not a multiple of it leaves most lanes idle during the last round -- 2^20 units over 196 608 lanes are
 // 5.33 per lane, i.e. the time of 6 (-11 %) -- so the chunk and the short first / last chunk are rounded to multiples of it.
@@ -1853,7 +1854,7 @@ static int decompress_dev(jj_ctx* c, size_t n, const void* di, unsigned flags, v
 JJ_API int jj_decompress(jj_ctx* c, size_t n, const void* in32, unsigned flags, void* out64, uint8_t* ok) {
   if (!c || (!ok && n)) return JJ_ERR_INVALID;
   JJ_ENTER(c);
-  if (const size_t ch = pipe_chunk_for(c, n, 20); ch && all_host({in32, out64, ok})) {
+  if (const size_t ch = pipe_chunk_for(c, n, 21); ch && all_host({in32, out64, ok})) {
     const HostIn in[1] = {{in32, 32}};
     const HostOut ho[2] = {{out64, 64}, {ok, 1}};
     const int prc = run_pipelined(c, n, ch, in, ho, [&](size_t cn, const void* const* di, void* const* dout) -> int {
