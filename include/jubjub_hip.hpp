@@ -330,6 +330,36 @@ inline Bytes64 msm_combine(const std::vector<MsmRecord>& records) {
   if (rc) throw Error(rc, "jj_msm_combine: damaged or mismatched records");
   return out;
 }
+// Round 4: page-locked host memory for batches that come back call after call (jj_host_alloc); the raw entry points then copy straight
+// from and to it.  (std::vector arguments are pageable: the library moves them through its own page-locked staging buffers.)
+class HostBuffer {
+ public:
+  explicit HostBuffer(size_t bytes) : n_(bytes) { const int rc = jj_host_alloc(bytes, &p_); if (rc) throw Error(rc, "jj_host_alloc failed"); }
+  ~HostBuffer() { (void)jj_host_free(p_); }
+  HostBuffer(const HostBuffer&) = delete;
+  HostBuffer& operator=(const HostBuffer&) = delete;
+  uint8_t* data() { return static_cast<uint8_t*>(p_); }
+  const uint8_t* data() const { return static_cast<const uint8_t*>(p_); }
+  size_t size() const { return n_; }
+ private:
+  void* p_ = nullptr;
+  size_t n_ = 0;
+};
+// points[i] * scalars[i] on raw wire-format buffers (any kind of host memory, e.g. HostBuffers kept by the caller): out = n x 64 bytes
+inline void multiply_raw(const Context& c, size_t n, const uint8_t* scalars32, const uint8_t* points64, uint8_t* out64) {
+  c.check(jj_varbase_mul(c.raw(), n, scalars32, points64, out64));
+}
+// One process per GPU: the Sum over the terms of every rank of an RCCL communicator the application created (jj_ctx_set_comm +
+// jj_msm_allgather; examples/msm_rccl.cpp).  all_gather_fn: address of that RCCL library's ncclAllGather, or nullptr (looked up).
+inline void set_comm(const Context& c, void* nccl_comm, int rank, int nranks, void* all_gather_fn = nullptr) {
+  c.check(jj_ctx_set_comm(c.raw(), nccl_comm, rank, nranks, all_gather_fn));
+}
+inline Bytes64 msm_all_ranks(const Context& c, const AffineBatch& my_points, const FrBatch& my_scalars, bool by_windows = false) {
+  if (my_points.len() != my_scalars.len()) throw Error(JJ_ERR_INVALID, "length mismatch");
+  Bytes64 out;
+  c.check(jj_msm_allgather(c.raw(), my_points.len(), my_scalars.to_bytes().data(), my_points.coords().data(), by_windows ? 1 : 0, out.data()));
+  return out;
+}
 // `ExtendedPoint * Fr` with the reference's constant-time discipline (lib.rs:334-343, 357-379): no scalar-dependent address or branch
 inline AffineBatch multiply_ct(const Context& c, const AffineBatch& points, const FrBatch& scalars) {
   if (points.len() != scalars.len()) throw Error(JJ_ERR_INVALID, "length mismatch");

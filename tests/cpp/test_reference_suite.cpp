@@ -3,6 +3,7 @@
 // Golden data comes from a text file written by tests/test_cpp_host.py out of tests/golden/reference_vectors.json.
 // Usage: test_reference_suite <vectors.txt>      (exit code 0 = all passed)
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
@@ -221,6 +222,23 @@ int main(int argc, char** argv) {
       for (int b = 0; b < 3; b++) for (size_t i = 0; i < 200; i++) { ks[b][i] = Bytes32{}; for (int q = 0; q < 8; q++) ks[b][i][q] = k.to_bytes()[(b * 100 + i) % 500][q]; }
       FixedBase f0(c, bases[0]), f1(c, bases[1]), f2(c, bases[2]);
       CHECK(cb.multiply_bits(ks) == fixedbase_multi_mul({&f0, &f1, &f2}, ks));
+    }
+    // round-4 entry points through the mirror: page-locked host buffers on the chunked copy / compute pipeline (2^19 + 5 units: pipelined),
+    // against the same batch in std::vectors (pageable: the bounce path)
+    {
+      std::puts("HostBuffer + multiply_raw (page-locked, pipelined) against operator* (pageable vectors, bounce path)");
+      const size_t n = ((size_t)1 << 19) + 5;
+      const AffineBatch p = AffineBatch::random(c, n, 0x91, 0, false);
+      const FrBatch k = FrBatch::random(c, n, 0x92, 0);
+      HostBuffer hs(32 * n), hp(64 * n), ho(64 * n);
+      std::memcpy(hs.data(), k.to_bytes().data(), 32 * n);
+      std::memcpy(hp.data(), p.coords().data(), 64 * n);
+      multiply_raw(c, n, hs.data(), hp.data(), ho.data());
+      const AffineBatch want = p * k;
+      CHECK(std::memcmp(ho.data(), want.coords().data(), 64 * n) == 0);
+      bool refused = false;                                   // no communicator lent: the multi-rank sum is refused, not computed on one rank
+      try { (void)msm_all_ranks(c, p, k); } catch (const Error&) { refused = true; }
+      CHECK(refused);
     }
     // error behaviour: length mismatch is rejected like the assert at src/lib.rs:841
     bool threw = false;
