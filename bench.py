@@ -817,8 +817,7 @@ def run(a):
                 res["varbase_constant_time"]["equals_default_ladder_all_units"] = bool(torch.equal(co, out))
         if not a.no_cpu_baseline and n_gpus == 1:
             res["cpu_baseline"] = cpu_baseline(wl, a.cpu_seconds)
-        print(json.dumps(res))
-        sys.stdout.flush()
+        emit(json.dumps(res))
     if rccl_comm is not None:
         eng.set_comm(None)
         rccl_comm.close()
@@ -831,10 +830,29 @@ def run(a):
     return rc
 
 
+_OUT_FD = None
+
+
+def emit(line):
+    """the ONE line of rank 0, written to the process's real stdout (see main)"""
+    if _OUT_FD is None:
+        print(line)
+        sys.stdout.flush()
+    else:
+        os.write(_OUT_FD, (line + "\n").encode())
+
+
 def main():
+    global _OUT_FD
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(a))
+    # Native libraries print on stdout too (RCCL writes a version banner at its first communicator, through C stdio: when stdout is a
+    # pipe it surfaces at process exit, after the JSON line).  The rank keeps its real stdout for the JSON line alone and points fd 1 at
+    # stderr for everything else.
+    sys.stdout.flush()
+    _OUT_FD = os.dup(1)
+    os.dup2(2, 1)
     sys.exit(run(a))
 
 

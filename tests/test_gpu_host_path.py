@@ -160,28 +160,44 @@ def test_host_alloc_api(eng):
 
 
 # ------------------------------------------------------------------------------------------------ C-level RCCL exchange
-def test_msm_allgather_one_rank_rccl(eng):
-    """jj_ctx_set_comm + jj_msm_allgather with a real RCCL communicator of one rank: both partitions equal jj_msm and the oracle."""
-    import torch
+_ALLGATHER_SCRIPT = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, torch
+from jubjub_amd import Engine
+from jubjub_amd.dist import RcclComm
+from oracle import c_oracle as O
+from util import rand_points, rand_scalars
+torch.cuda.set_device(0)
+eng = Engine(0)
+comm = RcclComm(0, 1)
+eng.set_comm(comm)
+for n in (0, 1, 777, 40000):
+    s, p = rand_scalars(31 + n, n), rand_points(32 + n, n)
+    ds, dp = torch.from_numpy(s).cuda(), torch.from_numpy(p).cuda()
+    want = O.msm(s, p).reshape(64)
+    assert (eng.msm_allgather(ds, dp, "terms") == want).all(), n
+    assert (eng.msm_allgather(ds, dp, "window") == want).all(), n
+    assert (eng.msm_allgather(s, p, "terms") == want).all(), n         # host arrays are staged
+eng.set_comm(None)
+comm.close()
+try:
+    eng.msm_allgather(s, p)                                             # no communicator any more
+    print("NOT REFUSED")
+except Exception:
+    print("ALLGATHER OK", flush=True)
+eng.close()
+"""
 
-    from jubjub_amd.dist import RcclComm
 
-    torch.cuda.set_device(0)
-    comm = RcclComm(0, 1)
-    try:
-        eng.set_comm(comm)
-        for n in (0, 1, 777, 40000):
-            s, p = rand_scalars(31 + n, n), rand_points(32 + n, n)
-            ds, dp = torch.from_numpy(s).cuda(), torch.from_numpy(p).cuda()
-            want = O.msm(s, p).reshape(64)
-            assert (eng.msm_allgather(ds, dp, "terms") == want).all(), n
-            assert (eng.msm_allgather(ds, dp, "window") == want).all(), n
-            assert (eng.msm_allgather(s, p, "terms") == want).all(), n         # host arrays are staged
-    finally:
-        eng.set_comm(None)
-        comm.close()
-    with pytest.raises(Exception):
-        eng.msm_allgather(s, p)                                                 # no communicator
+def test_msm_allgather_one_rank_rccl():
+    """jj_ctx_set_comm + jj_msm_allgather with a real RCCL communicator of one rank (ncclCommInitRank through ctypes on the process's
+    librccl): both partitions equal the oracle, host and device inputs; without a communicator the call is refused.  Runs in a process of
+    its own: RCCL's teardown at interpreter exit must not be able to take the test session with it."""
+    import sys
+
+    r = subprocess.run([sys.executable, "-c", _ALLGATHER_SCRIPT % (ROOT, os.path.join(ROOT, "tests"))], capture_output=True, text=True, timeout=600)
+    assert "ALLGATHER OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
 def test_msm_rccl_example_one_rank(tmp_path):
