@@ -211,7 +211,8 @@ int jj_fixedbase_composite_mul(jj_ctx*, const jj_table* t, size_t n, const void*
  * The device reduces the terms to a record of partial window sums (two launches for small batches, Pippenger above); the last
  * step -- adding the partial sums of each window, Horner over the windows (a chain of 252 dependent doublings) and one
  * inversion -- runs on the calling host thread, so for every n this call waits for the stream even when all pointers are
- * device pointers (the 64-byte result is then copied to out64 asynchronously). */
+ * device pointers (the 64-byte result is then copied to out64 asynchronously).  HOST arrays of 2^19 terms and more are summed in
+ * two to eight passes, the copy of each pass's slice beside the kernels of the pass before (JJ_MSM_HOST_SPLIT=0: one pass). */
 int jj_msm(jj_ctx*, size_t n, const void* scalars32, const void* points64, void* out64);
 /* The same in two halves, so that the host tail of one MSM overlaps the kernels of the next: jj_msm_begin queues all device
  * work of one MSM plus the copy of its records into a page-locked buffer owned by the job and returns at once (device

@@ -184,6 +184,7 @@ struct jj_ctx {
   unsigned next_lane = 0;
   uint8_t host_out[8][64];       // results on their way to a device pointer (ring: the copies are asynchronous)
   int host_out_next = 0;
+  bool msm_host_split = true;    // host arrays of 2^19 terms and more: two passes, the second half's copy beside the first half's kernels (JJ_MSM_HOST_SPLIT=0: off)
   int msm_small_blk = 4;         // small-batch path: at most this many 64-quad workgroups per window (JJ_MSM_SMALL_BLK, 1..64; 4 x 64 windows = one per CU)
   int msm_windows = 0;           // number of windows W (0 = from n; JJ_MSM_WINDOWS, 16..36: the two-pass sort holds at most 128 coarse bins per window, i.e. windows of at most 16 bits)
   int msm_small_max = 1 << 14;   // batches up to this size take the two-launch small-batch path (JJ_MSM_SMALL_MAX; 0 = never)
@@ -252,7 +253,7 @@ static bool is_device_ptr(const void* p) {
 }
 
 static bool is_pinned_host(const void* p, size_t bytes);
-static int host_to_dev_bounced(jj_ctx* c, void* dev, const void* host, size_t bytes);
+static int host_to_dev_bounced(jj_ctx* c, void* dev, const void* host, size_t bytes, hipStream_t stream = nullptr);
 static int dev_to_host_bounced(jj_ctx* c, void* host, const void* dev, size_t bytes);
 constexpr size_t BOUNCE_MIN_BYTES = (size_t)16 << 20;     // smaller pageable arrays are copied by the runtime's own staging
 // Resolves an input pointer: device pointers pass through (must be 16-byte aligned), host data is copied into a
@@ -411,7 +412,8 @@ static int stage_ensure(jj_ctx* c, size_t in_bytes, size_t out_bytes) {
 // A large pageable array of an entry point that is not pipelined (the inputs of an MSM, the operands of a batched field or point
 // operation): hipMemcpyAsync from pageable memory goes through the runtime's own single-threaded staging (3 - 30 GB/s measured,
 // profiles/r4_pcie_probe.txt); here the copy pool fills page-locked staging slots while the previous slot's DMA runs.
-static int host_to_dev_bounced(jj_ctx* c, void* dev, const void* host, size_t bytes) {
+static int host_to_dev_bounced(jj_ctx* c, void* dev, const void* host, size_t bytes, hipStream_t stream) {
+  if (!stream) stream = c->stream;
   int rc = stage_ensure(c, std::max(BOUNCE_MIN_BYTES, c->stage_in_cap), c->stage_out_cap); if (rc) return rc;
   const size_t CHB = BOUNCE_MIN_BYTES;
   size_t k = 0;
@@ -419,8 +421,8 @@ static int host_to_dev_bounced(jj_ctx* c, void* dev, const void* host, size_t by
     const int g = (int)(k % 3); const size_t cn = std::min(CHB, bytes - lo);
     if (k >= 3) HIPCHK(c, hipEventSynchronize(c->ev_stage[g]));          // the slot's previous DMA has read it
     c->copy_pool->copy(c->stage_in[g], (const uint8_t*)host + lo, cn);
-    HIPCHK(c, hipMemcpyAsync((uint8_t*)dev + lo, c->stage_in[g], cn, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipEventRecord(c->ev_stage[g], c->stream));
+    HIPCHK(c, hipMemcpyAsync((uint8_t*)dev + lo, c->stage_in[g], cn, hipMemcpyHostToDevice, stream));
+    HIPCHK(c, hipEventRecord(c->ev_stage[g], stream));
   }
   for (size_t j = (k > 3 ? k - 3 : 0); j < k; j++) HIPCHK(c, hipEventSynchronize(c->ev_stage[j % 3]));   // the slots are free for the next user
   return JJ_OK;
@@ -660,6 +662,7 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
   if (const char* e = getenv("JJ_PIPE_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= 3) c->pipe_mode = v; }
   if (const char* e = getenv("JJ_PIPE_CHUNK_LOG2")) { int v = atoi(e); if (v >= 8 && v <= 24) c->pipe_chunk = (size_t)1 << v; }   // overrides the per-entry-point chunk
   if (const char* e = getenv("JJ_MSM_WINDOWS")) { int v = atoi(e); if (v >= MSM_WINDOWS_MIN && v <= MSM_WINDOWS_MAX) c->msm_windows = v; else fprintf(stderr, "libjubjub_hip: JJ_MSM_WINDOWS=%s ignored (valid: %d..%d)\n", e, MSM_WINDOWS_MIN, MSM_WINDOWS_MAX); }
+  if (const char* e = getenv("JJ_MSM_HOST_SPLIT")) c->msm_host_split = atoi(e) != 0;
   if (const char* e = getenv("JJ_MSM_LANES")) { int v = atoi(e); if (v >= 1 && v <= MSM_LANES_MAX) c->msm_lanes = v; }
   if (const char* e = getenv("JJ_MSM_SMALL_BLK")) { int v = atoi(e); if (v >= 1 && v <= MSM_TREE_QUADS) c->msm_small_blk = v; }
   if (const char* e = getenv("JJ_MSM_SMALL_MAX")) { int v = atoi(e); if (v >= 0 && v <= (1 << 20)) c->msm_small_max = v; }
@@ -1598,7 +1601,18 @@ static void msm_job_put(jj_ctx* c, jj_msm_job* j) {
 // spread: device-pointer jobs alternate over the context's lanes (jj_msm_begin); otherwise lane 0 (jj_msm; host arrays are staged
 // through buffers the launch stream owns)
 static int msm_begin_locked(jj_ctx* c, size_t n, const void* scalars, const void* points, int part_w0, int part_stride, bool spread, jj_msm_job** out) {
-  const size_t PASS = (size_t)1 << c->msm_pass_log2;
+  size_t PASS = (size_t)1 << c->msm_pass_log2;
+  // Host arrays of 2^19 terms and more are reduced in SEVERAL passes (one record each, one host tail): the copy of a pass's slice runs on the
+  // copy stream beside the kernels of the pass before it -- 96 bytes per term over the link cost more than the whole reduction (2^20 terms:
+  // 1.7 ms of copy, 1.3 ms of kernels).  Two to eight passes of at least 2^19 terms (smaller passes reduce less efficiently than the copy
+  // they hide): page-locked arrays 2^20 terms 3.15 -> 2.67 ms, 2^22 terms 12.3 -> 9.7 ms with two passes.  JJ_MSM_HOST_SPLIT=0: one pass
+  // after the whole copy (round 3).
+  const bool host_in = n && !is_device_ptr(scalars) && !is_device_ptr(points);
+  const bool split = host_in && c->msm_host_split && n >= ((size_t)1 << 19) && n <= PASS;
+  if (split) {
+    const size_t passes = std::min<size_t>(8, std::max<size_t>(2, n >> 19));
+    PASS = (((n + passes - 1) / passes) + 63) & ~(size_t)63;
+  }
   const size_t npass = n ? (n + PASS - 1) / PASS : 0;
   jj_msm_job* j;
   int rc = msm_job_get(c, npass, &j); if (rc) return rc;
@@ -1609,10 +1623,28 @@ static int msm_begin_locked(jj_ctx* c, size_t n, const void* scalars, const void
   auto fail = [&](int code) { (void)hipStreamSynchronize(L->stream); (void)hipGetLastError(); msm_job_put(c, j); return code; };   // kernels may still be writing into the job's buffer
   if (n) {
     const void *ds, *dp;
-    if ((rc = stage_in(c, 0, scalars, 32 * n, &ds)) || (rc = stage_in(c, 1, points, 64 * n, &dp))) return fail(rc);
+    if (split) {
+      // the passes' slices are copied on the copy stream (ordered after what the launch stream has queued: the staging buffers may still
+      // be read by an earlier call's kernels), each pass's kernels wait for their slice only
+      if ((rc = ensure(c, c->in[0], 32 * n)) || (rc = ensure(c, c->in[1], 64 * n)) || (rc = pipe_prepare(c, 0, 0))) return fail(rc);
+      ds = c->in[0].p; dp = c->in[1].p;
+      hipError_t e0 = hipEventRecord(c->order_ev, c->stream);
+      if (e0 == hipSuccess) e0 = hipStreamWaitEvent(c->pipe.h2d, c->order_ev, 0);
+      if (e0 != hipSuccess) { c->err = std::string("MSM staging failed: ") + hipGetErrorString(e0); return fail(JJ_ERR_HIP); }
+    } else if ((rc = stage_in(c, 0, scalars, 32 * n, &ds)) || (rc = stage_in(c, 1, points, 64 * n, &dp))) return fail(rc);
     for (size_t lo = 0; lo < n; lo += PASS) {
       const size_t cnt = std::min(PASS, n - lo);
       size_t used = 0;
+      if (split) {
+        const struct { const void* host; void* dev; size_t elem; } arr[2] = {{scalars, c->in[0].p, 32}, {points, c->in[1].p, 64}};
+        for (const auto& a : arr) {
+          const uint8_t* src = (const uint8_t*)a.host + lo * a.elem; uint8_t* dst = (uint8_t*)a.dev + lo * a.elem;
+          if (c->pipe_bounce && cnt * a.elem >= BOUNCE_MIN_BYTES && !is_pinned_host(src, cnt * a.elem)) { if ((rc = host_to_dev_bounced(c, dst, src, cnt * a.elem, c->pipe.h2d))) return fail(rc); }
+          else if (hipMemcpyAsync(dst, src, cnt * a.elem, hipMemcpyHostToDevice, c->pipe.h2d) != hipSuccess) { c->err = "MSM staging copy failed"; return fail(JJ_ERR_HIP); }
+        }
+        const int ei = (int)((lo / PASS) & 1);
+        if (hipEventRecord(c->pipe.ev_in[ei], c->pipe.h2d) != hipSuccess || hipStreamWaitEvent(L->stream, c->pipe.ev_in[ei], 0) != hipSuccess) { c->err = "MSM staging event failed"; return fail(JJ_ERR_HIP); }
+      }
       // the kernels that finish a window write its point straight into the job's page-locked buffer (device-visible host memory):
       // no copy operation between the last kernel and the host tail
       if ((rc = msm_enqueue(c, *L, cnt, (const uint8_t*)ds + lo * 32, (const uint8_t*)dp + lo * 64, part_w0, part_stride, j->host + j->nrec * jjhost::REC_MAX_BYTES, &used))) return fail(rc);

@@ -307,3 +307,32 @@ def test_large_pageable_arrays_of_unpipelined_entry_points(eng):
     assert (got[idx] == O.field_op(O.FQ, "mul", s[idx], s[::-1][idx])[0]).all()
     dbl = eng.point_double(p)                                                  # 67 MB in, 67 MB out
     assert (dbl[idx] == O.point_op("double", p[idx])).all()
+
+
+@pytest.mark.parametrize("n", [(1 << 19) + 77, 3 * (1 << 19) + 5])
+def test_msm_host_arrays_reduced_in_overlapped_passes(n, monkeypatch):
+    """Host arrays of 2^19 terms and more: the sum is taken in two to eight passes whose copies overlap the previous pass's kernels
+    (msm_begin_locked).  Same 64 bytes as the device-resident call, as one pass after the whole copy (JJ_MSM_HOST_SPLIT=0), and as the
+    CPU Pippenger of the oracle; page-locked and pageable arrays; the async begin/finish pair and the raw partial record too."""
+    import torch
+    from jubjub_amd import Engine
+
+    s, p = rand_scalars(61, n), rand_points(62, n)
+    p[5] = p[4]
+    s[7] = 0
+    want = O.msm_pippenger(s, p).reshape(64)
+    e = Engine(0)
+    dev = e.msm(torch.from_numpy(s).cuda(), torch.from_numpy(p).cuda()).cpu().numpy()
+    assert (dev == want).all()
+    assert (e.msm(s, p) == want).all()                                   # pageable: staged through the page-locked slots
+    hs, hp = e.host_alloc((n, 32)), e.host_alloc((n, 64))
+    hs[:], hp[:] = s, p
+    for _ in range(3):                                                   # the copy-stream events are reused call after call
+        assert (e.msm(hs, hp) == want).all()
+    rec = e.msm_partial(hs, hp, 0, 1)
+    assert (e.msm_combine(rec[None]) == want).all()
+    e.close()
+    monkeypatch.setenv("JJ_MSM_HOST_SPLIT", "0")
+    e = Engine(0)
+    assert (e.msm(s, p) == want).all()
+    e.close()
