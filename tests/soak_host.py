@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised soak of the host-pointer path (include/jubjub_hip.h "host buffers"): random batch sizes around the pipeline's chunk
 boundaries, every array independently page-locked (jj_host_alloc) or pageable, random chunk lengths, bounce / in-place page-locking,
-uniform / ramped chunk schedules -- against the device-resident entry points (bit-exact, all units) and an oracle sample.
+uniform / ramped chunk schedules, the MSM of the same host arrays in one or several passes -- against the device-resident entry points (bit-exact, all units) and an oracle sample.
 Usage: python tests/soak_host.py [seconds] [seed]   (needs an MI355X)"""
 import os
 import sys
@@ -36,6 +36,8 @@ while time.time() < t_end:
         env["JJ_PIPE_RAMP"] = "0"
     if rng.integers(0, 2):
         env["JJ_PIPE_COPY_THREADS"] = str(int(rng.integers(1, 9)))
+    if rng.integers(0, 4) == 0:
+        env["JJ_MSM_HOST_SPLIT"] = "0"
     os.environ.update(env)
     eng = Engine(0)
     for k in env:
@@ -71,7 +73,10 @@ while time.time() < t_end:
     assert (k1 == k2.cpu().numpy()).all() and (o1 == o2.cpu().numpy()).all(), ("decompress", rnd, env, n, flags)
     eo, ek = O.decompress(enc[idx], flags)
     assert (k1[idx] == ek).all() and (o1[idx] == eo).all(), ("decompress oracle", rnd)
-    assert (eng.msm(hS, hP) == ref.msm(dS, dP).cpu().numpy()).all(), ("msm from host arrays", rnd, env, n)
+    want = ref.msm(dS, dP).cpu().numpy()
+    assert (eng.msm(hS, hP) == want).all(), ("msm from host arrays", rnd, env, n)         # 2^19 terms and more: 2..8 passes, copies beside the kernels
+    if rnd % 4 == 0:
+        assert (want == O.msm_pippenger(S, P).reshape(64)).all(), ("msm oracle", rnd, n)
     tab.close(); rtab.close(); eng.close()
     units += n; rnd += 1
     print("round %d ok: n=%d %s (%d units so far, %.0f s left)" % (rnd, n, env, units, t_end - time.time()), flush=True)
