@@ -24,7 +24,9 @@ line; under `python -m torch.distributed.run --nproc-per-node N ... bench.py --g
                    configs[4]: 2^26 encodings over 8 GPUs with --log2n 26).
 --host-buffers   : pageable | pinned: the timed region is the C-ABI call on HOST arrays (H2D + kernels + D2H, pipelined by the
                    library); `metric` says so, `pcie_inclusive` is true and `roofline.pcie` prices both directions against the link.
-                   This is never the headline value (that one has its inputs resident in HBM).
+                   This is never the headline value (that one has its inputs resident in HBM).  `--workload msm`: jj_msm on host arrays
+                   (96 bytes per term in, one 64-byte point out; the library sums 2^19 terms and more in passes whose copies run beside
+                   the kernels).
 Rank 0 prints ONE JSON line.
 
 Inputs come from the library's counter-based generators (jj_synth_scalars / jj_random_points: Group::random semantics,
@@ -443,9 +445,9 @@ def run(a):
         rccl_comm = RcclComm(rank, world)          # this process's own communicator; the ncclUniqueId travels over torch.distributed
         eng.set_comm(rccl_comm)
     host = a.host_buffers
-    if host and (wl == "msm" or distributed):
+    if host and (distributed or (wl == "msm" and (host == "fresh" or a.msm_async > 1 or a.msm_contexts > 1))):
         if rank == 0:
-            print("bench.py: --host-buffers covers the varbase / fixedbase / decompress workloads on one GPU", file=sys.stderr)
+            print("bench.py: --host-buffers covers one GPU (msm: pinned | pageable, synchronous jj_msm calls: the result is 64 bytes, there is no result array to be fresh)", file=sys.stderr)
         return 2
     out_w = 32 if (a.compressed and wl in ("varbase", "fixedbase")) else 64
     if host:
@@ -457,10 +459,10 @@ def run(a):
             h[...] = t.cpu().numpy()
             return h
 
-        h_scalars = to_host(scalars) if wl in ("varbase", "fixedbase") else None
-        h_points = to_host(points) if wl == "varbase" else None
+        h_scalars = to_host(scalars) if wl in ("varbase", "fixedbase", "msm") else None
+        h_points = to_host(points) if wl in ("varbase", "msm") else None
         h_enc = to_host(enc) if wl == "decompress" else None
-        h_out = halloc((n, out_w))
+        h_out = halloc((n, out_w) if wl != "msm" else (64,))
         h_ok = halloc((n,)) if wl == "decompress" else None
         h_out[...] = 0                                            # touched once (a fresh pageable result buffer would be faulted in inside the first call)
         if h_ok is not None:
@@ -471,6 +473,8 @@ def run(a):
             return eng.varbase_mul_compressed(scalars, points) if a.compressed else eng.varbase_mul(scalars, points)
         if wl == "fixedbase":
             return eng.fixedbase_mul_compressed(table, scalars) if a.compressed else eng.fixedbase_mul(table, scalars)
+        if wl == "msm":
+            return eng.msm(scalars, points)
         return eng.decompress(enc, a.decompress_flags)
 
     call_s = [0.0]                                                 # host-buffer modes: time spent inside the C-ABI calls themselves
@@ -487,6 +491,9 @@ def run(a):
                 r = (eng.varbase_mul_compressed if a.compressed else eng.varbase_mul)(h_scalars, h_points, out=h_out)
             elif wl == "fixedbase":
                 r = (eng.fixedbase_mul_compressed if a.compressed else eng.fixedbase_mul)(table, h_scalars, out=h_out)
+            elif wl == "msm":
+                r = eng.msm(h_scalars, h_points)                   # 96 bytes per term in, 64 bytes out: passes of the terms, copies beside the kernels
+                h_out[...] = r
             else:
                 r = eng.decompress(h_enc, a.decompress_flags, out=(h_out, h_ok))
             call_s[0] += time.perf_counter() - tc
@@ -641,7 +648,7 @@ def run(a):
         res["config"]["host_buffers"] = {"pinned": "page-locked (jj_host_alloc), reused by every pass",
                                          "pageable": "pageable numpy memory, reused by every pass; every call page-locks them in place (hipHostRegister) and releases them",
                                          "fresh": "pageable numpy memory; the RESULT array is newly allocated (np.empty) for every call: its pages are faulted in and page-locked inside the call"}[host]
-        res["config"]["result_bytes"] = out_w
+        res["config"]["result_bytes"] = out_w if wl != "msm" else 64
         res["device_resident"] = dev_ref
         res["host_over_device_resident"] = value / dev_ref["value"]
     if wl == "msm":
@@ -703,8 +710,8 @@ def run(a):
             "build_id": build_id(),
         }
         if host:
-            in_b = {"varbase": 96, "fixedbase": 32, "decompress": 32}[wl]
-            out_b = out_w + (1 if wl == "decompress" else 0)
+            in_b = {"varbase": 96, "fixedbase": 32, "decompress": 32, "msm": 96}[wl]
+            out_b = (out_w + (1 if wl == "decompress" else 0)) if wl != "msm" else 64.0 / n
             per_pass = dt / a.steps / passes
             h2d, d2h = n * in_b / per_pass / 1e9, n * out_b / per_pass / 1e9
             res["roofline"]["note"] = "kernel_ms / frac: the same entry point on device-resident tensors in this process (2 passes after the timed region)"

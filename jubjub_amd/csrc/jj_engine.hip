@@ -253,7 +253,7 @@ static bool is_device_ptr(const void* p) {
 }
 
 static bool is_pinned_host(const void* p, size_t bytes);
-static int host_to_dev_bounced(jj_ctx* c, void* dev, const void* host, size_t bytes, hipStream_t stream = nullptr);
+static int host_to_dev_bounced(jj_ctx* c, void* dev, const void* host, size_t bytes, hipStream_t stream = nullptr, size_t* seq = nullptr);
 static int dev_to_host_bounced(jj_ctx* c, void* host, const void* dev, size_t bytes);
 constexpr size_t BOUNCE_MIN_BYTES = (size_t)16 << 20;     // smaller pageable arrays are copied by the runtime's own staging
 // Resolves an input pointer: device pointers pass through (must be 16-byte aligned), host data is copied into a
@@ -412,11 +412,14 @@ static int stage_ensure(jj_ctx* c, size_t in_bytes, size_t out_bytes) {
 // A large pageable array of an entry point that is not pipelined (the inputs of an MSM, the operands of a batched field or point
 // operation): hipMemcpyAsync from pageable memory goes through the runtime's own single-threaded staging (3 - 30 GB/s measured,
 // profiles/r4_pcie_probe.txt); here the copy pool fills page-locked staging slots while the previous slot's DMA runs.
-static int host_to_dev_bounced(jj_ctx* c, void* dev, const void* host, size_t bytes, hipStream_t stream) {
+static int host_to_dev_bounced(jj_ctx* c, void* dev, const void* host, size_t bytes, hipStream_t stream, size_t* seq) {
+  // seq: a slot counter the caller keeps over SEVERAL arrays (and drains once with stage_in_drain): the last slots' DMA of one array then
+  // runs beside the host copy of the next array's first slots, instead of being waited for between the arrays
   if (!stream) stream = c->stream;
   int rc = stage_ensure(c, std::max(BOUNCE_MIN_BYTES, c->stage_in_cap), c->stage_out_cap); if (rc) return rc;
   const size_t CHB = BOUNCE_MIN_BYTES;
-  size_t k = 0;
+  size_t k0 = 0;
+  size_t& k = seq ? *seq : k0;
   for (size_t lo = 0; lo < bytes; lo += CHB, k++) {
     const int g = (int)(k % 3); const size_t cn = std::min(CHB, bytes - lo);
     if (k >= 3) HIPCHK(c, hipEventSynchronize(c->ev_stage[g]));          // the slot's previous DMA has read it
@@ -424,7 +427,11 @@ static int host_to_dev_bounced(jj_ctx* c, void* dev, const void* host, size_t by
     HIPCHK(c, hipMemcpyAsync((uint8_t*)dev + lo, c->stage_in[g], cn, hipMemcpyHostToDevice, stream));
     HIPCHK(c, hipEventRecord(c->ev_stage[g], stream));
   }
-  for (size_t j = (k > 3 ? k - 3 : 0); j < k; j++) HIPCHK(c, hipEventSynchronize(c->ev_stage[j % 3]));   // the slots are free for the next user
+  if (!seq) for (size_t j = (k > 3 ? k - 3 : 0); j < k; j++) HIPCHK(c, hipEventSynchronize(c->ev_stage[j % 3]));   // the slots are free for the next user
+  return JJ_OK;
+}
+static int stage_in_drain(jj_ctx* c, size_t seq) {
+  for (size_t j = (seq > 3 ? seq - 3 : 0); j < seq; j++) HIPCHK(c, hipEventSynchronize(c->ev_stage[j % 3]));
   return JJ_OK;
 }
 static int dev_to_host_bounced(jj_ctx* c, void* host, const void* dev, size_t bytes) {
@@ -1620,7 +1627,7 @@ static int msm_begin_locked(jj_ctx* c, size_t n, const void* scalars, const void
   if (spread && n && c->msm_lanes > 1 && is_device_ptr(scalars) && is_device_ptr(points)) k = (int)(c->next_lane++ % (unsigned)c->msm_lanes);
   MsmLane* L = nullptr;
   if ((rc = msm_lane(c, k, &L))) { msm_job_put(c, j); return rc; }
-  auto fail = [&](int code) { (void)hipStreamSynchronize(L->stream); (void)hipGetLastError(); msm_job_put(c, j); return code; };   // kernels may still be writing into the job's buffer
+  auto fail = [&](int code) { if (split && c->pipe.h2d) (void)hipStreamSynchronize(c->pipe.h2d); (void)hipStreamSynchronize(L->stream); (void)hipGetLastError(); msm_job_put(c, j); return code; };   // kernels may still be writing into the job's buffer
   if (n) {
     const void *ds, *dp;
     if (split) {
@@ -1632,6 +1639,7 @@ static int msm_begin_locked(jj_ctx* c, size_t n, const void* scalars, const void
       if (e0 == hipSuccess) e0 = hipStreamWaitEvent(c->pipe.h2d, c->order_ev, 0);
       if (e0 != hipSuccess) { c->err = std::string("MSM staging failed: ") + hipGetErrorString(e0); return fail(JJ_ERR_HIP); }
     } else if ((rc = stage_in(c, 0, scalars, 32 * n, &ds)) || (rc = stage_in(c, 1, points, 64 * n, &dp))) return fail(rc);
+    size_t stage_seq = 0;             // staging slots of the bounce path, counted over all arrays of all passes
     for (size_t lo = 0; lo < n; lo += PASS) {
       const size_t cnt = std::min(PASS, n - lo);
       size_t used = 0;
@@ -1639,7 +1647,7 @@ static int msm_begin_locked(jj_ctx* c, size_t n, const void* scalars, const void
         const struct { const void* host; void* dev; size_t elem; } arr[2] = {{scalars, c->in[0].p, 32}, {points, c->in[1].p, 64}};
         for (const auto& a : arr) {
           const uint8_t* src = (const uint8_t*)a.host + lo * a.elem; uint8_t* dst = (uint8_t*)a.dev + lo * a.elem;
-          if (c->pipe_bounce && cnt * a.elem >= BOUNCE_MIN_BYTES && !is_pinned_host(src, cnt * a.elem)) { if ((rc = host_to_dev_bounced(c, dst, src, cnt * a.elem, c->pipe.h2d))) return fail(rc); }
+          if (c->pipe_bounce && cnt * a.elem >= BOUNCE_MIN_BYTES / 2 && !is_pinned_host(src, cnt * a.elem)) { if ((rc = host_to_dev_bounced(c, dst, src, cnt * a.elem, c->pipe.h2d, &stage_seq))) return fail(rc); }
           else if (hipMemcpyAsync(dst, src, cnt * a.elem, hipMemcpyHostToDevice, c->pipe.h2d) != hipSuccess) { c->err = "MSM staging copy failed"; return fail(JJ_ERR_HIP); }
         }
         const int ei = (int)((lo / PASS) & 1);
@@ -1650,6 +1658,7 @@ static int msm_begin_locked(jj_ctx* c, size_t n, const void* scalars, const void
       if ((rc = msm_enqueue(c, *L, cnt, (const uint8_t*)ds + lo * 32, (const uint8_t*)dp + lo * 64, part_w0, part_stride, j->host + j->nrec * jjhost::REC_MAX_BYTES, &used))) return fail(rc);
       j->nrec++;
     }
+    if (stage_seq && (rc = stage_in_drain(c, stage_seq))) return fail(rc);     // the staging slots are free for the next call
   }
   hipError_t e = hipEventRecord(j->ev, L->stream);
   if (e == hipSuccess) e = hipGetLastError();

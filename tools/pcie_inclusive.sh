@@ -38,6 +38,14 @@ JJ_PIPE_PAGEABLE=register line fixedbase_fresh_register --workload fixedbase --h
 JJ_PIPE_PAGEABLE=register JJ_PIPE_PREFAULT=0 line fixedbase_fresh_register_noprefault --workload fixedbase --host-buffers fresh
 line decompress_fresh --workload decompress --host-buffers fresh
 line varbase_fresh --workload varbase --host-buffers fresh
+# MSM of host arrays (96 bytes per term in, 64 bytes out): two to eight passes whose copies run beside the previous pass's kernels, and one pass
+# after the whole copy (round 3)
+for hb in pinned pageable; do
+  line msm20_$hb --workload msm --host-buffers $hb
+  line msm22_$hb --workload msm --log2n 22 --host-buffers $hb
+done
+JJ_MSM_HOST_SPLIT=0 line msm20_pinned_one_pass --workload msm --host-buffers pinned
+JJ_MSM_HOST_SPLIT=0 line msm22_pinned_one_pass --workload msm --log2n 22 --host-buffers pinned
 # uniform chunks (no short first / last chunk)
 JJ_PIPE_RAMP=0 line fixedbase_pinned_uniform_chunks --workload fixedbase --host-buffers pinned
 JJ_PIPE_RAMP=0 line decompress_pinned_uniform_chunks --workload decompress --host-buffers pinned
