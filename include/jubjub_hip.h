@@ -90,6 +90,16 @@ int jj_host_alloc(size_t bytes, void** out);
 int jj_host_free(void* p);
 int jj_host_register(void* p, size_t bytes);
 int jj_host_unregister(void* p);
+/* How a host batch is cut -- pure functions of their arguments (no context, no device: the CPU-side tests call them).
+ * jj_plan_host_chunks: the chunk boundaries of a pipelined host batch of n >= 1 units with chunks of `chunk` units (what the library
+ * picks per entry point or JJ_PIPE_CHUNK_LOG2 sets): chunk k = [bounds[k], bounds[k + 1]), *count = entries of bounds (chunks + 1).
+ * ramp != 0: the first and the last chunk are chunk / 4 when the batch has at least four chunks of at least 2^18 units -- the first
+ * copy in and the last copy out are the two transfers nothing overlaps; `quantum` (0 = none): the units one round of the kernel's
+ * lanes takes, edges are whole multiples of it.  cap = 0 (bounds may be NULL) returns the count only.
+ * jj_plan_msm_host_passes: terms per pass and number of passes of jj_msm over HOST arrays of n terms (2^pass_log2 terms per pass at
+ * most, 24 by default; split != 0: arrays of 2^19 terms and more are cut into two to eight passes whose copies overlap the kernels). */
+int jj_plan_host_chunks(size_t n, size_t chunk, size_t quantum, int ramp, size_t* bounds, size_t cap, size_t* count);
+int jj_plan_msm_host_passes(size_t n, int pass_log2, int split, size_t* pass_terms, size_t* passes);
 
 /* ---- fields: Fq (base, = bls12_381::Scalar, src/lib.rs:62) and Fr (scalar, src/fr.rs) ------------------------ */
 /* Elements are 32-byte little-endian integers; inputs are reduced mod p like from_raw (src/fr.rs:347-349),
@@ -256,7 +266,9 @@ int jj_msm_combine(size_t count, const void* records_host, void* out64_host);
  * jj_msm_allgather: every rank calls it with ITS terms (partition 0) or with ALL terms (partition 1: rank g reduces windows g, g + G,
  * ... of the whole batch; same n on every rank): record of window sums (jj_msm_partial) -> ncclAllGather of JJ_MSM_PARTIAL_BYTES per
  * rank on the context's stream -> one copy of the G records to the host -> one host tail (jj_msm_combine).  Every rank returns the
- * same point; out64 may be a host or a device pointer.  A collective: all ranks must call it, in the same order. */
+ * same point; out64 may be a host or a device pointer.  A collective: all ranks must call it, in the same order -- a rank whose call
+ * fails BEFORE the gather (bad arguments, out of memory) never enters it and the other ranks wait for it: treat an error of
+ * jj_msm_allgather as fatal for the communicator (as with any RCCL collective). */
 int jj_ctx_set_comm(jj_ctx*, void* nccl_comm, int rank, int nranks, void* all_gather_fn);
 int jj_msm_allgather(jj_ctx*, size_t n, const void* scalars32, const void* points64, int partition, void* out64);
 

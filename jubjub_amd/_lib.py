@@ -79,7 +79,8 @@ _SIGS.update({
 EXPORTS = sorted(list(_SIGS) + ["jj_ctx_create", "jj_ctx_destroy", "jj_last_error", "jj_version", "jj_device_info", "jj_recommended_wnaf_for_num_scalars",
                                 "jj_fixedbase_table_create", "jj_fr_char_le_bits", "jj_multi_create", "jj_multi_ctx", "jj_multi_last_error",
                                 "jj_msm_fold_partials", "jj_msm_finish", "jj_msm_combine",
-                                "jj_host_alloc", "jj_host_free", "jj_host_register", "jj_host_unregister"])
+                                "jj_host_alloc", "jj_host_free", "jj_host_register", "jj_host_unregister",
+                                "jj_plan_host_chunks", "jj_plan_msm_host_passes"])
 
 _lib = None
 
@@ -151,6 +152,10 @@ def load():
     lib.jj_host_register.argtypes = [_vp, C.c_size_t]
     lib.jj_host_unregister.restype = C.c_int
     lib.jj_host_unregister.argtypes = [_vp]
+    lib.jj_plan_host_chunks.restype = C.c_int
+    lib.jj_plan_host_chunks.argtypes = [C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(C.c_size_t), C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.jj_plan_msm_host_passes.restype = C.c_int
+    lib.jj_plan_msm_host_passes.argtypes = [C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     lib.jj_fr_char_le_bits.restype = C.c_int
     lib.jj_fr_char_le_bits.argtypes = [C.POINTER(C.c_uint8)]
     lib.jj_device_info.restype = C.c_int

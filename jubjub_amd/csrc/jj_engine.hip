@@ -377,6 +377,46 @@ static size_t pipe_chunk_for(const jj_ctx* c, size_t n, int pref_log2, size_t qu
   if (quantum && ch >= 2 * quantum) ch = ((ch + quantum / 2) / quantum) * quantum;
   return ch;
 }
+// Chunk schedule of a pipelined host batch (n >= 1 units, chunks of CH): chunk k = [bounds[k], bounds[k + 1]).  With `ramp` the first and
+// the last chunk are a quarter of CH when the batch has at least four chunks of at least 2^18 units (rounded to whole `quantum`s, the
+// kernel's lanes per round, when CH is a multiple of it); no chunk is longer than CH + the edge.  Exported as jj_plan_host_chunks for
+// the CPU-side tests.
+static std::vector<size_t> pipe_chunk_bounds(size_t n, size_t CH, size_t quantum, bool ramp) {
+  std::vector<size_t> bounds;
+  size_t edge = (ramp && n >= 4 * CH && CH >= ((size_t)1 << 18)) ? CH / 4 : 0;
+  if (edge && quantum && CH % quantum == 0) edge = std::max(quantum, (edge / quantum) * quantum);      // whole rounds of the kernel's lanes
+  size_t lo = 0;
+  bounds.push_back(0);
+  if (edge) { lo = edge; bounds.push_back(lo); }
+  while (n - lo > CH + edge) { lo += CH; bounds.push_back(lo); }
+  if (edge && n - lo > edge) { lo = n - edge; bounds.push_back(lo); }
+  bounds.push_back(n);
+  return bounds;
+}
+JJ_API int jj_plan_host_chunks(size_t n, size_t chunk, size_t quantum, int ramp, size_t* bounds, size_t cap, size_t* count) {
+  if (!n || !chunk || !count || (cap && !bounds)) return JJ_ERR_INVALID;
+  const std::vector<size_t> b = pipe_chunk_bounds(n, chunk, quantum, ramp != 0);
+  *count = b.size();
+  if (b.size() > cap) return bounds ? JJ_ERR_INVALID : JJ_OK;        // cap = 0: the count only
+  std::copy(b.begin(), b.end(), bounds);
+  return JJ_OK;
+}
+// Terms per pass of an MSM over HOST arrays (msm_begin_locked): one pass of 2^pass_log2 terms at most; arrays of 2^19 terms and more that
+// fit one pass are cut into two to eight passes of at least 2^18 terms (a multiple of 64) so that the copies overlap the kernels.
+static size_t msm_host_pass_terms(size_t n, int pass_log2, bool split) {
+  size_t PASS = (size_t)1 << pass_log2;
+  if (split && n >= ((size_t)1 << 19) && n <= PASS) {
+    const size_t passes = std::min<size_t>(8, std::max<size_t>(2, n >> 19));
+    PASS = (((n + passes - 1) / passes) + 63) & ~(size_t)63;
+  }
+  return PASS;
+}
+JJ_API int jj_plan_msm_host_passes(size_t n, int pass_log2, int split, size_t* pass_terms, size_t* passes) {
+  if (!pass_terms || !passes || pass_log2 < 10 || pass_log2 > 24) return JJ_ERR_INVALID;
+  *pass_terms = msm_host_pass_terms(n, pass_log2, split != 0);
+  *passes = n ? (n + *pass_terms - 1) / *pass_terms : 0;
+  return JJ_OK;
+}
 // Inside a pipelined call in stream mode 3: the launches that follow go to the tail stream, ordered after what the chunk has queued on
 // its main stream so far.  A no-op everywhere else.
 static int pipe_to_tail(jj_ctx* c) {
@@ -499,17 +539,7 @@ static int run_pipelined(jj_ctx* c, size_t n, size_t CH, const HostIn (&in)[NIN]
   // Chunk schedule: chunks of CH units, except that the first and the last one are a quarter of that when the batch has at least four
   // chunks -- the copy in of the first chunk and the copy out of the last one are the two transfers nothing overlaps
   // (2^24 fixed-base units, chunks of 2^20: 0.6 ms + 1.3 ms of 31.5 ms; JJ_PIPE_RAMP=0: uniform chunks).
-  std::vector<size_t> bounds;       // chunk k = [bounds[k], bounds[k + 1])
-  {
-    size_t edge = (c->pipe_ramp && n >= 4 * CH && CH >= ((size_t)1 << 18)) ? CH / 4 : 0;
-    if (edge && quantum && CH % quantum == 0) edge = std::max(quantum, (edge / quantum) * quantum);      // whole rounds of the kernel's lanes
-    size_t lo = 0;
-    bounds.push_back(0);
-    if (edge) { lo = edge; bounds.push_back(lo); }
-    while (n - lo > CH + edge) { lo += CH; bounds.push_back(lo); }
-    if (edge && n - lo > edge) { lo = n - edge; bounds.push_back(lo); }
-    bounds.push_back(n);
-  }
+  const std::vector<size_t> bounds = pipe_chunk_bounds(n, CH, quantum, c->pipe_ramp);       // chunk k = [bounds[k], bounds[k + 1])
   const size_t nchunks = bounds.size() - 1;
   // bounce path: the host stages chunk k in and queues it, THEN moves the results of chunk k - 2 from their staging slot to the caller's array
   // (waiting for that chunk's copy out of the device): it stays two chunks ahead of the GPU, which therefore never waits for a host copy.
@@ -1616,10 +1646,7 @@ static int msm_begin_locked(jj_ctx* c, size_t n, const void* scalars, const void
   // after the whole copy (round 3).
   const bool host_in = n && !is_device_ptr(scalars) && !is_device_ptr(points);
   const bool split = host_in && c->msm_host_split && n >= ((size_t)1 << 19) && n <= PASS;
-  if (split) {
-    const size_t passes = std::min<size_t>(8, std::max<size_t>(2, n >> 19));
-    PASS = (((n + passes - 1) / passes) + 63) & ~(size_t)63;
-  }
+  PASS = msm_host_pass_terms(n, c->msm_pass_log2, split);
   const size_t npass = n ? (n + PASS - 1) / PASS : 0;
   jj_msm_job* j;
   int rc = msm_job_get(c, npass, &j); if (rc) return rc;

@@ -402,12 +402,22 @@ __global__ void __launch_bounds__(1024) k_msm_part_plan(size_t n, u32 m, const u
   if (s == 0 && threadIdx.x < MSM_COUNTER_WORDS) counters[threadIdx.x] = 0;
   const u32* in = tc + (size_t)s * m;
   u32* out = tcs + (size_t)s * (m + 1);
-  const u32 per = (m + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < m ? lo + per : m;
+  // a thread owns `per` consecutive counts, a multiple of 4 read as 16-byte words (m = HB ptiles is a multiple of 16 and tc is 16-byte
+  // aligned): the loads of a thread are independent of each other, where a scalar loop waited for each one (18.7 -> 6 us at 2^20 terms)
+  const u32 per = ((m + 1023) / 1024 + 3u) & ~3u, lo = threadIdx.x * per, hi = lo + per < m ? lo + per : m;
   u32 sum = 0;
-  for (u32 k = lo; k < hi; k++) sum += in[k];
+  if (lo < hi) {
+    _Pragma("unroll 4") for (u32 k = lo; k < hi; k += 4) { const uint4 q = *reinterpret_cast<const uint4*>(in + k); sum += q.x + q.y + q.z + q.w; }
+  }
   u32 total;
-  u32 run = (u32)(s * n) + block_exclusive_scan_1024(lo < m ? sum : 0u, part, &total);
-  for (u32 k = lo; k < hi; k++) { out[k] = run; run += in[k]; }
+  u32 run = (u32)(s * n) + block_exclusive_scan_1024(sum, part, &total);
+  if (lo < hi) {
+    _Pragma("unroll 4") for (u32 k = lo; k < hi; k += 4) {
+      const uint4 q = *reinterpret_cast<const uint4*>(in + k);
+      out[k] = run; out[k + 1] = run + q.x; out[k + 2] = run + q.x + q.y; out[k + 3] = run + q.x + q.y + q.z;
+      run += q.x + q.y + q.z + q.w;
+    }
+  }
   if (threadIdx.x == 0) out[m] = (u32)(s * n) + total;
 }
 // tile of at most MSM_P1_TILE terms: ranks from one LDS atomic per entry, the tile ordered by bin in LDS, then copied out run by run

@@ -112,6 +112,72 @@ def test_host_buffer_api_without_a_gpu():
     assert lib.jj_host_register(buf, 1 << 16) == _lib.JJ_ERR_NODEVICE
 
 
+def test_host_batch_chunk_schedule_properties():
+    """jj_plan_host_chunks is the function run_pipelined cuts a host batch with (jj_engine.hip pipe_chunk_bounds): the chunks tile [0, n)
+    in order, none is empty or longer than chunk + the edge, the ramp's short first and last chunk appear exactly when the batch has four
+    chunks of at least 2^18 units, and with a quantum the edges are whole rounds of the kernel's lanes."""
+    import random
+
+    from jubjub_amd import _lib
+
+    lib = _lib.load()
+
+    def plan(n, ch, q=0, ramp=1):
+        cnt = ctypes.c_size_t()
+        assert lib.jj_plan_host_chunks(n, ch, q, ramp, None, 0, ctypes.byref(cnt)) == 0
+        b = (ctypes.c_size_t * cnt.value)()
+        assert lib.jj_plan_host_chunks(n, ch, q, ramp, b, cnt.value, ctypes.byref(cnt)) == 0
+        return list(b)
+
+    rnd = random.Random(7)
+    cases = [(1, 1 << 20, 0, 1), (1 << 24, 1 << 20, 0, 1), (1 << 24, 1 << 20, 0, 0), (1 << 24, 1 << 20, 196608, 1), ((1 << 22) - 1, 1 << 20, 0, 1),
+             (4 << 20, 1 << 20, 0, 1), ((4 << 20) - 1, 1 << 20, 0, 1), (1 << 20, 1 << 16, 0, 1), (5 << 18, 1 << 18, 0, 1), ((1 << 23) + 12345, 1 << 21, 0, 1)]
+    cases += [(rnd.randrange(1, 1 << 25), 1 << rnd.randrange(14, 22), rnd.choice([0, 0, 49152, 196608]), rnd.randrange(2)) for _ in range(300)]
+    for n, ch, q, ramp in cases:
+        b = plan(n, ch, q, ramp)
+        assert b[0] == 0 and b[-1] == n and all(x < y for x, y in zip(b, b[1:])), (n, ch, q, ramp, b[:4])
+        ramped = bool(ramp) and n >= 4 * ch and ch >= (1 << 18)
+        edge = ch // 4 if ramped else 0
+        if ramped and q and ch % q == 0:
+            edge = max(q, edge // q * q)
+        sizes = [y - x for x, y in zip(b, b[1:])]
+        assert max(sizes) <= ch + edge, (n, ch, q, ramp, max(sizes))
+        if ramped:
+            assert sizes[0] == edge and sizes[-1] <= max(edge, ch + edge) and len(sizes) >= 4
+            assert all(sz == ch for sz in sizes[1:-2]), (n, ch, sizes[:3], sizes[-3:])       # whole chunks between the edges (the one before the last may be longer)
+        else:
+            assert all(sz == ch for sz in sizes[:-1]) or len(sizes) == 1
+        assert len(sizes) <= n // ch + 3
+    cnt = ctypes.c_size_t()
+    assert lib.jj_plan_host_chunks(0, 1 << 20, 0, 1, None, 0, ctypes.byref(cnt)) == _lib.JJ_ERR_INVALID
+    assert lib.jj_plan_host_chunks(100, 0, 0, 1, None, 0, ctypes.byref(cnt)) == _lib.JJ_ERR_INVALID
+    small = (ctypes.c_size_t * 2)()
+    assert lib.jj_plan_host_chunks(1 << 24, 1 << 20, 0, 1, small, 2, ctypes.byref(cnt)) == _lib.JJ_ERR_INVALID and cnt.value > 2     # too small a buffer: the count is still reported
+
+
+def test_msm_host_pass_plan_properties():
+    """jj_plan_msm_host_passes is the function msm_begin_locked cuts host arrays with: below 2^19 terms (or with the split off) one pass per
+    2^pass_log2 terms; from 2^19 terms two to eight passes of at least 2^18 terms, a multiple of 64 each, that cover n."""
+    from jubjub_amd import _lib
+
+    lib = _lib.load()
+
+    def plan(n, lg=24, split=1):
+        pt, ps = ctypes.c_size_t(), ctypes.c_size_t()
+        assert lib.jj_plan_msm_host_passes(n, lg, split, ctypes.byref(pt), ctypes.byref(ps)) == 0
+        return pt.value, ps.value
+
+    assert plan(0) == (1 << 24, 0) and plan(1) == (1 << 24, 1) and plan((1 << 19) - 1) == (1 << 24, 1)
+    assert plan(1 << 19) == (1 << 18, 2) and plan(1 << 20) == (1 << 19, 2) and plan(1 << 22) == (1 << 19, 8) and plan(1 << 24) == (1 << 21, 8)
+    assert plan(1 << 22, split=0) == (1 << 24, 1) and plan((1 << 24) + 1) == (1 << 24, 2) and plan(1 << 25) == (1 << 24, 2)
+    assert plan(1 << 20, lg=19) == (1 << 19, 2)                       # more than one pass of the override: no further split
+    for n in [(1 << 19) + 1, (1 << 19) + 77, 3 * (1 << 19) + 5, (1 << 21) - 1, (1 << 23) + 4097, (1 << 24) - 63]:
+        pt, ps = plan(n)
+        assert pt % 64 == 0 and pt >= (1 << 18) and 2 <= ps <= 8 and pt * ps >= n > pt * (ps - 1), (n, pt, ps)
+    pt, ps = ctypes.c_size_t(), ctypes.c_size_t()
+    assert lib.jj_plan_msm_host_passes(1, 9, 1, ctypes.byref(pt), ctypes.byref(ps)) == _lib.JJ_ERR_INVALID
+
+
 def test_msm_fold_partials_host_only():
     """jj_msm_fold_partials (the last step of an MSM cut across devices / ranks) is a host-only function: partial points incl. the
     identity, 8-torsion points and P, -P pairs against the oracle's fold (reference `Sum`, src/lib.rs:183-193)."""
