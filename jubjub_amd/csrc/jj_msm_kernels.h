@@ -313,7 +313,7 @@ __global__ void __launch_bounds__(1024) k_msm_plan(size_t n, u32 B, u32 ntiles, 
   u32 tot[MSM_PLAN_PER], sum = 0;
   _Pragma("unroll") for (int j = 0; j < MSM_PLAN_PER; j++) {
     tot[j] = 0;
-    if ((u32)j < per && b0 + j < B) for (u32 t = 0; t < ntiles; t++) tot[j] += tc[(size_t)t * B + b0 + j];
+    if ((u32)j < per && b0 + j < B) { _Pragma("unroll 8") for (u32 t = 0; t < ntiles; t++) tot[j] += tc[(size_t)t * B + b0 + j]; }     // independent loads in flight together
     sum += tot[j];
   }
   u32 total;
@@ -323,7 +323,11 @@ __global__ void __launch_bounds__(1024) k_msm_plan(size_t n, u32 B, u32 ntiles, 
     if ((u32)j >= per || b0 + j >= B) break;
     o[b0 + j] = run;
     u32 r2 = run;
-    for (u32 t = 0; t < ntiles; t++) { u32* p = tc + (size_t)t * B + b0 + j; const u32 c = *p; *p = r2; r2 += c; }
+    for (u32 t0 = 0; t0 < ntiles; t0 += 8) {                  // eight counts read together, then replaced by their first slots
+      u32 cc[8];
+      _Pragma("unroll") for (u32 q = 0; q < 8; q++) cc[q] = t0 + q < ntiles ? tc[(size_t)(t0 + q) * B + b0 + j] : 0u;
+      _Pragma("unroll") for (u32 q = 0; q < 8; q++) if (t0 + q < ntiles) { tc[(size_t)(t0 + q) * B + b0 + j] = r2; r2 += cc[q]; }
+    }
     run += tot[j];
   }
   if (threadIdx.x == 0) o[B] = (u32)(s * n) + total;
