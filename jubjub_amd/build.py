@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "jj_engine.hip")
 OUT = os.path.join(HERE, "lib", "libjubjub_hip.so")
-DEPS = [os.path.join(HERE, "csrc", f) for f in ("jj_engine.hip", "jj_kernels.h", "jj_curve.h", "jj_field.h", "jj_constants.h", "jj_host_tail.h", "jj_msm_kernels.h")] + [
+DEPS = [os.path.join(HERE, "csrc", f) for f in ("jj_engine.hip", "jj_kernels.h", "jj_curve.h", "jj_field.h", "jj_constants.h", "jj_host_tail.h", "jj_host_tail_ifma.h", "jj_msm_kernels.h")] + [
     os.path.join(HERE, "..", "include", "jubjub_hip.h")]
 
 

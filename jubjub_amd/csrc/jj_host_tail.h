@@ -2,13 +2,17 @@
 // point per window: U, V, Z, T = T1 T2, already in the 4 x 64-bit Montgomery form used here); the window sums of several records
 // (passes, devices, ranks) are added window by window, the windows are combined by Horner (252 dependent point doublings in all)
 // and the result is converted to affine.  That chain has no parallelism a GPU could use -- a quad of lanes needs two rounds of
-// ~300 instructions, 1.4 us, per doubling -- while a host core does the same doubling in ~0.15 us.
+// ~300 instructions, 1.4 us, per doubling -- while a host core does the same doubling in ~0.1 us (scalar code below) or ~0.04 us
+// (jj_host_tail_ifma.h: the four coordinates in the lanes of AVX-512 IFMA vectors, two products per doubling; taken at run time when
+// the CPU has it, for the Horner chain and the window-by-window sums; this file's scalar code is the fallback and the reference the
+// tests hold it to).
 //
 // Plain 4 x 64-bit Montgomery arithmetic (radix 2^256) modulo q; every constant is derived at start-up from q and
 // d = -10240/10241, nothing is tabulated.  Point formulas: the same completed-point formulas as jj_curve.h
 // (reference src/lib.rs:739-828 double, 883-920 add, 1052-1060 into_extended).
 #pragma once
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace jjhost {
@@ -127,6 +131,13 @@ static inline bool rec_header(const uint8_t* rec, RecHeader* h) {
   return h->magic == REC_MAGIC && h->version == 2 && h->W >= 1 && h->W <= (uint32_t)REC_MAX_W && h->nblk == 1;
 }
 static inline size_t rec_bytes(int W) { return REC_HDR_BYTES + (size_t)W * REC_PT_BYTES; }
+#if defined(__x86_64__) && !defined(JJ_NO_IFMA)
+#define JJ_HAVE_IFMA_TAIL 1
+}  // namespace jjhost (closed around the system header the next file includes)
+#include <immintrin.h>
+namespace jjhost {
+#include "jj_host_tail_ifma.h"        // ifma::available(), ifma::horner(): the Horner chain on AVX-512 IFMA, chosen at run time
+#endif
 // a window's point: four field elements in Montgomery form, each below q (checked: a damaged record must not reach the arithmetic)
 static inline bool ext_from_record(const uint8_t* p, Ext* out) {
   Fe c[4];
@@ -140,7 +151,10 @@ static inline bool ext_from_record(const uint8_t* p, Ext* out) {
 struct WindowSums {
   int W = 0;
   bool have[REC_MAX_W];
-  Ext sum[REC_MAX_W];
+  Ext sum[REC_MAX_W];                 // scalar path
+#ifdef JJ_HAVE_IFMA_TAIL
+  ifma::P4 vsum[REC_MAX_W];           // AVX-512 IFMA path: the same sums as [U, V, Z, T] limb vectors
+#endif
   bool add_record(const uint8_t* rec) {
     RecHeader h;
     if (!rec_header(rec, &h)) return false;
@@ -148,14 +162,31 @@ struct WindowSums {
     if ((int)h.W != W) return false;
     for (int w = 0; w < W; w++) {
       if (!((h.mask >> w) & 1)) continue;
+      const uint8_t* pt = rec + REC_HDR_BYTES + (size_t)w * REC_PT_BYTES;
+#ifdef JJ_HAVE_IFMA_TAIL
+      if (ifma::available()) {
+        Fe c[4];
+        memcpy(c, pt, 128);
+        for (int i = 0; i < 4; i++) if (geq_q(c[i].l)) return false;
+        ifma::accumulate(vsum[w], have[w], c);
+        have[w] = true;
+        continue;
+      }
+#endif
       Ext p;
-      if (!ext_from_record(rec + REC_HDR_BYTES + (size_t)w * REC_PT_BYTES, &p)) return false;
+      if (!ext_from_record(pt, &p)) return false;
       if (have[w]) sum[w] = point_add(sum[w], p); else { sum[w] = p; have[w] = true; }
     }
     return true;
   }
   // sum_w 2^(start_w) S_w by Horner from the top window: width(w) doublings, then + S_w
   Ext finish() const {
+#ifdef JJ_HAVE_IFMA_TAIL
+    if (ifma::available()) return ifma::horner(W, have, vsum);
+#endif
+    return finish_scalar();
+  }
+  Ext finish_scalar() const {
     Ext acc = identity();
     bool any = false;
     for (int w = W - 1; w >= 0; w--) {

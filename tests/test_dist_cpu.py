@@ -128,6 +128,52 @@ def test_world2_gloo_sharding_and_msm():
         assert r[7] == want_msm                         # window partition: same point
 
 
+def test_msm_combine_scalar_and_ifma_chains_agree():
+    """The host tail has two implementations of its Horner chain and of the window-by-window sums (jj_host_tail.h: scalar 4 x 64-bit;
+    jj_host_tail_ifma.h: AVX-512 IFMA, taken when the CPU has it): the test above in a process that forces the scalar one, and random records
+    (1..9 records, layouts 16 / 17 / 23 / 64, equal points in several records = doublings through the addition, P and -P = the identity in the
+    middle of a chain, the identity and 8-torsion points as window sums) through both."""
+    import subprocess
+    import sys
+
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import test_dist_cpu as T\nT.test_msm_combine_host_only()\nT._combine_random_records()\nprint('COMBINE OK')\n") % (
+                os.path.dirname(os.path.abspath(__file__)), os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    for mode in ("scalar", "auto"):
+        env = dict(os.environ, JJ_HOST_TAIL=mode)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "COMBINE OK" in r.stdout, (mode, r.stdout[-2000:], r.stderr[-2000:])
+
+
+def _combine_random_records():
+    import ctypes
+
+    from jubjub_amd import _lib
+    from oracle import c_oracle as O
+    from oracle import jubjub_ref as J
+    from util import arr64, oracle_msm_record, rand_points, rand_scalars
+
+    lib = _lib.load()
+    rng = np.random.default_rng(77)
+    g8 = J.scalar_mul_fast(J.GENERATOR, J.R_MOD)
+    for trial in range(12):
+        G = int(rng.integers(1, 10))
+        W = int(rng.choice([16, 17, 23, 64]))
+        n = int(rng.integers(G, 4 * G + 2))
+        S, P = rand_scalars(500 + trial, n, full_width=True), rand_points(600 + trial, n)
+        if n >= 4:
+            P[1] = P[0]; S[1] = S[0]                                  # the same term twice: equal window sums meet (a doubling through the addition)
+            P[3] = arr64([J.affine_neg(tuple(int.from_bytes(bytes(P[2][k:k + 32]), "little") for k in (0, 32)))])[0]; S[3] = S[2]     # P and -P
+        if n >= 6:
+            P[4] = arr64([g8])[0]; P[5] = arr64([J.AFFINE_IDENTITY])[0]
+        order = rng.permutation(n)
+        cut = [n * g // G for g in range(G + 1)]
+        recs = np.ascontiguousarray(np.stack([oracle_msm_record(S[order[cut[g]:cut[g + 1]]], P[order[cut[g]:cut[g + 1]]], W=W) for g in range(G)]))
+        out = np.empty(64, np.uint8)
+        assert lib.jj_msm_combine(ctypes.c_size_t(G), recs.ctypes.data, out.ctypes.data) == 0
+        assert (out == O.msm(S, P).reshape(64)).all(), (trial, G, W, n)
+
+
 def test_msm_combine_host_only():
     """jj_msm_combine against oracle-built records: one record, a term partition into records of the same layout, a window
     partition (disjoint window masks), mixed window layouts in one call, edge scalars on special points, damaged records."""
