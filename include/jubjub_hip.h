@@ -97,7 +97,8 @@ int jj_host_unregister(void* p);
  * copy in and the last copy out are the two transfers nothing overlaps; `quantum` (0 = none): the units one round of the kernel's
  * lanes takes, edges are whole multiples of it.  cap = 0 (bounds may be NULL) returns the count only.
  * jj_plan_msm_host_passes: terms per pass and number of passes of jj_msm over HOST arrays of n terms (2^pass_log2 terms per pass at
- * most, 24 by default; split != 0: arrays of 2^19 terms and more are cut into two to eight passes whose copies overlap the kernels). */
+ * most, 24 by default; split != 0: arrays of 2^19 terms and more are cut into two to eight passes -- more when eight would exceed
+ * 2^pass_log2 terms each -- whose copies overlap the kernels). */
 int jj_plan_host_chunks(size_t n, size_t chunk, size_t quantum, int ramp, size_t* bounds, size_t cap, size_t* count);
 int jj_plan_msm_host_passes(size_t n, int pass_log2, int split, size_t* pass_terms, size_t* passes);
 

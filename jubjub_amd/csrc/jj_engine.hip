@@ -401,13 +401,14 @@ JJ_API int jj_plan_host_chunks(size_t n, size_t chunk, size_t quantum, int ramp,
   std::copy(b.begin(), b.end(), bounds);
   return JJ_OK;
 }
-// Terms per pass of an MSM over HOST arrays (msm_begin_locked): one pass of 2^pass_log2 terms at most; arrays of 2^19 terms and more that
-// fit one pass are cut into two to eight passes of at least 2^18 terms (a multiple of 64) so that the copies overlap the kernels.
+// Terms per pass of an MSM over HOST arrays (msm_begin_locked): 2^pass_log2 terms at most; arrays of 2^19 terms and more are cut into two
+// to eight passes of at least 2^18 terms (a multiple of 64; more passes when eight would exceed 2^pass_log2 terms each) so that the copy of
+// a pass overlaps the kernels of the pass before.
 static size_t msm_host_pass_terms(size_t n, int pass_log2, bool split) {
   size_t PASS = (size_t)1 << pass_log2;
-  if (split && n >= ((size_t)1 << 19) && n <= PASS) {
+  if (split && n >= ((size_t)1 << 19)) {
     const size_t passes = std::min<size_t>(8, std::max<size_t>(2, n >> 19));
-    PASS = (((n + passes - 1) / passes) + 63) & ~(size_t)63;
+    PASS = std::min(PASS, (((n + passes - 1) / passes) + 63) & ~(size_t)63);      // (arrays beyond eight full passes: more passes of 2^pass_log2 terms)
   }
   return PASS;
 }
@@ -1645,7 +1646,7 @@ static int msm_begin_locked(jj_ctx* c, size_t n, const void* scalars, const void
   // they hide): page-locked arrays 2^20 terms 3.15 -> 2.67 ms, 2^22 terms 12.3 -> 9.7 ms with two passes.  JJ_MSM_HOST_SPLIT=0: one pass
   // after the whole copy (round 3).
   const bool host_in = n && !is_device_ptr(scalars) && !is_device_ptr(points);
-  const bool split = host_in && c->msm_host_split && n >= ((size_t)1 << 19) && n <= PASS;
+  const bool split = host_in && c->msm_host_split && n >= ((size_t)1 << 19);
   PASS = msm_host_pass_terms(n, c->msm_pass_log2, split);
   const size_t npass = n ? (n + PASS - 1) / PASS : 0;
   jj_msm_job* j;

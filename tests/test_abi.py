@@ -157,7 +157,8 @@ def test_host_batch_chunk_schedule_properties():
 
 def test_msm_host_pass_plan_properties():
     """jj_plan_msm_host_passes is the function msm_begin_locked cuts host arrays with: below 2^19 terms (or with the split off) one pass per
-    2^pass_log2 terms; from 2^19 terms two to eight passes of at least 2^18 terms, a multiple of 64 each, that cover n."""
+    2^pass_log2 terms; from 2^19 terms two to eight passes of at least 2^18 terms, a multiple of 64 each, that cover n (more passes of
+    2^pass_log2 terms when eight would be longer than that)."""
     from jubjub_amd import _lib
 
     lib = _lib.load()
@@ -169,9 +170,10 @@ def test_msm_host_pass_plan_properties():
 
     assert plan(0) == (1 << 24, 0) and plan(1) == (1 << 24, 1) and plan((1 << 19) - 1) == (1 << 24, 1)
     assert plan(1 << 19) == (1 << 18, 2) and plan(1 << 20) == (1 << 19, 2) and plan(1 << 22) == (1 << 19, 8) and plan(1 << 24) == (1 << 21, 8)
-    assert plan(1 << 22, split=0) == (1 << 24, 1) and plan((1 << 24) + 1) == (1 << 24, 2) and plan(1 << 25) == (1 << 24, 2)
-    assert plan(1 << 20, lg=19) == (1 << 19, 2)                       # more than one pass of the override: no further split
-    for n in [(1 << 19) + 1, (1 << 19) + 77, 3 * (1 << 19) + 5, (1 << 21) - 1, (1 << 23) + 4097, (1 << 24) - 63]:
+    assert plan(1 << 22, split=0) == (1 << 24, 1) and plan((1 << 24) + 1, split=0) == (1 << 24, 2) and plan(1 << 25) == (1 << 22, 8)
+    assert plan(1 << 28) == (1 << 24, 16)                             # eight passes would exceed 2^24 terms each: more passes of 2^24
+    assert plan(1 << 20, lg=19) == (1 << 19, 2) and plan(3 << 20, lg=18) == (1 << 18, 12)
+    for n in [(1 << 19) + 1, (1 << 19) + 77, 3 * (1 << 19) + 5, (1 << 21) - 1, (1 << 23) + 4097, (1 << 24) - 63, (1 << 24) + 1, (1 << 26) + 12345]:
         pt, ps = plan(n)
         assert pt % 64 == 0 and pt >= (1 << 18) and 2 <= ps <= 8 and pt * ps >= n > pt * (ps - 1), (n, pt, ps)
     pt, ps = ctypes.c_size_t(), ctypes.c_size_t()

@@ -336,3 +336,23 @@ def test_msm_host_arrays_reduced_in_overlapped_passes(n, monkeypatch):
     e = Engine(0)
     assert (e.msm(s, p) == want).all()
     e.close()
+
+
+def test_msm_host_arrays_more_passes_than_eight(monkeypatch):
+    """Host arrays longer than eight full passes (JJ_MSM_PASS_LOG2 = 18 stands in for 2^24 here: 3 * 2^19 + 5 terms are 7 passes of 2^18):
+    every pass's copy still runs beside the previous pass's kernels, the records of all passes -- the last one of another window layout --
+    meet in one host tail."""
+    import torch
+    from jubjub_amd import Engine
+
+    monkeypatch.setenv("JJ_MSM_PASS_LOG2", "18")
+    n = 3 * (1 << 19) + 5
+    s, p = rand_scalars(71, n), rand_points(72, n)
+    want = O.msm_pippenger(s, p).reshape(64)
+    e = Engine(0)
+    assert (e.msm(s, p) == want).all()
+    hs, hp = e.host_alloc((n, 32)), e.host_alloc((n, 64))
+    hs[:], hp[:] = s, p
+    assert (e.msm(hs, hp) == want).all()
+    assert (e.msm(torch.from_numpy(s).cuda(), torch.from_numpy(p).cuda()).cpu().numpy() == want).all()      # device-resident: passes of 2^18, no split
+    e.close()
