@@ -2089,21 +2089,28 @@ JJ_API int jj_msm_fold_partials(size_t count, const void* parts64, void* out64) 
 JJ_API int jj_multi_msm(jj_multi* m, size_t n, const void* scalars, const void* points, void* out64) {
   if (!m || !out64 || is_device_ptr(out64) || !host_args(m, {scalars, points}, n)) return JJ_ERR_INVALID;
   const int G = (int)m->ctx.size();
-  const size_t PASS = (size_t)1 << m->ctx[0]->msm_pass_log2;
-  std::vector<size_t> first(G + 1, 0);
-  for (int g = 0; g < G; g++) { size_t lo, hi; shard_of(n, g, G, &lo, &hi); first[g + 1] = first[g] + std::max<size_t>(1, (hi - lo + PASS - 1) / PASS); }
-  std::vector<uint8_t> recs(first[G] * (size_t)JJ_MSM_PARTIAL_BYTES);
+  // every device: the passes of its shard as ONE job (msm_begin_locked: shards of 2^19 terms and more are cut so that the copy of a pass
+  // runs beside the kernels of the pass before), its records collected here; one host tail over the records of all devices
+  std::vector<std::vector<uint8_t>> recs(G);
   (void)hipSetDevice(m->ctx[0]->device);
   MultiPin pin; pin.add(scalars, 32 * n); pin.add(points, 64 * n);
-  const int rc = multi_run(m, n, [&](jj_ctx* c, int g, size_t lo, size_t hi) {
-    size_t k = first[g];
-    if (lo == hi) return jj_msm_partial(c, 0, nullptr, nullptr, 0, 1, &recs[k * JJ_MSM_PARTIAL_BYTES]);
-    for (size_t p = lo; p < hi; p += PASS, k++) {
-      const int r2 = jj_msm_partial(c, std::min(PASS, hi - p), U8(scalars) + 32 * p, U8(points) + 64 * p, 0, 1, &recs[k * JJ_MSM_PARTIAL_BYTES]);
+  const int rc = multi_run(m, n, [&](jj_ctx* c, int g, size_t lo, size_t hi) -> int {
+    jj_msm_job* j = nullptr;
+    {
+      JJ_ENTER(c);
+      const int r2 = msm_begin_locked(c, hi - lo, U8(scalars) + 32 * lo, U8(points) + 64 * lo, 0, 1, false, &j);
       if (r2) return r2;
     }
+    const hipError_t e = hipEventSynchronize(j->ev);
+    if (e == hipSuccess) recs[g].assign(j->host, j->host + j->nrec * jjhost::REC_MAX_BYTES);
+    JJ_ENTER(c);
+    msm_job_put(c, j);
+    if (e != hipSuccess) { c->err = std::string("hipEventSynchronize failed: ") + hipGetErrorString(e); return (int)JJ_ERR_HIP; }
     return (int)JJ_OK;
   });
   if (rc) return rc;
-  return jj_msm_combine(first[G], recs.data(), out64);
+  std::vector<uint8_t> all;
+  for (int g = 0; g < G; g++) all.insert(all.end(), recs[g].begin(), recs[g].end());
+  static_assert(JJ_MSM_PARTIAL_BYTES == jjhost::REC_MAX_BYTES, "record size");
+  return jj_msm_combine(all.size() / JJ_MSM_PARTIAL_BYTES, all.data(), out64);
 }
