@@ -25,6 +25,7 @@ for f in gpurun_out/${TAG}_bench_host_*.json gpurun_out/${TAG}_bench_msm20_rccl1
 (echo "$HDR"; echo "# command: python tools/multi_bench.py   (jj_multi_* with page-locked host buffers on ONE GPU listed once and twice, beside the single-context entry points)"; grep -v amdgpu gpurun_out/${TAG}_multi_bench.txt) > profiles/${TAG}_multi_bench.txt
 (echo "$HDR"; echo "# command: python tools/msm_dev_finish.py"; grep -v amdgpu gpurun_out/${TAG}_msm_dev_finish.txt) > profiles/${TAG}_msm_dev_finish.txt
 (echo "$HDR"; grep -v amdgpu gpurun_out/${TAG}_fixedbase_select_pmc.txt) > profiles/${TAG}_fixedbase_select_pmc.txt
+[ -s gpurun_out/${TAG}_stall_pmc.txt ] && (echo "$HDR"; echo "# command: bash tools/stall_pmc.sh"; grep -v amdgpu gpurun_out/${TAG}_stall_pmc.txt) > profiles/${TAG}_stall_pmc.txt
 (echo "$HDR"; echo "# command: ./experiments/lds_probe/energy_probe ; ./experiments/lds_probe/probe"; cat gpurun_out/${TAG}_issue_energy_probe.txt) > profiles/${TAG}_issue_energy_probe.txt
 (echo "$HDR"; echo "# command: python tests/host_tail_time.py 1 8 (default, then JJ_HOST_TAIL=scalar); then bench.py --workload msm --log2n 17 with the two chains in turn"; grep -v amdgpu gpurun_out/${TAG}_host_tail.txt) > profiles/${TAG}_host_tail.txt
 (echo "$HDR"; echo "# command: python tests/soak_host.py 120"; grep -v amdgpu gpurun_out/${TAG}_soak_host.txt | tail -4) > profiles/${TAG}_soak_host.txt

@@ -36,6 +36,7 @@ bash tools/pcie_inclusive.sh $TAG > /dev/null 2>&1
 python tools/multi_bench.py > gpurun_out/${TAG}_multi_bench.txt 2>&1
 python tools/msm_dev_finish.py > gpurun_out/${TAG}_msm_dev_finish.txt 2>&1
 bash tools/fixedbase_select_pmc.sh > gpurun_out/${TAG}_fixedbase_select_pmc.txt 2>&1
+bash tools/stall_pmc.sh > gpurun_out/${TAG}_stall_pmc.txt 2>&1
 [ -x experiments/lds_probe/probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o experiments/lds_probe/probe experiments/lds_probe/probe.hip
 [ -x experiments/lds_probe/energy_probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o experiments/lds_probe/energy_probe experiments/lds_probe/energy_probe.hip
 (./experiments/lds_probe/energy_probe; ./experiments/lds_probe/probe) > gpurun_out/${TAG}_issue_energy_probe.txt 2>&1
