@@ -710,22 +710,36 @@ __global__ void __launch_bounds__(256) k_seg_scatter(size_t nb, u32 B, u32 per_t
   for (u32 k = threadIdx.x; k <= P; k += 256) cur[k] += bh[(size_t)k * gridDim.x + blockIdx.x];
   __syncthreads();
   const size_t base = (size_t)blockIdx.x * per_tile;
-  for (u32 j = threadIdx.x; j < per_tile; j += 256) {
+  const u32 lane = threadIdx.x & 63u;
+  for (u32 j0 = 0; j0 < per_tile; j0 += 256) {                  // the same trips for every lane: the wave-wide sums below need all of them
+    const u32 j = j0 + threadIdx.x;
     const size_t b = base + j;
-    if (b >= nb) break;
-    u32 lo, c; seg_bucket(off, B, b, lo, c);
-    if (c == 0) continue;
+    u32 lo = 0, c = 0;
+    if (j < per_tile && b < nb) seg_bucket(off, B, b, lo, c);
     const u32 full = c / P, rem = c - full * P, nseg = full + (rem ? 1u : 0u);
-    u32 h0 = 0;
-    if (nseg > 1) {
-      h0 = atomicAdd(&counters[0], nseg - 1);
-      bool listed = false;
-      if (nseg - 1 > FIXUP_SERIAL_MAX) {
-        const u32 slot = atomicAdd(&counters[2], 1u);
-        if (slot < FIXUP_BIG_MAX) { big[slot].bucket = (u32)b; big[slot].t_first = h0; big[slot].t_last = h0 + nseg - 2; big[slot].pad = 0; listed = true; }
-      }
-      if (!listed) { const u32 mi = atomicAdd(&counters[1], 1u); merge[mi].bucket = (u32)b; merge[mi].h0 = h0; merge[mi].k = nseg - 1; merge[mi].pad = 0; }
+    const u32 extra = nseg > 1 ? nseg - 1 : 0u;                  // heads this bucket needs beyond its own slot
+    // ONE global atomic per wave for the heads and one for the merge items, instead of one each per bucket with several segments: uniform
+    // scalars give almost none of those (mean bucket 32 entries, P = 64), skewed ones tens of thousands, all on the same two addresses
+    u32 incl = extra;
+    _Pragma("unroll") for (int d = 1; d < 64; d <<= 1) { const u32 o = (u32)__shfl_up((int)incl, d, 64); if ((int)lane >= d) incl += o; }
+    const u32 total = (u32)__shfl((int)incl, 63, 64);
+    u32 wbase = 0;
+    if (total) { if (lane == 63) wbase = atomicAdd(&counters[0], total); wbase = (u32)__shfl((int)wbase, 63, 64); }
+    const u32 h0 = wbase + incl - extra;
+    bool listed = false;
+    if (extra > FIXUP_SERIAL_MAX) {                               // (rare: heavily repeated scalars)
+      const u32 slot = atomicAdd(&counters[2], 1u);
+      if (slot < FIXUP_BIG_MAX) { big[slot].bucket = (u32)b; big[slot].t_first = h0; big[slot].t_last = h0 + nseg - 2; big[slot].pad = 0; listed = true; }
     }
+    const bool want = extra && !listed;
+    const unsigned long long mball = __ballot(want);
+    u32 mbase = 0;
+    if (mball) {
+      const int leader = __ffsll((long long)mball) - 1;
+      if ((int)lane == leader) mbase = atomicAdd(&counters[1], (u32)__popcll(mball));
+      mbase = (u32)__shfl((int)mbase, leader, 64);
+    }
+    if (want) { const u32 mi = mbase + (u32)__popcll(mball & ((1ull << lane) - 1ull)); merge[mi].bucket = (u32)b; merge[mi].h0 = h0; merge[mi].k = nseg - 1; merge[mi].pad = 0; }
     for (u32 sgi = 0; sgi < nseg; sgi++) {
       const u32 len = sgi < full ? P : rem;
       const u32 slot = atomicAdd(&cur[P - len], 1u);
