@@ -1566,6 +1566,7 @@ static int msm_enqueue_pippenger(jj_ctx* c, MsmLane& ln, size_t n, const void* d
   }
   const ExtAoS head{(u32*)ra.p}, bk{(u32*)buckets.p};
   SoA partial = soa_of(ln.bigpart, (size_t)FIXUP_BIG_MAX * FIXUP_BIG_QUADS);
+  const MergeItem* merge_list = nullptr;
   if (use_segments) {
     u32* bh = (u32*)ln.seg.p; u32* soff = bh + bh_words + (P + 1);
     MergeItem* merge = (MergeItem*)(((uintptr_t)(bh + hdr_words) + 15) & ~(uintptr_t)15);
@@ -1574,12 +1575,13 @@ static int msm_enqueue_pippenger(jj_ctx* c, MsmLane& ln, size_t n, const void* d
     hipLaunchKernelGGL(k_seg_plan, dim3(P + 1), dim3(256), 0, st, stiles, bh, soff);
     hipLaunchKernelGGL(k_seg_scatter, dim3(stiles), dim3(256), 0, st, nb, B, per_tile, P, (const u32*)off, (const u32*)bh, (const u32*)soff, soff + (P + 1), seg, counters, merge, big);
     hipLaunchKernelGGL(k_msm_accumulate_seg, dim3(blocks_for(max_segs)), dim3(256), 0, st, (const u32*)(soff + (P + 1)), (const Seg*)seg, (const u32*)idx.p, (const u32*)niels.p, bk, head);
-    hipLaunchKernelGGL(k_msm_merge, dim3(std::min<unsigned>(blocks_for(4 * std::min(nb, max_segs)), 4u * c->cus)), dim3(256), 0, st, (const u32*)counters, (const MergeItem*)merge, bk, head);
+    merge_list = merge;
   } else {
     hipLaunchKernelGGL(k_msm_accumulate, dim3(blocks_for(nchunk), Ws), dim3(256), 0, st, n, B, chunk, nchunk, (const u32*)off, (const u32*)idx.p, (const u32*)niels.p, bk, head);
     hipLaunchKernelGGL(k_msm_fixup, dim3(blocks_for(2 * nb)), dim3(256), 0, st, n, B, Ws, chunk, nchunk, (const u32*)off, bk, head, counters, big);
   }
-  hipLaunchKernelGGL(k_msm_fixup_big, dim3(256), dim3(256), 0, st, counters, (const BigBucket*)big, bk, head, partial);
+  // (segment path: 512 workgroups, the merge list of repeated scalars is walked by the same launch)
+  hipLaunchKernelGGL(k_msm_fixup_big, dim3(merge_list ? 2u * (unsigned)c->cus : 256u), dim3(256), 0, st, counters, (const BigBucket*)big, bk, head, partial, merge_list);
   if (K > MSM_TREE_QUADS * nblk) hipLaunchKernelGGL(k_msm_reduce_fold<true>, dim3(reduce_grid), dim3(4 * MSM_TREE_QUADS), 0, st, n, mp, L, nblk, jbits, bk, part, counters, (u32*)rec_dev);
   else hipLaunchKernelGGL(k_msm_reduce_fold<false>, dim3(reduce_grid), dim3(4 * MSM_TREE_QUADS), 0, st, n, mp, L, nblk, jbits, bk, part, counters, (u32*)rec_dev);
   return JJ_OK;

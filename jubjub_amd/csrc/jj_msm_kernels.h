@@ -21,7 +21,7 @@
 //                                    window's histogram in LDS (k_msm_hist / _plan / _scatter) or two passes for >= 4096 buckets
 //                                    per window (k_msm_part_hist / _plan / _scatter / _sort); bucket accumulation over fixed
 //                                    chunks (k_msm_accumulate + k_msm_fixup) or length-sorted segments (k_seg_*,
-//                                    k_msm_accumulate_seg, k_msm_merge); k_msm_fixup_big; k_msm_reduce_fold
+//                                    k_msm_accumulate_seg); k_msm_fixup_big (+ the segment path's merge list); k_msm_reduce_fold
 #pragma once
 // (inside namespace jj: this file is included from the middle of jj_kernels.h)
 
@@ -638,7 +638,7 @@ __global__ void __launch_bounds__(256) k_msm_fixup(size_t n, u32 B, u32 Ws, u32 
 // segments are counting-sorted by length (longest first), and each lane adds up one segment: lanes of a wave run the
 // same number of iterations, no lane ever switches buckets inside its loop, and a bucket with a single segment (the
 // common case) is finished by its lane.  Buckets with several segments (repeated scalars) get their extra segments as `head`
-// partials that k_msm_merge (few) or k_msm_fixup_big (many) folds in.
+// partials that k_msm_fixup_big folds in (a merge list for few, the big-bucket list for many).
 #ifndef JJ_MSM_ACC_MINBLOCKS
 #define JJ_MSM_ACC_MINBLOCKS 1        // resident 256-thread blocks per CU the accumulate kernel is compiled for: 1 = no register cap (137 VGPRs,
 #endif                                // 3 waves per SIMD); capping at 128 (4 waves) changes nothing, 96 (5 waves) spills (profiles/r2_msm_acc_occupancy.txt)
@@ -768,24 +768,25 @@ __global__ void __launch_bounds__(256, JJ_MSM_ACC_MINBLOCKS) k_msm_accumulate_se
   }
   if (sg.dst >> 31) aos_put_ext(head, sg.dst & 0x7fffffffu, acc); else aos_put_ext(buckets, sg.dst, acc);
 }
-// buckets with a few extra segments: one quad of lanes folds them in
-__global__ void __launch_bounds__(256) k_msm_merge(const u32* counters, const MergeItem* merge, ExtAoS buckets, ExtAoS head) {
-  const u32 role = threadIdx.x & 3u, cnt = counters[1];
-  // grid-stride over the list: it is short (or empty) unless scalars repeat, and the launch is sized for that
-  #pragma unroll 1
-  for (size_t m = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2; m < cnt; m += (size_t)gridDim.x * (blockDim.x >> 2)) {
-    const MergeItem it = merge[m];
-    Ext acc = aos_ext(buckets, it.bucket);
-    #pragma unroll 1
-    for (u32 j = 0; j < it.k; j++) acc = quad_add_ext(acc, aos_ext(head, (size_t)it.h0 + j), role);
-    if (role == 0) aos_put_ext(buckets, it.bucket, acc);
-  }
-}
-// Big buckets, one launch: every workgroup folds a strided share of the listed buckets' heads into FIXUP_BIG_QUADS partials each
+// Buckets with a few extra segments (`merge`, segment path only; nullptr otherwise): one quad of lanes folds them in, grid-stride over
+// the list -- it is short or empty unless scalars repeat.  (Its own launch until round 4: an empty pass over 1024 workgroups cost 13-16 us
+// between the accumulation and the reduce; here it rides in the launch of the big buckets.)
+// Big buckets: every workgroup folds a strided share of the listed buckets' heads into FIXUP_BIG_QUADS partials each
 // (written to `partial[item][quad]`); the LAST workgroup to finish (a device-side counter) folds the partials of every item
-// into its bucket.  The list is empty for anything but heavily repeated scalars, and the launch is then a no-op.
-__global__ void __launch_bounds__(256) k_msm_fixup_big(u32* counters, const BigBucket* big, ExtAoS buckets, ExtAoS head, SoA partial) {
+// into its bucket.  The list is empty for anything but heavily repeated scalars.  The two lists name different buckets.
+__global__ void __launch_bounds__(256) k_msm_fixup_big(u32* counters, const BigBucket* big, ExtAoS buckets, ExtAoS head, SoA partial, const MergeItem* merge) {
   __shared__ u32 last_s;
+  if (merge) {
+    const u32 role_m = threadIdx.x & 3u, mcnt = counters[1];
+    #pragma unroll 1
+    for (size_t m = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2; m < mcnt; m += (size_t)gridDim.x * (blockDim.x >> 2)) {
+      const MergeItem it = merge[m];
+      Ext acc = aos_ext(buckets, it.bucket);
+      #pragma unroll 1
+      for (u32 j = 0; j < it.k; j++) acc = quad_add_ext(acc, aos_ext(head, (size_t)it.h0 + j), role_m);
+      if (role_m == 0) aos_put_ext(buckets, it.bucket, acc);
+    }
+  }
   u32 cnt = counters[2]; if (cnt > FIXUP_BIG_MAX) cnt = FIXUP_BIG_MAX;
   if (cnt == 0) return;
   const u32 role = threadIdx.x & 3u, quad = threadIdx.x >> 2;
