@@ -79,13 +79,18 @@ int jj_peak_imad32_samples(jj_ctx* ctx, int count, double* out_per_sec);
  *     from and to it (2^24 fixed-base units: 0.90 of the device-resident rate, profiles/r4_pcie_inclusive.txt);
  *   - any other (pageable) array passes through page-locked staging buffers of the context, copied by a few host threads (default
  *     8, JJ_PIPE_COPY_THREADS) beside the GPU's work: within 2-3 % of the page-locked rates, nothing of the caller's is registered,
- *     and a result array the caller has only just allocated costs no more than its page faults.  JJ_PIPE_PAGEABLE=register selects
- *     round 3's way instead (the arrays are page-locked in place for the call: no CPU copies, but a freshly allocated 1 GB result
- *     array then costs ~65 ms of serial page faults and pinning inside the call).
+ *     and a result array the caller has only just allocated costs no more than its page faults.  The GPU never touches the caller's
+ *     pageable pages: arrays of 1 MB and more are not handed to the HIP runtime either (which would page-lock them itself).
+ *     JJ_PIPE_PAGEABLE=register selects round 3's way instead for arrays of 64 MB and more (page-locked in place for the call: no
+ *     CPU copies, but a freshly allocated 1 GB result array then costs ~65 ms of serial page faults and pinning inside the call);
+ *     smaller arrays are staged in that mode too -- they live on the C heap, and page-locking them in place would hand the
+ *     neighbouring heap objects' pages to the GPU as well (two GPU write faults in ~3000 randomised test rounds came from that).
  * Page-locked buffers that are reused across calls are the fastest arrangement and cost the host no copy threads.
  * These four functions need no context and no HIP headers on the caller's side.  jj_host_alloc: page-locked, visible to every
  * device of the node, *out = NULL for bytes = 0.  jj_host_register: p .. p + bytes must be mapped and stay mapped until
- * jj_host_unregister(p); registering overlapping ranges twice fails with JJ_ERR_INVALID. */
+ * jj_host_unregister(p); registering overlapping ranges twice fails with JJ_ERR_INVALID.  p must be page-aligned (JJ_ERR_INVALID
+ * otherwise): register mappings of your own (mmap, aligned allocations) -- an array on the C heap shares its first and last page with
+ * other heap objects, and page-locking those for the GPU and releasing them again ended in GPU memory faults on later transfers. */
 int jj_host_alloc(size_t bytes, void** out);
 int jj_host_free(void* p);
 int jj_host_register(void* p, size_t bytes);

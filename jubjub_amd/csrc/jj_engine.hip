@@ -16,6 +16,7 @@
 #include <atomic>
 #include <functional>
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include "../../include/jubjub_hip.h"
 #include "jj_kernels.h"
@@ -255,7 +256,19 @@ static bool is_device_ptr(const void* p) {
 static bool is_pinned_host(const void* p, size_t bytes);
 static int host_to_dev_bounced(jj_ctx* c, void* dev, const void* host, size_t bytes, hipStream_t stream = nullptr, size_t* seq = nullptr);
 static int dev_to_host_bounced(jj_ctx* c, void* host, const void* dev, size_t bytes);
-constexpr size_t BOUNCE_MIN_BYTES = (size_t)16 << 20;     // smaller pageable arrays are copied by the runtime's own staging
+constexpr size_t BOUNCE_MIN_BYTES = (size_t)16 << 20;     // one staging slot
+// Pageable arrays of 1 MB and more never reach the runtime: from that size (GPU_PINNED_MIN_XFER_SIZE) hipMemcpy page-locks the CALLER's pages
+// for the transfer -- for a copy to the device, read-only -- and keeps such ranges cached.  Caller arrays on the C heap share their first and
+// last page with their neighbours: a later transfer (or registration) that WRITES through such a page met the cached read-only mapping once in
+// ~2000 rounds of tests/soak_host.py ("Memory access fault by GPU ... Write access to a read-only page").  Through the context's own page-locked
+// slots the GPU never touches caller pages at all (in every mode: JJ_PIPE_PAGEABLE=register page-locks caller arrays itself, read-write, for the
+// pipelined entry points only).  Smaller arrays go through the runtime's staging buffer, which does not page-lock them either.
+constexpr size_t BOUNCE_THRESHOLD = (size_t)1 << 20;
+// The library page-locks CALLER memory itself in two places only -- JJ_PIPE_PAGEABLE=register and the whole-batch registration of jj_multi_*
+// -- and only arrays of 64 MB and more: those are mappings of their own (the C library's mmap threshold never exceeds 32 MB), while smaller
+// arrays sit on the C heap between other objects, whose pages a registration would hand to the GPU as well.  Both GPU faults of the soak
+// (above) were writes into heap-sized result arrays (the decoder's `ok` bytes, 256 KB and 1 MB) registered in place.
+constexpr size_t REGISTER_MIN_BYTES = (size_t)64 << 20;
 // Resolves an input pointer: device pointers pass through (must be 16-byte aligned), host data is copied into a
 // staging buffer (large pageable arrays through the page-locked staging slots, see host_to_dev_bounced).
 static int stage_in(jj_ctx* c, int slot, const void* p, size_t bytes, const void** dev) {
@@ -266,7 +279,7 @@ static int stage_in(jj_ctx* c, int slot, const void* p, size_t bytes, const void
     *dev = p; return JJ_OK;
   }
   int rc = ensure(c, c->in[slot], bytes); if (rc) return rc;
-  if (c->pipe_bounce && bytes >= BOUNCE_MIN_BYTES && !is_pinned_host(p, bytes)) { if ((rc = host_to_dev_bounced(c, c->in[slot].p, p, bytes))) return rc; }
+  if (bytes >= BOUNCE_THRESHOLD && !is_pinned_host(p, bytes)) { if ((rc = host_to_dev_bounced(c, c->in[slot].p, p, bytes))) return rc; }
   else HIPCHK(c, hipMemcpyAsync(c->in[slot].p, p, bytes, hipMemcpyHostToDevice, c->stream));
   *dev = c->in[slot].p; return JJ_OK;
 }
@@ -284,7 +297,7 @@ static int stage_out(jj_ctx* c, DevBuf& buf, void* p, size_t bytes, OutRef* o) {
 }
 static int finish_out(jj_ctx* c, const OutRef& o, bool* need_sync) {
   if (o.host) {
-    if (c->pipe_bounce && o.bytes >= BOUNCE_MIN_BYTES && !is_pinned_host(o.user, o.bytes)) { const int rc = dev_to_host_bounced(c, o.user, o.dev, o.bytes); if (rc) return rc; }
+    if (o.bytes >= BOUNCE_THRESHOLD && !is_pinned_host(o.user, o.bytes)) { const int rc = dev_to_host_bounced(c, o.user, o.dev, o.bytes); if (rc) return rc; }
     else if (o.bytes) HIPCHK(c, hipMemcpyAsync(o.user, o.dev, o.bytes, hipMemcpyDeviceToHost, c->stream));
     *need_sync = true;
   }
@@ -457,8 +470,10 @@ static int host_to_dev_bounced(jj_ctx* c, void* dev, const void* host, size_t by
   // seq: a slot counter the caller keeps over SEVERAL arrays (and drains once with stage_in_drain): the last slots' DMA of one array then
   // runs beside the host copy of the next array's first slots, instead of being waited for between the arrays
   if (!stream) stream = c->stream;
-  int rc = stage_ensure(c, std::max(BOUNCE_MIN_BYTES, c->stage_in_cap), c->stage_out_cap); if (rc) return rc;
-  const size_t CHB = BOUNCE_MIN_BYTES;
+  // slots of whole MB, 16 MB at most; a caller that keeps `seq` over several arrays has copies in flight between them, so its slots must not
+  // be re-allocated on the way: full-size slots from the start
+  const size_t CHB = seq ? BOUNCE_MIN_BYTES : std::min(BOUNCE_MIN_BYTES, (bytes + 0xfffff) & ~(size_t)0xfffff);
+  int rc = stage_ensure(c, std::max(CHB, c->stage_in_cap), c->stage_out_cap); if (rc) return rc;
   size_t k0 = 0;
   size_t& k = seq ? *seq : k0;
   for (size_t lo = 0; lo < bytes; lo += CHB, k++) {
@@ -476,8 +491,8 @@ static int stage_in_drain(jj_ctx* c, size_t seq) {
   return JJ_OK;
 }
 static int dev_to_host_bounced(jj_ctx* c, void* host, const void* dev, size_t bytes) {
-  int rc = stage_ensure(c, c->stage_in_cap, std::max(BOUNCE_MIN_BYTES, c->stage_out_cap)); if (rc) return rc;
-  const size_t CHB = BOUNCE_MIN_BYTES;
+  const size_t CHB = std::min(BOUNCE_MIN_BYTES, (bytes + 0xfffff) & ~(size_t)0xfffff);
+  int rc = stage_ensure(c, c->stage_in_cap, std::max(CHB, c->stage_out_cap)); if (rc) return rc;
   const size_t nch = (bytes + CHB - 1) / CHB;
   auto drain = [&](size_t k) -> hipError_t {
     const hipError_t e = hipEventSynchronize(c->ev_stage[k % 3]);
@@ -509,23 +524,24 @@ static int run_pipelined(jj_ctx* c, size_t n, size_t CH, const HostIn (&in)[NIN]
   void* locked[NIN + NOUT]; int nlocked = 0; bool ok = true;
   for (int k = 0; k < NIN; k++) pin_in[k] = is_pinned_host(in[k].p, n * in[k].elem);
   for (int k = 0; k < NOUT; k++) pin_out[k] = is_pinned_host(out[k].p, n * out[k].elem);
-  if (c->pipe_bounce) {
-    for (int k = 0; k < NIN; k++) any_bounce |= !pin_in[k];
-    for (int k = 0; k < NOUT; k++) any_bounce |= !pin_out[k];
-    if (any_bounce && (rc = stage_ensure(c, in_stride * CH, out_stride * CH))) return rc;
-  } else {
+  if (!c->pipe_bounce) {
+    // JJ_PIPE_PAGEABLE=register: arrays of REGISTER_MIN_BYTES and more are page-locked in place for this call; smaller ones take the staging
+    // slots like in the default mode (see REGISTER_MIN_BYTES)
     for (int k = 0; k < NIN && ok; k++) {
-      if (pin_in[k]) continue;
+      if (pin_in[k] || n * in[k].elem < REGISTER_MIN_BYTES) continue;
       if (hipHostRegister(const_cast<void*>(in[k].p), n * in[k].elem, hipHostRegisterDefault) == hipSuccess) { locked[nlocked++] = const_cast<void*>(in[k].p); pin_in[k] = true; } else ok = false;
     }
     for (int k = 0; k < NOUT && ok; k++) {
-      if (pin_out[k]) continue;
+      if (pin_out[k] || n * out[k].elem < REGISTER_MIN_BYTES) continue;
       if (c->pipe_prefault) prefault_parallel(out[k].p, n * out[k].elem);
       if (hipHostRegister(out[k].p, n * out[k].elem, hipHostRegisterDefault) == hipSuccess) { locked[nlocked++] = out[k].p; pin_out[k] = true; } else ok = false;
     }
   }
+  for (int k = 0; k < NIN; k++) any_bounce |= !pin_in[k];
+  for (int k = 0; k < NOUT; k++) any_bounce |= !pin_out[k];
   auto unlock = [&]() { for (int k = 0; k < nlocked; k++) (void)hipHostUnregister(locked[k]); };
   if (!ok) { (void)hipGetLastError(); unlock(); return 1; }
+  if (any_bounce && (rc = stage_ensure(c, in_stride * CH, out_stride * CH))) { unlock(); return rc; }
   clock_gettime(CLOCK_MONOTONIC, &ts1);
   jj_ctx::Pipe& P = c->pipe;
   hipStream_t saved = c->stream;
@@ -644,6 +660,9 @@ JJ_API int jj_host_free(void* p) {
 }
 JJ_API int jj_host_register(void* p, size_t bytes) {
   if (!p || !bytes) return JJ_ERR_INVALID;
+  // a page-aligned start: the buffer owns the pages it is on (see REGISTER_MIN_BYTES: page-locking C-heap arrays in place hands the
+  // neighbouring objects' pages to the GPU and ended in GPU memory faults)
+  if ((uintptr_t)p & ((uintptr_t)sysconf(_SC_PAGESIZE) - 1)) return JJ_ERR_INVALID;
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); return JJ_ERR_NODEVICE; }
   const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterPortable);
@@ -1677,7 +1696,7 @@ static int msm_begin_locked(jj_ctx* c, size_t n, const void* scalars, const void
         const struct { const void* host; void* dev; size_t elem; } arr[2] = {{scalars, c->in[0].p, 32}, {points, c->in[1].p, 64}};
         for (const auto& a : arr) {
           const uint8_t* src = (const uint8_t*)a.host + lo * a.elem; uint8_t* dst = (uint8_t*)a.dev + lo * a.elem;
-          if (c->pipe_bounce && cnt * a.elem >= BOUNCE_MIN_BYTES / 2 && !is_pinned_host(src, cnt * a.elem)) { if ((rc = host_to_dev_bounced(c, dst, src, cnt * a.elem, c->pipe.h2d, &stage_seq))) return fail(rc); }
+          if (cnt * a.elem >= BOUNCE_THRESHOLD && !is_pinned_host(src, cnt * a.elem)) { if ((rc = host_to_dev_bounced(c, dst, src, cnt * a.elem, c->pipe.h2d, &stage_seq))) return fail(rc); }
           else if (hipMemcpyAsync(dst, src, cnt * a.elem, hipMemcpyHostToDevice, c->pipe.h2d) != hipSuccess) { c->err = "MSM staging copy failed"; return fail(JJ_ERR_HIP); }
         }
         const int ei = (int)((lo / PASS) & 1);
@@ -2022,7 +2041,7 @@ static int multi_run(jj_multi* m, size_t n, Body body) {
 struct MultiPin {
   std::vector<void*> locked;
   void add(const void* p, size_t bytes) {
-    if (!p || bytes < ((size_t)1 << 20) || is_pinned_host(p, bytes)) return;       // small batches are staged, not pipelined
+    if (!p || bytes < REGISTER_MIN_BYTES || is_pinned_host(p, bytes)) return;         // smaller arrays: through each context's staging slots
     if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) == hipSuccess) locked.push_back(const_cast<void*>(p));
     else (void)hipGetLastError();                                                    // not fatal: the shards fall back to staging
   }

@@ -149,7 +149,8 @@ class Engine:
         return np.frombuffer(buf, dtype=np.uint8).reshape(shape)
 
     def host_register(self, array):
-        """page-locks an existing numpy array once (jj_host_register); pair with host_unregister(array)"""
+        """page-locks an existing numpy array once (jj_host_register); pair with host_unregister(array).  The array must start on a page
+        boundary, i.e. be a mapping of its own (np.frombuffer over an anonymous mmap, or host_alloc instead): arrays on the C heap are refused."""
         a = np.ascontiguousarray(array)
         if a is not array and a.ctypes.data != array.ctypes.data:
             raise ValueError("a contiguous array is required")

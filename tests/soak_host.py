@@ -30,7 +30,7 @@ while time.time() < t_end:
     env = {}
     if rng.integers(0, 2):
         env["JJ_PIPE_CHUNK_LOG2"] = str(int(rng.integers(14, 20)))
-    if rng.integers(0, 3) == 0:
+    if rng.integers(0, 3) == 0 or os.environ.get("SOAK_FORCE_REGISTER"):
         env["JJ_PIPE_PAGEABLE"] = "register"
     if rng.integers(0, 3) == 0:
         env["JJ_PIPE_RAMP"] = "0"
@@ -56,11 +56,14 @@ while time.time() < t_end:
     dS, dP = torch.from_numpy(S).cuda(), torch.from_numpy(P).cuda()
     hS, hP = host(S), host(P)
     out = host(np.zeros((n, 64), np.uint8)) if rng.integers(0, 2) else None            # None: a fresh pageable result array
+    trace = (lambda what: print("  [%d] %s" % (rnd, what), flush=True)) if os.environ.get("SOAK_TRACE") else (lambda what: None)
+    trace("varbase n=%d %s" % (n, env))
     got = eng.varbase_mul(hS, hP, out=out)
     assert (got == ref.varbase_mul(dS, dP).cpu().numpy()).all(), ("varbase", rnd, env, n)
     assert (got[idx] == O.varbase_mul(S[idx], P[idx])).all(), ("varbase oracle", rnd)
     tab, rtab = eng.fixedbase_table(base), ref.fixedbase_table(base)
     out32 = host(np.zeros((n, 32), np.uint8)) if rng.integers(0, 2) else None
+    trace("fixedbase")
     got = eng.fixedbase_mul_compressed(tab, hS, out=out32)
     assert (got == ref.fixedbase_mul_compressed(rtab, dS).cpu().numpy()).all(), ("fixedbase compressed", rnd, env, n)
     assert (got[idx] == O.compress(O.fixedbase_mul(S[idx], base))).all(), ("fixedbase oracle", rnd)
@@ -68,15 +71,18 @@ while time.time() < t_end:
     bad = rng.integers(0, n, size=n // 20)
     enc[bad] = rng.integers(0, 256, size=(len(bad), 32), dtype=np.uint8)
     flags = int(rng.choice([1, 5, 13, 15]))
+    trace("decompress")
     o1, k1 = eng.decompress(host(enc), flags, out=(host(np.zeros((n, 64), np.uint8)), host(np.zeros((n,), np.uint8))) if rng.integers(0, 2) else None)
     o2, k2 = ref.decompress(torch.from_numpy(enc).cuda(), flags)
     assert (k1 == k2.cpu().numpy()).all() and (o1 == o2.cpu().numpy()).all(), ("decompress", rnd, env, n, flags)
     eo, ek = O.decompress(enc[idx], flags)
     assert (k1[idx] == ek).all() and (o1[idx] == eo).all(), ("decompress oracle", rnd)
+    trace("msm")
     want = ref.msm(dS, dP).cpu().numpy()
     assert (eng.msm(hS, hP) == want).all(), ("msm from host arrays", rnd, env, n)         # 2^19 terms and more: 2..8 passes, copies beside the kernels
     if rnd % 4 == 0:
         assert (want == O.msm_pippenger(S, P).reshape(64)).all(), ("msm oracle", rnd, n)
+    trace("close")
     tab.close(); rtab.close(); eng.close()
     units += n; rnd += 1
     print("round %d ok: n=%d %s (%d units so far, %.0f s left)" % (rnd, n, env, units, t_end - time.time()), flush=True)

@@ -108,8 +108,13 @@ def test_host_buffer_api_without_a_gpu():
         pytest.skip("GPU present: covered by tests/test_gpu_host_path.py")
     p = ctypes.c_void_p()
     assert lib.jj_host_alloc(1 << 20, ctypes.byref(p)) == _lib.JJ_ERR_NODEVICE and not p.value
-    buf = ctypes.create_string_buffer(1 << 16)
+    import mmap
+
+    m = mmap.mmap(-1, 1 << 16)                                            # a page-aligned mapping of its own: what jj_host_register takes
+    buf = (ctypes.c_char * (1 << 16)).from_buffer(m)
     assert lib.jj_host_register(buf, 1 << 16) == _lib.JJ_ERR_NODEVICE
+    assert lib.jj_host_register(ctypes.c_void_p(ctypes.addressof(buf) + 64), 1 << 12) == _lib.JJ_ERR_INVALID      # not page-aligned: refused before anything else
+    del buf
 
 
 def test_host_batch_chunk_schedule_properties():

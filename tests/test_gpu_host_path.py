@@ -37,16 +37,32 @@ def _inputs(n, seed):
     return s, np.ascontiguousarray(p)
 
 
+def _own_mapping(shape):
+    """a uint8 array that is a mapping of its own (anonymous mmap, page-aligned, written once): what include/jubjub_hip.h asks callers to hand
+    to jj_host_register -- an array on the C heap shares its first and last page with other heap objects, and page-locking such pages for the
+    GPU and releasing them again left the runtime with stale mappings that a later transfer into recycled heap memory tripped over
+    (GPU memory access fault in this file, once in ~6 runs, until round 4)"""
+    import mmap
+
+    nbytes = int(np.prod(shape))
+    m = mmap.mmap(-1, max(nbytes, mmap.PAGESIZE))
+    a = np.frombuffer(m, dtype=np.uint8, count=nbytes).reshape(shape)
+    a[...] = 0
+    return a
+
+
 def _host(eng, kind, a):
     """the array in the requested kind of host memory: 'pinned' (jj_host_alloc), 'registered' (jj_host_register), 'pageable'"""
     if kind == "pinned":
         h = eng.host_alloc(a.shape)
         h[...] = a
         return h
-    h = np.array(a, copy=True)
     if kind == "registered":
+        h = _own_mapping(a.shape)
+        h[...] = a
         eng.host_register(h)
-    return h
+        return h
+    return np.array(a, copy=True)
 
 
 @pytest.mark.parametrize("kind", ["pinned", "registered", "pageable"])
@@ -107,8 +123,9 @@ def test_decompress_host_pipeline(eng, kind, flags):
 
 
 def test_pageable_arrays_page_locked_in_place(monkeypatch):
-    """JJ_PIPE_PAGEABLE=register: pageable arrays are page-locked in place for the call instead of passing through the staging buffers
-    (round 3's way, kept as an option); with uniform chunks and a freshly allocated result array"""
+    """JJ_PIPE_PAGEABLE=register: pageable arrays of 64 MB and more are page-locked in place for the call instead of passing through the staging
+    buffers (round 3's way, kept as an option; smaller arrays -- C-heap memory -- are staged in this mode too); with uniform chunks and a freshly
+    allocated result array, at sizes where all three arrays, none, and only the 64-byte ones are registered."""
     import torch
 
     from jubjub_amd import Engine
@@ -116,11 +133,11 @@ def test_pageable_arrays_page_locked_in_place(monkeypatch):
     monkeypatch.setenv("JJ_PIPE_PAGEABLE", "register")
     monkeypatch.setenv("JJ_PIPE_RAMP", "0")
     e = Engine(0)
-    n = N_PIPE
-    s, p = _inputs(n, 77)
-    out = e.varbase_mul(s, p)                                   # a new numpy result array
-    dev = e.varbase_mul(torch.from_numpy(s).cuda(), torch.from_numpy(p).cuda()).cpu().numpy()
-    assert (out == dev).all()
+    for n in (1 << 21, N_PIPE, (1 << 20) + 5):                  # all arrays registered | all staged | points + result registered, scalars staged
+        s, p = _inputs(n, 77)
+        out = e.varbase_mul(s, p)                               # a new numpy result array
+        dev = e.varbase_mul(torch.from_numpy(s).cuda(), torch.from_numpy(p).cuda()).cpu().numpy()
+        assert (out == dev).all(), n
     e.close()
 
 
@@ -148,7 +165,10 @@ def test_host_alloc_api(eng):
     assert lib.jj_host_free(p) == 0
     assert lib.jj_host_free(None) == 0
     assert lib.jj_host_register(None, 16) != 0
-    a = np.zeros(1 << 20, np.uint8)
+    heap = np.zeros((1 << 20) + 64, np.uint8)
+    off = 16 if heap.ctypes.data % 4096 == 0 else 0
+    assert lib.jj_host_register(C.c_void_p(heap.ctypes.data + off), C.c_size_t(1 << 20)) != 0       # not page-aligned: a C-heap array is refused
+    a = _own_mapping((1 << 20,))
     eng.host_register(a)
     eng.host_unregister(a)
     assert lib.jj_host_unregister(C.c_void_p(a.ctypes.data)) != 0            # not registered any more
