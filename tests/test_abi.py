@@ -185,6 +185,23 @@ def test_msm_host_pass_plan_properties():
     assert lib.jj_plan_msm_host_passes(1, 9, 1, ctypes.byref(pt), ctypes.byref(ps)) == _lib.JJ_ERR_INVALID
 
 
+def test_ifma_host_tail_unit(tmp_path):
+    """tests/cpp/test_host_tail_ifma.cpp: the four-lane AVX-512 IFMA field product, point doubling / addition and Horner chain of
+    jj_host_tail_ifma.h against the scalar host tail, lane by lane and with the ranges of long chains (skipped on CPUs without avx512ifma)."""
+    import subprocess
+
+    flags = open("/proc/cpuinfo").read()
+    if "avx512ifma" not in flags or "avx512vl" not in flags:
+        pytest.skip("no AVX-512 IFMA on this CPU (the library then takes the scalar chain)")
+    exe = tmp_path / "test_host_tail_ifma"
+    src = os.path.join(ROOT, "tests", "cpp", "test_host_tail_ifma.cpp")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-mavx512f", "-mavx512vl", "-mavx512ifma", "-o", str(exe), src])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "IFMA HOST TAIL OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    for marker in ("field mul ok", "point ops ok", "horner ok"):
+        assert marker in r.stdout
+
+
 def test_msm_fold_partials_host_only():
     """jj_msm_fold_partials (the last step of an MSM cut across devices / ranks) is a host-only function: partial points incl. the
     identity, 8-torsion points and P, -P pairs against the oracle's fold (reference `Sum`, src/lib.rs:183-193)."""
