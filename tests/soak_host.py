@@ -2,7 +2,8 @@
 """Randomised soak of the host-pointer path (include/jubjub_hip.h "host buffers"): random batch sizes around the pipeline's chunk
 boundaries, every array independently page-locked (jj_host_alloc) or pageable, random chunk lengths, bounce / in-place page-locking,
 uniform / ramped chunk schedules, the MSM of the same host arrays in one or several passes -- against the device-resident entry points (bit-exact, all units) and an oracle sample.
-Usage: python tests/soak_host.py [seconds] [seed]   (needs an MI355X)"""
+Usage: python tests/soak_host.py [seconds] [seed]   (needs an MI355X)
+SOAK_FORCE_REGISTER=1: every round in JJ_PIPE_PAGEABLE=register mode; SOAK_TRACE=1: one line before every entry point (where a crash happened)."""
 import os
 import sys
 import time
