@@ -75,6 +75,15 @@ struct CurveT {
     const Fe d = F::mul(p.z, n.z2);
     return add_tail(a, b, c, d);
   }
+  // the same with T = T1*T2 of p supplied by the caller: an accumulator that is both added to and handed on as an operand
+  // (the running sum of the bucket reduce) forms that product once
+  static JJ_DEV Ext add_t(const Ext& p, const Fe& T, const ENiels& n) {
+    const Fe a = F::mul(F::sub(p.v, p.u), n.vmu);
+    const Fe b = F::mul(F::add(p.v, p.u), n.vpu);
+    const Fe c = F::mul(T, n.t2d);
+    const Fe d = F::mul(p.z, n.z2);
+    return add_tail(a, b, c, d);
+  }
   // lib.rs:922-940
   template <bool T1_SMALL = false>
   static JJ_DEV Ext sub(const Ext& p, const ENiels& n) {
@@ -135,6 +144,15 @@ struct CurveT {
     n.vmu = F::sub(p.v, p.u);
     n.z2 = F::add(p.z, p.z);
     n.t2d = F::mul(tt<T1_SMALL>(p), F::konst(FqP::D2));
+    return n;
+  }
+  // lib.rs:728-735 with T = T1*T2 supplied by the caller
+  static JJ_DEV ENiels to_niels_t(const Ext& p, const Fe& T) {
+    ENiels n;
+    n.vpu = F::carry(F::add(p.v, p.u));
+    n.vmu = F::sub(p.v, p.u);
+    n.z2 = F::add(p.z, p.z);
+    n.t2d = F::mul(T, F::konst(FqP::D2));
     return n;
   }
   // -(vpu, vmu, t2d) = (vmu, vpu, -t2d)   (negation of the underlying point, lib.rs:92-104)

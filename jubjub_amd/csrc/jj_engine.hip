@@ -140,6 +140,9 @@ struct jj_ctx {
   int msm_seg_len = 0;           // segment length override (JJ_MSM_SEG_LEN; 0 = twice the mean bucket of the widest windows, clamped to [32, 1024])
   int msm_chunk = 0;             // accumulation chunk override (JJ_MSM_CHUNK; 0 = scale with n)
   int msm_reduce_chunk = 0;      // bucket-reduce chunk length (0 = from the bucket count, see msm_enqueue_pippenger; JJ_MSM_REDUCE_CHUNK, a power of two)
+  int msm_l1_rows = -1;          // two-level bucket reduce (k_msm_reduce_l1 / _l2): rows R of the bucket matrix a level-1 lane sums (a power of two, 2..64); 0 = one level (k_msm_reduce_fold);
+                                 // -1 = from the bucket count (msm_enqueue_pippenger; JJ_MSM_REDUCE_L1)
+  int msm_l2_chunk = 0;          // elements per level-2 quad (0 = the shortest for which the workgroups fit one per CU; JJ_MSM_REDUCE_L2_CHUNK, a power of two)
   int msm_two_pass = -1;         // counting sort in two passes (coarse bin, then low 8 bits): always above 4096 buckets per window, never below; at exactly 4096: 0 = one pass, else two (JJ_MSM_SORT=1pass|2pass)
   int msm_pass_log2 = 24;        // terms per Pippenger pass (JJ_MSM_PASS_LOG2 overrides; for tests)
   // optional per-call kernel timing (HIP events on the launch stream): e0 | main kernel | e1 | normalise tail | e2
@@ -727,6 +730,8 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
   if (const char* e = getenv("JJ_MSM_SEG_LEN")) c->msm_seg_len = atoi(e);
   if (const char* e = getenv("JJ_MSM_CHUNK")) { int v = atoi(e); if (v >= 8 && v <= 1024) c->msm_chunk = v; }
   if (const char* e = getenv("JJ_MSM_REDUCE_CHUNK")) { int v = atoi(e); if (v >= 2 && v <= 256 && (v & (v - 1)) == 0) c->msm_reduce_chunk = v; }
+  if (const char* e = getenv("JJ_MSM_REDUCE_L1")) { int v = atoi(e); if (v == 0 || (v >= 2 && v <= 64 && (v & (v - 1)) == 0)) c->msm_l1_rows = v; }
+  if (const char* e = getenv("JJ_MSM_REDUCE_L2_CHUNK")) { int v = atoi(e); if (v >= 2 && v <= 64 && (v & (v - 1)) == 0) c->msm_l2_chunk = v; }
   if (const char* e = getenv("JJ_MSM_SORT")) c->msm_two_pass = !strcmp(e, "2pass") ? 1 : (!strcmp(e, "1pass") ? 0 : -1);
   if (const char* e = getenv("JJ_MSM_PASS_LOG2")) { int v = atoi(e); if (v >= 10 && v <= 24) c->msm_pass_log2 = v; }
   if (const char* e = getenv("JJ_VB_QUAD_MAX")) { int v = atoi(e); if (v >= 0 && v <= (1 << 20)) c->vb_quad_max = v; }
@@ -1528,6 +1533,25 @@ static int msm_enqueue_pippenger(jj_ctx* c, MsmLane& ln, size_t n, const void* d
   const u32 K = B / L, nblk = std::min<u32>(MSM_TREE_QUADS, (K + MSM_TREE_QUADS - 1) / MSM_TREE_QUADS);      // workgroups of 64 quads per window, at most
   const u32 reduce_grid = reduce_blocks(L);
   int jbits = 0; while ((1u << jbits) < B) jbits++;
+  // Two-level reduce (k_msm_reduce_l1 + k_msm_reduce_l2) for wide windows: level 1 sums R rows of the bucket matrix per lane (whole-lane
+  // additions at full throughput), level 2 is the quad chain over M = B / R columns per window.  Narrow windows (2^17-term passes: 1024
+  // buckets per window) keep the one-level kernel: level 1 would be an extra launch and ~20 us of chain for a level 2 that is as deep.
+  u32 l1_rows = 0;
+  if (c->msm_l1_rows > 0) l1_rows = (u32)c->msm_l1_rows;
+  else if (c->msm_l1_rows < 0 && B >= 16384) l1_rows = B >= 32768 ? 8 : 4;
+  const u32 Bmin = mp.r ? B / 2 : B;                                     // buckets of the narrowest window of the layout
+  while (l1_rows > 1 && (l1_rows > Bmin || B / l1_rows < 64)) l1_rows >>= 1;     // every window has at least one row; whole waves per window
+  if (l1_rows < 2) l1_rows = 0;
+  int mbits = 0; u32 L2 = 0, nblk2 = 0;
+  if (l1_rows) {
+    const u32 M = B / l1_rows;
+    while ((1u << mbits) < M) mbits++;
+    L2 = 4;
+    while (L2 < M && ((u64)Ws * ((M / L2 + MSM_TREE_QUADS - 1) / MSM_TREE_QUADS) > (u64)c->cus || (M / L2 + MSM_TREE_QUADS - 1) / MSM_TREE_QUADS > (u32)MSM_TREE_QUADS)) L2 <<= 1;
+    if (c->msm_l2_chunk && (u32)c->msm_l2_chunk <= M && (M / (u32)c->msm_l2_chunk + MSM_TREE_QUADS - 1) / MSM_TREE_QUADS <= (u32)MSM_TREE_QUADS) L2 = (u32)c->msm_l2_chunk;
+    nblk2 = (M / L2 + MSM_TREE_QUADS - 1) / MSM_TREE_QUADS;
+  }
+  const size_t l1_bytes = l1_rows ? (size_t)Ws * (B / l1_rows) * ENIELS_WORDS * 4 : 0;      // one array of extended-Niels records (S, then T)
   int rc;
   DevBuf &kprime = ln.buf[0], &niels = ln.buf[1], &offb = ln.buf[2], &idx = ln.buf[3], &buckets = ln.buf[4], &ra = ln.buf[5], &tcnt = ln.buf[7];
   u32 chunk = MSM_CHUNK_MIN;                           // 16 entries per lane up to 2^19 terms, 32 at 2^20, then proportional to n (measured)
@@ -1558,7 +1582,8 @@ static int msm_enqueue_pippenger(jj_ctx* c, MsmLane& ln, size_t n, const void* d
   if ((rc = ensure(c, tcnt, two_pass ? ((size_t)Ws * (2 * pm + 1)) * 4 : (size_t)Ws * ntiles * B * 4))) return rc;
   if ((rc = ensure(c, buckets, (size_t)EXT_AOS_WORDS * 4 * nb))) return rc;
   // ra: first the two-pass sort's records (4 + 1 bytes per entry), then the chunk heads / segment heads
-  if ((rc = ensure(c, ra, std::max<size_t>((size_t)EXT_AOS_WORDS * 4 * std::max<size_t>((size_t)Ws * nchunk, (n * (size_t)Ws) / 8 + 1), n * (size_t)Ws * 5 + 64)))) return rc;
+  // (and, once the heads are folded in, the two arrays level 1 of the reduce hands to level 2)
+  if ((rc = ensure(c, ra, std::max<size_t>(std::max<size_t>((size_t)EXT_AOS_WORDS * 4 * std::max<size_t>((size_t)Ws * nchunk, (n * (size_t)Ws) / 8 + 1), n * (size_t)Ws * 5 + 64), 2 * l1_bytes)))) return rc;
   if ((rc = msm_ensure_ctl(c, ln))) return rc;                                                           // counters, big-bucket work list, workgroup partial sums
   if ((rc = ensure(c, ln.bigpart, (size_t)5 * NL * 4 * FIXUP_BIG_MAX * FIXUP_BIG_QUADS))) return rc;      // the big buckets' partial sums
   if (use_segments && (rc = ensure(c, ln.seg, hdr_words * 4 + 16 + nb * sizeof(MergeItem) + max_segs * sizeof(Seg)))) return rc;   // bh [stiles][P+1] | count [P+1] | offset [P+2] | merge list | segments
@@ -1601,7 +1626,11 @@ static int msm_enqueue_pippenger(jj_ctx* c, MsmLane& ln, size_t n, const void* d
   }
   // (segment path: 512 workgroups, the merge list of repeated scalars is walked by the same launch)
   hipLaunchKernelGGL(k_msm_fixup_big, dim3(merge_list ? 2u * (unsigned)c->cus : 256u), dim3(256), 0, st, counters, (const BigBucket*)big, bk, head, partial, merge_list);
-  if (K > MSM_TREE_QUADS * nblk) hipLaunchKernelGGL(k_msm_reduce_fold<true>, dim3(reduce_grid), dim3(4 * MSM_TREE_QUADS), 0, st, n, mp, L, nblk, jbits, bk, part, counters, (u32*)rec_dev);
+  if (l1_rows) {
+    u32* SN = (u32*)ra.p; u32* TN = (u32*)((uint8_t*)ra.p + l1_bytes);        // the heads are dead: k_msm_fixup_big was their last reader
+    hipLaunchKernelGGL(k_msm_reduce_l1, dim3(blocks_for((size_t)Ws << mbits)), dim3(256), 0, st, mp, mbits, bk, SN, TN);
+    hipLaunchKernelGGL(k_msm_reduce_l2, dim3(Ws * nblk2), dim3(4 * MSM_TREE_QUADS), 0, st, n, mp, mbits, L2, nblk2, (const u32*)SN, (const u32*)TN, part, counters, (u32*)rec_dev);
+  } else if (K > MSM_TREE_QUADS * nblk) hipLaunchKernelGGL(k_msm_reduce_fold<true>, dim3(reduce_grid), dim3(4 * MSM_TREE_QUADS), 0, st, n, mp, L, nblk, jbits, bk, part, counters, (u32*)rec_dev);
   else hipLaunchKernelGGL(k_msm_reduce_fold<false>, dim3(reduce_grid), dim3(4 * MSM_TREE_QUADS), 0, st, n, mp, L, nblk, jbits, bk, part, counters, (u32*)rec_dev);
   return JJ_OK;
 }

@@ -913,6 +913,103 @@ __global__ void __launch_bounds__(4 * MSM_TREE_QUADS) k_msm_reduce_fold(size_t n
   msm_finish_window(st, quad, role, nblk_s, nblk, blk, s, w, acc, Tacc, part, counters, rec);
 }
 
+// ---- Two-level reduction for wide windows (round 5).  The quad chains above spend as many instructions on exchanges, role selects
+// and idle lanes as on the mathematics (~4x the products' own cost), and with 2^15 buckets per window every quad walks 32 of them.
+// Level 1 runs in LANE form, at the throughput of whole-lane additions: the window's Bw buckets are read as an R x M matrix
+// (bucket j = i M + m, M = 2^mbits, R = Bw / M rows), lane m takes column m, i.e. the STRIDED buckets m, m + M, ..., and leaves
+//     S_m = sum_i b_{i M + m}          T_m = sum_i i b_{i M + m}            (running sums from the top row: 2 (R - 2) + 1 additions)
+// so that   sum_j (j + 1) b_j = sum_m (m + 1) S_m + M sum_m T_m.   Level 2 (quads again) sees an R-times smaller weighted sum over
+// the S_m and a plain sum of the T_m; the weight M = 2^mbits of that plain sum costs nothing: a chunk's j0 * (sum S) is a
+// double-and-add over the bits [lb, mbits) of j0, and the chunk's sum of T_m is simply the value that chain starts from (bit mbits).
+// Both arrays leave level 1 as extended-Niels records (144 B), the form level 2's two-round additions consume.
+__global__ void __launch_bounds__(256) k_msm_reduce_l1(MsmParams mp, int mbits, ExtAoS buckets, u32* SN, u32* TN) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ((size_t)mp.Ws << mbits)) return;
+  const u32 M = 1u << mbits, s = (u32)(t >> mbits), m = (u32)t & (M - 1u);
+  const int w = msm_slot_window(mp, (int)s);
+  const u32 R = (1u << (msm_win_width(mp, w) - 1)) >> mbits;          // rows of this window (the host keeps M <= the narrowest window's buckets): uniform over a wave
+  const size_t base = (size_t)s * mp.B + m;
+  // running = b_i + ... + b_{R-1} on entry to step i; T = sum_{i >= 1} running_i.  Both additions of a step read the SAME running sum
+  // (total += running_i, running_{i-1} = running_i + b_{i-1}), so a step is two independent chains of products: one wave per SIMD is all
+  // this kernel has, and a lone wave issues dependent multiply-adds at ~0.8 of the SIMD's rate (experiments/lone_wave)
+  Ext running = aos_ext(buckets, base + (size_t)(R - 1) * M);
+  Fe Tr = Curve::tt<true>(running);                                    // stored t1, t2 are carried
+  Ext total = Curve::identity();
+  Fe Tt = Fq::zero();
+  if (R > 1) {
+    total = running; Tt = Tr;                                          // step R - 1: total = running_{R-1}
+    Ext nxt = aos_ext(buckets, base + (size_t)(R - 2) * M);
+    running = Curve::add_t(running, Tr, Curve::to_niels<true>(nxt));   // running_{R-2}
+    Tr = Curve::tt<true>(running);
+    if (R > 2) nxt = aos_ext(buckets, base + (size_t)(R - 3) * M);
+    #pragma unroll 1
+    for (int i = (int)R - 2; i >= 1; i--) {                            // on entry: running = running_i, nxt = b_{i-1}
+      const Ext cur = nxt;
+      if (i > 1) nxt = aos_ext(buckets, base + (size_t)(i - 2) * M);  // the next bucket is in flight while this one is added
+      const ENiels rn = Curve::to_niels_t(running, Tr);
+      const Ext run2 = Curve::add_t(running, Tr, Curve::to_niels<true>(cur));
+      total = Curve::add_t(total, Tt, rn);
+      const Fe Tr2 = Curve::tt<true>(run2);
+      Tt = Curve::tt<true>(total);
+      running = run2; Tr = Tr2;
+    }
+  }
+  store_eniels(SN + t * ENIELS_WORDS, Curve::to_niels_t(running, Tr));
+  store_eniels(TN + t * ENIELS_WORDS, Curve::to_niels_t(total, Tt));
+}
+// level 2, chunk k of slot s: elements m = k L .. k L + L - 1;  sum (m + 1) S_m + M sum T_m  =  sum (m - j0 + 1) S_m  +  [2^mbits sum T_m + j0 sum S_m]
+static JJ_DEV Ext msm_reduce2_chunk(u32 s, u32 k, u32 L, int lb, int mbits, const u32* SN, const u32* TN, u32 role, Fe& Tout) {
+  const size_t first = (((size_t)s << mbits) + (size_t)k * L) * ENIELS_WORDS;
+  const u32 j0 = k * L;
+  Ext running = Curve::identity(), total = Curve::identity(), plain = Curve::identity();
+  Fe Tr = Fq::zero(), Tt = Fq::zero(), Tp = Fq::zero(), dummy;
+  ENiels sn = load_eniels(SN + first + (size_t)(L - 1) * ENIELS_WORDS), tn = load_eniels(TN + first + (size_t)(L - 1) * ENIELS_WORDS);
+  #pragma unroll 1
+  for (int j = (int)L - 1; j >= 0; j--) {
+    const ENiels cs = sn, ct = tn;
+    if (j > 0) { sn = load_eniels(SN + first + (size_t)(j - 1) * ENIELS_WORDS); tn = load_eniels(TN + first + (size_t)(j - 1) * ENIELS_WORDS); }
+    running = quad_add_eniels(running, Tr, cs, 0u, role, Tr);
+    total = quad_add_ext_t(total, Tt, running, Tr, role, Tt, Tr, Tr, dummy);
+    plain = quad_add_eniels(plain, Tp, ct, 0u, role, Tp);
+  }
+  // m = 2^mbits plain + j0 running: double-and-add over the bits [lb, mbits) of j0 (a multiple of L = 2^lb) starting from `plain`
+  ENiels rn;
+  rn.vpu = Fq::carry(Fq::add(running.v, running.u)); rn.vmu = Fq::sub(running.v, running.u); rn.z2 = Fq::add(running.z, running.z);
+  rn.t2d = Fq::mul(Tr, Fq::konst(FqP::D2));
+  const ENiels idn = Curve::eniels_identity();
+  Ext m = plain;
+  Fe Tm = Tp;
+  #pragma unroll 1
+  for (int bit = mbits - 1; bit >= lb; bit--) {
+    m = quad_dbl_t(m, role, Tm);
+    const u32 mask = ((j0 >> bit) & 1u) ? ~0u : 0u;
+    m = quad_add_eniels(m, Tm, Curve::select(idn, rn, mask), 0u, role, Tm);
+  }
+  #pragma unroll 1
+  for (int bit = 0; bit < lb; bit++) m = quad_dbl_t(m, role, Tm);
+  total = quad_add_ext_t(total, Tt, m, Tm, role, Tt, Tr, Tr, dummy);
+  Tout = Tt;
+  return total;
+}
+// grid: Ws * nblk workgroups of 64 quads, nblk = ceil(M / L / 64) <= 64 per window (the same for every window: M does not depend on it)
+__global__ void __launch_bounds__(4 * MSM_TREE_QUADS) k_msm_reduce_l2(size_t n, MsmParams mp, int mbits, u32 L, u32 nblk, const u32* SN, const u32* TN, u32* part, u32* counters, u32* rec) {
+  __shared__ __attribute__((aligned(16))) u32 st[MSM_TREE_QUADS * LDS_PT_WORDS];
+  const u32 role = threadIdx.x & 3u, quad = threadIdx.x >> 2;
+  const u32 s = blockIdx.x / nblk, blk = blockIdx.x % nblk;
+  const int w = msm_slot_window(mp, (int)s);
+  if (blockIdx.x == 0 && threadIdx.x == 0) msm_write_header(rec, mp, n);
+  const u32 K = (1u << mbits) / L;
+  const int lb = __ffs((int)L) - 1;
+  Ext acc = Curve::identity();
+  Fe Tacc = Fq::zero();
+  const u32 k = blk * MSM_TREE_QUADS + quad;
+  if (k < K) acc = msm_reduce2_chunk(s, k, L, lb, mbits, SN, TN, role, Tacc);
+  const u32 base = blk * MSM_TREE_QUADS;
+  const u32 live = base >= K ? 0u : (K - base < (u32)MSM_TREE_QUADS ? K - base : (u32)MSM_TREE_QUADS);
+  quad_tree_sum(st, quad, role, live, acc, Tacc);
+  msm_finish_window(st, quad, role, nblk, nblk, blk, s, w, acc, Tacc, part, counters, rec);
+}
+
 // ================================================================================================ device-side finish (opt-in)
 // jj_msm_dev: the host tail's work -- Horner over the windows of ONE record (252 dependent doublings + one addition per window),
 // one inversion, canonical (u, v) -- on one quad of lanes, so that the sum never leaves the device and no host thread waits.

@@ -467,6 +467,44 @@ def test_msm_window_counts_both_sorts(monkeypatch, window, sort):
     e2.close()
 
 
+@pytest.mark.parametrize("window,rows,l2chunk", [(16, 8, 0), (16, 4, 8), (16, 32, 2), (16, 0, 0), (17, 4, 0), (17, 16, 4), (19, 8, 0), (20, 2, 16), (23, 4, 0), (32, 2, 0)])
+def test_msm_two_level_bucket_reduce(monkeypatch, window, rows, l2chunk):
+    """JJ_MSM_REDUCE_L1 / JJ_MSM_REDUCE_L2_CHUNK: the two-level bucket reduce (lane-form column sums S_m, T_m over `rows` rows of the
+    bucket matrix, then the quad chain over the columns; the default from 16 384 buckets per window) forced over window layouts with
+    one and two window widths, every level-2 chunk length class, one workgroup and several per window, and switched off (rows = 0);
+    ragged sizes, equal scalars (one bucket per window holds everything), zero digits and the largest top-window digit."""
+    from jubjub_amd import Engine
+
+    monkeypatch.setenv("JJ_MSM_WINDOWS", str(window))
+    monkeypatch.setenv("JJ_MSM_REDUCE_L1", str(rows))
+    if l2chunk:
+        monkeypatch.setenv("JJ_MSM_REDUCE_L2_CHUNK", str(l2chunk))
+    monkeypatch.setenv("JJ_MSM_SMALL_MAX", "0")
+    e2 = Engine(0)
+    for n in (1, 2, 301, 30011):
+        S = rand_scalars(1512 + n + window, n, full_width=True)
+        P = rand_points(1513 + n, n, subgroup=(n % 2 == 0))
+        assert (e2.msm(S, P) == O.msm(S, P)).all(), (window, rows, l2chunk, n)
+    n = 9000
+    P = rand_points(1661, n)
+    S = np.repeat(rand_scalars(1662, 1, full_width=True), n, axis=0)
+    assert (e2.msm(S, P) == O.msm(S, P)).all()
+    S2 = rand_scalars(1663, n)
+    S2[: n // 2] = S2[0]
+    S2[n // 2: n // 2 + 500] = 0
+    S2[-1] = 0xFF
+    S2[-1, 31] = 0x0F
+    assert (e2.msm(S2, P) == O.msm(S2, P)).all()
+    # every bucket of the low windows in use: scalars 1 .. 2^15 and their negatives' neighbours (digits of both signs, all rows and columns)
+    n = 1 << 15
+    S3 = np.zeros((n, 32), np.uint8)
+    v = np.arange(1, n + 1, dtype=np.uint32)
+    S3[:, 0] = v & 0xFF; S3[:, 1] = (v >> 8) & 0xFF; S3[:, 2] = (v >> 16) & 0xFF
+    P3 = np.repeat(rand_points(1664, 8), n // 8, axis=0)
+    assert (e2.msm(S3, P3) == O.msm(S3, P3)).all()
+    e2.close()
+
+
 def test_msm_back_to_back_sizes(monkeypatch):
     """Pippenger calls of changing sizes back to back on one context: every call reuses (and regrows) the workspaces of the one
     before it, including the LDS-staged conversion's ragged last workgroup (n not a multiple of 64)."""

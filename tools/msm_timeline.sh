@@ -18,7 +18,7 @@ q = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols el
 rows = db.execute("select name, start, end, %s from kernels order by start" % q).fetchall()
 # the last MSM: the kernels after the second-to-last record-writing kernel (reduce_fold / small_sum) up to the last one
 rows = [r for r in rows if "jj::" in r[0] and "k_peak_mad" not in r[0]]
-ends = [i for i, r in enumerate(rows) if "k_msm_reduce_fold" in r[0] or "k_msm_small_sum" in r[0]]
+ends = [i for i, r in enumerate(rows) if "k_msm_reduce_fold" in r[0] or "k_msm_small_sum" in r[0] or "k_msm_reduce_l2" in r[0]]
 sel = rows[ends[-2] + 1: ends[-1] + 1]
 t0 = sel[0][1]
 print("# 2^%s-term MSM, last call of the run: kernel, queue, start us, duration us, gap to the previous END on any queue us" % lg)
