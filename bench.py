@@ -87,7 +87,7 @@ WORK = {
 
 def tail_work(wl, n, cus=256):
     """field operations per unit of the normalisation that follows the ladder kernels: 6M per point + one inversion (255S + 75M) per
-    chunk; the chunk length is the one normalize_launch (jj_engine.hip) picks for n units"""
+    chunk; the chunk length is the one normalize_launch (jj_abi.hip) picks for n units"""
     if wl not in ("varbase", "fixedbase"):
         return 0, 0
     lanes = cus * 64 * 8

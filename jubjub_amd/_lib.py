@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 # HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue serialise; a context's
-# copy / compute pipeline beside PyTorch's streams needs more (jj_engine.hip jj_default_hw_queues has the measurements).  Read when the
+# copy / compute pipeline beside PyTorch's streams needs more (DESIGN.md 5a has the measurements).  Read when the
 # HIP runtime initialises, so it is set at import time, before torch or this library makes the first HIP call; a user's value wins.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 

@@ -1,14 +1,21 @@
-"""Builds libjubjub_hip.so (gfx950) in-tree with hipcc.  No torch involved: the product is a plain C-ABI library."""
+"""Builds libjubjub_hip.so (gfx950) in-tree with hipcc.  No torch involved: the product is a plain C-ABI library.
+
+Four translation units (csrc/jj_pipeline.hip, jj_abi.hip, jj_msm.hip, jj_multi.hip) are compiled side by side into lib/obj/*.o and
+linked; a unit is recompiled when one of the files it includes is newer than its object."""
 import os
 import shutil
 import subprocess
 import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, "csrc", "jj_engine.hip")
+CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libjubjub_hip.so")
-DEPS = [os.path.join(HERE, "csrc", f) for f in ("jj_engine.hip", "jj_kernels.h", "jj_curve.h", "jj_field.h", "jj_constants.h", "jj_host_tail.h", "jj_host_tail_ifma.h", "jj_msm_kernels.h")] + [
-    os.path.join(HERE, "..", "include", "jubjub_hip.h")]
+OBJ = os.path.join(HERE, "lib", "obj")
+COMMON = ["jj_engine.h", "jj_kernels.h", "jj_curve.h", "jj_field.h", "jj_constants.h", "jj_host_tail.h", "jj_host_tail_ifma.h", os.path.join("..", "..", "include", "jubjub_hip.h")]
+UNITS = {"jj_pipeline": [], "jj_abi": [], "jj_msm": ["jj_msm_kernels.h"], "jj_multi": []}
+SOURCES = [os.path.join(CSRC, u + ".hip") for u in UNITS]
 
 
 def hipcc():
@@ -18,21 +25,54 @@ def hipcc():
     raise RuntimeError("hipcc not found")
 
 
+def flags():
+    return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"] + os.environ.get("JJ_CXXFLAGS", "").split()
+
+
+def _deps(unit):
+    return [os.path.join(CSRC, unit + ".hip")] + [os.path.join(CSRC, f) for f in COMMON + UNITS[unit]]
+
+
+def _obj(unit):
+    return os.path.join(OBJ, unit + ".o")
+
+
+def _stale(unit):
+    o = _obj(unit)
+    if not os.path.exists(o):
+        return True
+    t = os.path.getmtime(o)
+    return any(os.path.getmtime(d) > t for d in _deps(unit)) or os.path.getmtime(os.path.abspath(__file__)) > t
+
+
 def needs_build():
     if not os.path.exists(OUT):
         return True
-    t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(d) > t for d in DEPS)
+    return any(_stale(u) or os.path.getmtime(_obj(u)) > os.path.getmtime(OUT) for u in UNITS)
 
 
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return OUT
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden",
-           "-Wall", "-Wno-unused-function", "-o", OUT, SRC] + os.environ.get("JJ_CXXFLAGS", "").split()
+    os.makedirs(OBJ, exist_ok=True)
+    cc = hipcc()
+    todo = [u for u in UNITS if force or _stale(u)]
+
+    def compile_unit(u):
+        t0 = time.time()
+        cmd = [cc] + flags() + ["-c", "-o", _obj(u), os.path.join(CSRC, u + ".hip")]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return u, time.time() - t0
+
+    with ThreadPoolExecutor(max_workers=max(1, len(todo))) as ex:
+        for u, dt in ex.map(compile_unit, todo):
+            if verbose:
+                print("  %s: %.1f s" % (u, dt), flush=True)
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + [_obj(u) for u in UNITS]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     return OUT
 

@@ -1,5 +1,7 @@
 // HIP kernels of the Jubjub engine (gfx950).  One field element / one curve point per lane, limbs in VGPRs.
-// Included by jj_engine.hip only.
+// Included through jj_engine.h by the library's translation units.  The device helpers and argument types are always visible; the
+// __global__ kernels are compiled into the ONE translation unit that launches them: JJ_KERNELS_BATCH (jj_abi.hip: fields, points,
+// ladders, fixed-base, codec, generators), JJ_KERNELS_MSM (jj_msm.hip: jj_msm_kernels.h), JJ_KERNELS_PROBE (jj_pipeline.hip: k_peak_mad).
 #pragma once
 #include "jj_curve.h"
 
@@ -98,6 +100,7 @@ static JJ_DEV Fe fq_sqrt_fast(const Fe& a, bool& ok, const SqrtTables& T) {
   return xr;
 }
 // builds the tables once per context: thread k (< 256): dlog entry of gamma^k; thread 256 + (i*256 + k): g^(-k 2^(8i))
+#ifdef JJ_KERNELS_BATCH
 __global__ void __launch_bounds__(256) k_sqrt_tables_init(uint8_t* dlog, u32* npow) {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid < 256) {
@@ -115,7 +118,9 @@ __global__ void __launch_bounds__(256) k_sqrt_tables_init(uint8_t* dlog, u32* np
     _Pragma("unroll") for (int l = 0; l < NL; l++) npow[((size_t)i * 256 + k) * NL + l] = c.l[l];
   }
 }
+#endif  // JJ_KERNELS_BATCH
 
+#ifdef JJ_KERNELS_BATCH
 template <class P, int OP>
 __global__ void __launch_bounds__(256) k_field_op(size_t n, const void* a, const void* b, void* out, uint8_t* okp, SqrtTables tabs) {
   typedef Field<P> F;
@@ -153,9 +158,11 @@ __global__ void __launch_bounds__(256) k_field_op(size_t n, const void* a, const
   store8(out, i, wo);
   if (okp) okp[i] = ok ? 1 : 0;
 }
+#endif  // JJ_KERNELS_BATCH
 
 // Fr::pow / Fq::pow (reference src/fr.rs:403-414): constant-time square-and-multiply over all 256 exponent bits,
 // one (base, exponent) pair per lane; the exponent is a little-endian 256-bit integer.
+#ifdef JJ_KERNELS_BATCH
 template <class P>
 __global__ void __launch_bounds__(256) k_field_pow(size_t n, const void* a, const void* e, void* out) {
   typedef Field<P> F;
@@ -176,8 +183,10 @@ __global__ void __launch_bounds__(256) k_field_pow(size_t n, const void* a, cons
   F::to_words(wo, res);
   store8(out, i, wo);
 }
+#endif  // JJ_KERNELS_BATCH
 
 // PrimeFieldBits::to_le_bits (reference src/fr.rs:746-785): the canonical integer, one byte (0/1) per bit, little-endian
+#ifdef JJ_KERNELS_BATCH
 template <class P>
 __global__ void __launch_bounds__(256) k_field_to_bits(size_t n, const void* a, void* out256) {
   typedef Field<P> F;
@@ -194,6 +203,7 @@ __global__ void __launch_bounds__(256) k_field_to_bits(size_t n, const void* a, 
     o[v] = make_uint4(q[0], q[1], q[2], q[3]);
   }
 }
+#endif  // JJ_KERNELS_BATCH
 
 // ------------------------------------------------------------------------------------------------ K2: point ops
 enum PointOp { PT_DOUBLE = 0, PT_ADD, PT_SUB, PT_NEG, PT_COFACTOR, PT_TO_NIELS,
@@ -201,6 +211,7 @@ enum PointOp { PT_DOUBLE = 0, PT_ADD, PT_SUB, PT_NEG, PT_COFACTOR, PT_TO_NIELS,
 
 // Elementwise point ops.  Results leave as extended (U,V,Z) in the SoA buffer `ext` and are normalised by
 // k_normalize (one shared inversion per chunk), except the byte-valued predicates / to_niels.
+#ifdef JJ_KERNELS_BATCH
 template <int OP>
 __global__ void __launch_bounds__(256) k_point_op(size_t n, const void* p, const void* q, SoA ext, void* out) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -224,9 +235,11 @@ __global__ void __launch_bounds__(256) k_point_op(size_t n, const void* p, const
   if constexpr (OP == PT_IS_SMALL_ORDER) static_cast<uint8_t*>(out)[i] = Curve::is_small_order(e);
   if constexpr (OP == PT_IS_ON_CURVE) static_cast<uint8_t*>(out)[i] = Curve::is_on_curve(a);
 }
+#endif  // JJ_KERNELS_BATCH
 
 // decode follow-up for jj_decompress flags 4 (reject small order: U([4]P) == 0, reference src/lib.rs:699-705) and 8 (clear
 // the cofactor, src/lib.rs:722-724) in one pass over the decoded points: the two tests share the first two doublings.
+#ifdef JJ_KERNELS_BATCH
 __global__ void __launch_bounds__(256) k_small_order_cofactor(size_t n, const void* pts, unsigned flags, SoA ext, uint8_t* ok) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -234,12 +247,14 @@ __global__ void __launch_bounds__(256) k_small_order_cofactor(size_t n, const vo
   if ((flags & 4u) && Fq::is_zero(e.u)) ok[i] = 0;
   if (flags & 8u) { e = Curve::dbl(e); ext.put(0, i, e.u); ext.put(1, i, e.v); ext.put(2, i, e.z); }
 }
+#endif  // JJ_KERNELS_BATCH
 
 // ------------------------------------------------------------------------------------------------ K5: normalise
 // batch_normalize (reference src/lib.rs:1084-1107, ff::BatchInverter): each lane owns CHUNK elements
 // (element j of lane t is index t + j*T, so every access is coalesced), multiplies their Z's through, inverts
 // once, and walks back.  Zero Z's are skipped like ff's BatchInverter (cannot occur for valid points).
 // mode 0: write affine 64 B; any other mode: write compressed 32 B (AffinePoint::to_bytes, src/lib.rs:455-464).
+#ifdef JJ_KERNELS_BATCH
 template <int CHUNK>
 __global__ void __launch_bounds__(256) k_normalize(size_t n, size_t T, SoA ext, SoA scratch, void* out, int mode) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -278,8 +293,10 @@ __global__ void __launch_bounds__(256) k_normalize(size_t n, size_t T, SoA ext, 
     }
   }
 }
+#endif  // JJ_KERNELS_BATCH
 
 // extended SoA -> is_identity byte (reference src/lib.rs:691-696), optionally AND/ANDN into an existing ok byte
+#ifdef JJ_KERNELS_BATCH
 __global__ void __launch_bounds__(256) k_is_identity_ext(size_t n, SoA ext, uint8_t* out, int combine /*0 set,1 and,2 and-not*/) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -288,22 +305,27 @@ __global__ void __launch_bounds__(256) k_is_identity_ext(size_t n, SoA ext, uint
   else if (combine == 1) out[i] = out[i] & (id ? 1 : 0);
   else out[i] = out[i] & (id ? 0 : 1);
 }
+#endif  // JJ_KERNELS_BATCH
 
 // subgroup test by Tate pairing (Curve::is_torsion_free); combine: 0 set, 1 and
+#ifdef JJ_KERNELS_BATCH
 __global__ void __launch_bounds__(256) k_torsion_free(size_t n, const void* pts, uint8_t* out, int combine) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const bool tf = Curve::is_torsion_free(load_affine(pts, i));
   out[i] = combine ? (out[i] & (tf ? 1 : 0)) : (tf ? 1 : 0);
 }
+#endif  // JJ_KERNELS_BATCH
 
 // user-facing batch_normalize input: 160-byte canonical (U,V,Z,T1,T2) -> SoA
+#ifdef JJ_KERNELS_BATCH
 __global__ void __launch_bounds__(256) k_ext160_to_soa(size_t n, const void* ext160, SoA ext) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   u32 w[8];
   _Pragma("unroll") for (int c = 0; c < 3; c++) { load8(w, ext160, 5 * i + c); ext.put(c, i, Fq::from_words(w)); }
 }
+#endif  // JJ_KERNELS_BATCH
 
 // ------------------------------------------------------------------------------------------------ K3: variable-base
 // Signed fixed-window ladder (w = 5 by default), one scalar-mul per lane.  k (low 252 bits) is recoded as
@@ -423,6 +445,7 @@ static JJ_DEV bool next_wave_units(unsigned long long* cursor, size_t n, size_t&
 // SHARED: `scalars` is ONE 32-byte scalar for the whole batch (group::Wnaf's `scalar(..)` then many `base(..)`, reference
 // src/lib.rs:1318-1336): it is read through a wave-uniform address, so the recoding and every window digit live in scalar
 // registers and cost no vector instruction, and no broadcast buffer is written.
+#ifdef JJ_KERNELS_BATCH
 template <bool FIVE, bool SHARED>
 __global__ void __launch_bounds__(256, JJ_VB_MINWAVES) k_varbase(size_t n, const void* scalars, const void* points, u32* tables, SoA ext, unsigned long long* cursor) {
   const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -443,7 +466,9 @@ __global__ void __launch_bounds__(256, JJ_VB_MINWAVES) k_varbase(size_t n, const
     }
   }
 }
+#endif  // JJ_KERNELS_BATCH
 // the reference's exact ladder; writes all five projective coordinates canonically (160 B)
+#ifdef JJ_KERNELS_BATCH
 __global__ void __launch_bounds__(256) k_varbase_exact(size_t n, const void* scalars, const void* points, void* out160) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -468,6 +493,7 @@ __global__ void __launch_bounds__(256) k_varbase_exact(size_t n, const void* sca
   Fq::to_words(w, acc.t1); store8(out160, 5 * i + 3, w);
   Fq::to_words(w, acc.t2); store8(out160, 5 * i + 4, w);
 }
+#endif  // JJ_KERNELS_BATCH
 
 // Constant-time variable-base ladder (jj_varbase_mul_ct): for SECRET scalars on variable bases.  The default ladder above reads
 // its per-lane table at a digit-dependent address; the reference ladder (src/lib.rs:357-379 with conditional_select, 334-343) has
@@ -508,6 +534,7 @@ static JJ_DEV Ext varbase_ct(const Affine& P, u32 (&k)[8]) {
   }
   return acc;
 }
+#ifdef JJ_KERNELS_BATCH
 __global__ void __launch_bounds__(256) k_varbase_ct(size_t n, const void* scalars, const void* points, SoA ext) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -517,6 +544,7 @@ __global__ void __launch_bounds__(256) k_varbase_ct(size_t n, const void* scalar
   const Ext r = varbase_ct(P, k);
   ext.put(0, i, r.u); ext.put(1, i, r.v); ext.put(2, i, r.z);
 }
+#endif  // JJ_KERNELS_BATCH
 
 // ------------------------------------------------------------------------------------------------ K4: fixed-base
 // Signed 6-bit windows: k = sum_{i<42} d_i 64^i + d_42 64^42, d_i in [-32,31], d_42 in {0,1} (k' = k + 0x820820..).
@@ -561,6 +589,7 @@ static JJ_DEV Ext soa_ext(const SoA& s, size_t i);
 #define JJ_FB_SINGLE_BUFFER 0
 #endif
 constexpr int FB_THREADS = JJ_FB_THREADS;
+#ifdef JJ_KERNELS_BATCH
 template <bool CT>
 __global__ void __launch_bounds__(FB_THREADS) k_fixedbase(size_t n, const void* scalars, const u32* table, SoA ext, int chain) {
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
@@ -649,6 +678,7 @@ __global__ void __launch_bounds__(FB_THREADS) k_fixedbase(size_t n, const void* 
     }
   }
 }
+#endif  // JJ_KERNELS_BATCH
 // ---- Signed comb (jj_fixedbase_table_create window_bits = 7; the default): 8 teeth 32 bits apart, 8 column blocks.
 // k (252 bits) is made odd, kk = k | 1, and written with digits +-1 only: kk = sum_{p<256} s_p 2^p, s_255 = +1, s_p = +1 iff bit
 // p + 1 of kk is set (p < 255).  Column j (0..31) collects the eight signs s_{j + 32 i}, i.e. bit j of the eight 32-bit words of
@@ -678,6 +708,7 @@ constexpr int FBC_LDS_BYTES = FBC_ENTRIES * ANIELS_WORDS * 4;
 #define JJ_FBC_SINGLE_BUFFER 1
 #endif
 constexpr int FBC_THREADS = JJ_FBC_THREADS;                  // one workgroup per CU (the table fills the LDS): waves per SIMD = FBC_THREADS / 256
+#ifdef JJ_KERNELS_BATCH
 template <bool CT>
 __global__ void __launch_bounds__(FBC_THREADS) k_fixedbase_comb(size_t n, const void* scalars, const u32* table, SoA ext, int chain) {
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
@@ -794,6 +825,7 @@ __global__ void __launch_bounds__(FBC_THREADS) k_fixedbase_comb(size_t n, const 
     }
   }
 }
+#endif  // JJ_KERNELS_BATCH
 // ---- Several fixed bases with SHORT scalars in ONE pass over ONE LDS table set (Pedersen-style sums
 // sum_b k_b B_b built from AffineNielsPoint::multiply_bits, reference src/lib.rs:297-301).  The windows of k_fixedbase need not
 // belong to one base: a composite table gives window slots [off_b, off_b + W_b) to base b (entries j 64^(i - off_b) B_b), and
@@ -802,6 +834,7 @@ __global__ void __launch_bounds__(FBC_THREADS) k_fixedbase_comb(size_t n, const 
 // per lane, 43 additions, constant-time shuffle select -- computes sum_b (k_b mod 2^bits_b) B_b unchanged.
 constexpr int FBX_MAX_BASES = 21;      // 42 window slots, at least two per base
 struct FbxParams { int nb; int off[FBX_MAX_BASES]; int bits[FBX_MAX_BASES]; };
+#ifdef JJ_KERNELS_BATCH
 __global__ void __launch_bounds__(256) k_pack_composite(size_t n, const void* scalars, FbxParams fx, void* virt32) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -826,6 +859,7 @@ __global__ void __launch_bounds__(256) k_pack_composite(size_t n, const void* sc
   }
   store8(virt32, i, v);
 }
+#endif  // JJ_KERNELS_BATCH
 
 // Wide-window variant: table of (j+1) * 2^(w i) * B for w = 8..12 (0.5 - 5 MB) kept in global memory, L2-resident;
 // each lane gathers its entry (7 x dwordx4 of one 128-byte line) one window ahead of its use.  Fewer additions than the LDS
@@ -842,6 +876,7 @@ static JJ_DEV u32 fb_window(const u32 (&k)[8], int w, int i) {
   const u64 both = ((u64)hi << 32) | lo;
   return (u32)(both >> sh) & ((1u << w) - 1u);
 }
+#ifdef JJ_KERNELS_BATCH
 __global__ void __launch_bounds__(256) k_fixedbase_gather(size_t n, const void* scalars, const u32* table, FbParams fp, SoA ext, int chain) {
   const size_t T = (size_t)gridDim.x * blockDim.x;
   #pragma unroll 1
@@ -873,7 +908,9 @@ __global__ void __launch_bounds__(256) k_fixedbase_gather(size_t n, const void* 
     if (chain & 2) { ext.put(3, idx, Fq::carry(acc.t1)); ext.put(4, idx, Fq::carry(acc.t2)); }
   }
 }
+#endif  // JJ_KERNELS_BATCH
 // affine points (64 B canonical) -> table entries (AffineNiels limbs, 112 B)
+#ifdef JJ_KERNELS_BATCH
 __global__ void __launch_bounds__(256) k_affine_to_table(size_t n, const void* pts, u32* table, int stride) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -884,9 +921,11 @@ __global__ void __launch_bounds__(256) k_affine_to_table(size_t n, const void* p
   _Pragma("unroll") for (int l = 0; l < NL; l++) { e[l] = a.l[l]; e[NL + l] = b.l[l]; e[2 * NL + l] = c.l[l]; }
   for (int l = 27; l < stride; l++) e[l] = 0;
 }
+#endif  // JJ_KERNELS_BATCH
 
 // ------------------------------------------------------------------------------------------------ sums (MSM tail, point_sum)
 // Each lane folds FOLD strided extended points (Ext + Ext = to_niels + add, reference src/lib.rs:992-999).
+#ifdef JJ_KERNELS_BATCH
 template <int FOLD>
 __global__ void __launch_bounds__(256) k_sum_pass(size_t n, size_t T, SoA in, SoA out) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -907,6 +946,7 @@ __global__ void __launch_bounds__(256) k_affine_to_soa5(size_t n, const void* pt
   const Affine a = load_affine(pts, i);
   ext.put(0, i, a.u); ext.put(1, i, a.v); ext.put(2, i, Fq::one()); ext.put(3, i, a.u); ext.put(4, i, a.v);
 }
+#endif  // JJ_KERNELS_BATCH
 // ------------------------------------------------------------------------------------------------ K6: decompress
 // AffinePoint::from_bytes_inner / batch_from_bytes (reference src/lib.rs:492-534, 541-627): u^2 = (v^2-1)/(1+d v^2).
 // Like batch_from_bytes the denominators share one inversion: each lane owns CHUNK strided encodings, multiplies
@@ -921,6 +961,7 @@ static JJ_DEV void decode_v(const void* in32, size_t i, Fe& v, Fe& v2, Fe& den, 
   v2 = Fq::sqr(v);
   den = Fq::carry(Fq::add(Fq::one(), Fq::mul(Fq::konst(FqP::D), v2)));
 }
+#ifdef JJ_KERNELS_BATCH
 template <int CHUNK>
 __global__ void __launch_bounds__(256) k_decompress(size_t n, size_t T, const void* in32, unsigned flags, SoA scratch, SqrtTables tabs,
                                                      void* out64, uint8_t* okp) {
@@ -963,7 +1004,9 @@ __global__ void __launch_bounds__(256) k_decompress(size_t n, size_t T, const vo
     okp[i] = ok ? 1 : 0;
   }
 }
+#endif  // JJ_KERNELS_BATCH
 // AffinePoint::to_bytes (reference src/lib.rs:455-464) for affine input
+#ifdef JJ_KERNELS_BATCH
 __global__ void __launch_bounds__(256) k_compress(size_t n, const void* pts, void* out32) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -973,7 +1016,9 @@ __global__ void __launch_bounds__(256) k_compress(size_t n, const void* pts, voi
   wv[7] |= (wu[0] & 1u) << 31;
   store8(out32, i, wv);
 }
+#endif  // JJ_KERNELS_BATCH
 // zero the 64-byte outputs whose ok byte is 0
+#ifdef JJ_KERNELS_BATCH
 __global__ void __launch_bounds__(256) k_mask_outputs(size_t n, void* out64, const uint8_t* ok) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -991,6 +1036,7 @@ __global__ void __launch_bounds__(256) k_and_bytes(size_t n, uint8_t* a, const u
   if (i >= n) return;
   a[i] = a[i] & (negate_b ? (b[i] ^ 1) : b[i]);
 }
+#endif  // JJ_KERNELS_BATCH
 
 // ------------------------------------------------------------------------------------------------ point records + quad-lane point operations
 // (shared by the small-batch ladder and the MSM kernels in jj_msm_kernels.h)
@@ -1177,6 +1223,7 @@ static JJ_DEV Ext varbase_windowed_quad(const Affine& P, u32 (&k)[8], u32* slot,
   }
   return acc;
 }
+#ifdef JJ_KERNELS_BATCH
 template <bool FIVE>
 __global__ void __launch_bounds__(256) k_varbase_quad(size_t n, const void* scalars, const void* points, u32* tables, SoA ext) {
   const size_t q = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
@@ -1191,9 +1238,12 @@ __global__ void __launch_bounds__(256) k_varbase_quad(size_t n, const void* scal
     if constexpr (FIVE) { ext.put(3, q, Fq::carry(r.t1)); ext.put(4, q, Fq::carry(r.t2)); }
   }
 }
+#endif  // JJ_KERNELS_BATCH
 
 
+#ifdef JJ_KERNELS_MSM
 #include "jj_msm_kernels.h"
+#endif
 
 // ------------------------------------------------------------------------------------------------ synthetic inputs
 // Counter-based generator of SURVEY 8(d): word j of unit i is splitmix64(seed + i * stride + j), so any index can be
@@ -1207,6 +1257,7 @@ static JJ_DEV u64 splitmix64(u64 x) {
 }
 // scalar_i = four PRNG words, top 4 bits cleared, minus r if >= r (uniform-ish in [0, r)); raw != 0: the 32 PRNG bytes
 // as they are (arbitrary bit patterns: inputs >= q, sign-bit noise for the decoder)
+#ifdef JJ_KERNELS_BATCH
 __global__ void __launch_bounds__(256) k_synth_scalars(size_t n, u64 seed, u64 first, int raw, void* out32) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -1220,12 +1271,14 @@ __global__ void __launch_bounds__(256) k_synth_scalars(size_t n, u64 seed, u64 f
   }
   store8(out32, i, w);
 }
+#endif  // JJ_KERNELS_BATCH
 // Group::random (reference src/lib.rs:1244-1267; SubgroupPoint::random 1290-1298 with `subgroup`): rejection sampling
 //   loop { v = Fq::random (64 PRNG bytes, from_bytes_wide); flip = next_u32 % 2; u = sqrt((v^2-1)/(1+d v^2)) or retry;
 //          p = (flip ? -u : u, v); retry if identity; [subgroup: p = [8]p; retry if identity] }
 // The reference draws from one sequential RNG; here every unit owns the counter range [(first+i) << 16, ...) and attempt t
 // reads words 16 t .. 16 t + 8 of it (8 for v, 1 for the flip), so the result is a pure function of (seed, index).
 constexpr int RANDOM_POINT_STRIDE_LOG2 = 16;
+#ifdef JJ_KERNELS_BATCH
 __global__ void __launch_bounds__(256) k_random_points(size_t n, u64 seed, u64 first, int subgroup, SqrtTables tabs, void* out64, u32* attempts) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -1264,9 +1317,11 @@ __global__ void __launch_bounds__(256) k_random_points(size_t n, u64 seed, u64 f
   }
   if (attempts) attempts[i] = t;
 }
+#endif  // JJ_KERNELS_BATCH
 
 // ------------------------------------------------------------------------------------------------ roofline probe
 // 8 independent v_mad_u64_u32 chains per lane, 64 mads per loop iteration: the measured peak IMAD32 rate.
+#ifdef JJ_KERNELS_PROBE
 __global__ void __launch_bounds__(256) k_peak_mad(u32* out, int iters, u32 seed) {
   u64 acc[8];
   const u32 a = seed * 2654435761u + threadIdx.x, b = (seed ^ (blockIdx.x * 40503u)) | 1u;
@@ -1280,5 +1335,6 @@ __global__ void __launch_bounds__(256) k_peak_mad(u32* out, int iters, u32 seed)
   _Pragma("unroll") for (int k = 0; k < 8; k++) s ^= acc[k];
   out[blockIdx.x * blockDim.x + threadIdx.x] = (u32)s ^ (u32)(s >> 32);
 }
+#endif  // JJ_KERNELS_PROBE
 
 }  // namespace jj

@@ -1,5 +1,5 @@
 // Multi-scalar multiplication kernels (gfx950).  Included by jj_kernels.h after the point records and the quad-lane point
-// operations; launched by msm_* in jj_engine.hip.
+// operations; launched by msm_* in jj_msm.hip.
 //
 // sum_i k_i P_i  (reference semantics: the iterator `Sum` of `p * k`, src/lib.rs:183-193 + 873-879; the reference has no MSM
 // algorithm of its own).  Only +-P is used, so the result is exact on the whole curve (cofactor-8 points, scalars >= r).
@@ -929,30 +929,28 @@ __global__ void __launch_bounds__(256) k_msm_reduce_l1(MsmParams mp, int mbits, 
   const int w = msm_slot_window(mp, (int)s);
   const u32 R = (1u << (msm_win_width(mp, w) - 1)) >> mbits;          // rows of this window (the host keeps M <= the narrowest window's buckets): uniform over a wave
   const size_t base = (size_t)s * mp.B + m;
-  // running = b_i + ... + b_{R-1} on entry to step i; T = sum_{i >= 1} running_i.  Both additions of a step read the SAME running sum
-  // (total += running_i, running_{i-1} = running_i + b_{i-1}), so a step is two independent chains of products: one wave per SIMD is all
-  // this kernel has, and a lone wave issues dependent multiply-adds at ~0.8 of the SIMD's rate (experiments/lone_wave)
+  // running sums from the top row: running_i = b_i + ... + b_{R-1}, T = sum_{i >= 1} running_i, S = running_0.  T1*T2 of each accumulator
+  // is formed once per step and serves both the addition into it and its hand-over as an operand: 19 products per row.
+  // (Written as two independent chains per step -- total += running_i beside running_{i-1} = running_i + b_{i-1} -- it needs 272
+  // registers and runs no faster: 70.0 against 70.5 us.)
   Ext running = aos_ext(buckets, base + (size_t)(R - 1) * M);
   Fe Tr = Curve::tt<true>(running);                                    // stored t1, t2 are carried
-  Ext total = Curve::identity();
-  Fe Tt = Fq::zero();
-  if (R > 1) {
-    total = running; Tt = Tr;                                          // step R - 1: total = running_{R-1}
+  Ext total = running;
+  Fe Tt = Tr;
+  if (R == 1) { total = Curve::identity(); Tt = Fq::zero(); }
+  else {
     Ext nxt = aos_ext(buckets, base + (size_t)(R - 2) * M);
-    running = Curve::add_t(running, Tr, Curve::to_niels<true>(nxt));   // running_{R-2}
-    Tr = Curve::tt<true>(running);
-    if (R > 2) nxt = aos_ext(buckets, base + (size_t)(R - 3) * M);
     #pragma unroll 1
-    for (int i = (int)R - 2; i >= 1; i--) {                            // on entry: running = running_i, nxt = b_{i-1}
+    for (int i = (int)R - 2; i >= 1; i--) {
       const Ext cur = nxt;
-      if (i > 1) nxt = aos_ext(buckets, base + (size_t)(i - 2) * M);  // the next bucket is in flight while this one is added
-      const ENiels rn = Curve::to_niels_t(running, Tr);
-      const Ext run2 = Curve::add_t(running, Tr, Curve::to_niels<true>(cur));
-      total = Curve::add_t(total, Tt, rn);
-      const Fe Tr2 = Curve::tt<true>(run2);
+      nxt = aos_ext(buckets, base + (size_t)(i - 1) * M);            // the next bucket is in flight while this one is added
+      running = Curve::add_t(running, Tr, Curve::to_niels<true>(cur));
+      Tr = Curve::tt<true>(running);
+      total = Curve::add_t(total, Tt, Curve::to_niels_t(running, Tr));
       Tt = Curve::tt<true>(total);
-      running = run2; Tr = Tr2;
     }
+    running = Curve::add_t(running, Tr, Curve::to_niels<true>(nxt));   // + b_0: S complete
+    Tr = Curve::tt<true>(running);
   }
   store_eniels(SN + t * ENIELS_WORDS, Curve::to_niels_t(running, Tr));
   store_eniels(TN + t * ENIELS_WORDS, Curve::to_niels_t(total, Tt));
@@ -964,13 +962,15 @@ static JJ_DEV Ext msm_reduce2_chunk(u32 s, u32 k, u32 L, int lb, int mbits, cons
   Ext running = Curve::identity(), total = Curve::identity(), plain = Curve::identity();
   Fe Tr = Fq::zero(), Tt = Fq::zero(), Tp = Fq::zero(), dummy;
   ENiels sn = load_eniels(SN + first + (size_t)(L - 1) * ENIELS_WORDS), tn = load_eniels(TN + first + (size_t)(L - 1) * ENIELS_WORDS);
+  // each record is fetched again right after its last use, five (S) or seven (T) multiplication rounds before the next one: no second
+  // register set for the prefetch
   #pragma unroll 1
   for (int j = (int)L - 1; j >= 0; j--) {
-    const ENiels cs = sn, ct = tn;
-    if (j > 0) { sn = load_eniels(SN + first + (size_t)(j - 1) * ENIELS_WORDS); tn = load_eniels(TN + first + (size_t)(j - 1) * ENIELS_WORDS); }
-    running = quad_add_eniels(running, Tr, cs, 0u, role, Tr);
+    running = quad_add_eniels(running, Tr, sn, 0u, role, Tr);
+    if (j > 0) sn = load_eniels(SN + first + (size_t)(j - 1) * ENIELS_WORDS);
     total = quad_add_ext_t(total, Tt, running, Tr, role, Tt, Tr, Tr, dummy);
-    plain = quad_add_eniels(plain, Tp, ct, 0u, role, Tp);
+    plain = quad_add_eniels(plain, Tp, tn, 0u, role, Tp);
+    if (j > 0) tn = load_eniels(TN + first + (size_t)(j - 1) * ENIELS_WORDS);
   }
   // m = 2^mbits plain + j0 running: double-and-add over the bits [lb, mbits) of j0 (a multiple of L = 2^lb) starting from `plain`
   ENiels rn;

@@ -118,7 +118,7 @@ def test_host_buffer_api_without_a_gpu():
 
 
 def test_host_batch_chunk_schedule_properties():
-    """jj_plan_host_chunks is the function run_pipelined cuts a host batch with (jj_engine.hip pipe_chunk_bounds): the chunks tile [0, n)
+    """jj_plan_host_chunks is the function run_pipelined cuts a host batch with (jj_pipeline.hip pipe_chunk_bounds): the chunks tile [0, n)
     in order, none is empty or longer than chunk + the edge, the ramp's short first and last chunk appear exactly when the batch has four
     chunks of at least 2^18 units, and with a quantum the edges are whole rounds of the kernel's lanes."""
     import random

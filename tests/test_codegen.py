@@ -10,20 +10,18 @@ assembly of the shipped source (no GPU needed):
 import collections
 import os
 import re
-import subprocess
+import sys
 
 import pytest
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-SRC = os.path.join(ROOT, "jubjub_amd", "csrc", "jj_engine.hip")
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from gfx_asm import assembly  # noqa: E402
 
 
 @pytest.fixture(scope="module")
-def asm(tmp_path_factory):
-    td = str(tmp_path_factory.mktemp("codegen"))
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-save-temps", "-c", "-x", "hip", SRC,
-                           "-I", os.path.dirname(SRC), "-o", os.path.join(td, "e.o")], cwd=td, stderr=subprocess.DEVNULL)
-    return open(os.path.join(td, "jj_engine-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
+def asm():
+    return assembly()              # every translation unit of the library, compiled side by side
 
 
 def kernel_body(asm, needle):

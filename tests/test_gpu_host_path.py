@@ -1,7 +1,7 @@
 """
 The path a drop-in caller takes: HOST arrays handed to the C ABI (include/jubjub_hip.h "host buffers"): page-locked buffers from
 jj_host_alloc, buffers registered once with jj_host_register, and plain pageable memory, each through the chunked copy / compute
-pipeline (run_pipelined, jj_engine.hip) -- bit-exact against the device-resident path and the oracle.
+pipeline (run_pipelined, jj_engine.h) -- bit-exact against the device-resident path and the oracle.
 Also the C-level multi-rank MSM exchange (jj_ctx_set_comm + jj_msm_allgather, examples/msm_rccl.cpp) with one rank over RCCL.
 Boundary semantics: /root/reference/src/lib.rs:873-879 (ExtendedPoint * Fr), 1109-1115 (AffineNielsPoint * Fr), 469-627 (from_bytes).
 """

@@ -6,20 +6,15 @@ Usage: python tools/instr_mix.py [kernel-substring ...]      (default: k_varbase
 import collections
 import os
 import re
-import subprocess
 import sys
-import tempfile
 
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-SRC = os.path.join(ROOT, "jubjub_amd", "csrc", "jj_engine.hip")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from gfx_asm import assembly  # noqa: E402
 
 
 def main():
     want = sys.argv[1:] or ["k_varbaseILb0ELb0", "k_fixedbaseILb1", "k_field_opINS_3FqPELi2", "k_field_opINS_3FqPELi4"]
-    with tempfile.TemporaryDirectory() as td:
-        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-save-temps", "-c", "-x", "hip", SRC,
-                               "-I", os.path.dirname(SRC), "-o", os.path.join(td, "e.o")] + os.environ.get("JJ_CXXFLAGS", "").split(), cwd=td, stderr=subprocess.DEVNULL)
-        asm = open(os.path.join(td, "jj_engine-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
+    asm = assembly()
     kernels = re.split(r"\n(?=_Z\w+:\s)", asm)
     for k in kernels:
         name = k.split(":", 1)[0]

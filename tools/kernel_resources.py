@@ -1,21 +1,16 @@
 #!/usr/bin/env python3
-"""Registers and scratch per kernel, from hipcc's gfx950 assembly of jj_engine.hip (-save-temps).
+"""Registers and scratch per kernel, from hipcc's gfx950 assembly of the library's translation units (tools/gfx_asm.py).
 Usage: python tools/kernel_resources.py   (honours JJ_CXXFLAGS)"""
 import os
 import re
-import subprocess
-import tempfile
+import sys
 
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-SRC = os.path.join(ROOT, "jubjub_amd", "csrc", "jj_engine.hip")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from gfx_asm import assembly  # noqa: E402
 
 
 def main():
-    with tempfile.TemporaryDirectory() as td:
-        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-save-temps", "-c", "-x", "hip", SRC,
-                               "-I", os.path.dirname(SRC), "-o", os.path.join(td, "e.o")] + os.environ.get("JJ_CXXFLAGS", "").split(),
-                              cwd=td, stderr=subprocess.DEVNULL)
-        asm = open(os.path.join(td, "jj_engine-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
+    asm = assembly()
     print("%-58s %5s %5s %7s" % ("kernel", "vgpr", "sgpr", "scratch"))
     for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", asm, re.S):
         name, body = m.group(1), m.group(2)
