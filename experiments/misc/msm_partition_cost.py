@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """One rank's share of a 2^log2n-term MSM cut G ways, on ONE GPU: by terms (all windows of n / G terms) and by
 windows (windows g, g + G, ... of all n terms), device work only (jj_msm_partial, record left on the device) and with the host tail
-of one record; plus the host tail over G records (what every rank runs after the all_gather).
+of one record; plus what every rank runs after the all_gather: the G records folded on the device + one 8 KB copy + the host tail of
+one record (jj_msm_combine_dev, round 5) against round 4's copy of all G records + the host's additions (JJ_MSM_FOLD=host); and the
+HYBRID partitions (terms / a  x  windows / b with a b = G: rank (i, j) reduces windows j, j + b, ... of term slice i).
   python experiments/misc/msm_partition_cost.py [log2n] [G]"""
 import os
 import sys
@@ -43,11 +45,26 @@ for g in (0, G - 1):
     print("  term partition, rank %d: all windows of %d terms      : %.3f / %.3f  (record left on the device)" % ((g, m) + timed(lambda: eng.msm_partial(S[g * m:(g + 1) * m], P[g * m:(g + 1) * m]))))
 for g in (0, G - 1):
     print("  window partition, rank %d: windows %d, %d.. of all terms : %.3f / %.3f  (record left on the device)" % ((g, g, g + G) + timed(lambda: eng.msm_partial(S, P, g, G))))
+# hybrid partitions: a term slices x b window classes
+for a in (2, 4):
+    b = G // a
+    if a * b != G or b < 2:
+        continue
+    ma = n // a
+    for (i, j) in ((0, 0), (a - 1, b - 1)):
+        print("  hybrid %d term slices x %d window classes, rank (%d, %d): windows %d, %d.. of %d terms : %.3f / %.3f" % ((a, b, i, j, j, j + b, ma) + timed(lambda: eng.msm_partial(S[i * ma:(i + 1) * ma], P[i * ma:(i + 1) * ma], j, b))))
+    recs_h = torch.stack([eng.msm_partial(S[i * ma:(i + 1) * ma], P[i * ma:(i + 1) * ma], j, b) for i in range(a) for j in range(b)])
+    assert (eng.msm_combine(recs_h) == eng.msm(S, P).cpu().numpy()).all()
+    print("    its %d gathered records folded on the device + one host tail : %.3f / %.3f" % ((G,) + timed(lambda: eng.msm_combine(recs_h))))
 recs_t = torch.stack([eng.msm_partial(S[g * m:(g + 1) * m], P[g * m:(g + 1) * m]) for g in range(G)])
 recs_w = torch.stack([eng.msm_partial(S, P, g, G) for g in range(G)])
 want = eng.msm(S, P).cpu().numpy()
 assert (eng.msm_combine(recs_t) == want).all() and (eng.msm_combine(recs_w) == want).all()
-print("  copy of %d gathered records to the host + ONE host tail : terms %.3f / %.3f   windows %.3f / %.3f" % ((G,) + timed(lambda: eng.msm_combine(recs_t)) + timed(lambda: eng.msm_combine(recs_w))))
+print("  %d gathered records folded on the device + 8 KB copy + host tail of ONE record : terms %.3f / %.3f   windows %.3f / %.3f" % ((G,) + timed(lambda: eng.msm_combine(recs_t)) + timed(lambda: eng.msm_combine(recs_w))))
+os.environ["JJ_MSM_FOLD"] = "host"
+eng_h = Engine(0)
+assert (eng_h.msm_combine(recs_t) == want).all()
+print("  round 4: copy of all %d records to the host + the host adds them (JJ_MSM_FOLD=host)     : terms %.3f / %.3f   windows %.3f / %.3f" % ((G,) + timed(lambda: eng_h.msm_combine(recs_t)) + timed(lambda: eng_h.msm_combine(recs_w))))
 ht, hw = recs_t.cpu().numpy(), recs_w.cpu().numpy()
 print("  host tail alone (records already on the host)          : terms %.3f / %.3f   windows %.3f / %.3f" % (timed(lambda: eng.msm_combine(ht)) + timed(lambda: eng.msm_combine(hw))))
 print("  both partitions give the point of the one-GPU MSM: ok")

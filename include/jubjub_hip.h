@@ -261,6 +261,12 @@ int jj_msm_dev(jj_ctx*, size_t n, const void* scalars32, const void* points64, v
 #define JJ_MSM_PARTIAL_BYTES 8256u   /* 64 + 64 windows x 128 */
 int jj_msm_partial(jj_ctx*, size_t n, const void* scalars32, const void* points64, int part_index, int part_count, void* record);
 int jj_msm_combine(size_t count, const void* records_host, void* out64_host);
+/* The same sum (Sum for ExtendedPoint, src/lib.rs:183-193, over the parts) for records that are in DEVICE memory -- what an all_gather
+ * delivered, JJ_MSM_PARTIAL_BYTES apart, 16-byte aligned: the records are added window by window on the device into ONE record
+ * (a quad of lanes per record and window, an LDS tree over the records), which takes one 8 KB copy and the single-record host tail
+ * whatever `count` is.  Records of different window layouts fall back to one copy of all of them and the host's additions.
+ * out64 may be a host or a device pointer. */
+int jj_msm_combine_dev(jj_ctx*, size_t count, const void* records_dev, void* out64);
 
 /* The same exchange behind ONE call, for callers that run one process per GPU (the context holds "streams, tables,
  * RCCL comm"; 8(e)).  jj_ctx_set_comm lends the context an RCCL communicator that the CALLER created (ncclCommInitRank; the
@@ -271,7 +277,7 @@ int jj_msm_combine(size_t count, const void* records_host, void* out64_host);
  * destroys it.
  * jj_msm_allgather: every rank calls it with ITS terms (partition 0) or with ALL terms (partition 1: rank g reduces windows g, g + G,
  * ... of the whole batch; same n on every rank): record of window sums (jj_msm_partial) -> ncclAllGather of JJ_MSM_PARTIAL_BYTES per
- * rank on the context's stream -> one copy of the G records to the host -> one host tail (jj_msm_combine).  Every rank returns the
+ * rank on the context's stream -> the G records folded into one on the device (jj_msm_combine_dev) -> one 8 KB copy -> one host tail.  Every rank returns the
  * same point; out64 may be a host or a device pointer.  A collective: all ranks must call it, in the same order -- a rank whose call
  * fails BEFORE the gather (bad arguments, out of memory) never enters it and the other ranks wait for it: treat an error of
  * jj_msm_allgather as fatal for the communicator (as with any RCCL collective). */

@@ -105,6 +105,9 @@ static int msm_enqueue_pippenger(jj_ctx* c, MsmLane& ln, size_t n, const void* d
   if (c->msm_seg_len >= 8 && c->msm_seg_len <= SEG_PMAX) P = (u32)c->msm_seg_len;
   const u32 stiles = (u32)std::max<size_t>(1, std::min<size_t>(4096, (nb + 255) / 256));          // tiles of the two segment passes: 256 buckets each, more above 2^20 buckets
   const u32 per_tile = (u32)((nb + stiles - 1) / stiles);
+  // with the two-pass sort a tile of the segment passes is exactly the 256 buckets of one k_msm_part_sort workgroup, which then writes the tile's
+  // histogram of segment lengths itself (no k_seg_hist launch)
+  const bool seg_fused = use_segments && two_pass && per_tile == (1u << MSM_LO_BITS) && (size_t)stiles * per_tile == nb && stiles == Ws * HB;
   const size_t max_segs = nb + (n * (size_t)Ws) / P + 1;
   const size_t bh_words = (size_t)stiles * (P + 1), hdr_words = bh_words + 2 * (P + 2) + 16;
   if ((rc = ensure(c, kprime, n * 32))) return rc;
@@ -134,7 +137,8 @@ static int msm_enqueue_pippenger(jj_ctx* c, MsmLane& ln, size_t n, const void* d
     hipLaunchKernelGGL(k_msm_part_hist, dim3(ptiles, Ws), dim3(MSM_SORT_THREADS), 0, st, n, (size_t)MSM_P1_TILE, mp, (const u32*)kprime.p, tc);
     hipLaunchKernelGGL(k_msm_part_plan, dim3(Ws), dim3(1024), 0, st, n, (u32)pm, (const u32*)tc, tcs, counters);
     hipLaunchKernelGGL(k_msm_part_scatter, dim3(ptiles, Ws), dim3(MSM_SORT_THREADS), 0, st, n, (size_t)MSM_P1_TILE, mp, (const u32*)kprime.p, (const u32*)tcs, rec, lo8);
-    hipLaunchKernelGGL(k_msm_part_sort, dim3(HB, Ws), dim3(MSM_P2_THREADS), 0, st, mp, ptiles, (const u32*)tcs, (const u32*)rec, (const uint8_t*)lo8, (u32*)idx.p, off);
+    if (seg_fused) hipLaunchKernelGGL(k_msm_part_sort<true>, dim3(HB, Ws), dim3(MSM_P2_THREADS), 0, st, mp, ptiles, (const u32*)tcs, (const u32*)rec, (const uint8_t*)lo8, (u32*)idx.p, off, P, ExtAoS{(u32*)buckets.p}, (u32*)ln.seg.p);
+    else hipLaunchKernelGGL(k_msm_part_sort<false>, dim3(HB, Ws), dim3(MSM_P2_THREADS), 0, st, mp, ptiles, (const u32*)tcs, (const u32*)rec, (const uint8_t*)lo8, (u32*)idx.p, off, P, ExtAoS{nullptr}, (u32*)nullptr);
   } else {
     hipLaunchKernelGGL(k_msm_hist, dim3(ntiles, Ws), dim3(MSM_SORT_THREADS), B * 4, st, n, tile, mp, (const u32*)kprime.p, (u32*)tcnt.p);
     hipLaunchKernelGGL(k_msm_plan, dim3(Ws), dim3(1024), 0, st, n, B, ntiles, (u32*)tcnt.p, off, counters);
@@ -147,7 +151,7 @@ static int msm_enqueue_pippenger(jj_ctx* c, MsmLane& ln, size_t n, const void* d
     u32* bh = (u32*)ln.seg.p; u32* soff = bh + bh_words + (P + 1);
     MergeItem* merge = (MergeItem*)(((uintptr_t)(bh + hdr_words) + 15) & ~(uintptr_t)15);
     Seg* seg = (Seg*)(merge + nb);
-    hipLaunchKernelGGL(k_seg_hist, dim3(stiles), dim3(256), 0, st, nb, B, per_tile, P, (const u32*)off, bk, bh);
+    if (!seg_fused) hipLaunchKernelGGL(k_seg_hist, dim3(stiles), dim3(256), 0, st, nb, B, per_tile, P, (const u32*)off, bk, bh);
     hipLaunchKernelGGL(k_seg_plan, dim3(P + 1), dim3(256), 0, st, stiles, bh, soff);
     hipLaunchKernelGGL(k_seg_scatter, dim3(stiles), dim3(256), 0, st, nb, B, per_tile, P, (const u32*)off, (const u32*)bh, (const u32*)soff, soff + (P + 1), seg, counters, merge, big);
     hipLaunchKernelGGL(k_msm_accumulate_seg, dim3(blocks_for(max_segs)), dim3(256), 0, st, (const u32*)(soff + (P + 1)), (const Seg*)seg, (const u32*)idx.p, (const u32*)niels.p, bk, head);
@@ -401,39 +405,66 @@ JJ_API int jj_ctx_set_comm(jj_ctx* c, void* nccl_comm, int rank, int nranks, voi
 // One MSM over the terms (partition 0: each rank passes ITS terms) or the windows (partition 1: each rank passes ALL terms) of every
 // rank of the communicator: record of window sums on this device -> ncclAllGather of JJ_MSM_PARTIAL_BYTES per rank over xGMI -> ONE
 // copy of the gathered records to the host -> ONE host tail (jj_msm_combine) on every rank.  Every rank gets the same point.
-JJ_API int jj_msm_allgather(jj_ctx* c, size_t n, const void* scalars, const void* points, int partition, void* out64) {
-  if (!c || !out64 || (partition != 0 && partition != 1)) return JJ_ERR_INVALID;
-  {
-    JJ_ENTER(c);
-    if (!c->comm || !c->all_gather) { c->err = "jj_msm_allgather: no communicator (jj_ctx_set_comm)"; return JJ_ERR_INVALID; }
+// `count` records in DEVICE memory (JJ_MSM_PARTIAL_BYTES apart: what an all_gather delivered) -> the sum of the MSMs they stand for.
+// The records are folded window by window ON THE DEVICE into one (k_msm_fold_records), that one is copied to the host (8 KB, whatever
+// count is) and takes the single-record host tail.  Records of different window layouts, or JJ_MSM_FOLD=host: all records are copied and
+// the host adds them (round 4's path).  The context's lock is held by the caller.
+static int msm_combine_dev_locked(jj_ctx* c, size_t count, const uint8_t* recs_dev, jjhost::Ext* total) {
+  *total = jjhost::identity();
+  if (count == 0) return JJ_OK;
+  const size_t host_need = std::max<size_t>(count, 1) * JJ_MSM_PARTIAL_BYTES;
+  if (c->gather_host_cap < host_need) {
+    if (c->gather_host) (void)hipHostFree(c->gather_host);
+    c->gather_host = nullptr; c->gather_host_cap = 0;
+    // (coherent: the fold kernel writes its record straight into this buffer, as the MSM kernels write theirs into a job's)
+    if (hipHostMalloc((void**)&c->gather_host, host_need, hipHostMallocCoherent | hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); c->err = "hipHostMalloc failed"; return JJ_ERR_NOMEM; }
+    c->gather_host_cap = host_need;
   }
-  const int G = c->comm_nranks;
-  int rc;
-  {
-    JJ_ENTER(c);
-    if ((rc = ensure(c, c->gather_dev, (size_t)(G + 1) * JJ_MSM_PARTIAL_BYTES))) return rc;
-    if (c->gather_host_cap < (size_t)G * JJ_MSM_PARTIAL_BYTES) {
-      if (c->gather_host) (void)hipHostFree(c->gather_host);
-      c->gather_host = nullptr; c->gather_host_cap = 0;
-      if (hipHostMalloc((void**)&c->gather_host, (size_t)G * JJ_MSM_PARTIAL_BYTES, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); c->err = "hipHostMalloc failed"; return JJ_ERR_NOMEM; }
-      c->gather_host_cap = (size_t)G * JJ_MSM_PARTIAL_BYTES;
-    }
+  bool folded = false;
+  if (c->msm_fold_dev && count >= (size_t)c->msm_fold_min) {
+    memset(c->gather_host, 0, jjhost::REC_HDR_BYTES);               // a stale header must never validate
+    hipLaunchKernelGGL(k_msm_fold_records, dim3(jjhost::REC_MAX_W), dim3(4 * MSM_TREE_QUADS), 0, c->stream, (const u32*)recs_dev, (u32)count, (u32)(JJ_MSM_PARTIAL_BYTES / 4), (u32*)c->gather_host);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    uint32_t magic; memcpy(&magic, c->gather_host, 4);
+    folded = magic == MSM_REC_MAGIC;                    // 0: the records have different window layouts (or one is damaged: the host path reports it)
   }
-  uint8_t* mine = (uint8_t*)c->gather_dev.p;                       // this rank's record, then the G gathered ones
-  uint8_t* all = mine + JJ_MSM_PARTIAL_BYTES;
-  if ((rc = jj_msm_partial(c, n, scalars, points, partition ? c->comm_rank : 0, partition ? G : 1, mine))) return rc;
-  JJ_ENTER(c);
-  const int nrc = c->all_gather(mine, all, JJ_MSM_PARTIAL_BYTES, /* ncclUint8 */ 1, c->comm, c->stream);
-  if (nrc != 0) { c->err = "ncclAllGather failed with ncclResult_t " + std::to_string(nrc); return JJ_ERR_HIP; }
-  HIPCHK(c, hipMemcpyAsync(c->gather_host, all, (size_t)G * JJ_MSM_PARTIAL_BYTES, hipMemcpyDeviceToHost, c->stream));
+  if (folded) { if (!jjhost::combine_records(c->gather_host, 1, JJ_MSM_PARTIAL_BYTES, total)) { c->err = "the folded MSM record is damaged (bad header)"; return JJ_ERR_HIP; } return JJ_OK; }
+  HIPCHK(c, hipMemcpyAsync(c->gather_host, recs_dev, count * JJ_MSM_PARTIAL_BYTES, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  jjhost::Ext total = jjhost::identity();
-  if (!jjhost::combine_records(c->gather_host, (size_t)G, JJ_MSM_PARTIAL_BYTES, &total)) { c->err = "a gathered MSM record is damaged (bad header)"; return JJ_ERR_HIP; }
+  if (!jjhost::combine_records(c->gather_host, count, JJ_MSM_PARTIAL_BYTES, total)) { c->err = "a gathered MSM record is damaged (bad header)"; return JJ_ERR_HIP; }
+  return JJ_OK;
+}
+static int msm_write_total(jj_ctx* c, const jjhost::Ext& total, void* out64) {
   if (is_device_ptr(out64)) {
     jjhost::to_affine64(c->host_out[c->host_out_next], total);
     HIPCHK(c, hipMemcpyAsync(out64, c->host_out[c->host_out_next], 64, hipMemcpyHostToDevice, c->stream));
     c->host_out_next = (c->host_out_next + 1) % 8;
   } else jjhost::to_affine64((uint8_t*)out64, total);
   return JJ_OK;
+}
+JJ_API int jj_msm_combine_dev(jj_ctx* c, size_t count, const void* records_dev, void* out64) {
+  if (!c || !out64 || (count && !records_dev)) return JJ_ERR_INVALID;
+  JJ_ENTER(c);
+  if (count && (!is_device_ptr(records_dev) || ((uintptr_t)records_dev & 15u))) { c->err = "jj_msm_combine_dev takes records in (16-byte aligned) device memory; jj_msm_combine takes host records"; return JJ_ERR_INVALID; }
+  jjhost::Ext total;
+  const int rc = msm_combine_dev_locked(c, count, (const uint8_t*)records_dev, &total);
+  if (rc) return rc;
+  return msm_write_total(c, total, out64);
+}
+JJ_API int jj_msm_allgather(jj_ctx* c, size_t n, const void* scalars, const void* points, int partition, void* out64) {
+  if (!c || !out64 || (partition != 0 && partition != 1)) return JJ_ERR_INVALID;
+  JJ_ENTER(c);                                                       // held through the gather and the host tail (jj_msm_partial re-enters it: the mutex is recursive)
+  if (!c->comm || !c->all_gather) { c->err = "jj_msm_allgather: no communicator (jj_ctx_set_comm)"; return JJ_ERR_INVALID; }
+  const int G = c->comm_nranks;
+  int rc;
+  if ((rc = ensure(c, c->gather_dev, (size_t)(G + 1) * JJ_MSM_PARTIAL_BYTES))) return rc;
+  uint8_t* mine = (uint8_t*)c->gather_dev.p;                       // this rank's record, then the G gathered ones
+  uint8_t* all = mine + JJ_MSM_PARTIAL_BYTES;
+  if ((rc = jj_msm_partial(c, n, scalars, points, partition ? c->comm_rank : 0, partition ? G : 1, mine))) return rc;
+  const int nrc = c->all_gather(mine, all, JJ_MSM_PARTIAL_BYTES, /* ncclUint8 */ 1, c->comm, c->stream);
+  if (nrc != 0) { c->err = "ncclAllGather failed with ncclResult_t " + std::to_string(nrc); return JJ_ERR_HIP; }
+  jjhost::Ext total;
+  if ((rc = msm_combine_dev_locked(c, (size_t)G, all, &total))) return rc;
+  return msm_write_total(c, total, out64);
 }
 

@@ -472,12 +472,18 @@ __global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_part_scatter(size_t n,
     lo8[g] = st_lo[j];
   }
 }
-__global__ void __launch_bounds__(MSM_P2_THREADS) k_msm_part_sort(MsmParams mp, u32 ptiles, const u32* tcs, const u32* rec, const uint8_t* lo8, u32* idx, u32* off) {
+// SEGH: the block also does what k_seg_hist would do for its 256 buckets (it holds their counts anyway): the histogram of segment lengths of
+// tile s HB + coarse, key-major in bh, and the identity for empty buckets -- one launch and one pass over the offsets fewer (round 5).
+constexpr int SEG_PMAX = 1024;
+template <bool SEGH>
+__global__ void __launch_bounds__(MSM_P2_THREADS) k_msm_part_sort(MsmParams mp, u32 ptiles, const u32* tcs, const u32* rec, const uint8_t* lo8, u32* idx, u32* off, u32 P, ExtAoS buckets, u32* bh) {
   constexpr u32 NLO = 1u << MSM_LO_BITS;
   constexpr int PER = MSM_P2_CAP / MSM_P2_THREADS;
   __shared__ u32 cnt[NLO];
   __shared__ u32 stage[MSM_P2_CAP];
+  __shared__ u32 seg_h[SEGH ? SEG_PMAX + 1 : 1];
   const u32 coarse = blockIdx.x, HB = gridDim.x, s = blockIdx.y, tid = threadIdx.x;
+  if constexpr (SEGH) { for (u32 k = tid; k <= P; k += MSM_P2_THREADS) seg_h[k] = 0; }
   const u32* run0 = tcs + (size_t)s * ((size_t)HB * ptiles + 1);
   const u32 gb = run0[(size_t)coarse * ptiles], ge = run0[(size_t)(coarse + 1) * ptiles];
   const bool staged = ge - gb <= MSM_P2_CAP;
@@ -518,6 +524,20 @@ __global__ void __launch_bounds__(MSM_P2_THREADS) k_msm_part_sort(MsmParams mp, 
     if (coarse + 1 == HB && tid == 0) o[mp.B] = ge;
   }
   __syncthreads();
+  if constexpr (SEGH) {
+    if (tid < NLO) {                                                    // one bucket per thread: its count from the scanned offsets
+      const u32 c = (tid + 1 < NLO ? cnt[tid + 1] : ge - gb) - cnt[tid];
+      if (c == 0) aos_put_ext(buckets, (size_t)s * mp.B + ((size_t)coarse << MSM_LO_BITS) + tid, Curve::identity());
+      else {
+        const u32 full = c / P, rem = c - full * P;
+        if (full) atomicAdd(&seg_h[0], full);
+        if (rem) atomicAdd(&seg_h[P - rem], 1u);
+      }
+    }
+    __syncthreads();
+    const size_t stiles = (size_t)gridDim.x * gridDim.y, tile = (size_t)s * HB + coarse;
+    for (u32 k = tid; k <= P; k += MSM_P2_THREADS) bh[(size_t)k * stiles + tile] = seg_h[k];
+  }
   if (staged) {
     _Pragma("unroll") for (int q = 0; q < PER; q++) if (b[q] != ~0u) stage[cnt[b[q]] + rank[q]] = r[q];
     __syncthreads();
@@ -642,7 +662,6 @@ __global__ void __launch_bounds__(256) k_msm_fixup(size_t n, u32 B, u32 Ws, u32 
 #ifndef JJ_MSM_ACC_MINBLOCKS
 #define JJ_MSM_ACC_MINBLOCKS 1        // resident 256-thread blocks per CU the accumulate kernel is compiled for: 1 = no register cap (137 VGPRs,
 #endif                                // 3 waves per SIMD); capping at 128 (4 waves) changes nothing, 96 (5 waves) spills (profiles/r2_msm_acc_occupancy.txt)
-constexpr int SEG_PMAX = 1024;
 struct Seg { u32 start, len, dst, pad; };            // dst: bucket index, or 0x80000000 | head index
 struct MergeItem { u32 bucket, h0, k, pad; };         // buckets[bucket] += head[h0 .. h0 + k)
 // bucket g = s B + j of the pass: its entries are [lo, lo + c)
@@ -1008,6 +1027,84 @@ __global__ void __launch_bounds__(4 * MSM_TREE_QUADS) k_msm_reduce_l2(size_t n, 
   const u32 live = base >= K ? 0u : (K - base < (u32)MSM_TREE_QUADS ? K - base : (u32)MSM_TREE_QUADS);
   quad_tree_sum(st, quad, role, live, acc, Tacc);
   msm_finish_window(st, quad, role, nblk, nblk, blk, s, w, acc, Tacc, part, counters, rec);
+}
+
+// ================================================================================================ fold of gathered records
+// The multi-rank MSM all-gathers one record per rank (jj_msm_allgather).  Until round 4 every rank copied all G records to
+// the host and added them window by window on one CPU thread: the only part of the exchange that grows with G.  Here workgroup w
+// sums window w of the G records on quads of lanes (quad g takes records g, g + 64, ...; LDS tree) and writes ONE record whose window
+// mask is the union and whose term count is the sum: one 8 KB copy and the single-record host tail follow, whatever G is.  Both
+// partitions (terms: every record holds every window; windows: the masks are disjoint) and empty shards (mask 0) pass through the same code.
+// Records of DIFFERENT window layouts (a shard small enough for the 64-window small-batch path beside Pippenger shards) cannot be added
+// window by window: the output header then carries magic 0 and the caller falls back to the host's combine_records over all G.
+static JJ_DEV bool msm_rec_point(const u32* rec, int w, u32 role, Ext& p, Fe& T) {      // window w of one record -> Montgomery form; false if the record lacks it
+  const u64 mask = (u64)rec[4] | ((u64)rec[5] << 32);
+  if (!((mask >> w) & 1ull)) return false;
+  u32 wd[8];
+  load8(wd, rec + MSM_REC_HDR_WORDS + (size_t)w * MSM_REC_PT_WORDS, role);               // lane r converts coordinate r (U, V, Z, T)
+  const Fe cr = Fq::mul(Fq::unpack(wd), Fq::konst(FqP::FROM_HOST));
+  p.u = quad_bcast<0>(cr); p.v = quad_bcast<1>(cr); p.z = quad_bcast<2>(cr); T = quad_bcast<3>(cr);
+  p.t1 = p.u; p.t2 = p.v;                                                                // unused by the T-carrying quad operations
+  return true;
+}
+// the same record entry written by the four lanes of a quad together (lane r converts and stores coordinate r): one product round
+// instead of four in a row on one lane
+static JJ_DEV void msm_store_window_quad(u32* points, int w, const Ext& acc, const Fe& T, u32 role) {
+  u32 wd[8];
+  Fq::pack(wd, Fq::canon_plain_product(Fq::mul(role_select4(acc.u, acc.v, acc.z, T, role), Fq::konst(FqP::HOST_R))));
+  store8(points + (size_t)w * MSM_REC_PT_WORDS, role, wd);
+}
+__global__ void __launch_bounds__(4 * MSM_TREE_QUADS) k_msm_fold_records(const u32* recs, u32 G, u32 stride_words, u32* out) {
+  __shared__ __attribute__((aligned(16))) u32 st[MSM_TREE_QUADS * LDS_PT_WORDS];
+  __shared__ u32 hdr_s[8];
+  const u32 role = threadIdx.x & 3u, quad = threadIdx.x >> 2;
+  const int w = (int)blockIdx.x;
+  // every workgroup reads the G headers itself (32 bytes each, one thread per record, G <= 256 at a time): layout, union mask, term count
+  if (threadIdx.x < 8) hdr_s[threadIdx.x] = threadIdx.x == 0 ? 1u : 0u;        // [0] ok  [1] Wref  [2..3] mask  [4..5] n
+  __syncthreads();
+  for (u32 g0 = 0; g0 < G; g0 += blockDim.x) {
+    const u32 g = g0 + threadIdx.x;
+    if (g < G) {
+      const uint4* hp = reinterpret_cast<const uint4*>(recs + (size_t)g * stride_words);
+      const uint4 h0 = hp[0], h1 = hp[1];
+      if (h0.x != MSM_REC_MAGIC || h0.y != 2u || h0.z == 0 || h0.z > 64u) atomicAnd(&hdr_s[0], 0u);
+      else {
+        if (h1.x | h1.y) { atomicMax(&hdr_s[1], h0.z); atomicOr(&hdr_s[2], h1.x); atomicOr(&hdr_s[3], h1.y); }      // (an empty shard: any layout)
+        const u32 old = atomicAdd(&hdr_s[4], h1.z);
+        if (old + h1.z < old) atomicAdd(&hdr_s[5], 1u);
+        if (h1.w) atomicAdd(&hdr_s[5], h1.w);
+      }
+    }
+  }
+  __syncthreads();
+  // all non-empty records must share one layout: the largest W seen is the reference, a second pass finds any other
+  const u32 Wmax = hdr_s[1];
+  for (u32 g0 = 0; g0 < G; g0 += blockDim.x) {
+    const u32 g = g0 + threadIdx.x;
+    if (g < G) {
+      const u32* h = recs + (size_t)g * stride_words;
+      if ((h[4] | h[5]) && h[2] != Wmax) atomicAnd(&hdr_s[0], 0u);
+    }
+  }
+  __syncthreads();
+  const u32 ok = hdr_s[0], Wref = Wmax ? Wmax : (G ? recs[2] : (u32)SM_W);
+  const u64 mask = (u64)hdr_s[2] | ((u64)hdr_s[3] << 32);
+  if (w == 0 && threadIdx.x == 0) {
+    out[1] = 2u; out[2] = Wref; out[3] = 1u; out[4] = hdr_s[2]; out[5] = hdr_s[3]; out[6] = hdr_s[4]; out[7] = hdr_s[5];
+    for (int j = 8; j < MSM_REC_HDR_WORDS; j++) out[j] = 0;
+    out[0] = ok ? MSM_REC_MAGIC : 0u;
+  }
+  if (!ok || w >= (int)Wref || !((mask >> w) & 1ull)) return;          // uniform over the workgroup
+  Ext acc = Curve::identity();
+  Fe Tacc = Fq::zero();
+  #pragma unroll 1
+  for (u32 g = quad; g < G; g += MSM_TREE_QUADS) {
+    Ext p; Fe Tp, dummy;
+    if (msm_rec_point(recs + (size_t)g * stride_words, w, role, p, Tp)) acc = quad_add_ext_t(acc, Tacc, p, Tp, role, Tacc, Tp, Tp, dummy);
+  }
+  const u32 live = G < (u32)MSM_TREE_QUADS ? G : (u32)MSM_TREE_QUADS;
+  quad_tree_sum(st, quad, role, live, acc, Tacc);
+  if (quad == 0) msm_store_window_quad(out + MSM_REC_HDR_WORDS, w, acc, Tacc, role);
 }
 
 // ================================================================================================ device-side finish (opt-in)

@@ -360,6 +360,8 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
   if (const char* e = getenv("JJ_PIPE_CHUNK_LOG2")) { int v = atoi(e); if (v >= 8 && v <= 24) c->pipe_chunk = (size_t)1 << v; }   // overrides the per-entry-point chunk
   if (const char* e = getenv("JJ_MSM_WINDOWS")) { int v = atoi(e); if (v >= MSM_WINDOWS_MIN && v <= MSM_WINDOWS_MAX) c->msm_windows = v; else fprintf(stderr, "libjubjub_hip: JJ_MSM_WINDOWS=%s ignored (valid: %d..%d)\n", e, MSM_WINDOWS_MIN, MSM_WINDOWS_MAX); }
   if (const char* e = getenv("JJ_MSM_HOST_SPLIT")) c->msm_host_split = atoi(e) != 0;
+  if (const char* e = getenv("JJ_MSM_FOLD")) c->msm_fold_dev = strcmp(e, "host") != 0;
+  if (const char* e = getenv("JJ_MSM_FOLD_MIN")) { int v = atoi(e); if (v >= 2 && v <= 4096) c->msm_fold_min = v; }
   if (const char* e = getenv("JJ_MSM_LANES")) { int v = atoi(e); if (v >= 1 && v <= MSM_LANES_MAX) c->msm_lanes = v; }
   if (const char* e = getenv("JJ_MSM_SMALL_BLK")) { int v = atoi(e); if (v >= 1 && v <= MSM_SMALL_BLK_MAX) c->msm_small_blk = v; }
   if (const char* e = getenv("JJ_MSM_SMALL_MAX")) { int v = atoi(e); if (v >= 0 && v <= (1 << 20)) c->msm_small_max = v; }

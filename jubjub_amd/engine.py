@@ -449,9 +449,17 @@ class Engine:
         return out
 
     def msm_combine(self, records):
-        """Second half (jj_msm_combine, host only): any number of records (count x MSM_PARTIAL_BYTES bytes; numpy, or a torch
-        tensor on any device: copied to the host once) -> the 64-byte affine sum as a numpy array."""
+        """Second half: any number of records (count x MSM_PARTIAL_BYTES bytes) -> the 64-byte affine sum as a numpy array.  A CUDA
+        tensor takes jj_msm_combine_dev (the records are added on the device, ONE record is copied to the host tail); numpy / CPU
+        tensors take jj_msm_combine (host only)."""
         is_torch = type(records).__module__.startswith("torch")
+        if is_torch and records.is_cuda:
+            # device-resident records (what all_gather delivered): folded window by window on the device, one record goes to the host tail
+            t = records.detach().contiguous().view(-1, _lib.MSM_PARTIAL_BYTES)
+            self._bind_stream([_Arg(t, _lib.MSM_PARTIAL_BYTES)] if t.shape[0] else [])
+            out = np.empty((64,), np.uint8)
+            self._check(self._lib.jj_msm_combine_dev(self._ctx, C.c_size_t(t.shape[0]), C.c_void_p(t.data_ptr()) if t.shape[0] else None, out.ctypes.data))
+            return out
         host = np.ascontiguousarray((records.detach().cpu().numpy() if is_torch else np.asarray(records)).reshape(-1, _lib.MSM_PARTIAL_BYTES), dtype=np.uint8)
         out = np.empty((64,), np.uint8)
         rc = self._lib.jj_msm_combine(C.c_size_t(host.shape[0]), host.ctypes.data if host.shape[0] else None, out.ctypes.data)

@@ -629,6 +629,49 @@ def test_msm_partial_records_term_and_window_partition(eng, G):
     assert recs.is_cuda and (eng.msm_combine(recs) == O.msm(S, P)).all()
 
 
+@pytest.mark.parametrize("fold", ["device", "host"])
+def test_msm_gathered_records_folded_on_the_device(monkeypatch, fold):
+    """jj_msm_combine_dev (what jj_msm_allgather runs after ncclAllGather): G device-resident records are added window by window on the
+    device into ONE record (k_msm_fold_records) before the host tail -- both partitions, G = 2, 3, 8 and 70 (more records than the
+    fold's 64 quads), an empty shard between the others, and records of different window layouts (host fallback).  JJ_MSM_FOLD=host
+    keeps round 4's path (every record copied, the host adds them): both must give the oracle's point."""
+    import torch
+
+    from jubjub_amd import Engine, _lib
+    from jubjub_amd.dist import shard_bounds
+
+    monkeypatch.setenv("JJ_MSM_FOLD", fold)
+    monkeypatch.setenv("JJ_MSM_FOLD_MIN", "2")                       # (the default folds on the device from 8 records)
+    e2 = Engine(0)
+    dev = torch.device("cuda", 0)
+    n = 70000
+    S, P = rand_scalars(2950, n, full_width=True), rand_points(2951, n)
+    want = O.msm(S, P)
+    Sd, Pd = torch.from_numpy(S).to(dev), torch.from_numpy(P).to(dev)
+    for G in (2, 3, 8, 70):
+        parts = []
+        for g in range(G):
+            lo, hi = shard_bounds(n, g, G)
+            parts.append(e2.msm_partial(Sd[lo:hi], Pd[lo:hi]))
+        assert (e2.msm_combine(torch.stack(parts)) == want).all(), ("terms", G)
+        if G <= 8:
+            recs = torch.stack([e2.msm_partial(Sd, Pd, g, G) for g in range(G)])
+            assert (e2.msm_combine(recs) == want).all(), ("windows", G)
+    # Pippenger shards of one layout with an empty shard in the middle; then a small-batch shard among them (64 windows against 23)
+    a, b = e2.msm_partial(Sd[:30000], Pd[:30000]), e2.msm_partial(Sd[30000:60000], Pd[30000:60000])
+    empty = e2.msm_partial(Sd[:0], Pd[:0])
+    assert (e2.msm_combine(torch.stack([a, empty, b])) == O.msm(S[:60000], P[:60000])).all()
+    small = e2.msm_partial(Sd[60000:], Pd[60000:])
+    assert (e2.msm_combine(torch.stack([a, small, b, empty])) == want).all()
+    assert to_pt(e2.msm_combine(torch.zeros((0, _lib.MSM_PARTIAL_BYTES), dtype=torch.uint8, device=dev))) == J.AFFINE_IDENTITY
+    assert (e2.msm_combine(a[None, :]) == O.msm(S[:30000], P[:30000])).all()            # one record: no fold
+    bad = torch.stack([a, b]).clone()
+    bad[1, 0] ^= 1                                                                       # damaged magic in a gathered record
+    with pytest.raises(Exception):
+        e2.msm_combine(bad)
+    e2.close()
+
+
 def test_serialization_golden(eng, golden):
     encs = np.array(golden["serialization_16"]["encodings"], np.uint8)
     gen8 = eng.mul_by_cofactor(arr64([J.GENERATOR]))
