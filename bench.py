@@ -69,9 +69,10 @@ RAW_SEED = SEED ^ 0x5DEECE66D
 # kernel ("main": what roofline.kernel_ms times) and the normalisation tail that follows it.
 # IMAD32 convention: M = 128, S = 100.
 WORK = {
-    # k_varbase: 2 from_words + to_niels(P) 2M; table {1..16}P: to_niels 2M + 15 x (mixed add 7M + to_niels 2M);
-    # 51 additions x 8M; 250 doublings x (3S + 4M: 2UV is a product here, jj_curve.h).   normalisation tail: tail_work() below
-    "varbase": {"S": 250 * 3, "M": 2 + 2 + 2 + 15 * 9 + 51 * 8 + 250 * 4, "bytes": 32 + 64 + 64},
+    # k_varbase_ct3 (jj_varbase_mul, the constant-time default since round 5): 2 from_words; table {P, 2P, 3P, 4P}: 4 to_niels x 2M, two doublings,
+    # one addition 8M; the carry window's addition + 84 window additions x 8M; 252 doublings x (3S + 4M: 2UV is a product here, jj_curve.h).
+    # normalisation tail: tail_work() below
+    "varbase": {"S": 252 * 3 + 2 * 3, "M": 2 + 4 * 2 + 2 * 4 + 8 + 85 * 8 + 252 * 4, "bytes": 32 + 64 + 64},
     # k_fixedbase_comb (default, --fb-window 0/7): 32 mixed additions x 7M + three doublings (3S + 4M each); --fb-window 6: k_fixedbase, 43 x 7M
     "fixedbase": {"S": 9, "M": 32 * 7 + 12, "bytes": 32 + 64},
     # Pippenger, c = 16: per term 2M load + 2M to_niels + 16 windows x 7M mixed add; bucket reduce 2 x 10M per bucket
@@ -95,8 +96,13 @@ def tail_work(wl, n, cus=256):
     return -(-255 // chunk), 6 + -(-75 // chunk)
 
 
+# k_varbase (jj_varbase_mul_vartime: per-lane table {0..16}P in memory, signed 5-bit windows): 2 from_words + to_niels(P) 2M; table: to_niels 2M +
+# 15 x (mixed add 7M + to_niels 2M); 51 additions x 8M; 250 doublings x (3S + 4M)
+WORK_VARTIME = {"S": 250 * 3, "M": 2 + 2 + 2 + 15 * 9 + 51 * 8 + 250 * 4}
 REFERENCE_WORK = {"varbase": {"S": 1008, "M": 2774}, "fixedbase": {"S": 1008, "M": 2520}}   # the reference's own ladders
-PASSES = {"varbase": 4, "fixedbase": 2, "msm": 32, "decompress": 4}       # passes per step: >= ~50 ms of kernels per step
+# passes per step: ~0.33 s of kernels per step, so that the default --steps 20 keeps the GPU busy for 6-7 s (a 5-second utilisation sampler around the
+# run then sees it; rounds 1-4 ran ~50 ms steps: 1 s of GPU work inside a 40 s process)
+PASSES = {"varbase": 24, "fixedbase": 12, "msm": 256, "decompress": 20}
 DEFAULT_LOG2N = {"varbase": 20, "fixedbase": 24, "msm": 20, "decompress": 23}
 UNIT = {"varbase": "scalar-muls/s", "fixedbase": "scalar-muls/s", "msm": "terms/s", "decompress": "points/s"}
 GEN_U = 0x62EDCBB8BF3787C88B0F03DDD60A8187CAF55D1B29BF81AFE4B3D35DF1A7ADFE   # generator (u, 11), reference src/lib.rs:1380-1396
@@ -699,7 +705,7 @@ def run(a):
             "mad_issue_frac": n * (153 * w["M"] + 117 * w["S"]) / (kern_ms * 1e-3) / peak,
             "traffic": traffic["bytes_per_launch"] if traffic else None,
             "traffic_detail": traffic if traffic else traffic_note,
-            "kernel": {"varbase": "k_varbase", "fixedbase": ("k_fixedbase_comb" if a.fb_window in (0, 7) else "k_fixedbase") if a.fb_window < 8 else "k_fixedbase_gather(w=%d)" % a.fb_window, "msm": "whole MSM: k_msm_accumulate(_seg) + sort / fix-up / reduce; Horner on the host", "decompress": "k_decompress"}[wl],
+            "kernel": {"varbase": "k_varbase_ct3", "fixedbase": ("k_fixedbase_comb" if a.fb_window in (0, 7) else "k_fixedbase") if a.fb_window < 8 else "k_fixedbase_gather(w=%d)" % a.fb_window, "msm": "whole MSM: k_msm_accumulate(_seg) + sort / fix-up / reduce; Horner on the host", "decompress": "k_decompress"}[wl],
             "kernel_ms": kern_ms, "tail_ms": tail, "units_per_launch": n,
             "work_per_unit": {"field_squares": w["S"], "field_muls": w["M"], "imad32": work_main, "convention": "M=128,S=100 (SURVEY 8d); the kernel named above only",
                               "tail_kernel": {"field_squares": tail_s, "field_muls": tail_m, "imad32": imad32(tail_s, tail_m)}},
@@ -801,27 +807,32 @@ def run(a):
             wt.close()
             del fs, fo
         if wl == "varbase" and not a.no_extras and n_gpus == 1 and not host:
-            # the constant-time ladder (jj_varbase_mul_ct: table {P, 2P} in registers, signed 2-bit windows, mask selects) on the same batch
+            # the variable-time ladder (jj_varbase_mul_vartime: per-lane window table in memory, signed 5-bit windows, digit-dependent addresses) on the same batch
             for _ in range(2):
-                co = eng.varbase_mul_ct(scalars, points)
+                co = eng.varbase_mul_vartime(scalars, points)
             torch.cuda.synchronize(dev)
             eng.profile(True)
             t1 = time.perf_counter()
             for _ in range(4):
-                co = eng.varbase_mul_ct(scalars, points)
+                co = eng.varbase_mul_vartime(scalars, points)
             torch.cuda.synchronize(dev)
             cdt = (time.perf_counter() - t1) / 4
             cm, _ct = eng.profile_read()
             eng.profile(False)
             ckm = sum(cm) / max(len(cm), 1)
-            cw = {"S": 252 * 3 + 3, "M": 2 + 4 + 4 + 252 * 4 + 128 * 8}      # 2 from_words, 2 to_niels + 1 doubling, 252 doublings, 128 additions
-            res["varbase_constant_time"] = {"value": n / cdt, "unit": "scalar-muls/s per GPU", "units_per_pass": n, "ms_per_pass": cdt * 1e3, "kernel_ms": ckm,
-                                            "roofline_frac": n * imad32(cw["S"], cw["M"]) / (ckm * 1e-3) / peak, "work_per_unit": cw,
-                                            "relative_to_default": (n / cdt) / value,
-                                            "note": "no scalar-dependent address or branch: the reference's conditional_select discipline (src/lib.rs:334-343, 357-379)"}
+            cw = WORK_VARTIME
+            res["varbase_vartime"] = {"value": n / cdt, "unit": "scalar-muls/s per GPU", "units_per_pass": n, "ms_per_pass": cdt * 1e3, "kernel_ms": ckm, "kernel": "k_varbase",
+                                      "roofline_frac": n * imad32(cw["S"], cw["M"]) / (ckm * 1e-3) / peak, "work_per_unit": cw,
+                                      "relative_to_default": (n / cdt) / value,
+                                      "note": "jj_varbase_mul_vartime: the window table of every lane lives in memory and is read at a digit-dependent address (rounds 1-4's default); for public scalars"}
             if not a.no_verify:
-                res["varbase_constant_time"]["verified"], _ = verify_sample("varbase", a, lo, n, co, None, None)
-                res["varbase_constant_time"]["equals_default_ladder_all_units"] = bool(torch.equal(co, out))
+                res["varbase_vartime"]["verified"], _ = verify_sample("varbase", a, lo, n, co, None, None)
+                res["varbase_vartime"]["equals_default_ladder_all_units"] = bool(torch.equal(co, out))
+            res["value_vartime"] = n / cdt
+        if wl == "varbase":
+            # the headline IS the constant-time ladder: jj_varbase_mul has no scalar-dependent address or branch (the reference's conditional_select
+            # discipline, src/lib.rs:334-343, 357-379)
+            res["value_constant_time"] = res["value"]
         if not a.no_cpu_baseline and n_gpus == 1:
             res["cpu_baseline"] = cpu_baseline(wl, a.cpu_seconds)
         emit(json.dumps(res))

@@ -172,19 +172,27 @@ int jj_point_sum(jj_ctx*, size_t n, const void* p, void* out64);
 
 /* ---- scalar multiplication ----------------------------------------------------------------------------- */
 /* out[i] = to_affine(points[i] * scalars[i])   (`ExtendedPoint * Fr`, src/lib.rs:873-879 -> 831-833 -> 357-379).
- * scalars are raw 32-byte patterns; only the low 252 bits are used, as in the reference ladder.
- * Windowed signed-digit ladder with a per-lane table; results are specified for on-curve points.
- * Scalar-independent instruction stream; the per-lane table lookups use digit-dependent addresses. */
+ * scalars are raw 32-byte patterns; only the low 252 bits are used, as in the reference ladder.  Results are specified for on-curve points.
+ * CONSTANT-TIME like the reference's ladder (conditional_select, src/lib.rs:334-343): neither the instruction stream nor any memory
+ * address depends on the scalar.  Signed 3-bit windows (k' = k + sum 4 * 8^i: 84 windows tile the 252 bits, bit 252 is the recoding carry),
+ * table {P, 2P, 3P, 4P}: {P, 2P} in registers, {3P, 4P} in a per-lane LDS slot that is read whole for every window; the entry is picked
+ * with bit masks, the sign applied through the subtraction formulas: 85 additions + 252 doublings.  Batches up to JJ_VB_QUAD_MAX
+ * (32 768) units run one scalar multiplication per quad of lanes (every lane keeps its own coordinate of the four entries in
+ * registers): same discipline, a third of the latency. */
 int jj_varbase_mul(jj_ctx*, size_t n, const void* scalars32, const void* points64, void* out64);
 /* same, result written as 32-byte compressed encodings (to_bytes of the product, src/lib.rs:455-464, 1419-1421) */
 int jj_varbase_mul_compressed(jj_ctx*, size_t n, const void* scalars32, const void* points64, void* out32);
-/* Constant-time variant for SECRET scalars: same result, but neither the instruction stream nor any memory address depends on
- * the scalar -- the reference's own discipline (conditional_select ladder, src/lib.rs:334-343, 357-379).  The table {P, 2P} is
- * held in registers (no table in memory), windows are signed 2-bit digits picked with bit masks: 127 additions + 252 doublings,
- * about 1.3x the time of jj_varbase_mul. */
+/* the name rounds 3-4 gave the constant-time ladder when it was the opt-in: the same as jj_varbase_mul, whatever JJ_VARBASE_DEFAULT says */
 int jj_varbase_mul_ct(jj_ctx*, size_t n, const void* scalars32, const void* points64, void* out64);
+/* VARIABLE-TIME variants for PUBLIC scalars (what rounds 1-4 shipped as jj_varbase_mul): signed 5-bit windows, the lane's table
+ * {0 .. 16} P in device memory, read at a digit-dependent address: a scalar-independent instruction stream but scalar-dependent
+ * memory addresses (cache timing).  About 2.5 % faster than jj_varbase_mul at 2^20 units (profiles/r5_vb_ct_window.txt).
+ * JJ_VARBASE_DEFAULT=vartime makes jj_varbase_mul / _compressed take this ladder as well (A/B measurements). */
+int jj_varbase_mul_vartime(jj_ctx*, size_t n, const void* scalars32, const void* points64, void* out64);
+int jj_varbase_mul_vartime_compressed(jj_ctx*, size_t n, const void* scalars32, const void* points64, void* out32);
 /* One scalar, many bases: out[i] = points[i] * scalar (the `Wnaf::scalar(..).base(..)` reuse pattern of the group crate,
- * cf. WnafGroup src/lib.rs:1318-1336).  Same kernel as jj_varbase_mul after broadcasting the 32-byte scalar. */
+ * cf. WnafGroup src/lib.rs:1318-1336; the crate's Wnaf machinery is variable-time by design).  The kernel of jj_varbase_mul_vartime with the
+ * one scalar read through a wave-uniform address. */
 int jj_varbase_mul_scalar(jj_ctx*, size_t n, const void* scalar32, const void* points64, void* out64);
 /* Same group element, but computed with the reference's exact 252-step double-and-add-always ladder and
  * returned in projective form: out = 160 bytes (U,V,Z,T1,T2 canonical LE) matching the Rust ExtendedPoint

@@ -209,7 +209,7 @@ class AffineBatch {
   std::vector<uint8_t> is_torsion_free() const { return pred(jj_is_torsion_free); }                    // lib.rs:441-443
   std::vector<uint8_t> is_prime_order() const { return pred(jj_is_prime_order); }                      // lib.rs:449-452
   std::vector<uint8_t> is_on_curve() const { return pred(jj_is_on_curve); }                            // lib.rs:670-675
-  // ExtendedPoint::multiply / multiply_bits: raw 32-byte patterns, low 252 bits used (lib.rs:357-385, 831-833)
+  // ExtendedPoint::multiply / multiply_bits: raw 32-byte patterns, low 252 bits used (lib.rs:357-385, 831-833); constant-time like the reference (jj_varbase_mul)
   AffineBatch multiply_bits(const std::vector<Bytes32>& by) const {
     if (by.size() != len()) throw Error(JJ_ERR_INVALID, "length mismatch");
     AffineBatch r(*c_, std::vector<Bytes64>(len()));
@@ -360,11 +360,19 @@ inline Bytes64 msm_all_ranks(const Context& c, const AffineBatch& my_points, con
   c.check(jj_msm_allgather(c.raw(), my_points.len(), my_scalars.to_bytes().data(), my_points.coords().data(), by_windows ? 1 : 0, out.data()));
   return out;
 }
-// `ExtendedPoint * Fr` with the reference's constant-time discipline (lib.rs:334-343, 357-379): no scalar-dependent address or branch
+// `ExtendedPoint * Fr` as operator* computes it: the reference's constant-time discipline (lib.rs:334-343, 357-379), no scalar-dependent
+// address or branch (jj_varbase_mul; multiply_ct is the name rounds 3-4 gave it)
 inline AffineBatch multiply_ct(const Context& c, const AffineBatch& points, const FrBatch& scalars) {
   if (points.len() != scalars.len()) throw Error(JJ_ERR_INVALID, "length mismatch");
   std::vector<Bytes64> out(points.len());
   c.check(jj_varbase_mul_ct(c.raw(), points.len(), scalars.to_bytes().data(), points.coords().data(), out.data()));
+  return AffineBatch(c, std::move(out));
+}
+// the same product by the variable-time ladder (per-lane window table in memory, digit-dependent addresses): for PUBLIC scalars only
+inline AffineBatch multiply_vartime(const Context& c, const AffineBatch& points, const FrBatch& scalars) {
+  if (points.len() != scalars.len()) throw Error(JJ_ERR_INVALID, "length mismatch");
+  std::vector<Bytes64> out(points.len());
+  c.check(jj_varbase_mul_vartime(c.raw(), points.len(), scalars.to_bytes().data(), points.coords().data(), out.data()));
   return AffineBatch(c, std::move(out));
 }
 // several fixed bases with short scalars through one LDS table set, one pass (sums of multiply_bits, lib.rs:297-301)

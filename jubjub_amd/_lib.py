@@ -36,6 +36,8 @@ _SIGS.update({
     "jj_varbase_mul": [_sz, _vp, _vp, _vp],
     "jj_varbase_mul_exact": [_sz, _vp, _vp, _vp],
     "jj_varbase_mul_ct": [_sz, _vp, _vp, _vp],
+    "jj_varbase_mul_vartime": [_sz, _vp, _vp, _vp],
+    "jj_varbase_mul_vartime_compressed": [_sz, _vp, _vp, _vp],
     "jj_varbase_mul_scalar": [_sz, _vp, _vp, _vp],
     "jj_varbase_mul_compressed": [_sz, _vp, _vp, _vp],
     "jj_fixedbase_mul_compressed": [_vp, _sz, _vp, _vp],

@@ -8,7 +8,8 @@ int jj_batch_init(jj_ctx* c) {
   // the fixed-base kernels need the full 160 KiB LDS carve-out
   const struct { const void* fn; int bytes; } lds_needs[] = {
     {reinterpret_cast<const void*>(k_fixedbase<true>), FB_LDS_BYTES}, {reinterpret_cast<const void*>(k_fixedbase<false>), FB_LDS_BYTES},
-    {reinterpret_cast<const void*>(k_fixedbase_comb<true>), FBC_LDS_BYTES}, {reinterpret_cast<const void*>(k_fixedbase_comb<false>), FBC_LDS_BYTES}};
+    {reinterpret_cast<const void*>(k_fixedbase_comb<true>), FBC_LDS_BYTES}, {reinterpret_cast<const void*>(k_fixedbase_comb<false>), FBC_LDS_BYTES},
+    {reinterpret_cast<const void*>(k_varbase_ct3), CT3_LDS_BYTES_PER_BLOCK}};
   for (const auto& a : lds_needs)
     if (hipFuncSetAttribute(a.fn, hipFuncAttributeMaxDynamicSharedMemorySize, a.bytes) != hipSuccess) return JJ_ERR_HIP;   // the kernels could not launch later
   // square-root tables (64 KiB dlog + 36 KiB powers), built on the device
@@ -148,7 +149,15 @@ static void varbase_geometry(jj_ctx* c, size_t n, unsigned* blocks, size_t* thre
   if (t == 0) t = 256;
   *blocks = (unsigned)(t / 256); *threads = t;
 }
-static int varbase_to_ext(jj_ctx* c, size_t n, const void* ds, const void* dp, SoA ext, bool five, bool shared_scalar = false) {
+// ct: the ladder with the reference's timing discipline (no scalar-dependent address or branch): k_varbase_ct3 / k_varbase_ct_quad; otherwise the
+// per-lane window table in memory (k_varbase / k_varbase_quad: digit-dependent addresses)
+static int varbase_to_ext(jj_ctx* c, size_t n, const void* ds, const void* dp, SoA ext, bool five, bool shared_scalar = false, bool ct = false) {
+  if (ct && !five && !shared_scalar) {
+    if (n <= (size_t)c->vb_quad_max) hipLaunchKernelGGL(k_varbase_ct_quad, dim3(blocks_for(4 * n)), dim3(256), 0, c->stream, n, ds, dp, ext);   // small batch: one scalar multiplication per quad of lanes
+    else if (c->vb_ct_window == 3) hipLaunchKernelGGL(k_varbase_ct3, dim3(blocks_for(n)), dim3(256), CT3_LDS_BYTES_PER_BLOCK, c->stream, n, ds, dp, ext);
+    else hipLaunchKernelGGL(k_varbase_ct, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, ds, dp, ext);
+    return JJ_OK;
+  }
   if (n <= (size_t)c->vb_quad_max && !shared_scalar) {      // small batch: one scalar multiplication per quad of lanes (3x lower latency)
     int rc = ensure(c, c->ws->tables, n * (size_t)(VB_SLOTS * ENIELS_WORDS) * 4); if (rc) return rc;
     if (five) hipLaunchKernelGGL(k_varbase_quad<true>, dim3(blocks_for(4 * n)), dim3(256), 0, c->stream, n, ds, dp, (u32*)c->ws->tables.p, ext);
@@ -165,7 +174,7 @@ static int varbase_to_ext(jj_ctx* c, size_t n, const void* ds, const void* dp, S
   else hipLaunchKernelGGL((k_varbase<false, false>), dim3(blocks), dim3(256), 0, c->stream, n, ds, dp, (u32*)c->ws->tables.p, ext, (unsigned long long*)c->ws->cursor.p);
   return JJ_OK;
 }
-static int varbase_api(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out, int mode) {
+static int varbase_api(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out, int mode, bool ct) {
   if (!c) return JJ_ERR_INVALID;
   JJ_ENTER(c);
   if (const size_t ch = pipe_chunk_for(c, n, 18); ch && all_host({scalars, points, out})) {
@@ -175,7 +184,7 @@ static int varbase_api(jj_ctx* c, size_t n, const void* scalars, const void* poi
       int rc2;
       if ((rc2 = ensure_ext(c, cn, 3))) return rc2;
       SoA ext = soa_of(c->ws->ext, cn);
-      if ((rc2 = varbase_to_ext(c, cn, di[0], di[1], ext, false))) return rc2;
+      if ((rc2 = varbase_to_ext(c, cn, di[0], di[1], ext, false, false, ct))) return rc2;
       if ((rc2 = pipe_to_tail(c))) return rc2;
       return normalize_launch(c, cn, ext, dout[0], mode);
     });
@@ -189,7 +198,7 @@ static int varbase_api(jj_ctx* c, size_t n, const void* scalars, const void* poi
   SoA ext = soa_of(c->ws->ext, n);
   if (n) {
     prof_mark(c, 0);
-    if ((rc = varbase_to_ext(c, n, ds, dp, ext, false))) return rc;
+    if ((rc = varbase_to_ext(c, n, ds, dp, ext, false, false, ct))) return rc;
     prof_mark(c, 1);
     if ((rc = normalize_launch(c, n, ext, o.dev, mode))) return rc;
     prof_mark(c, 2);
@@ -198,8 +207,15 @@ static int varbase_api(jj_ctx* c, size_t n, const void* scalars, const void* poi
   if ((rc = finish_out(c, o, &sync))) return rc;
   return finish(c, sync);
 }
-JJ_API int jj_varbase_mul(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out) { return varbase_api(c, n, scalars, points, out, 0); }
-JJ_API int jj_varbase_mul_compressed(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out32) { return varbase_api(c, n, scalars, points, out32, 1); }
+// ExtendedPoint * Fr (reference src/lib.rs:873-879 -> 357-379): the reference's ladder is constant-time (conditional_select, 334-343), and so is
+// the default here (round 5): signed 3-bit windows, mask selects, no table in memory (k_varbase_ct3; one scalar multiplication per quad of lanes up
+// to JJ_VB_QUAD_MAX units: k_varbase_ct_quad).  The _vartime entry points keep the per-lane window table in memory and signed 5-bit windows
+// (digit-dependent addresses): ~2.5 % faster at 2^20 units, for public scalars.
+JJ_API int jj_varbase_mul(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out) { return varbase_api(c, n, scalars, points, out, 0, c && c->vb_default_ct); }
+JJ_API int jj_varbase_mul_compressed(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out32) { return varbase_api(c, n, scalars, points, out32, 1, c && c->vb_default_ct); }
+JJ_API int jj_varbase_mul_ct(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out) { return varbase_api(c, n, scalars, points, out, 0, true); }      // (the name rounds 3-4 gave the opt-in; always constant-time)
+JJ_API int jj_varbase_mul_vartime(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out) { return varbase_api(c, n, scalars, points, out, 0, false); }
+JJ_API int jj_varbase_mul_vartime_compressed(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out32) { return varbase_api(c, n, scalars, points, out32, 1, false); }
 // one scalar, many bases (group::Wnaf's `scalar(..).base(..)` reuse pattern): the ladder reads the one scalar through a
 // wave-uniform address (k_varbase<.., SHARED>): recoding and window digits are scalar-unit work, nothing is broadcast.
 // Small batches use the quad kernel on a broadcast copy (latency path).
@@ -220,27 +236,6 @@ JJ_API int jj_varbase_mul_scalar(jj_ctx* c, size_t n, const void* scalar32, cons
       if ((rc = varbase_to_ext(c, n, c->ws_tmp[0].p, dp, ext, false))) return rc;
     } else if ((rc = varbase_to_ext(c, n, c->ws_tmp[1].p, dp, ext, false, true))) return rc;
     if ((rc = normalize_launch(c, n, ext, o.dev, 0))) return rc;
-  }
-  bool sync = false;
-  if ((rc = finish_out(c, o, &sync))) return rc;
-  return finish(c, sync);
-}
-// constant-time ladder: table {P, 2P} in registers, signed 2-bit windows, mask selects (k_varbase_ct)
-JJ_API int jj_varbase_mul_ct(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out) {
-  if (!c) return JJ_ERR_INVALID;
-  JJ_ENTER(c);
-  const void *ds, *dp; int rc; OutRef o;
-  if ((rc = stage_in(c, 0, scalars, 32 * n, &ds))) return rc;
-  if ((rc = stage_in(c, 1, points, 64 * n, &dp))) return rc;
-  if ((rc = stage_out(c, c->out[0], out, 64 * n, &o))) return rc;
-  if ((rc = ensure_ext(c, n, 3))) return rc;
-  SoA ext = soa_of(c->ws->ext, n);
-  if (n) {
-    prof_mark(c, 0);
-    hipLaunchKernelGGL(k_varbase_ct, dim3(blocks_for(n)), dim3(256), 0, c->stream, n, ds, dp, ext);
-    prof_mark(c, 1);
-    if ((rc = normalize_launch(c, n, ext, o.dev, 0))) return rc;
-    prof_mark(c, 2);
   }
   bool sync = false;
   if ((rc = finish_out(c, o, &sync))) return rc;

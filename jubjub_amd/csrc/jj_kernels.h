@@ -546,6 +546,93 @@ __global__ void __launch_bounds__(256) k_varbase_ct(size_t n, const void* scalar
 }
 #endif  // JJ_KERNELS_BATCH
 
+// The same discipline with signed 3-bit windows (round 5): digits d in [-4, 3] from k' = k + sum 4 * 8^i (84 windows tile the 252 bits
+// exactly; bit 252 holds the recoding carry), table {P, 2P, 3P, 4P}: 84 + 1 additions instead of 126 + 1 for the same 252 doublings.  Four
+// extended-Niels entries are 144 registers -- with the accumulator and a product's temporaries more than the 256 a wave may hold at two
+// waves per SIMD -- so {P, 2P} stay in registers and {3P, 4P} wait in a per-lane slot of LDS (288 bytes per lane: 18 KB per wave, eight
+// waves per CU).  The slot's address depends on the lane only and BOTH entries are read for every window (sixteen-byte pieces, lane-major:
+// no bank conflicts, no digit in any address); the digit picks among the five candidates with bit masks.  No load, store, branch or
+// address of the loop depends on the scalar.
+constexpr int CT3_NWIN = 84;
+constexpr int CT3_LDS_WORDS_PER_LANE = 2 * ENIELS_WORDS;                       // 3P, 4P
+constexpr int CT3_LDS_BYTES_PER_BLOCK = 256 * CT3_LDS_WORDS_PER_LANE * 4;     // 72 KB per 256-thread workgroup
+static JJ_DEV u32 and_or(u32 a, u32 m, u32 c) { return (a & m) | c; }          // v_and_or_b32
+static JJ_DEV Ext varbase_ct3(const Affine& P, u32 (&k)[8], uint4* slot /* this lane's first piece; pieces are 64 uint4 apart */, u32* kmem, size_t kstride) {
+  const Ext p1 = Curve::from_affine(P);
+  const ENiels e1 = Curve::to_niels<true>(p1);
+  const Ext p2 = Curve::dbl(p1);
+  const ENiels e2 = Curve::to_niels<true>(p2);
+  {
+    const Ext p3 = Curve::add<true>(p2, e1);
+    const ENiels e3 = Curve::to_niels<true>(p3), e4 = Curve::to_niels<true>(Curve::dbl(p2));
+    u32 w[CT3_LDS_WORDS_PER_LANE];
+    _Pragma("unroll") for (int l = 0; l < NL; l++) {
+      w[l] = e3.vpu.l[l]; w[NL + l] = e3.vmu.l[l]; w[2 * NL + l] = e3.z2.l[l]; w[3 * NL + l] = e3.t2d.l[l];
+      w[ENIELS_WORDS + l] = e4.vpu.l[l]; w[ENIELS_WORDS + NL + l] = e4.vmu.l[l]; w[ENIELS_WORDS + 2 * NL + l] = e4.z2.l[l]; w[ENIELS_WORDS + 3 * NL + l] = e4.t2d.l[l];
+    }
+    _Pragma("unroll") for (int v = 0; v < CT3_LDS_WORDS_PER_LANE / 4; v++) slot[v * 64] = make_uint4(w[4 * v], w[4 * v + 1], w[4 * v + 2], w[4 * v + 3]);
+  }
+  // recode: k' = (k mod 2^252) + sum_{i<84} 4 * 8^i
+  k[7] &= 0x0fffffffu;
+  {
+    constexpr u32 RC[8] = {0x24924924u, 0x49249249u, 0x92492492u, 0x24924924u, 0x49249249u, 0x92492492u, 0x24924924u, 0x09249249u};
+    u64 cy = 0;
+    _Pragma("unroll") for (int j = 0; j < 8; j++) { const u64 t = (u64)k[j] + RC[j] + cy; k[j] = (u32)t; cy = t >> 32; }
+  }
+  const ENiels idn = Curve::eniels_identity();
+  const u32 top = (k[7] >> 28) & 1u;                           // bit 252: the carry window, 0 or 1
+  Ext acc = Curve::add<true>(Curve::identity(), Curve::select(idn, e1, 0u - top));
+  // k' waits in memory (the unit's own words of the output array, overwritten by the result at the end): the loop reads the one or two
+  // words that hold window i -- an address that depends on the unit and on i only -- instead of keeping eight registers of shift register
+  _Pragma("unroll") for (int q = 0; q < 8; q++) kmem[(size_t)q * kstride] = k[q];
+  #pragma unroll 1
+  for (int i = CT3_NWIN - 1; i >= 0; i--) {
+    const int bit = 3 * i, wi = bit >> 5, sh = bit & 31;
+    const u32 lo = kmem[(size_t)wi * kstride], hi = kmem[(size_t)(wi < 7 ? wi + 1 : 7) * kstride];
+    const int d = (int)((u32)((((u64)hi << 32) | lo) >> sh) & 7u) - 4;      // window - 4 in [-4, 3]
+    const u32 sgn = (u32)(d >> 31);                            // all-ones iff negative
+    const u32 a = ((u32)d ^ sgn) - sgn;                        // |d| in {0 .. 4}
+    u32 m4 = 0u - (a >> 2), m3 = 0u - ((a >> 1) & a & 1u), m2 = 0u - ((a >> 1) & ~a & 1u), m1 = 0u - (a & ~(a >> 1) & 1u);
+    asm("" : "+v"(m1), "+v"(m2), "+v"(m3), "+v"(m4));          // opaque: plain bit operations, no compare / v_cndmask rebuilt from them
+    const u32 m0 = ~(m1 | m2 | m3 | m4);
+    acc = Curve::dbl(Curve::dbl(acc));
+    acc = Curve::dbl(acc);
+    // entry |d| P: the register entries and the identity first, then the two LDS entries piece by piece (four words at a time)
+    u32 sel[ENIELS_WORDS];
+    _Pragma("unroll") for (int l = 0; l < NL; l++) {
+      sel[l] = and_or(e1.vpu.l[l], m1, and_or(e2.vpu.l[l], m2, idn.vpu.l[l] & m0));
+      sel[NL + l] = and_or(e1.vmu.l[l], m1, and_or(e2.vmu.l[l], m2, idn.vmu.l[l] & m0));
+      sel[2 * NL + l] = and_or(e1.z2.l[l], m1, and_or(e2.z2.l[l], m2, idn.z2.l[l] & m0));
+      sel[3 * NL + l] = and_or(e1.t2d.l[l], m1, e2.t2d.l[l] & m2);
+    }
+    _Pragma("unroll") for (int v = 0; v < ENIELS_WORDS / 4; v++) {
+      const uint4 x3 = slot[v * 64], x4 = slot[(ENIELS_WORDS / 4 + v) * 64];
+      sel[4 * v] = and_or(x3.x, m3, and_or(x4.x, m4, sel[4 * v]));
+      sel[4 * v + 1] = and_or(x3.y, m3, and_or(x4.y, m4, sel[4 * v + 1]));
+      sel[4 * v + 2] = and_or(x3.z, m3, and_or(x4.z, m4, sel[4 * v + 2]));
+      sel[4 * v + 3] = and_or(x3.w, m3, and_or(x4.w, m4, sel[4 * v + 3]));
+    }
+    ENiels e;
+    _Pragma("unroll") for (int l = 0; l < NL; l++) { e.vpu.l[l] = sel[l]; e.vmu.l[l] = sel[NL + l]; e.z2.l[l] = sel[2 * NL + l]; e.t2d.l[l] = sel[3 * NL + l]; }
+    acc = Curve::add_signed<true>(acc, e, sgn);
+  }
+  return acc;
+}
+#ifdef JJ_KERNELS_BATCH
+__global__ void __launch_bounds__(256, 2) k_varbase_ct3(size_t n, const void* scalars, const void* points, SoA ext) {
+  extern __shared__ __attribute__((aligned(16))) uint4 ct3_lds[];
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // the wave's region: CT3_LDS_WORDS_PER_LANE / 4 pieces of 64 lanes x 16 bytes; lane L owns piece v at [v * 64 + L]
+  uint4* slot = ct3_lds + (size_t)(threadIdx.x >> 6) * (CT3_LDS_WORDS_PER_LANE / 4) * 64 + (threadIdx.x & 63u);
+  if (i >= n) return;
+  u32 k[8];
+  load8(k, scalars, i);
+  const Affine P = load_affine(points, i);
+  const Ext r = varbase_ct3(P, k, slot, ext.base + i, ext.n);     // (k' is parked in the unit's limbs 0..7 of the U coordinate until the result lands there)
+  ext.put(0, i, r.u); ext.put(1, i, r.v); ext.put(2, i, r.z);
+}
+#endif  // JJ_KERNELS_BATCH
+
 // ------------------------------------------------------------------------------------------------ K4: fixed-base
 // Signed 6-bit windows: k = sum_{i<42} d_i 64^i + d_42 64^42, d_i in [-32,31], d_42 in {0,1} (k' = k + 0x820820..).
 // Table[i][j] = j * 64^i * B as AffineNiels (27 limbs + 1 pad = 112 B), i < 42, j <= 32 (j = 0: the identity entry, so
@@ -1223,6 +1310,85 @@ static JJ_DEV Ext varbase_windowed_quad(const Affine& P, u32 (&k)[8], u32* slot,
   }
   return acc;
 }
+// The constant-time ladder for small batches: one scalar multiplication per QUAD of lanes, signed 3-bit windows as k_varbase_ct3.  In a quad
+// addition lane r multiplies ONE coordinate of the table entry (lane 0: v-u or v+u, lane 1: the other one, lane 2: 2d T, lane 3: 2Z), so every lane
+// keeps just that coordinate of {P, 2P, 3P, 4P} -- for an addition and for a subtraction: 8 x 9 registers, no table in memory or LDS -- and picks
+// with bit masks.  84 windows x (3 doublings + 1 addition) x 2 multiplication rounds; no load, store, branch or address depends on the scalar.
+static JJ_DEV Ext varbase_ct3_quad(const Affine& P, u32 (&k)[8], u32 role) {
+  Fe pos[4], neg[4];                                           // this lane's coordinate of j P (j = 1 .. 4) for +j P / -j P
+  auto keep = [&](int j, const Ext& e, const Fe& T) {
+    const Fe vpu = Fq::carry(Fq::add(e.v, e.u)), vmu = Fq::sub(e.v, e.u), z2 = Fq::add(e.z, e.z), t2d = Fq::mul(T, Fq::konst(FqP::D2));
+    pos[j] = role_select4(vmu, vpu, t2d, z2, role);
+    neg[j] = role_select4(vpu, vmu, t2d, z2, role);
+  };
+  const Ext p1 = Curve::from_affine(P);
+  const Fe T1 = Fq::mul(P.u, P.v);
+  keep(0, p1, T1);
+  ENiels e1;
+  e1.vpu = Fq::carry(Fq::add(p1.v, p1.u)); e1.vmu = Fq::sub(p1.v, p1.u); e1.z2 = Fq::add(p1.z, p1.z); e1.t2d = Fq::mul(T1, Fq::konst(FqP::D2));
+  Fe T2, T3, T4;
+  const Ext p2 = quad_dbl_t(p1, role, T2);
+  keep(1, p2, T2);
+  const Ext p3 = quad_add_eniels(p2, T2, e1, 0u, role, T3);
+  keep(2, p3, T3);
+  const Ext p4 = quad_dbl_t(p2, role, T4);
+  keep(3, p4, T4);
+  // the identity entry as this lane sees it: 1, 1, 0, 2
+  const Fe one = Fq::one();
+  const Fe idn = role_select4(one, one, Fq::zero(), Fq::add(one, one), role);
+  k[7] &= 0x0fffffffu;
+  {
+    constexpr u32 RC[8] = {0x24924924u, 0x49249249u, 0x92492492u, 0x24924924u, 0x49249249u, 0x92492492u, 0x24924924u, 0x09249249u};
+    u64 cy = 0;
+    _Pragma("unroll") for (int j = 0; j < 8; j++) { const u64 t = (u64)k[j] + RC[j] + cy; k[j] = (u32)t; cy = t >> 32; }
+  }
+  const u32 top = 0u - ((k[7] >> 28) & 1u);                    // bit 252: the carry window, 0 or 1 -> the ladder starts from O or P
+  const Ext idp = Curve::identity();
+  Ext acc;
+  acc.u = Fq::select(idp.u, p1.u, top); acc.v = Fq::select(idp.v, p1.v, top); acc.z = Fq::select(idp.z, p1.z, top);
+  acc.t1 = Fq::select(idp.t1, p1.t1, top); acc.t2 = Fq::select(idp.t2, p1.t2, top);
+  Fe T = Fq::select(Fq::zero(), T1, top);
+  u32 ks[8];
+  _Pragma("unroll") for (int q = 7; q >= 1; q--) ks[q] = (k[q] << 4) | (k[q - 1] >> 28);
+  ks[0] = k[0] << 4;
+  #pragma unroll 1
+  for (int i = CT3_NWIN - 1; i >= 0; i--) {
+    const int d = (int)(ks[7] >> 29) - 4;
+    _Pragma("unroll") for (int q = 7; q >= 1; q--) ks[q] = (ks[q] << 3) | (ks[q - 1] >> 29);
+    ks[0] <<= 3;
+    const u32 sgn = (u32)(d >> 31);
+    const u32 a = ((u32)d ^ sgn) - sgn;
+    u32 m4 = 0u - (a >> 2), m3 = 0u - ((a >> 1) & a & 1u), m2 = 0u - ((a >> 1) & ~a & 1u), m1 = 0u - (a & ~(a >> 1) & 1u);
+    asm("" : "+v"(m1), "+v"(m2), "+v"(m3), "+v"(m4));
+    const u32 m0 = ~(m1 | m2 | m3 | m4);
+    acc = quad_dbl(acc, role);
+    acc = quad_dbl(acc, role);
+    acc = quad_dbl_t(acc, role, T);
+    Fe op;
+    _Pragma("unroll") for (int l = 0; l < NL; l++) {
+      const u32 pp = and_or(pos[0].l[l], m1, and_or(pos[1].l[l], m2, and_or(pos[2].l[l], m3, and_or(pos[3].l[l], m4, idn.l[l] & m0))));
+      const u32 nn = and_or(neg[0].l[l], m1, and_or(neg[1].l[l], m2, and_or(neg[2].l[l], m3, and_or(neg[3].l[l], m4, idn.l[l] & m0))));
+      op.l[l] = (nn & sgn) | (pp & ~sgn);
+    }
+    // quad_add_eniels with this lane's operand already picked: round 1 a, b, c = T * 2dT', d = Z * 2Z'; round 2 U, V, Z, T
+    const Fe r1 = Fq::mul(role_select4(Fq::sub(acc.v, acc.u), Fq::add(acc.v, acc.u), T, acc.z, role), op);
+    const Fe ra = quad_bcast<0>(r1), rb = quad_bcast<1>(r1), rc = Fq::cneg(quad_bcast<2>(r1), sgn), rd = quad_bcast<3>(r1);
+    acc = quad_add_finish(ra, rb, rc, rd, role, T);
+  }
+  return acc;
+}
+#ifdef JJ_KERNELS_BATCH
+__global__ void __launch_bounds__(256) k_varbase_ct_quad(size_t n, const void* scalars, const void* points, SoA ext) {
+  const size_t q = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  const u32 role = threadIdx.x & 3u;
+  if (q >= n) return;                                       // whole quads leave together
+  u32 k[8];
+  load8(k, scalars, q);
+  const Affine P = load_affine(points, q);
+  const Ext r = varbase_ct3_quad(P, k, role);
+  if (role == 0) { ext.put(0, q, r.u); ext.put(1, q, r.v); ext.put(2, q, r.z); }
+}
+#endif  // JJ_KERNELS_BATCH
 #ifdef JJ_KERNELS_BATCH
 template <bool FIVE>
 __global__ void __launch_bounds__(256) k_varbase_quad(size_t n, const void* scalars, const void* points, u32* tables, SoA ext) {

@@ -373,6 +373,8 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
   if (const char* e = getenv("JJ_MSM_REDUCE_L2_CHUNK")) { int v = atoi(e); if (v >= 2 && v <= 64 && (v & (v - 1)) == 0) c->msm_l2_chunk = v; }
   if (const char* e = getenv("JJ_MSM_SORT")) c->msm_two_pass = !strcmp(e, "2pass") ? 1 : (!strcmp(e, "1pass") ? 0 : -1);
   if (const char* e = getenv("JJ_MSM_PASS_LOG2")) { int v = atoi(e); if (v >= 10 && v <= 24) c->msm_pass_log2 = v; }
+  if (const char* e = getenv("JJ_VARBASE_DEFAULT")) c->vb_default_ct = strcmp(e, "vartime") != 0;
+  if (const char* e = getenv("JJ_VB_CT_WINDOW")) { int v = atoi(e); if (v == 2 || v == 3) c->vb_ct_window = v; }
   if (const char* e = getenv("JJ_VB_QUAD_MAX")) { int v = atoi(e); if (v >= 0 && v <= (1 << 20)) c->vb_quad_max = v; }
   if (const char* e = getenv("JJ_FB_GATHER_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) c->fb_gather_blocks_per_cu = v; }
   if (const char* e = getenv("JJ_VB_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) c->vb_blocks_per_cu = v; }

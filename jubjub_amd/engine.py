@@ -304,8 +304,15 @@ class Engine:
         return self._call("jj_varbase_mul", [scalars, points], [32, 64], [64], out=out)
 
     def varbase_mul_ct(self, scalars, points):
-        """constant-time ladder for secret scalars (jj_varbase_mul_ct): no scalar-dependent address or branch"""
+        """the constant-time ladder under the name rounds 3-4 gave it (jj_varbase_mul_ct): what varbase_mul runs by default since round 5"""
         return self._call("jj_varbase_mul_ct", [scalars, points], [32, 64], [64])
+
+    def varbase_mul_vartime(self, scalars, points, out=None):
+        """variable-time ladder for PUBLIC scalars (jj_varbase_mul_vartime): per-lane window table in memory, digit-dependent addresses"""
+        return self._call("jj_varbase_mul_vartime", [scalars, points], [32, 64], [64], out=out)
+
+    def varbase_mul_vartime_compressed(self, scalars, points, out=None):
+        return self._call("jj_varbase_mul_vartime_compressed", [scalars, points], [32, 64], [32], out=out)
 
     def varbase_mul_scalar(self, scalar, points):
         """points[i] * scalar for one 32-byte scalar (numpy or torch), every point of the batch."""

@@ -149,6 +149,7 @@ def test_varbase_edges(eng, golden):
             Pn.append(p)
     S, Pn = np.stack(S), np.stack(Pn)
     assert (eng.varbase_mul(S, Pn) == O.varbase_mul(S, Pn)).all()
+    assert (eng.varbase_mul_vartime(S, Pn) == O.varbase_mul(S, Pn)).all()          # the table ladder for public scalars
 
 
 def test_varbase_per_lane_and_per_quad_kernels(golden, monkeypatch):
@@ -165,16 +166,28 @@ def test_varbase_per_lane_and_per_quad_kernels(golden, monkeypatch):
     for quad_max in ("0", "1048576"):
         monkeypatch.setenv("JJ_VB_QUAD_MAX", quad_max)
         e2 = Engine(0)
-        assert (e2.varbase_mul(S, Pn) == want).all(), quad_max
+        assert (e2.varbase_mul(S, Pn) == want).all(), quad_max                     # constant-time: k_varbase_ct3 / k_varbase_ct_quad
+        assert (e2.varbase_mul_vartime(S, Pn) == want).all(), quad_max             # table ladder: k_varbase / k_varbase_quad
+        assert (e2.varbase_mul_vartime_compressed(S, Pn) == O.compress(want)).all(), quad_max
         for m in (1, 3, 15, 16, 17, 63, 64, 65, 255, 257):
             assert (e2.varbase_mul(S[:m], Pn[:m]) == want[:m]).all(), (quad_max, m)
+            assert (e2.varbase_mul_vartime(S[:m], Pn[:m]) == want[:m]).all(), (quad_max, m)
         e2.close()
 
 
-def test_varbase_constant_time_ladder(eng, golden):
-    """jj_varbase_mul_ct (table {P, 2P} in registers, signed 2-bit windows, mask selects: no scalar-dependent address or branch, the
-    reference's conditional_select discipline, src/lib.rs:334-343, 357-379): every edge scalar on random / torsion / generator /
-    identity points, random inputs, ragged and empty batches -- the same points as the default ladder and the oracle."""
+@pytest.mark.parametrize("window,quad_max", [("3", "0"), ("3", "32768"), ("2", "0")])
+def test_varbase_constant_time_ladder(golden, monkeypatch, window, quad_max):
+    """jj_varbase_mul_ct: no scalar-dependent address or branch, the reference's conditional_select discipline (src/lib.rs:334-343,
+    357-379).  Signed 3-bit windows (default; table {P, 2P} in registers, {3P, 4P} in a per-lane LDS slot that is read whole for every
+    window, mask selects) and signed 2-bit windows (JJ_VB_CT_WINDOW=2: {P, 2P} in registers alone): every edge scalar on random /
+    torsion / generator / identity points, random inputs, ragged and empty batches, digit patterns that put every window value into
+    every position class -- the same points as the table ladder and the oracle.  quad_max 32768: the batch runs one scalar
+    multiplication per quad of lanes (k_varbase_ct_quad: every lane keeps its own coordinate of {P .. 4P} in registers); 0: one per lane."""
+    from jubjub_amd import Engine
+
+    monkeypatch.setenv("JJ_VB_CT_WINDOW", window)
+    monkeypatch.setenv("JJ_VB_QUAD_MAX", quad_max)
+    eng = Engine(0)
     pts = np.concatenate([rand_points(3, 8), torsion_points(golden), arr64([J.GENERATOR, J.AFFINE_IDENTITY])])
     S = np.stack([b32(k) for k in EDGE_SCALARS for _ in pts])
     Pn = np.stack([p for _ in EDGE_SCALARS for p in pts])
@@ -183,13 +196,17 @@ def test_varbase_constant_time_ladder(eng, golden):
     want = O.varbase_mul(S, Pn)
     got = eng.varbase_mul_ct(S, Pn)
     assert (got == want).all()
-    assert (got == eng.varbase_mul(S, Pn)).all()
+    assert (got == eng.varbase_mul(S, Pn)).all() and (got == eng.varbase_mul_vartime(S, Pn)).all()
     for m in (0, 1, 63, 64, 65, 257):
         assert (eng.varbase_mul_ct(S[:m], Pn[:m]) == want[:m]).all(), m
     # two-bit patterns: every window value in every position class
     pat = arr32([int(d * 64, 4) & ((1 << 252) - 1) for d in "0123"] + [int("0123" * 16, 4), int("3210" * 16, 4), int("2" * 63, 4) * 4 + 3])
+    # three-bit patterns: every octal digit everywhere, rising / falling runs (carries of the signed recoding through whole runs of 3s and 4s)
+    pat = np.concatenate([pat, arr32([int(d * 84, 8) & ((1 << 252) - 1) for d in "01234567"] + [int("01234567" * 10 + "0123", 8), int("76543210" * 10 + "7654", 8) & ((1 << 252) - 1),
+                                                                                               int("34" * 42, 8), int("43" * 42, 8) & ((1 << 252) - 1)])])
     Pq = rand_points(153, len(pat))
     assert (eng.varbase_mul_ct(pat, Pq) == O.varbase_mul(pat, Pq)).all()
+    eng.close()
 
 
 def test_varbase_random(eng):

@@ -39,9 +39,9 @@ if d:
         print("default.fixed_base      %.1f M/s  kernel %.3f ms  frac %.3f  verified %s" % (fb["value"] / 1e6, fb["kernel_ms"], fb["roofline_frac"], fb.get("verified")))
     if fw:
         print("default.wide_window     %.1f M/s  verified %s" % (fw["value"] / 1e6, fw.get("verified")))
-    ct = d.get("varbase_constant_time")
+    ct = d.get("varbase_vartime") or d.get("varbase_constant_time")      # round 5: the default IS the constant-time ladder, the side measurement the table ladder
     if ct:
-        print("default.constant_time   %.1f M/s  kernel %.3f ms  frac %.3f  x%.3f of the default ladder  verified %s  equal on all units %s" % (
+        print("default.%s   %.1f M/s  kernel %.3f ms  frac %.3f  x%.3f of the default ladder  verified %s  equal on all units %s" % ("vartime_ladder" if "varbase_vartime" in d else "constant_time",
             ct["value"] / 1e6, ct["kernel_ms"], ct["roofline_frac"], ct["relative_to_default"], ct.get("verified"), ct.get("equals_default_ladder_all_units")))
     print("default.frac_min        %.4f (fastest dispatch), frac %.4f" % (d["roofline"].get("frac_min") or 0, d["roofline"]["frac"]))
     if cb:
