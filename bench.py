@@ -145,7 +145,7 @@ def parse():
     ap.add_argument("--msm-async", type=int, default=1, help="N = 1 MSM workload: jobs in flight per context (1 = synchronous jj_msm calls)")
     ap.add_argument("--msm-contexts", type=int, default=1, help="N = 1 MSM workload: contexts (each with its own stream and workspaces) driven by as many host threads on the one GPU: "
                     "the latency-bound tails of one MSM overlap the sort / accumulation of another")
-    ap.add_argument("--host-buffers", default=None, choices=["pageable", "pinned", "fresh"],
+    ap.add_argument("--host-buffers", default=None, choices=["pageable", "pinned", "fresh", "pooled"],
                     help="time the C-ABI call on HOST arrays (the path a drop-in caller takes) instead of device-resident tensors: pinned = page-locked "
                          "buffers from jj_host_alloc, pageable = plain numpy memory (page-locked in place by every call); inputs and result buffers are "
                          "allocated once and reused; fresh = pageable inputs and a NEWLY ALLOCATED pageable result array on every call (what a caller that "
@@ -451,7 +451,7 @@ def run(a):
         rccl_comm = RcclComm(rank, world)          # this process's own communicator; the ncclUniqueId travels over torch.distributed
         eng.set_comm(rccl_comm)
     host = a.host_buffers
-    if host and (distributed or (wl == "msm" and (host == "fresh" or a.msm_async > 1 or a.msm_contexts > 1))):
+    if host and (distributed or (wl == "msm" and (host in ("fresh", "pooled") or a.msm_async > 1 or a.msm_contexts > 1))):
         if rank == 0:
             print("bench.py: --host-buffers covers one GPU (msm: pinned | pageable, synchronous jj_msm calls: the result is 64 bytes, there is no result array to be fresh)", file=sys.stderr)
         return 2
@@ -468,11 +468,16 @@ def run(a):
         h_scalars = to_host(scalars) if wl in ("varbase", "fixedbase", "msm") else None
         h_points = to_host(points) if wl in ("varbase", "msm") else None
         h_enc = to_host(enc) if wl == "decompress" else None
-        h_out = halloc((n, out_w) if wl != "msm" else (64,))
-        h_ok = halloc((n,)) if wl == "decompress" else None
-        h_out[...] = 0                                            # touched once (a fresh pageable result buffer would be faulted in inside the first call)
-        if h_ok is not None:
-            h_ok[...] = 0
+        if host == "pooled":
+            # the caller returns a NEW result object per call (-> Vec): result buffers come from the library's pool (jj_result_acquire), the previous
+            # call's buffer is given back only AFTER the next one was acquired, so consecutive calls never write into the same object
+            h_out, h_ok = None, None
+        else:
+            h_out = halloc((n, out_w) if wl != "msm" else (64,))
+            h_ok = halloc((n,)) if wl == "decompress" else None
+            h_out[...] = 0                                            # touched once (a fresh pageable result buffer would be faulted in inside the first call)
+            if h_ok is not None:
+                h_ok[...] = 0
 
     def one_pass_device():
         if wl == "varbase":
@@ -491,6 +496,12 @@ def run(a):
             h_out = None; h_ok = None                              # (the previous result array itself is released when the caller drops it: `out = step()`)
             h_out = np.empty((n, out_w), np.uint8)
             h_ok = np.empty((n,), np.uint8) if wl == "decompress" else None
+        if host == "pooled":
+            prev = (h_out, h_ok)
+            h_out = eng.result_acquire((n, out_w))                 # a DIFFERENT buffer than the one the previous call filled (that one is still out)
+            h_ok = eng.result_acquire((n,)) if wl == "decompress" else None
+            assert prev[0] is None or prev[0].ctypes.data != h_out.ctypes.data
+            eng.result_release(prev[0]); eng.result_release(prev[1])    # the caller has consumed (converted / copied) the previous result by now
         if host:
             tc = time.perf_counter()
             if wl == "varbase":
@@ -652,7 +663,8 @@ def run(a):
     if host:
         res["pcie_inclusive"] = True
         res["config"]["host_buffers"] = {"pinned": "page-locked (jj_host_alloc), reused by every pass",
-                                         "pageable": "pageable numpy memory, reused by every pass; every call page-locks them in place (hipHostRegister) and releases them",
+                                         "pageable": "pageable numpy memory, reused by every pass; the chunks pass through the context's page-locked staging slots (bounce path; JJ_PIPE_PAGEABLE=register: arrays that consist of whole pages are page-locked in place instead)",
+                                         "pooled": "inputs: pageable numpy memory, reused; RESULT: a different page-locked buffer from the library's pool for every call (jj_result_acquire; the previous call's buffer is released after the next one was acquired)",
                                          "fresh": "pageable numpy memory; the RESULT array is newly allocated (np.empty) for every call: its pages are faulted in and page-locked inside the call"}[host]
         res["config"]["result_bytes"] = out_w if wl != "msm" else 64
         res["device_resident"] = dev_ref

@@ -73,7 +73,7 @@ int jj_peak_imad32_samples(jj_ctx* ctx, int count, double* out_per_sec);
 
 /* ---- host buffers ---------------------------------------------------------------------------------------------------------
  * A drop-in caller (the Rust shim of INTEGRATION.md, examples/scalar_mul.c) hands HOST arrays to the entry points below.  Large
- * batches (>= 2^19 units) of jj_varbase_mul(_compressed), jj_fixedbase_mul(_compressed) and jj_decompress are then cut into chunks
+ * batches (>= 2^18 units: four chunks of 2^16 and up) of jj_varbase_mul(_compressed), jj_fixedbase_mul(_compressed) and jj_decompress are then cut into chunks
  * that flow over two copy streams while the kernels of the neighbouring chunk run.  That needs PAGE-LOCKED memory:
  *   - memory from jj_host_alloc, or memory registered once with jj_host_register, is used as it is: the copies run straight
  *     from and to it (2^24 fixed-base units: 0.90 of the device-resident rate, profiles/r4_pcie_inclusive.txt);
@@ -81,20 +81,38 @@ int jj_peak_imad32_samples(jj_ctx* ctx, int count, double* out_per_sec);
  *     8, JJ_PIPE_COPY_THREADS) beside the GPU's work: within 2-3 % of the page-locked rates, nothing of the caller's is registered,
  *     and a result array the caller has only just allocated costs no more than its page faults.  The GPU never touches the caller's
  *     pageable pages: arrays of 1 MB and more are not handed to the HIP runtime either (which would page-lock them itself).
- *     JJ_PIPE_PAGEABLE=register selects round 3's way instead for arrays of 64 MB and more (page-locked in place for the call: no
- *     CPU copies, but a freshly allocated 1 GB result array then costs ~65 ms of serial page faults and pinning inside the call);
- *     smaller arrays are staged in that mode too -- they live on the C heap, and page-locking them in place would hand the
- *     neighbouring heap objects' pages to the GPU as well (two GPU write faults in ~3000 randomised test rounds came from that).
+ *     JJ_PIPE_PAGEABLE=register selects round 3's way instead for arrays that consist of whole pages (both ends page-aligned, 1 MB and
+ *     more: page-locked in place for the call: no CPU copies, but a freshly allocated 1 GB result array then costs ~65 ms of serial page
+ *     faults and pinning inside the call); all other arrays are staged in that mode too -- page-locking them in place would hand pages of
+ *     neighbouring objects to the GPU as well (two GPU write faults in ~3000 randomised test rounds followed that).
  * Page-locked buffers that are reused across calls are the fastest arrangement and cost the host no copy threads.
  * These four functions need no context and no HIP headers on the caller's side.  jj_host_alloc: page-locked, visible to every
  * device of the node, *out = NULL for bytes = 0.  jj_host_register: p .. p + bytes must be mapped and stay mapped until
- * jj_host_unregister(p); registering overlapping ranges twice fails with JJ_ERR_INVALID.  p must be page-aligned (JJ_ERR_INVALID
- * otherwise): register mappings of your own (mmap, aligned allocations) -- an array on the C heap shares its first and last page with
- * other heap objects, and page-locking those for the GPU and releasing them again ended in GPU memory faults on later transfers. */
+ * jj_host_unregister(p); registering overlapping ranges twice fails with JJ_ERR_INVALID.  The range must consist of WHOLE PAGES -- p
+ * page-aligned AND bytes a multiple of the page size (JJ_ERR_INVALID otherwise): register mappings of your own (mmap; or a page-aligned
+ * allocation whose length you rounded up to whole pages).  An array on the C heap shares its first and last page with other heap
+ * objects -- so does aligned_alloc(4096, 5000) at its end -- and page-locking those pages for the GPU and releasing them again was
+ * followed by GPU memory faults on later transfers.
+ * HARDWARE QUEUES: HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  A context's host pipeline uses
+ * three streams (plus one per extra MSM lane); beside other streams of the process two of them may share a queue and then serialise (pipelines
+ * 1.7-2x slower, profiles/r4_pcie_inclusive.txt).  Applications that drive host batches beside other HIP work should export
+ * GPU_MAX_HW_QUEUES=8 before the first HIP call; the library does not touch the process environment. */
 int jj_host_alloc(size_t bytes, void** out);
 int jj_host_free(void* p);
 int jj_host_register(void* p, size_t bytes);
 int jj_host_unregister(void* p);
+/* RESULT POOL: page-locked result buffers owned by the context, for callers whose API returns a NEW result per call -- the shape of
+ * every batch function of the reference (`-> Vec<..>`: batch_from_bytes src/lib.rs:541-627, batch_normalize 1084-1107).  A fresh
+ * pageable result array costs its page faults inside the call (2^24 fixed-base units: 195 M/s against 557 with reused page-locked
+ * buffers, profiles/r4_bench_host_*_fresh.json); jj_result_acquire hands out a buffer of at least `bytes` bytes instead (allocated on
+ * first use, recycled afterwards: the smallest free buffer that fits), the entry points recognise it as page-locked memory (copies run
+ * straight into it), and jj_result_release gives it back when the caller has consumed the result -- several buffers may be out at a
+ * time, so every call can return a DIFFERENT result object.  Released buffers are kept while the pool holds at most JJ_RESULT_POOL_MB
+ * (default 4096) megabytes, and freed with the context.  jj_result_release(NULL) is a no-op; a pointer the context did not hand out
+ * is JJ_ERR_INVALID.  Thread-safe per context like every entry point. */
+int jj_result_acquire(jj_ctx*, size_t bytes, void** out);
+int jj_result_release(jj_ctx*, void* p);
+int jj_result_pool_stats(jj_ctx*, size_t* buffers, size_t* bytes, size_t* in_use);
 /* How a host batch is cut -- pure functions of their arguments (no context, no device: the CPU-side tests call them).
  * jj_plan_host_chunks: the chunk boundaries of a pipelined host batch of n >= 1 units with chunks of `chunk` units (what the library
  * picks per entry point or JJ_PIPE_CHUNK_LOG2 sets): chunk k = [bounds[k], bounds[k + 1]), *count = entries of bounds (chunks + 1).

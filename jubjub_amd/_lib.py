@@ -3,10 +3,8 @@ there is no CPU fallback in the product path."""
 import ctypes as C
 import os
 
-# HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue serialise; a context's
-# copy / compute pipeline beside PyTorch's streams needs more (DESIGN.md 5a has the measurements).  Read when the
-# HIP runtime initialises, so it is set at import time, before torch or this library makes the first HIP call; a user's value wins.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues, default 4; applications that drive host batches beside other HIP work export
+# GPU_MAX_HW_QUEUES=8 before the first HIP call -- include/jubjub_hip.h.  Neither the library nor this module touches the process environment.)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("JJ_LIB_PATH") or os.path.join(HERE, "lib", "libjubjub_hip.so")   # JJ_LIB_PATH: A/B builds of the same library
@@ -83,6 +81,7 @@ EXPORTS = sorted(list(_SIGS) + ["jj_ctx_create", "jj_ctx_destroy", "jj_last_erro
                                 "jj_fixedbase_table_create", "jj_fr_char_le_bits", "jj_multi_create", "jj_multi_ctx", "jj_multi_last_error",
                                 "jj_msm_fold_partials", "jj_msm_finish", "jj_msm_combine",
                                 "jj_host_alloc", "jj_host_free", "jj_host_register", "jj_host_unregister",
+                                "jj_result_acquire", "jj_result_release", "jj_result_pool_stats",
                                 "jj_plan_host_chunks", "jj_plan_msm_host_passes"])
 
 _lib = None
@@ -149,6 +148,12 @@ def load():
     lib.jj_msm_combine.argtypes = [C.c_size_t, _vp, _vp]
     lib.jj_host_alloc.restype = C.c_int
     lib.jj_host_alloc.argtypes = [C.c_size_t, C.POINTER(_vp)]
+    lib.jj_result_acquire.restype = C.c_int
+    lib.jj_result_acquire.argtypes = [_vp, C.c_size_t, C.POINTER(_vp)]
+    lib.jj_result_release.restype = C.c_int
+    lib.jj_result_release.argtypes = [_vp, _vp]
+    lib.jj_result_pool_stats.restype = C.c_int
+    lib.jj_result_pool_stats.argtypes = [_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     lib.jj_host_free.restype = C.c_int
     lib.jj_host_free.argtypes = [_vp]
     lib.jj_host_register.restype = C.c_int

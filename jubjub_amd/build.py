@@ -77,5 +77,22 @@ def build(force=False, verbose=False):
     return OUT
 
 
+def build_variant(out, extra_flags, units=("jj_abi",)):
+    """A/B build for experiments (JJ_LIB_PATH=<out> selects it): `units` recompiled with extra flags, the other objects taken from the regular build."""
+    build()
+    cc = hipcc()
+    objs = []
+    for u in UNITS:
+        if u in units:
+            o = os.path.join(OBJ, "%s.variant.%s.o" % (u, os.path.basename(out)))
+            subprocess.check_call([cc] + flags() + list(extra_flags) + ["-c", "-o", o, os.path.join(CSRC, u + ".hip")])
+            objs.append(o)
+        else:
+            objs.append(_obj(u))
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    subprocess.check_call([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))

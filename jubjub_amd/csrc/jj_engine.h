@@ -211,6 +211,12 @@ struct jj_ctx {
   DevBuf gather_dev; uint8_t* gather_host = nullptr; size_t gather_host_cap = 0;
   bool msm_fold_dev = true;      // gathered records are folded window by window on the device before ONE record goes to the host tail (JJ_MSM_FOLD=host: every record is copied and the host adds them)
   int msm_fold_min = 8;          // ... from this many records (JJ_MSM_FOLD_MIN, 2..4096): at 8 the two paths cost the same (57 us per call, profiles/r5_msm_partition_cost.txt), beyond it the host path grows by ~2.3 us per record while the fold stays put
+  // result pool (jj_result_acquire / _release): page-locked result buffers owned by the context, handed out and taken back, so that a caller whose API
+  // returns a NEW result per call (every batch function of the reference: `-> Vec<..>`, src/lib.rs:541-627, 1084-1107) pays neither the page faults of a
+  // fresh array nor a registration per call
+  struct PoolBuf { uint8_t* p; size_t cap; bool in_use; };
+  std::vector<PoolBuf> result_pool;
+  size_t result_pool_keep = (size_t)4 << 30;      // released buffers are kept for reuse while the pool holds at most this many bytes (JJ_RESULT_POOL_MB)
   bool profile = false;
   struct Rec { hipEvent_t e0, e1, e2; };
   std::vector<Rec> recs;
@@ -241,10 +247,11 @@ constexpr size_t BOUNCE_MIN_BYTES = (size_t)16 << 20;     // one staging slot
 // pipelined entry points only).  Smaller arrays go through the runtime's staging buffer, which does not page-lock them either.
 constexpr size_t BOUNCE_THRESHOLD = (size_t)1 << 20;
 // The library page-locks CALLER memory itself in two places only -- JJ_PIPE_PAGEABLE=register and the whole-batch registration of jj_multi_*
-// -- and only arrays of 64 MB and more: those are mappings of their own (the C library's mmap threshold never exceeds 32 MB), while smaller
-// arrays sit on the C heap between other objects, whose pages a registration would hand to the GPU as well.  Both GPU faults of the soak
-// (above) were writes into heap-sized result arrays (the decoder's `ok` bytes, 256 KB and 1 MB) registered in place.
-constexpr size_t REGISTER_MIN_BYTES = (size_t)64 << 20;
+// -- and only ranges that OWN THEIR PAGES (owns_its_pages: both ends page-aligned; round 4 went by size alone -- 64 MB and more, "above the C
+// library's mmap threshold" -- which holds for glibc malloc only and still shares the first and last page of an unaligned mapping) of at least
+// 1 MB (below that the staging copy is cheaper than the two system calls).  Everything else takes the staging slots.
+constexpr size_t REGISTER_MIN_BYTES = (size_t)1 << 20;
+bool owns_its_pages(const void* p, size_t bytes);
 struct OutRef { void* user; void* dev; size_t bytes; bool host; };
 struct HostIn { const void* p; size_t elem; };
 struct HostOut { void* p; size_t elem; };
@@ -291,14 +298,14 @@ static int run_pipelined(jj_ctx* c, size_t n, size_t CH, const HostIn (&in)[NIN]
   for (int k = 0; k < NIN; k++) pin_in[k] = is_pinned_host(in[k].p, n * in[k].elem);
   for (int k = 0; k < NOUT; k++) pin_out[k] = is_pinned_host(out[k].p, n * out[k].elem);
   if (!c->pipe_bounce) {
-    // JJ_PIPE_PAGEABLE=register: arrays of REGISTER_MIN_BYTES and more are page-locked in place for this call; smaller ones take the staging
-    // slots like in the default mode (see REGISTER_MIN_BYTES)
+    // JJ_PIPE_PAGEABLE=register: arrays that own their pages (both ends page-aligned) are page-locked in place for this call; all others take the
+    // staging slots like in the default mode (see REGISTER_MIN_BYTES)
     for (int k = 0; k < NIN && ok; k++) {
-      if (pin_in[k] || n * in[k].elem < REGISTER_MIN_BYTES) continue;
+      if (pin_in[k] || n * in[k].elem < REGISTER_MIN_BYTES || !owns_its_pages(in[k].p, n * in[k].elem)) continue;
       if (hipHostRegister(const_cast<void*>(in[k].p), n * in[k].elem, hipHostRegisterDefault) == hipSuccess) { locked[nlocked++] = const_cast<void*>(in[k].p); pin_in[k] = true; } else ok = false;
     }
     for (int k = 0; k < NOUT && ok; k++) {
-      if (pin_out[k] || n * out[k].elem < REGISTER_MIN_BYTES) continue;
+      if (pin_out[k] || n * out[k].elem < REGISTER_MIN_BYTES || !owns_its_pages(out[k].p, n * out[k].elem)) continue;
       if (c->pipe_prefault) prefault_parallel(out[k].p, n * out[k].elem);
       if (hipHostRegister(out[k].p, n * out[k].elem, hipHostRegisterDefault) == hipSuccess) { locked[nlocked++] = out[k].p; pin_out[k] = true; } else ok = false;
     }

@@ -856,6 +856,12 @@ __global__ void __launch_bounds__(FBC_THREADS) k_fixedbase_comb(size_t n, const 
     };
     auto fetch = [&](int tab, u32 j) -> ANiels {
       const u32* tb = lds + (size_t)tab * FBC_TENT * ANIELS_WORDS;
+#if defined(JJ_EXPERIMENTS) && defined(JJ_FBC_PROBE)
+      // WRONG results, probe builds only (tools/fixedbase_floor.sh): what the comb costs without its select (1: the lane's own staged entry) and with
+      // one shuffle round instead of two (2: the low half of the table only)
+      if (JJ_FBC_PROBE == 1) return lds_aniels(tb + (size_t)lane * ANIELS_WORDS);
+      if (JJ_FBC_PROBE == 2) return bperm(lds_aniels(tb + (size_t)lane * ANIELS_WORDS), j);
+#endif
       if constexpr (CT) {
         const ANiels lo = bperm(lds_aniels(tb + (size_t)lane * ANIELS_WORDS), j);
         return Curve::select(lo, bperm(lds_aniels(tb + (size_t)(64 + lane) * ANIELS_WORDS), j), 0u - (j >> 6));

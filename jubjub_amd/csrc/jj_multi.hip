@@ -63,7 +63,7 @@ static int multi_run(jj_multi* m, size_t n, Body body) {
 struct MultiPin {
   std::vector<void*> locked;
   void add(const void* p, size_t bytes) {
-    if (!p || bytes < REGISTER_MIN_BYTES || is_pinned_host(p, bytes)) return;         // smaller arrays: through each context's staging slots
+    if (!p || bytes < REGISTER_MIN_BYTES || !owns_its_pages(p, bytes) || is_pinned_host(p, bytes)) return;         // arrays that share pages with other objects, and small ones: through each context's staging slots
     if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) == hipSuccess) locked.push_back(const_cast<void*>(p));
     else (void)hipGetLastError();                                                    // not fatal: the shards fall back to staging
   }

@@ -275,9 +275,8 @@ int dev_to_host_bounced(jj_ctx* c, void* host, const void* dev, size_t bytes) {
 // buffer pipeline (compute, copy in, copy out) and one more per extra MSM lane; beside PyTorch's or the caller's own streams that
 // exceeds four, and two streams that share a hardware queue serialise -- measured: jj_multi_* with a second context in the process
 // 268 -> 523 M fixed-base scalar-muls/s, a fourth pipeline stream 316 -> 520 M/s (profiles/r4_pcie_inclusive.txt).  The runtime reads
-// the variable when it initialises (first HIP call), so setting it here works whenever this library is loaded before that; a value
-// the user has set is left alone.
-__attribute__((constructor)) static void jj_default_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// the variable when it initialises (first HIP call).  It is the APPLICATION's to set (bench.py does): rounds 3-4 set it
+// from a load-time constructor here, which changed the HIP configuration of the whole host process behind its back.
 
 // ---------------------------------------------------------------------------------------------------- host buffers
 // Page-locked host memory for callers that do not link HIP themselves (include/jubjub_hip.h).  The entry points recognise such
@@ -298,11 +297,18 @@ JJ_API int jj_host_free(void* p) {
   if (hipHostFree(p) != hipSuccess) { (void)hipGetLastError(); return JJ_ERR_INVALID; }
   return JJ_OK;
 }
+// [p, p + bytes) consists of whole pages: both ends page-aligned.  Only such a range can be page-locked for the GPU without handing it pages that
+// belong to other objects of the process (the first and last page of an unaligned range do).
+bool owns_its_pages(const void* p, size_t bytes) {
+  const uintptr_t pg = (uintptr_t)sysconf(_SC_PAGESIZE);
+  return p && bytes && ((uintptr_t)p & (pg - 1)) == 0 && (bytes & (pg - 1)) == 0;
+}
 JJ_API int jj_host_register(void* p, size_t bytes) {
   if (!p || !bytes) return JJ_ERR_INVALID;
-  // a page-aligned start: the buffer owns the pages it is on (see REGISTER_MIN_BYTES: page-locking C-heap arrays in place hands the
-  // neighbouring objects' pages to the GPU and ended in GPU memory faults)
-  if ((uintptr_t)p & ((uintptr_t)sysconf(_SC_PAGESIZE) - 1)) return JJ_ERR_INVALID;
+  // whole pages only (both ends page-aligned): the buffer owns every page it touches.  An aligned start alone is not enough -- aligned_alloc(4096, 5000)
+  // shares its LAST page with the next heap object -- and page-locking pages that belong to neighbouring objects, then releasing them,
+  // is what the GPU memory faults of round 4 followed (experiments/hsa_stale_mapping/).
+  if (!owns_its_pages(p, bytes)) return JJ_ERR_INVALID;
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); return JJ_ERR_NODEVICE; }
   const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterPortable);
@@ -312,6 +318,55 @@ JJ_API int jj_host_register(void* p, size_t bytes) {
 JJ_API int jj_host_unregister(void* p) {
   if (!p) return JJ_ERR_INVALID;
   if (hipHostUnregister(p) != hipSuccess) { (void)hipGetLastError(); return JJ_ERR_INVALID; }
+  return JJ_OK;
+}
+
+// ---- result pool: library-owned page-locked result buffers (include/jubjub_hip.h)
+JJ_API int jj_result_acquire(jj_ctx* c, size_t bytes, void** out) {
+  if (!c || !out) return JJ_ERR_INVALID;
+  *out = nullptr;
+  if (bytes == 0) return JJ_OK;
+  JJ_ENTER(c);
+  int best = -1;
+  for (size_t i = 0; i < c->result_pool.size(); i++) {           // the smallest free buffer that is large enough (and not more than twice too large)
+    const auto& b = c->result_pool[i];
+    if (!b.in_use && b.cap >= bytes && b.cap <= 2 * bytes + ((size_t)2 << 20) && (best < 0 || b.cap < c->result_pool[best].cap)) best = (int)i;
+  }
+  if (best >= 0) { c->result_pool[best].in_use = true; *out = c->result_pool[best].p; return JJ_OK; }
+  const size_t cap = (bytes + (((size_t)2 << 20) - 1)) & ~(((size_t)2 << 20) - 1);          // whole 2 MB
+  uint8_t* p = nullptr;
+  if (hipHostMalloc((void**)&p, cap, hipHostMallocPortable) != hipSuccess) {
+    (void)hipGetLastError();
+    // make room: drop the free buffers, try once more
+    for (size_t i = 0; i < c->result_pool.size();) { if (!c->result_pool[i].in_use) { (void)hipHostFree(c->result_pool[i].p); c->result_pool.erase(c->result_pool.begin() + i); } else i++; }
+    if (hipHostMalloc((void**)&p, cap, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); c->err = "jj_result_acquire: hipHostMalloc failed"; return JJ_ERR_NOMEM; }
+  }
+  c->result_pool.push_back({p, cap, true});
+  *out = p;
+  return JJ_OK;
+}
+JJ_API int jj_result_release(jj_ctx* c, void* p) {
+  if (!c) return JJ_ERR_INVALID;
+  if (!p) return JJ_OK;
+  JJ_ENTER(c);
+  size_t held = 0;
+  int at = -1;
+  for (size_t i = 0; i < c->result_pool.size(); i++) { held += c->result_pool[i].cap; if (c->result_pool[i].p == p && c->result_pool[i].in_use) at = (int)i; }
+  if (at < 0) { c->err = "jj_result_release: not a buffer this context handed out (or released twice)"; return JJ_ERR_INVALID; }
+  // copies into the buffer were waited for by the call that produced them; a buffer the caller passed as an INPUT to a call that is still queued must
+  // not be released before jj_ctx_sync
+  if (held > c->result_pool_keep) { (void)hipHostFree(c->result_pool[at].p); c->result_pool.erase(c->result_pool.begin() + at); }
+  else c->result_pool[at].in_use = false;
+  return JJ_OK;
+}
+JJ_API int jj_result_pool_stats(jj_ctx* c, size_t* buffers, size_t* bytes, size_t* in_use) {
+  if (!c) return JJ_ERR_INVALID;
+  JJ_ENTER(c);
+  size_t nb = 0, by = 0, iu = 0;
+  for (const auto& b : c->result_pool) { nb++; by += b.cap; iu += b.in_use ? 1 : 0; }
+  if (buffers) *buffers = nb;
+  if (bytes) *bytes = by;
+  if (in_use) *in_use = iu;
   return JJ_OK;
 }
 
@@ -353,6 +408,7 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
   c->stream = c->own_stream;
   if (const char* e = getenv("JJ_DEC_C_MID")) { int v = atoi(e); if (v == 8 || v == 16) c->dec_c_mid = v; }
   if (const char* e = getenv("JJ_PIPE_PAGEABLE")) c->pipe_bounce = strcmp(e, "register") != 0;
+  if (const char* e = getenv("JJ_RESULT_POOL_MB")) { long v = atol(e); if (v >= 0 && v <= (1L << 20)) c->result_pool_keep = (size_t)v << 20; }
   if (const char* e = getenv("JJ_PIPE_COPY_THREADS")) { int v = atoi(e); if (v >= 0 && v <= 64) c->pipe_copy_threads = v; }
   if (const char* e = getenv("JJ_PIPE_RAMP")) c->pipe_ramp = atoi(e) != 0;
   if (const char* e = getenv("JJ_PIPE_PREFAULT")) c->pipe_prefault = atoi(e) != 0;
@@ -405,6 +461,7 @@ JJ_API int jj_ctx_destroy(jj_ctx* c) {
   for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
   delete c->copy_pool;
   for (int i = 0; i < 3; i++) { if (c->stage_in[i]) (void)hipHostFree(c->stage_in[i]); if (c->stage_out[i]) (void)hipHostFree(c->stage_out[i]); if (c->ev_stage[i]) (void)hipEventDestroy(c->ev_stage[i]); }
+  for (auto& b : c->result_pool) (void)hipHostFree(b.p);
   if (c->gather_dev.p) (void)hipFree(c->gather_dev.p);
   if (c->gather_host) (void)hipHostFree(c->gather_host);
   if (c->pipe.ready) {

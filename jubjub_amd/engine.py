@@ -148,13 +148,36 @@ class Engine:
         buf._jj_owner = _HostBlock(self._lib, p.value)   # numpy keeps `buf` alive through .base; the block is freed with it
         return np.frombuffer(buf, dtype=np.uint8).reshape(shape)
 
-    def host_register(self, array):
-        """page-locks an existing numpy array once (jj_host_register); pair with host_unregister(array).  The array must start on a page
-        boundary, i.e. be a mapping of its own (np.frombuffer over an anonymous mmap, or host_alloc instead): arrays on the C heap are refused."""
+    def result_acquire(self, shape):
+        """numpy uint8 array over a page-locked result buffer from the context's pool (jj_result_acquire): pass it as `out=`; give it back with
+        result_release(array) when the result has been consumed.  Several may be out at a time: every call can return a different result object."""
+        shape = tuple(shape) if isinstance(shape, (tuple, list)) else (int(shape),)
+        nbytes = int(np.prod(shape, dtype=np.int64))
+        if nbytes == 0:
+            return np.empty(shape, np.uint8)
+        p = C.c_void_p()
+        self._check(self._lib.jj_result_acquire(self._ctx, C.c_size_t(nbytes), C.byref(p)))
+        buf = (C.c_uint8 * nbytes).from_address(p.value)
+        return np.frombuffer(buf, dtype=np.uint8).reshape(shape)
+
+    def result_release(self, array):
+        if array is not None and array.size:
+            self._check(self._lib.jj_result_release(self._ctx, C.c_void_p(array.ctypes.data)))
+
+    def result_pool_stats(self):
+        nb, by, iu = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        self._check(self._lib.jj_result_pool_stats(self._ctx, C.byref(nb), C.byref(by), C.byref(iu)))
+        return {"buffers": nb.value, "bytes": by.value, "in_use": iu.value}
+
+    def host_register(self, array, nbytes=None):
+        """page-locks an existing numpy array once (jj_host_register); pair with host_unregister(array).  The array must consist of whole pages
+        (page-aligned start AND a whole number of pages: np.frombuffer over an anonymous mmap; or host_alloc instead): anything else is refused."""
         a = np.ascontiguousarray(array)
         if a is not array and a.ctypes.data != array.ctypes.data:
             raise ValueError("a contiguous array is required")
-        rc = self._lib.jj_host_register(C.c_void_p(a.ctypes.data), C.c_size_t(a.nbytes))
+        # nbytes: the length of the mapping the array lies at the start of, when that is longer than the array (a mapping is whole pages, an array of
+        # n x 64 bytes usually is not: the caller vouches that [data, data + nbytes) is mapped and its own)
+        rc = self._lib.jj_host_register(C.c_void_p(a.ctypes.data), C.c_size_t(a.nbytes if nbytes is None else int(nbytes)))
         if rc:
             raise JubjubError("jj_host_register failed with %d" % rc)
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised soak of the host-pointer path (include/jubjub_hip.h "host buffers"): random batch sizes around the pipeline's chunk
-boundaries, every array independently page-locked (jj_host_alloc) or pageable, random chunk lengths, bounce / in-place page-locking,
+boundaries, every array independently page-locked (jj_host_alloc), pageable, or -- results -- a buffer of the library's pool (jj_result_acquire), random chunk lengths, bounce / in-place page-locking,
 uniform / ramped chunk schedules, the MSM of the same host arrays in one or several passes -- against the device-resident entry points (bit-exact, all units) and an oracle sample.
 Usage: python tests/soak_host.py [seconds] [seed]   (needs an MI355X)
 SOAK_FORCE_REGISTER=1: every round in JJ_PIPE_PAGEABLE=register mode; SOAK_TRACE=1: one line before every entry point (where a crash happened)."""
@@ -45,9 +45,16 @@ while time.time() < t_end:
         del os.environ[k]
     n = int(rng.choice([(1 << 18) + int(rng.integers(-3, 4)), int(rng.integers(1 << 16, 1 << 21)), (1 << 20) + int(rng.integers(-70000, 70000))]))
 
-    def host(a):
-        if rng.integers(0, 2):
+    pooled = []                                      # result buffers from the library's pool (jj_result_acquire), released at the end of the round
+
+    def host(a, result=False):
+        k = int(rng.integers(0, 3 if result else 2))
+        if k == 1:
             h = eng.host_alloc(a.shape); h[...] = a
+            return h
+        if k == 2:
+            h = eng.result_acquire(a.shape)          # contents are whatever the previous user left: a result buffer is written, never read
+            pooled.append(h)
             return h
         return np.array(a, copy=True)
 
@@ -56,14 +63,14 @@ while time.time() < t_end:
     idx = np.concatenate([rng.integers(0, n, size=300), [0, n - 1]])
     dS, dP = torch.from_numpy(S).cuda(), torch.from_numpy(P).cuda()
     hS, hP = host(S), host(P)
-    out = host(np.zeros((n, 64), np.uint8)) if rng.integers(0, 2) else None            # None: a fresh pageable result array
+    out = host(np.zeros((n, 64), np.uint8), result=True) if rng.integers(0, 2) else None            # None: a fresh pageable result array
     trace = (lambda what: print("  [%d] %s" % (rnd, what), flush=True)) if os.environ.get("SOAK_TRACE") else (lambda what: None)
     trace("varbase n=%d %s" % (n, env))
     got = eng.varbase_mul(hS, hP, out=out)
     assert (got == ref.varbase_mul(dS, dP).cpu().numpy()).all(), ("varbase", rnd, env, n)
     assert (got[idx] == O.varbase_mul(S[idx], P[idx])).all(), ("varbase oracle", rnd)
     tab, rtab = eng.fixedbase_table(base), ref.fixedbase_table(base)
-    out32 = host(np.zeros((n, 32), np.uint8)) if rng.integers(0, 2) else None
+    out32 = host(np.zeros((n, 32), np.uint8), result=True) if rng.integers(0, 2) else None
     trace("fixedbase")
     got = eng.fixedbase_mul_compressed(tab, hS, out=out32)
     assert (got == ref.fixedbase_mul_compressed(rtab, dS).cpu().numpy()).all(), ("fixedbase compressed", rnd, env, n)
@@ -73,7 +80,7 @@ while time.time() < t_end:
     enc[bad] = rng.integers(0, 256, size=(len(bad), 32), dtype=np.uint8)
     flags = int(rng.choice([1, 5, 13, 15]))
     trace("decompress")
-    o1, k1 = eng.decompress(host(enc), flags, out=(host(np.zeros((n, 64), np.uint8)), host(np.zeros((n,), np.uint8))) if rng.integers(0, 2) else None)
+    o1, k1 = eng.decompress(host(enc), flags, out=(host(np.zeros((n, 64), np.uint8), result=True), host(np.zeros((n,), np.uint8), result=True)) if rng.integers(0, 2) else None)
     o2, k2 = ref.decompress(torch.from_numpy(enc).cuda(), flags)
     assert (k1 == k2.cpu().numpy()).all() and (o1 == o2.cpu().numpy()).all(), ("decompress", rnd, env, n, flags)
     eo, ek = O.decompress(enc[idx], flags)
@@ -84,6 +91,10 @@ while time.time() < t_end:
     if rnd % 4 == 0:
         assert (want == O.msm_pippenger(S, P).reshape(64)).all(), ("msm oracle", rnd, n)
     trace("close")
+    if pooled and rng.integers(0, 2):
+        for h in pooled:
+            eng.result_release(h)                    # (otherwise the context frees them with itself)
+        assert eng.result_pool_stats()["in_use"] == 0
     tab.close(); rtab.close(); eng.close()
     units += n; rnd += 1
     print("round %d ok: n=%d %s (%d units so far, %.0f s left)" % (rnd, n, env, units, t_end - time.time()), flush=True)

@@ -114,6 +114,16 @@ def test_host_buffer_api_without_a_gpu():
     buf = (ctypes.c_char * (1 << 16)).from_buffer(m)
     assert lib.jj_host_register(buf, 1 << 16) == _lib.JJ_ERR_NODEVICE
     assert lib.jj_host_register(ctypes.c_void_p(ctypes.addressof(buf) + 64), 1 << 12) == _lib.JJ_ERR_INVALID      # not page-aligned: refused before anything else
+    # a page-aligned START is not enough: 5000 bytes from a 4096-aligned address share their last page with whatever follows
+    assert lib.jj_host_register(buf, 5000) == _lib.JJ_ERR_INVALID
+    libc = ctypes.CDLL(None)
+    libc.aligned_alloc.restype = ctypes.c_void_p
+    libc.aligned_alloc.argtypes = [ctypes.c_size_t, ctypes.c_size_t]
+    pa = libc.aligned_alloc(4096, 8192)
+    assert lib.jj_host_register(ctypes.c_void_p(pa), 5000) == _lib.JJ_ERR_INVALID
+    assert lib.jj_host_register(ctypes.c_void_p(pa), 8192) == _lib.JJ_ERR_NODEVICE       # whole pages: accepted as far as the (absent) device
+    libc.free.argtypes = [ctypes.c_void_p]
+    libc.free(pa)
     del buf
 
 

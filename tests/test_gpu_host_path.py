@@ -51,6 +51,12 @@ def _own_mapping(shape):
     return a
 
 
+def _pages(nbytes):
+    import mmap
+
+    return (max(nbytes, 1) + mmap.PAGESIZE - 1) // mmap.PAGESIZE * mmap.PAGESIZE
+
+
 def _host(eng, kind, a):
     """the array in the requested kind of host memory: 'pinned' (jj_host_alloc), 'registered' (jj_host_register), 'pageable'"""
     if kind == "pinned":
@@ -60,7 +66,7 @@ def _host(eng, kind, a):
     if kind == "registered":
         h = _own_mapping(a.shape)
         h[...] = a
-        eng.host_register(h)
+        eng.host_register(h, nbytes=_pages(h.nbytes))           # whole pages: the anonymous mapping behind h is that long
         return h
     return np.array(a, copy=True)
 
@@ -169,6 +175,7 @@ def test_host_alloc_api(eng):
     off = 16 if heap.ctypes.data % 4096 == 0 else 0
     assert lib.jj_host_register(C.c_void_p(heap.ctypes.data + off), C.c_size_t(1 << 20)) != 0       # not page-aligned: a C-heap array is refused
     a = _own_mapping((1 << 20,))
+    assert lib.jj_host_register(C.c_void_p(a.ctypes.data), C.c_size_t(5000)) != 0                    # a page-aligned start, but not whole pages: refused
     eng.host_register(a)
     eng.host_unregister(a)
     assert lib.jj_host_unregister(C.c_void_p(a.ctypes.data)) != 0            # not registered any more
@@ -376,3 +383,42 @@ def test_msm_host_arrays_more_passes_than_eight(monkeypatch):
     assert (e.msm(hs, hp) == want).all()
     assert (e.msm(torch.from_numpy(s).cuda(), torch.from_numpy(p).cuda()).cpu().numpy() == want).all()      # device-resident: passes of 2^18, no split
     e.close()
+
+
+def test_result_pool(eng):
+    """jj_result_acquire / jj_result_release (the buffers a caller that returns a NEW result per call takes its results in; reference API shape:
+    `-> Vec<..>`, /root/reference/src/lib.rs:541-627, 1084-1107): page-locked (the pipeline copies straight into them), several out at a time and all
+    different, recycled after release (the smallest free buffer that fits), foreign / double releases refused; results equal the device-resident path."""
+    import torch
+
+    n = N_PIPE
+    s, p = _inputs(n, 9100)
+    want = eng.varbase_mul(torch.from_numpy(s).cuda(), torch.from_numpy(p).cuda()).cpu().numpy()
+    a = eng.result_acquire((n, 64))
+    b = eng.result_acquire((n, 64))
+    assert a.ctypes.data != b.ctypes.data and eng.result_pool_stats()["in_use"] >= 2
+    ra = eng.varbase_mul(s, p, out=a)
+    rb = eng.varbase_mul(s, p, out=b)                       # the previous result object is still out: a different one is written
+    assert ra.ctypes.data == a.ctypes.data and (a == want).all() and (b == want).all()
+    addr_a = a.ctypes.data
+    eng.result_release(a)
+    c = eng.result_acquire((n, 64))                         # recycled: the buffer just released
+    assert c.ctypes.data == addr_a
+    small = eng.result_acquire((1000, 32))                  # a much smaller request does not take a 50 MB buffer
+    assert small.ctypes.data not in (addr_a, b.ctypes.data)
+    tab = eng.fixedbase_table(pt64(J.GENERATOR))
+    enc = eng.result_acquire((n, 32))
+    assert (eng.fixedbase_mul_compressed(tab, s, out=enc) == eng.fixedbase_mul_compressed(tab, torch.from_numpy(s).cuda()).cpu().numpy()).all()
+    ok = eng.result_acquire((n,))
+    o1, k1 = eng.decompress(np.array(enc), 13, out=(c, ok))
+    o2, k2 = eng.decompress(torch.from_numpy(np.array(enc)).cuda(), 13)
+    assert (o1 == o2.cpu().numpy()).all() and (k1 == k2.cpu().numpy()).all() and k1.all()
+    tab.close()
+    for h in (b, c, small, enc, ok):
+        eng.result_release(h)
+    assert eng.result_pool_stats()["in_use"] == 0
+    with pytest.raises(Exception):
+        eng.result_release(b)                               # released twice
+    with pytest.raises(Exception):
+        eng.result_release(np.zeros((64,), np.uint8))      # not a pool buffer
+    assert eng.result_acquire((0, 64)).shape == (0, 64)

@@ -1,0 +1,13 @@
+#!/usr/bin/env python3
+"""Builds the two probe libraries tools/fixedbase_floor.sh times (CPU only; they travel to the GPU box with the snapshot):
+   python tools/fixedbase_floor.py build"""
+import os
+import sys
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+from jubjub_amd import build as jb  # noqa: E402
+
+for probe in (1, 2):
+    out = os.path.join(ROOT, "experiments", "probe_lib", "libjj_fbc_probe%d.so" % probe)
+    print(jb.build_variant(out, ["-DJJ_EXPERIMENTS", "-DJJ_FBC_PROBE=%d" % probe]))
