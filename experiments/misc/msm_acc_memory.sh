@@ -14,6 +14,6 @@ PY
   rm -rf gpurun_out/accmem
 }
 for flags in "" "-DJJ_ACC_IDXMASK=1023u" "-DJJ_ACC_DEPTH=2" "-DJJ_ACC_DEPTH=2 -DJJ_ACC_IDXMASK=1023u" ""; do
-  JJ_CXXFLAGS="$flags" python -m jubjub_amd.build --force > /dev/null 2>&1
+  JJ_CXXFLAGS="-DJJ_EXPERIMENTS $flags" python -m jubjub_amd.build --force > /dev/null 2>&1
   echo "== flags: '$flags'"; one
 done

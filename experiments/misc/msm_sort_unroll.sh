@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")/../.."
 export TMPDIR=/tmp
 for U in 4 8 16 2; do
-  JJ_CXXFLAGS="-DJJ_MSM_SORT_UNROLL=$U" python -m jubjub_amd.build --force > /dev/null 2>&1
+  JJ_CXXFLAGS="-DJJ_EXPERIMENTS -DJJ_MSM_SORT_UNROLL=$U" python -m jubjub_amd.build --force > /dev/null 2>&1
   rm -rf /tmp/msu; rocprofv3 --kernel-trace --stats -d /tmp/msu -o m -- python bench.py --workload msm --steps 3 --warmup 1 --no-cpu-baseline --no-verify > /tmp/msu.log 2>&1
   python - "$U" <<'PY'
 import glob, sqlite3, sys, json

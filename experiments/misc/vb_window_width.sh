@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/../.."
 export TMPDIR=/tmp
 for W in 5 4; do
-  JJ_CXXFLAGS="-DJJ_VB_W=$W" python -m jubjub_amd.build --force > /dev/null
+  JJ_CXXFLAGS="-DJJ_EXPERIMENTS -DJJ_VB_W=$W" python -m jubjub_amd.build --force > /dev/null
   echo "== window width $W"
   python bench.py --no-extras --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('   %.2f M scalar-muls/s, k_varbase %.3f ms, verified %s' % (d['value']/1e6, r['kernel_ms'], d['verified']))"
   for C in FETCH_SIZE WRITE_SIZE; do

@@ -288,7 +288,11 @@ static int run_pipelined(jj_ctx* c, size_t n, size_t CH, const HostIn (&in)[NIN]
   for (int k = 0; k < NIN; k++) in_stride += in[k].elem;
   for (int k = 0; k < NOUT; k++) out_stride += out[k].elem;
   int rc = pipe_prepare(c, in_stride * CH, out_stride * CH); if (rc) return rc;
+#ifdef JJ_EXPERIMENTS
   const bool dbg = getenv("JJ_PIPE_DEBUG") != nullptr;
+#else
+  const bool dbg = false;
+#endif
   timespec ts0, ts1, ts2, ts3; clock_gettime(CLOCK_MONOTONIC, &ts0);
   // Memory that is page-locked already (jj_host_alloc / hipHostMalloc, or registered by the caller -- jj_multi_* registers the whole
   // batch once before it cuts it into per-device shards, whose boundaries are not page-aligned) is copied from and to as it is.

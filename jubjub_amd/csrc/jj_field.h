@@ -29,6 +29,14 @@
 //   lazy: limb-wise sums/differences of a few N's; |limb| < 2^31 always
 //   mul/sqr: every 64-bit column accumulator stays inside (-2^63, 2^63):  9 * max|a_i| * max|b_j| + 9 * 2^58 + carry
 #pragma once
+// Tuning and probe macros (window widths, workgroup sizes, register caps, buffering schemes, the probe builds that compute WRONG results on purpose)
+// belong to experiments (experiments/, tools/fixedbase_floor.py): the shipped library is built with the defaults, and a build that overrides one
+// must say so with -DJJ_EXPERIMENTS.
+#if !defined(JJ_EXPERIMENTS) && (defined(JJ_MUL_PIN) || defined(JJ_OPAQUE_MODE) || defined(JJ_VB_MINWAVES) || defined(JJ_VB_W) || defined(JJ_VB_PROBE_SHARED_READS) || \
+    defined(JJ_FB_THREADS) || defined(JJ_FB_SINGLE_BUFFER) || defined(JJ_FBC_THREADS) || defined(JJ_FBC_SINGLE_BUFFER) || defined(JJ_FBC_PROBE) || \
+    defined(JJ_MSM_SORT_UNROLL) || defined(JJ_MSM_P2_THREADS) || defined(JJ_MSM_ACC_MINBLOCKS))
+#error "tuning / probe macros (JJ_VB_W, JJ_FB_THREADS, JJ_FBC_PROBE, ...) need -DJJ_EXPERIMENTS: the shipped library is built with the defaults"
+#endif
 #ifndef JJ_HOST_EMU
 #include <hip/hip_runtime.h>
 #endif
