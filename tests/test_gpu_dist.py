@@ -147,7 +147,7 @@ def test_one_rank_rccl_leg_every_workload(workload, extra):
     assert 0 < res["roofline"]["frac_nominal"] < res["roofline"]["frac_at_peak_min"] * 1.2
 
 
-@pytest.mark.parametrize("kind", ["pinned", "pageable"])
+@pytest.mark.parametrize("kind", ["pinned", "pageable", "pooled"])
 def test_bench_host_buffers_line(kind):
     """--host-buffers: the timed region is the C-ABI call on host arrays; the line carries roofline.pcie and is verified"""
     res = run_bench(["--workload", "fixedbase", "--log2n", "20", "--host-buffers", kind, "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], {})
