@@ -10,7 +10,7 @@ OUT=gpurun_out/${TAG}_pcie_inclusive.txt
 : > $OUT
 line() {  # name, bench args...
   local name=$1; shift
-  python bench.py "$@" --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_bench_host_$name.json 2>/dev/null
+  python bench.py "$@" --steps 5 --warmup 2 --passes $( [[ "$*" == *msm* ]] && echo 8 || echo 4 ) --no-cpu-baseline > gpurun_out/${TAG}_bench_host_$name.json 2>/dev/null
   python - "$name" gpurun_out/${TAG}_bench_host_$name.json >> $OUT <<'PY'
 import json, sys
 d = json.load(open(sys.argv[2])); p = d["roofline"]["pcie"]
@@ -38,6 +38,10 @@ JJ_PIPE_PAGEABLE=register line fixedbase_fresh_register --workload fixedbase --h
 JJ_PIPE_PAGEABLE=register JJ_PIPE_PREFAULT=0 line fixedbase_fresh_register_noprefault --workload fixedbase --host-buffers fresh
 line decompress_fresh --workload decompress --host-buffers fresh
 line varbase_fresh --workload varbase --host-buffers fresh
+# ... and the same caller taking its result buffers from the library's pool (jj_result_acquire / _release, round 5): a DIFFERENT page-locked buffer per call
+line fixedbase_pooled --workload fixedbase --host-buffers pooled
+line decompress_pooled --workload decompress --host-buffers pooled
+line varbase_pooled --workload varbase --host-buffers pooled
 # MSM of host arrays (96 bytes per term in, 64 bytes out): two to eight passes whose copies run beside the previous pass's kernels, and one pass
 # after the whole copy (round 3)
 for hb in pinned pageable; do

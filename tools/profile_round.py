@@ -30,7 +30,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (build_id, WORK)
 
-DOMINANT = {"varbase": "k_varbase<", "fixedbase": "k_fixedbase_comb<", "msm": "k_msm_accumulate_seg", "decompress": "k_decompress<"}
+DOMINANT = {"varbase": "k_varbase_ct3", "fixedbase": "k_fixedbase_comb<", "msm": "k_msm_accumulate_seg", "decompress": "k_decompress<"}
 SQ_SET = "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES"
 
 
@@ -110,7 +110,7 @@ def main():
                "the last (steady-state) dispatch of the dominant kernel in the pass", "workloads": {}}
     for wl in a.workloads.split(","):
         log2n = bench.DEFAULT_LOG2N[wl]
-        args = "--workload %s --steps 3 --warmup 1 --no-cpu-baseline --no-extras" % wl
+        args = "--workload %s --steps 3 --warmup 1 --passes %d --no-cpu-baseline --no-extras" % (wl, {"msm": 32}.get(wl, 4))
         d = os.path.join(scratch, "stats_%s" % wl)
         shutil.rmtree(d, ignore_errors=True)
         cmd = "rocprofv3 --kernel-trace --stats -d %s -o %s -- python bench.py %s" % (d, wl, args)

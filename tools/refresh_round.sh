@@ -2,9 +2,10 @@
 # Runs ON THE GPU BOX (through gpurun): the whole evidence set of a round at one build.
 #   gpurun -- 'bash tools/refresh_round.sh r3'     then locally: bash tools/collect_round.sh r3
 set -e
-TAG=${1:-r4}
+TAG=${1:-r5}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
+export GPU_MAX_HW_QUEUES=8        # the host-buffer pipeline beside torch's streams (include/jubjub_hip.h: the application sets it, not the library)
 mkdir -p gpurun_out
 python tools/profile_round.py --tag $TAG > gpurun_out/${TAG}_profile.log 2>&1
 python bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err
@@ -35,7 +36,7 @@ python experiments/misc/msm_partition_cost.py 20 8 > gpurun_out/${TAG}_msm_parti
 bash tools/pcie_inclusive.sh $TAG > /dev/null 2>&1
 python tools/multi_bench.py > gpurun_out/${TAG}_multi_bench.txt 2>&1
 python tools/msm_dev_finish.py > gpurun_out/${TAG}_msm_dev_finish.txt 2>&1
-bash tools/fixedbase_select_pmc.sh > gpurun_out/${TAG}_fixedbase_select_pmc.txt 2>&1
+bash tools/fixedbase_floor.sh > gpurun_out/${TAG}_fixedbase_select_pmc.txt 2>&1          # round 5: the comb with two / one / no shuffle round (probe libraries built on the CPU: python tools/fixedbase_floor.py build)
 bash tools/stall_pmc.sh > gpurun_out/${TAG}_stall_pmc.txt 2>&1
 [ -x experiments/lds_probe/probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o experiments/lds_probe/probe experiments/lds_probe/probe.hip
 [ -x experiments/lds_probe/energy_probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o experiments/lds_probe/energy_probe experiments/lds_probe/energy_probe.hip
@@ -46,4 +47,8 @@ python bench.py --workload msm > gpurun_out/${TAG}_bench_msm20_cpu.json 2>/dev/n
 for m in auto scalar auto scalar; do JJ_HOST_TAIL=$m python bench.py --workload msm --log2n 17 --steps 10 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('JJ_HOST_TAIL=$m  msm 2^17: %.4f ms per call (kernels %.4f ms), verified %s' % (d['config']['ms_per_pass'], d['roofline']['kernel_ms'], d['verified']))"; done >> gpurun_out/${TAG}_host_tail.txt 2>&1
 timeout 300 python tests/soak_host.py 120 > gpurun_out/${TAG}_soak_host.txt 2>&1 || echo "HOST SOAK FAILED" >> gpurun_out/${TAG}_soak_host.txt
 timeout 600 python tests/soak.py 240 3000 > gpurun_out/${TAG}_soak.txt 2>&1 || echo "SOAK FAILED" >> gpurun_out/${TAG}_soak.txt
+# round 5: constant-time ladder window widths against the table ladder; the two-level bucket reduce's sweep; the stand-alone fault reproducer
+python experiments/misc/vb_ct_window.py > gpurun_out/${TAG}_vb_ct_window.txt 2>&1
+python experiments/misc/msm_reduce_l1_sweep.py 18 19 20 21 22 > gpurun_out/${TAG}_msm_reduce_l1_sweep.txt 2>&1
+(cd experiments/hsa_stale_mapping; [ -x repro ] || /opt/rocm/bin/hipcc -O2 -o repro repro.cpp; for v in 0 1 2 3 4 5; do timeout 200 ./repro $v 3000 2>&1 | tail -1; done) > gpurun_out/${TAG}_hsa_stale_mapping.txt 2>&1
 tail -1 gpurun_out/${TAG}_profile.log

@@ -11,7 +11,7 @@ for wl in varbase fixedbase decompress msm; do
 done
 python - <<'PY'
 import csv, glob
-KER = {"varbase": "k_varbase<", "fixedbase": "k_fixedbase_comb", "decompress": "k_decompress<", "msm": "k_msm_accumulate_seg"}
+KER = {"varbase": "k_varbase_ct3", "fixedbase": "k_fixedbase_comb", "decompress": "k_decompress<", "msm": "k_msm_accumulate_seg"}
 print("# rocprofv3 --kernel-trace --pmc <set> -- python bench.py --workload W --steps 1 --warmup 1 --passes 1 --no-cpu-baseline --no-extras --no-verify   (last dispatch of the named kernel)")
 for wl, ker in KER.items():
     vals = {}
