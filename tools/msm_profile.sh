@@ -8,8 +8,8 @@ R=$PWD
 export TMPDIR=/tmp
 D=$R/gpurun_out/prof_${TAG}_msm$LOG2N
 rm -rf $D
-CMD="python bench.py --workload msm --log2n $LOG2N --steps 3 --warmup 1 --no-cpu-baseline --no-extras"
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $D -o msm -- python $R/bench.py --workload msm --log2n $LOG2N --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $D.log 2>&1)
+CMD="python bench.py --workload msm --log2n $LOG2N --steps 3 --warmup 1 --passes 32 --no-cpu-baseline --no-extras"
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $D -o msm -- python $R/bench.py --workload msm --log2n $LOG2N --steps 3 --warmup 1 --passes 32 --no-cpu-baseline --no-extras > $D.log 2>&1)
 python3 - "$TAG" "$LOG2N" "$D" "$CMD" <<'PY'
 import glob, json, os, sys
 sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
