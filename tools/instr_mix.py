@@ -13,7 +13,7 @@ from gfx_asm import assembly  # noqa: E402
 
 
 def main():
-    want = sys.argv[1:] or ["k_varbaseILb0ELb0", "k_fixedbaseILb1", "k_field_opINS_3FqPELi2", "k_field_opINS_3FqPELi4"]
+    want = sys.argv[1:] or ["k_varbase_ct3", "k_varbase_ct_quad", "k_varbaseILb0ELb0", "k_fixedbase_combILb1", "k_fixedbaseILb1", "k_field_opINS_3FqPELi2", "k_field_opINS_3FqPELi4"]
     asm = assembly()
     kernels = re.split(r"\n(?=_Z\w+:\s)", asm)
     for k in kernels:
@@ -35,6 +35,15 @@ def main():
                 print("   block %-10s %5d instr: %5d v_mad_u64_u32, %5d other VALU, %4d SALU, %4d memory/LDS" % (
                     label, len(ops), mad, valu - mad, sum(v for o, v in c.items() if o.startswith("s_")),
                     sum(v for o, v in c.items() if o.startswith(("global_", "ds_", "buffer_", "scratch_", "flat_")))))
+        if "k_varbase_ct" in name:
+            # the constant-time claim, checkable: every memory and control-flow instruction of the ladder's loop (the block with the most multiply-adds)
+            loops = [b for b in blocks if b.startswith(".LBB") and re.search(r"s_cbranch_\w+\s+" + re.escape(b.split(":", 1)[0]) + r"\b", b)]   # blocks that branch back to their own label
+            loop = max(loops or blocks, key=lambda b: len(re.findall(r"v_mad_i64_i32", b)))
+            loop = loop[:max(m.end() for m in re.finditer(r"s_cbranch_\w+\s+" + re.escape(loop.split(":", 1)[0]) + r"\b", loop))] if loops else loop      # up to the back edge
+            mc = collections.Counter(m.group(1) for m in re.finditer(r"^\s+((?:global|ds|buffer|scratch|flat|s_load|s_cbranch|s_branch|v_cmp|v_cndmask)[a-z0-9_]*)\s", loop, re.M))
+            print("   loop block: memory / control instructions: %s" % ", ".join("%s x%d" % kv for kv in sorted(mc.items())))
+            print("   (ct3: the two global loads are the words of k' that hold window i -- address = f(unit, i) --, the ds_read_b128 the lane's own LDS slot, read whole; the one"
+                  " compare / select clamps the word index, a function of i; the branch is the loop counter's.  ct_quad: no memory instruction at all)")
         mad = total["v_mad_u64_u32"]
         valu = sum(v for o, v in total.items() if o.startswith("v_"))
         print("   TOTAL %d instr: %d v_mad_u64_u32 (%.0f%% of VALU), %d other VALU; top other ops: %s" % (
