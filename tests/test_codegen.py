@@ -80,3 +80,30 @@ def test_no_kernel_spills(asm):
         if scratch or vgpr > 256:
             bad.append((name, vgpr, scratch))
     assert not bad, "kernels with scratch / more than 256 VGPRs: %r" % bad
+
+
+def ladder_loop(asm, needle):
+    """the basic block of the kernel that branches back to its own label and holds the most multiply-adds, up to its back edge"""
+    blocks = re.split(r"\n(?=\.LBB\d+_\d+:)", kernel_body(asm, needle))
+    loops = [b for b in blocks if b.startswith(".LBB") and re.search(r"s_cbranch_\w+\s+" + re.escape(b.split(":", 1)[0]) + r"\b", b)]
+    assert loops, "no loop found in %s" % needle
+    loop = max(loops, key=lambda b: len(re.findall(r"v_mad_i64_i32", b)))
+    return loop[:max(m.end() for m in re.finditer(r"s_cbranch_\w+\s+" + re.escape(loop.split(":", 1)[0]) + r"\b", loop))]
+
+
+def test_constant_time_ladders_have_no_scalar_dependent_memory_access_or_branch(asm):
+    """The default variable-base ladder (jj_varbase_mul, reference discipline: conditional_select, /root/reference/src/lib.rs:334-343, 357-379): the loop
+    of k_varbase_ct3 holds exactly the eighteen sixteen-byte reads of the lane's own LDS slot (both entries, every window) and the two words of the parked
+    k' (address = unit and window index), no store, no shuffle, no scratch, and ONE branch (the window counter's); the loop of k_varbase_ct_quad holds no
+    memory instruction at all.  A table lookup at a digit-dependent address or a branch on a digit would show up here as another load / branch."""
+    mem = r"^\s+((?:global|ds|buffer|scratch|flat|s_load)[a-z0-9_]*)\s"
+    ct3 = ladder_loop(asm, "k_varbase_ct3")
+    ops = collections.Counter(m.group(1) for m in re.finditer(mem, ct3, re.M))
+    assert ops == {"ds_read_b128": 18, "global_load_dword": 2}, ops
+    assert len(re.findall(r"^\s+s_cbranch", ct3, re.M)) == 1 and not re.search(r"^\s+(s_setpc|s_swappc|s_call)", ct3, re.M)
+    quad = ladder_loop(asm, "k_varbase_ct_quad")
+    assert not re.search(mem, quad, re.M), "k_varbase_ct_quad touches memory inside its loop"
+    assert len(re.findall(r"^\s+s_cbranch", quad, re.M)) == 1
+    # for contrast: the variable-time table ladder does load inside its window loop (its per-lane table, at a digit-dependent address)
+    vt = kernel_body(asm, "k_varbaseILb0ELb0")
+    assert len(re.findall(r"^\s+global_load_dwordx4", vt, re.M)) >= 9

@@ -42,8 +42,8 @@ def main():
             loop = loop[:max(m.end() for m in re.finditer(r"s_cbranch_\w+\s+" + re.escape(loop.split(":", 1)[0]) + r"\b", loop))] if loops else loop      # up to the back edge
             mc = collections.Counter(m.group(1) for m in re.finditer(r"^\s+((?:global|ds|buffer|scratch|flat|s_load|s_cbranch|s_branch|v_cmp|v_cndmask)[a-z0-9_]*)\s", loop, re.M))
             print("   loop block: memory / control instructions: %s" % ", ".join("%s x%d" % kv for kv in sorted(mc.items())))
-            print("   (ct3: the two global loads are the words of k' that hold window i -- address = f(unit, i) --, the ds_read_b128 the lane's own LDS slot, read whole; the one"
-                  " compare / select clamps the word index, a function of i; the branch is the loop counter's.  ct_quad: no memory instruction at all)")
+            print("   (ct3: the two global loads are the words of k' that hold window i -- address = f(unit, i) --, the ds_read_b128 the lane's own LDS slot, read whole;"
+                  " ct_quad: no memory instruction at all.  The compare / select pairs build an all-ones mask or clamp the word index: data flow only; the one branch is the loop counter's)")
         mad = total["v_mad_u64_u32"]
         valu = sum(v for o, v in total.items() if o.startswith("v_"))
         print("   TOTAL %d instr: %d v_mad_u64_u32 (%.0f%% of VALU), %d other VALU; top other ops: %s" % (
