@@ -89,6 +89,12 @@ def test_varbase_fixedbase_host_pipeline(eng, kind):
         assert (out[idx] == O.varbase_mul(s[idx], p[idx])).all()
         eng.varbase_mul_compressed(hs, hp, out=out32)
         assert (out32[idx] == O.compress(O.varbase_mul(s[idx], p[idx]))).all()
+        if kind == "pageable":                                   # the variable-time table ladder through the same pipeline
+            out[...] = 0
+            eng.varbase_mul_vartime(hs, hp, out=out)
+            assert (out == dev).all()
+            eng.varbase_mul_vartime_compressed(hs, hp, out=out32)
+            assert (out32[idx] == O.compress(O.varbase_mul(s[idx], p[idx]))).all()
         base = pt64(J.GENERATOR)
         tab = eng.fixedbase_table(base)
         eng.fixedbase_mul(tab, hs, out=out)
