@@ -108,7 +108,8 @@ struct jj_ctx;
 struct MsmLane {
   hipStream_t stream = nullptr;                     // lane 0: the context's launch stream, filled in at every use; other lanes: owned
   hipEvent_t ready_ev = nullptr;
-  DevBuf buf[8], ctl, bigpart, seg, rec;             // kprime, niels, offsets, idx, buckets, heads/records, -, tile counts | counters + lists | big-bucket partials | segments | record
+  DevBuf buf[8], ctl, bigpart, seg, rec, bins;        // ... | totals + cursors per (slot, coarse bin) of the two-pass sort, two parities (bins_parity: the half the next pass uses)
+  int bins_parity = 0;             // kprime, niels, offsets, idx, buckets, heads/records, -, tile counts | counters + lists | big-bucket partials | segments | record
   bool owned = false;
 };
 constexpr int MSM_LANES_MAX = 4;
@@ -148,6 +149,7 @@ struct jj_ctx {
   int msm_l1_rows = -1;          // two-level bucket reduce (k_msm_reduce_l1 / _l2): rows R of the bucket matrix a level-1 lane sums (a power of two, 2..64); 0 = one level (k_msm_reduce_fold);
                                  // -1 = from the bucket count (msm_enqueue_pippenger; JJ_MSM_REDUCE_L1)
   int msm_l2_chunk = 0;          // elements per level-2 quad (0 = the shortest for which the workgroups fit one per CU; JJ_MSM_REDUCE_L2_CHUNK, a power of two)
+  bool msm_fused_hist = true;    // two-pass sort: coarse histogram inside the conversion kernel + atomic run reservation (JJ_MSM_SORT_HIST=separate: k_msm_part_hist / _plan, round 4)
   int msm_two_pass = -1;         // counting sort in two passes (coarse bin, then low 8 bits): always above 4096 buckets per window, never below; at exactly 4096: 0 = one pass, else two (JJ_MSM_SORT=1pass|2pass)
   int msm_pass_log2 = 24;        // terms per Pippenger pass (JJ_MSM_PASS_LOG2 overrides; for tests)
   // optional per-call kernel timing (HIP events on the launch stream): e0 | main kernel | e1 | normalise tail | e2

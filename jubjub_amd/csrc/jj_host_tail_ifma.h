@@ -165,7 +165,7 @@ JJ_IFMA static inline V4 second_round(const V4& w) {
   V4 l, r;
   for (int j = 0; j < 5; j++) {
     l.l[j] = _mm256_permute4x64_epi64(w.l[j], JJ_LANES(0, 1, 2, 0));                        // E G F E
-    r.l[j] = _mm256_permute4x64_epi64(w.l[j], AGAIN ? JJ_LANES(2, 3, 1, 2) : JJ_LANES(2, 3, 1, 3));     // F H G H | F H G F
+    r.l[j] = _mm256_permute4x64_epi64(w.l[j], AGAIN ? JJ_LANES(2, 3, 1, 2) : JJ_LANES(2, 3, 1, 3));     // AGAIN: F H G F (lane 3 = E F = U again)  |  else: F H G H (lane 3 = E H = T)
   }
   return mul(l, r);
 }

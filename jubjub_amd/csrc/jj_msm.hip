@@ -130,16 +130,40 @@ static int msm_enqueue_pippenger(jj_ctx* c, MsmLane& ln, size_t n, const void* d
   // One conversion launch for scalars and points.  (Rounds 2-3 ran the point half on a second stream beside the sort from 2^18
   // terms; with the entries staged through LDS the conversion is short enough that the fork, its two events and the contention
   // with the sort's first kernel cost more than the overlap returns: 2^18 terms 0.565 -> 0.556 ms, 2^20 1.262 -> 1.254 ms.)
-  hipLaunchKernelGGL(k_msm_convert, dim3(blocks_for(n)), dim3(256), 0, st, n, ds, dp, mp, (u32*)kprime.p, (u32*)niels.p, 3);
-  if (two_pass) {
+  // Two-pass sort, round 5: the coarse histogram is taken by the conversion kernel itself (k_msm_convert_hist: totals per (slot, bin)), the tiles of
+  // the first pass reserve their runs with one global atomic per bin: no k_msm_part_hist, no k_msm_part_plan.  JJ_MSM_SORT_HIST=separate keeps the
+  // round-4 kernels (per-tile counts + a scan: the order of the entries inside a bucket is then the order of the terms).
+  // (measured, experiments/misc/msm_sort_hist_ab.py: 2^20 terms 1.26 -> 1.21 ms, 2^19 -1 %, 2^18 and 2^21 equal, 2^22 +0.7 %: from 2^22 terms the 8192 tiles' atomics on the
+  // same 2048 cursors cost more than the histogram pass they replace, so the fused form stops at 3 x 2^20 terms)
+  const bool fused_hist = two_pass && c->msm_fused_hist && Ws <= 64 && Ws * HB <= 4096 && n <= ((size_t)3 << 20);
+  if (fused_hist) {
+    const bool fresh = ln.bins.cap == 0;
+    if ((rc = ensure(c, ln.bins, (size_t)2 * 2 * MSM_BINS_WORDS * 4))) return rc;
+    if (fresh) { HIPCHK(c, hipMemsetAsync(ln.bins.p, 0, ln.bins.cap, st)); ln.bins_parity = 0; }     // afterwards every pass clears the other parity's half
+    static bool lds_set = false;
+    if (!lds_set) { HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_convert_hist), hipFuncAttributeMaxDynamicSharedMemorySize, MSM_CH_STAGE_WORDS * 4 + 16384)); lds_set = true; }      // 160 KB: the staging of sixteen waves + up to 4096 counters
+    u32* totals = (u32*)ln.bins.p + (size_t)ln.bins_parity * 2 * MSM_BINS_WORDS;
+    u32* cursor = totals + MSM_BINS_WORDS;
+    u32* other = (u32*)ln.bins.p + (size_t)(ln.bins_parity ^ 1) * 2 * MSM_BINS_WORDS;
+    ln.bins_parity ^= 1;
+    u32* rec = (u32*)ra.p; uint8_t* lo8 = (uint8_t*)ra.p + n * (size_t)Ws * 4;     // the head buffer is free until the accumulation
+    // terms per thread: four (4096 per workgroup: the fewest counter flushes) when that still gives every CU a workgroup, fewer for smaller inputs
+    const int per = (int)std::max<size_t>(1, std::min<size_t>(MSM_CH_PER, n / ((size_t)c->cus * MSM_CH_THREADS)));
+    hipLaunchKernelGGL(k_msm_convert_hist, dim3((unsigned)((n + (size_t)per * MSM_CH_THREADS - 1) / ((size_t)per * MSM_CH_THREADS))), dim3(MSM_CH_THREADS), MSM_CH_STAGE_WORDS * 4 + Ws * HB * 4, st, n, ds, dp, mp, (u32*)kprime.p, (u32*)niels.p, totals, other, counters, per);
+    hipLaunchKernelGGL(k_msm_part_scatter, dim3(ptiles, Ws), dim3(MSM_SORT_THREADS), 0, st, n, (size_t)MSM_P1_TILE, mp, (const u32*)kprime.p, (const u32*)nullptr, rec, lo8, (const u32*)totals, cursor);
+    if (seg_fused) hipLaunchKernelGGL(k_msm_part_sort<true>, dim3(HB, Ws), dim3(MSM_P2_THREADS), 0, st, mp, (u32)n, (const u32*)nullptr, (const u32*)rec, (const uint8_t*)lo8, (u32*)idx.p, off, P, ExtAoS{(u32*)buckets.p}, (u32*)ln.seg.p, (const u32*)totals);
+    else hipLaunchKernelGGL(k_msm_part_sort<false>, dim3(HB, Ws), dim3(MSM_P2_THREADS), 0, st, mp, (u32)n, (const u32*)nullptr, (const u32*)rec, (const uint8_t*)lo8, (u32*)idx.p, off, P, ExtAoS{nullptr}, (u32*)nullptr, (const u32*)totals);
+  } else if (two_pass) {
+    hipLaunchKernelGGL(k_msm_convert, dim3(blocks_for(n)), dim3(256), 0, st, n, ds, dp, mp, (u32*)kprime.p, (u32*)niels.p, 3);
     u32* tc = (u32*)tcnt.p; u32* tcs = tc + (size_t)Ws * pm;
     u32* rec = (u32*)ra.p; uint8_t* lo8 = (uint8_t*)ra.p + n * (size_t)Ws * 4;     // the head buffer is free until the accumulation
     hipLaunchKernelGGL(k_msm_part_hist, dim3(ptiles, Ws), dim3(MSM_SORT_THREADS), 0, st, n, (size_t)MSM_P1_TILE, mp, (const u32*)kprime.p, tc);
     hipLaunchKernelGGL(k_msm_part_plan, dim3(Ws), dim3(1024), 0, st, n, (u32)pm, (const u32*)tc, tcs, counters);
-    hipLaunchKernelGGL(k_msm_part_scatter, dim3(ptiles, Ws), dim3(MSM_SORT_THREADS), 0, st, n, (size_t)MSM_P1_TILE, mp, (const u32*)kprime.p, (const u32*)tcs, rec, lo8);
-    if (seg_fused) hipLaunchKernelGGL(k_msm_part_sort<true>, dim3(HB, Ws), dim3(MSM_P2_THREADS), 0, st, mp, ptiles, (const u32*)tcs, (const u32*)rec, (const uint8_t*)lo8, (u32*)idx.p, off, P, ExtAoS{(u32*)buckets.p}, (u32*)ln.seg.p);
-    else hipLaunchKernelGGL(k_msm_part_sort<false>, dim3(HB, Ws), dim3(MSM_P2_THREADS), 0, st, mp, ptiles, (const u32*)tcs, (const u32*)rec, (const uint8_t*)lo8, (u32*)idx.p, off, P, ExtAoS{nullptr}, (u32*)nullptr);
+    hipLaunchKernelGGL(k_msm_part_scatter, dim3(ptiles, Ws), dim3(MSM_SORT_THREADS), 0, st, n, (size_t)MSM_P1_TILE, mp, (const u32*)kprime.p, (const u32*)tcs, rec, lo8, (const u32*)nullptr, (u32*)nullptr);
+    if (seg_fused) hipLaunchKernelGGL(k_msm_part_sort<true>, dim3(HB, Ws), dim3(MSM_P2_THREADS), 0, st, mp, ptiles, (const u32*)tcs, (const u32*)rec, (const uint8_t*)lo8, (u32*)idx.p, off, P, ExtAoS{(u32*)buckets.p}, (u32*)ln.seg.p, (const u32*)nullptr);
+    else hipLaunchKernelGGL(k_msm_part_sort<false>, dim3(HB, Ws), dim3(MSM_P2_THREADS), 0, st, mp, ptiles, (const u32*)tcs, (const u32*)rec, (const uint8_t*)lo8, (u32*)idx.p, off, P, ExtAoS{nullptr}, (u32*)nullptr, (const u32*)nullptr);
   } else {
+    hipLaunchKernelGGL(k_msm_convert, dim3(blocks_for(n)), dim3(256), 0, st, n, ds, dp, mp, (u32*)kprime.p, (u32*)niels.p, 3);
     hipLaunchKernelGGL(k_msm_hist, dim3(ntiles, Ws), dim3(MSM_SORT_THREADS), B * 4, st, n, tile, mp, (const u32*)kprime.p, (u32*)tcnt.p);
     hipLaunchKernelGGL(k_msm_plan, dim3(Ws), dim3(1024), 0, st, n, B, ntiles, (u32*)tcnt.p, off, counters);
     hipLaunchKernelGGL(k_msm_scatter, dim3(ntiles * 8 * ((Ws + 7) / 8)), dim3(MSM_SORT_THREADS), B * 4, st, n, tile, ntiles, mp, (const u32*)kprime.p, (const u32*)tcnt.p, (u32*)idx.p);

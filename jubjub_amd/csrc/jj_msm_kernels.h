@@ -255,6 +255,71 @@ __global__ void __launch_bounds__(256) k_msm_convert(size_t n, const void* scala
   }
 }
 
+// The same conversion with the COARSE HISTOGRAM of the two-pass sort done on the way (round 5): the recoded scalar is in registers here, so the
+// window digits cost no second pass over k' (k_msm_part_hist re-read it: 25 us at 2^20 terms, bound by its 16.7 M LDS atomics, which now overlap this
+// kernel's memory traffic), and the per-(tile, bin) counts of k_msm_part_hist / the scan of k_msm_part_plan are not needed at all: the kernel leaves
+// only the totals per (window slot, coarse bin) -- one global atomic per workgroup and bin -- and k_msm_part_scatter reserves the run of a tile in a
+// bin with one global atomic per (tile, bin).  Workgroups of 1024 threads x 4 terms (4096 terms: 2048 counters flushed per workgroup; 256-thread
+// workgroups would flush 7 M atomics onto the same 2048 addresses); per-wave staging of the 128-byte entries as in k_msm_convert.
+constexpr int MSM_CH_THREADS = 1024, MSM_CH_PER = 4, MSM_CH_TERMS = MSM_CH_THREADS * MSM_CH_PER;
+constexpr int MSM_BINS_WORDS = 64 * 128;                 // totals [slot][bin] (as many again for the cursors), sized for 64 slots x MSM_HB_MAX bins
+constexpr int MSM_CH_STAGE_WORDS = (MSM_CH_THREADS / 64) * 64 * (GNIELS_WORDS / 4 + 1) * 4;
+__global__ void __launch_bounds__(MSM_CH_THREADS) k_msm_convert_hist(size_t n, const void* scalars, const void* points, MsmParams mp, u32* kprime, u32* niels,
+                                                                     u32* totals, u32* clear_next /* the other parity's totals + cursors */, u32* counters, int per /* terms per thread: 1 .. MSM_CH_PER */) {
+  constexpr int PIECES = GNIELS_WORDS / 4, ROW = PIECES + 1;
+  extern __shared__ __attribute__((aligned(16))) u32 ch_lds[];
+  uint4* my = reinterpret_cast<uint4*>(ch_lds) + (size_t)(threadIdx.x >> 6) * 64 * ROW;      // this wave's staging area
+  u32* hist = ch_lds + MSM_CH_STAGE_WORDS;
+  const u32 HB = mp.B >> 8, NH = (u32)mp.Ws * HB, lane = threadIdx.x & 63u;
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < MSM_COUNTER_WORDS) counters[threadIdx.x] = 0;                         // (the plan kernel's job on the other sort paths)
+    for (u32 j = threadIdx.x; j < 2 * MSM_BINS_WORDS; j += MSM_CH_THREADS) clear_next[j] = 0;
+  }
+  for (u32 j = threadIdx.x; j < NH; j += MSM_CH_THREADS) hist[j] = 0;
+  __syncthreads();
+  #pragma unroll 1
+  for (int it = 0; it < per; it++) {
+    const size_t i = ((size_t)blockIdx.x * per + it) * MSM_CH_THREADS + threadIdx.x;
+    if (i < n) {
+      u32 k[8];
+      load8(k, scalars, i);
+      msm_recode(k, mp);
+      _Pragma("unroll") for (int j = 0; j < 8; j++) kprime[(size_t)j * n + i] = k[j];
+      // the windows tile k' from bit 0 upwards: a copy of k' is shifted right by one window's width per step (eight funnel shifts by a
+      // wave-uniform amount), the digit is its low bits -- no indexed access into the eight words
+      u32 sh[8];
+      _Pragma("unroll") for (int j = 0; j < 8; j++) sh[j] = k[j];
+      int next_slot_window = mp.w0, sl = 0;
+      #pragma unroll 1
+      for (int w = 0; w < mp.W && sl < mp.Ws; w++) {
+        const int width = msm_win_width(mp, w);
+        if (w == next_slot_window) {
+          u32 neg;
+          const u32 a = msm_digit_raw(sh[0] & ((1u << width) - 1u), mp, w, width, neg);
+          if (a) atomicAdd(&hist[(u32)sl * HB + ((a - 1) >> 8)], 1u);
+          sl++; next_slot_window += mp.wstride;
+        }
+        _Pragma("unroll") for (int j = 0; j < 7; j++) sh[j] = (u32)(((((u64)sh[j + 1]) << 32) | sh[j]) >> width);
+        sh[7] >>= width;
+      }
+      const ANiels t = Curve::to_niels(load_affine(points, i));
+      u32 wv[GNIELS_WORDS];
+      _Pragma("unroll") for (int l = 0; l < NL; l++) { wv[l] = t.vpu.l[l]; wv[NL + l] = t.vmu.l[l]; wv[2 * NL + l] = t.t2d.l[l]; }
+      _Pragma("unroll") for (int l = ANIELS_WORDS - 1; l < GNIELS_WORDS; l++) wv[l] = 0;
+      _Pragma("unroll") for (int v = 0; v < PIECES; v++) my[lane * ROW + v] = make_uint4(wv[4 * v], wv[4 * v + 1], wv[4 * v + 2], wv[4 * v + 3]);
+    }
+    __syncthreads();
+    const size_t r0 = ((size_t)blockIdx.x * per + it) * MSM_CH_THREADS + (threadIdx.x & ~63u);      // first entry of this wave
+    uint4* out = reinterpret_cast<uint4*>(niels + r0 * GNIELS_WORDS);
+    _Pragma("unroll") for (int cpc = 0; cpc < PIECES; cpc++) {
+      const u32 q = (u32)cpc * 64u + lane, rec = q / PIECES, piece = q % PIECES;
+      if (r0 + rec < n) out[q] = my[rec * ROW + piece];
+    }
+    __syncthreads();
+  }
+  for (u32 j = threadIdx.x; j < NH; j += MSM_CH_THREADS) { const u32 v = hist[j]; if (v) atomicAdd(&totals[j], v); }
+}
+
 // ================================================================================================ Pippenger: counting sort
 // Entries of slot s live in [s n, (s + 1) n) of idx (every term contributes at most one entry per window), and
 // off[s (B + 1) + j] is the first entry of bucket j of slot s (j = B: the end of the slot's entries): the windows are independent,
@@ -428,14 +493,27 @@ __global__ void __launch_bounds__(1024) k_msm_part_plan(size_t n, u32 m, const u
 // (consecutive stage slots of one bin are consecutive in rec / lo8: a wave's store touches a few lines instead of 64)
 constexpr u32 MSM_P1_TILE = 8192;
 constexpr int MSM_P1_PER = MSM_P1_TILE / MSM_SORT_THREADS;
-__global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_part_scatter(size_t n, size_t tile, MsmParams mp, const u32* kp, const u32* tcs, u32* rec, uint8_t* lo8) {
-  __shared__ u32 cnt[MSM_HB_MAX], delta[MSM_HB_MAX], live_s;
+// tcs == nullptr (round 5, after k_msm_convert_hist): no per-tile offsets exist; the block forms the bins' first entries from the TOTALS per (slot, bin)
+// itself (a scan over at most 128 values) and reserves its run in every bin with one global atomic on the bin's cursor.  The order of the tiles' runs
+// inside a bin then depends on the order the blocks arrive in -- the entries of a bucket are added in another order, the sum is the same point.
+__global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_part_scatter(size_t n, size_t tile, MsmParams mp, const u32* kp, const u32* tcs, u32* rec, uint8_t* lo8, const u32* totals, u32* cursor) {
+  __shared__ u32 cnt[MSM_HB_MAX], live_s;
   __shared__ u32 st_rec[MSM_P1_TILE];
   __shared__ uint8_t st_lo[MSM_P1_TILE], st_bin[MSM_P1_TILE];
   const int w = msm_slot_window(mp, (int)blockIdx.y);
   const u32 HB = mp.B >> MSM_LO_BITS, tid = threadIdx.x;
   const u32* run0 = tcs + (size_t)blockIdx.y * ((size_t)HB * gridDim.x + 1);
+  __shared__ u32 gbase[MSM_HB_MAX], loff[MSM_HB_MAX];      // first global slot of this tile's run of a bin | first stage slot of the bin
   if (tid < 128) cnt[tid] = 0;
+  if (!tcs && tid >= 64 && tid < 128) {                     // wave 1: the bins' first entries from the totals, while the digits are being loaded
+    const u32 j = tid - 64;
+    const u32* tot = totals + (size_t)blockIdx.y * HB;
+    const u32 t0 = 2 * j < HB ? tot[2 * j] : 0u, t1 = 2 * j + 1 < HB ? tot[2 * j + 1] : 0u;
+    u32 tinc = t0 + t1;
+    _Pragma("unroll") for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(tinc, d, 64); if ((int)j >= d) tinc += o; }
+    const u32 b0 = (u32)(blockIdx.y * n) + tinc - (t0 + t1);
+    gbase[2 * j] = b0; gbase[2 * j + 1] = b0 + t0;
+  }
   __syncthreads();
   const size_t lo = (size_t)blockIdx.x * tile, hi = lo + tile < n ? lo + tile : n;
   u32 a[MSM_P1_PER], neg[MSM_P1_PER], rank[MSM_P1_PER];
@@ -446,20 +524,27 @@ __global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_part_scatter(size_t n,
   }
   _Pragma("unroll") for (int q = 0; q < MSM_P1_PER; q++) rank[q] = a[q] ? atomicAdd(&cnt[(a[q] - 1) >> MSM_LO_BITS], 1u) : 0u;
   __syncthreads();
-  if (tid < 64) {                        // exclusive scan of the (at most 128) bin counts: two per lane
+  if (tid < 64) {                        // wave 0: exclusive scan of the (at most 128) bin counts, two per lane: the bins' first stage slots
     const u32 v0 = cnt[2 * tid], v1 = cnt[2 * tid + 1], sm = v0 + v1;
     u32 inc = sm;
     _Pragma("unroll") for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, d, 64); if ((int)tid >= d) inc += o; }
-    const u32 l0 = inc - sm, l1 = l0 + v0;
-    cnt[2 * tid] = l0; cnt[2 * tid + 1] = l1;
-    // first global slot of this tile's run of the bin, minus the run's first stage slot
-    delta[2 * tid] = (2 * tid < HB ? run0[(size_t)(2 * tid) * gridDim.x + blockIdx.x] : 0u) - l0;
-    delta[2 * tid + 1] = (2 * tid + 1 < HB ? run0[(size_t)(2 * tid + 1) * gridDim.x + blockIdx.x] : 0u) - l1;
+    const u32 l0 = inc - sm;
+    loff[2 * tid] = l0; loff[2 * tid + 1] = l0 + v0;
+    if (tcs) {
+      gbase[2 * tid] = 2 * tid < HB ? run0[(size_t)(2 * tid) * gridDim.x + blockIdx.x] : 0u;
+      gbase[2 * tid + 1] = 2 * tid + 1 < HB ? run0[(size_t)(2 * tid + 1) * gridDim.x + blockIdx.x] : 0u;
+    }
     if (tid == 63) live_s = inc;         // entries of the tile (terms with a nonzero digit)
+  } else if (!tcs && tid < 128) {        // wave 1, beside it: this tile's run in every bin, reserved with one global atomic per bin
+    const u32 j = tid - 64;
+    u32* cur = cursor + (size_t)blockIdx.y * HB;
+    const u32 v0 = cnt[2 * j], v1 = cnt[2 * j + 1];
+    const u32 g0 = v0 ? atomicAdd(&cur[2 * j], v0) : 0u, g1 = v1 ? atomicAdd(&cur[2 * j + 1], v1) : 0u;
+    gbase[2 * j] += g0; gbase[2 * j + 1] += g1;
   }
   __syncthreads();
   _Pragma("unroll") for (int q = 0; q < MSM_P1_PER; q++) if (a[q]) {
-    const u32 bin = (a[q] - 1) >> MSM_LO_BITS, slot = cnt[bin] + rank[q];
+    const u32 bin = (a[q] - 1) >> MSM_LO_BITS, slot = loff[bin] + rank[q];
     st_rec[slot] = (u32)(lo + tid + (size_t)q * MSM_SORT_THREADS) | (neg[q] << 31);
     st_lo[slot] = (uint8_t)((a[q] - 1) & ((1u << MSM_LO_BITS) - 1u));
     st_bin[slot] = (uint8_t)bin;
@@ -467,7 +552,7 @@ __global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_part_scatter(size_t n,
   __syncthreads();
   const u32 live = live_s;
   for (u32 j = tid; j < live; j += MSM_SORT_THREADS) {
-    const u32 g = j + delta[st_bin[j]];
+    const u32 bn = st_bin[j], g = j - loff[bn] + gbase[bn];
     rec[g] = st_rec[j];
     lo8[g] = st_lo[j];
   }
@@ -476,7 +561,7 @@ __global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_part_scatter(size_t n,
 // tile s HB + coarse, key-major in bh, and the identity for empty buckets -- one launch and one pass over the offsets fewer (round 5).
 constexpr int SEG_PMAX = 1024;
 template <bool SEGH>
-__global__ void __launch_bounds__(MSM_P2_THREADS) k_msm_part_sort(MsmParams mp, u32 ptiles, const u32* tcs, const u32* rec, const uint8_t* lo8, u32* idx, u32* off, u32 P, ExtAoS buckets, u32* bh) {
+__global__ void __launch_bounds__(MSM_P2_THREADS) k_msm_part_sort(MsmParams mp, u32 ptiles, const u32* tcs, const u32* rec, const uint8_t* lo8, u32* idx, u32* off, u32 P, ExtAoS buckets, u32* bh, const u32* totals) {
   constexpr u32 NLO = 1u << MSM_LO_BITS;
   constexpr int PER = MSM_P2_CAP / MSM_P2_THREADS;
   __shared__ u32 cnt[NLO];
@@ -484,8 +569,25 @@ __global__ void __launch_bounds__(MSM_P2_THREADS) k_msm_part_sort(MsmParams mp, 
   __shared__ u32 seg_h[SEGH ? SEG_PMAX + 1 : 1];
   const u32 coarse = blockIdx.x, HB = gridDim.x, s = blockIdx.y, tid = threadIdx.x;
   if constexpr (SEGH) { for (u32 k = tid; k <= P; k += MSM_P2_THREADS) seg_h[k] = 0; }
-  const u32* run0 = tcs + (size_t)s * ((size_t)HB * ptiles + 1);
-  const u32 gb = run0[(size_t)coarse * ptiles], ge = run0[(size_t)(coarse + 1) * ptiles];
+  u32 gb, ge;
+  if (tcs) {
+    const u32* run0 = tcs + (size_t)s * ((size_t)HB * ptiles + 1);
+    gb = run0[(size_t)coarse * ptiles]; ge = run0[(size_t)(coarse + 1) * ptiles];
+  } else {
+    // the bin's entries from the totals per (slot, bin): its first entry = the slot's base + the totals of the bins before it (ptiles = terms of the pass here)
+    __shared__ u32 range_s[2];
+    if (tid < 64) {
+      const u32* tot = totals + (size_t)s * HB;
+      const u32 t0 = 2 * tid < HB ? tot[2 * tid] : 0u, t1 = 2 * tid + 1 < HB ? tot[2 * tid + 1] : 0u;
+      u32 tinc = t0 + t1;
+      _Pragma("unroll") for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(tinc, d, 64); if ((int)tid >= d) tinc += o; }
+      const u32 b0 = s * ptiles + tinc - (t0 + t1);
+      if (2 * tid == coarse) { range_s[0] = b0; range_s[1] = b0 + t0; }
+      if (2 * tid + 1 == coarse) { range_s[0] = b0 + t0; range_s[1] = b0 + t0 + t1; }
+    }
+    __syncthreads();
+    gb = range_s[0]; ge = range_s[1];
+  }
   const bool staged = ge - gb <= MSM_P2_CAP;
   u32* o = off + (size_t)s * (mp.B + 1);
   if (tid < NLO) cnt[tid] = 0;

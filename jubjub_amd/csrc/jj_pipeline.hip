@@ -431,6 +431,7 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
   if (const char* e = getenv("JJ_MSM_REDUCE_CHUNK")) { int v = atoi(e); if (v >= 2 && v <= 256 && (v & (v - 1)) == 0) c->msm_reduce_chunk = v; }
   if (const char* e = getenv("JJ_MSM_REDUCE_L1")) { int v = atoi(e); if (v == 0 || (v >= 2 && v <= 64 && (v & (v - 1)) == 0)) c->msm_l1_rows = v; }
   if (const char* e = getenv("JJ_MSM_REDUCE_L2_CHUNK")) { int v = atoi(e); if (v >= 2 && v <= 64 && (v & (v - 1)) == 0) c->msm_l2_chunk = v; }
+  if (const char* e = getenv("JJ_MSM_SORT_HIST")) c->msm_fused_hist = strcmp(e, "separate") != 0;
   if (const char* e = getenv("JJ_MSM_SORT")) c->msm_two_pass = !strcmp(e, "2pass") ? 1 : (!strcmp(e, "1pass") ? 0 : -1);
   if (const char* e = getenv("JJ_MSM_PASS_LOG2")) { int v = atoi(e); if (v >= 10 && v <= 24) c->msm_pass_log2 = v; }
   if (const char* e = getenv("JJ_VARBASE_DEFAULT")) c->vb_default_ct = strcmp(e, "vartime") != 0;
@@ -453,7 +454,7 @@ JJ_API int jj_ctx_destroy(jj_ctx* c) {
   for (jj_msm_job* j : c->job_pool) { if (j->host) (void)hipHostFree(j->host); (void)hipEventDestroy(j->ev); delete j; }
   for (MsmLane& L : c->lanes) {
     if (L.owned) (void)hipStreamSynchronize(L.stream);
-    DevBuf* lb[] = {&L.buf[0], &L.buf[1], &L.buf[2], &L.buf[3], &L.buf[4], &L.buf[5], &L.buf[6], &L.buf[7], &L.ctl, &L.bigpart, &L.seg, &L.rec};
+    DevBuf* lb[] = {&L.buf[0], &L.buf[1], &L.buf[2], &L.buf[3], &L.buf[4], &L.buf[5], &L.buf[6], &L.buf[7], &L.ctl, &L.bigpart, &L.seg, &L.rec, &L.bins};
     for (DevBuf* b : lb) if (b->p) (void)hipFree(b->p);
     if (L.owned) {
       (void)hipEventDestroy(L.ready_ev);

@@ -522,6 +522,36 @@ def test_msm_two_level_bucket_reduce(monkeypatch, window, rows, l2chunk):
     e2.close()
 
 
+@pytest.mark.parametrize("mode", ["separate", "fused"])
+@pytest.mark.parametrize("window", [16, 17, 18])
+def test_msm_two_pass_sort_histogram_modes(monkeypatch, mode, window):
+    """JJ_MSM_SORT_HIST: the coarse histogram of the two-pass sort taken inside the conversion kernel, the tiles' runs reserved with global atomics
+    (k_msm_convert_hist; the default up to 3 x 2^20 terms), against the separate histogram + plan kernels (round 4; the default above): ragged sizes around
+    the 1024-term and 4096-term workgroups and the 8192-term tiles, a window partition (slots != windows), equal scalars (one bin holds every entry), zeros."""
+    from jubjub_amd import Engine
+
+    monkeypatch.setenv("JJ_MSM_SORT_HIST", mode)
+    monkeypatch.setenv("JJ_MSM_WINDOWS", str(window))
+    monkeypatch.setenv("JJ_MSM_SMALL_MAX", "0")
+    e2 = Engine(0)
+    for n in (1, 1023, 1025, 4097, 8191, 8193, 50021):
+        S = rand_scalars(3512 + n + window, n, full_width=True)
+        P = rand_points(3513 + n, n, subgroup=(n % 2 == 0))
+        assert (e2.msm(S, P) == O.msm(S, P)).all(), (mode, window, n)
+    n = 20000
+    S, P = rand_scalars(3600, n, full_width=True), rand_points(3601, n)
+    recs = np.stack([e2.msm_partial(S, P, g, 3) for g in range(3)])                 # windows g, g + 3, ...: slot s is window 3 s + g
+    assert (e2.msm_combine(recs) == O.msm(S, P)).all()
+    S1 = np.repeat(rand_scalars(3602, 1, full_width=True), n, axis=0)
+    assert (e2.msm(S1, P) == O.msm(S1, P)).all()
+    S2 = rand_scalars(3603, n)
+    S2[: n // 2] = 0
+    assert (e2.msm(S2, P) == O.msm(S2, P)).all()
+    for _ in range(3):                                                                # back to back: the two parities of the totals / cursors
+        assert (e2.msm(S, P) == O.msm(S, P)).all()
+    e2.close()
+
+
 def test_msm_back_to_back_sizes(monkeypatch):
     """Pippenger calls of changing sizes back to back on one context: every call reuses (and regrows) the workspaces of the one
     before it, including the LDS-staged conversion's ragged last workgroup (n not a multiple of 64)."""
