@@ -32,4 +32,5 @@ for f in gpurun_out/${TAG}_bench_host_*.json gpurun_out/${TAG}_bench_msm20_rccl1
 (echo "$HDR"; echo "# command: python experiments/misc/vb_ct_window.py   (2^20 units: the table ladder, the constant-time ladder with signed 2-bit and 3-bit windows)"; grep -v amdgpu gpurun_out/${TAG}_vb_ct_window.txt) > profiles/${TAG}_vb_ct_window.txt
 (echo "$HDR"; echo "# command: python experiments/misc/msm_reduce_l1_sweep.py 18 19 20 21 22"; grep -v amdgpu gpurun_out/${TAG}_msm_reduce_l1_sweep.txt) > profiles/${TAG}_msm_reduce_l1_sweep.txt
 (echo "$HDR"; echo "# command: experiments/hsa_stale_mapping/repro <variant> 3000   (six variants of a stand-alone reproducer of round 4's GPU memory fault)"; cat gpurun_out/${TAG}_hsa_stale_mapping.txt) > profiles/${TAG}_hsa_stale_mapping.txt
+(echo "$HDR"; echo "# command: python experiments/misc/msm_sort_hist_ab.py"; grep -v amdgpu gpurun_out/${TAG}_msm_sort_hist_ab.txt) > profiles/${TAG}_msm_sort_hist_ab.txt
 python3 tools/design_numbers.py $TAG

@@ -50,5 +50,6 @@ timeout 600 python tests/soak.py 240 3000 > gpurun_out/${TAG}_soak.txt 2>&1 || e
 # round 5: constant-time ladder window widths against the table ladder; the two-level bucket reduce's sweep; the stand-alone fault reproducer
 python experiments/misc/vb_ct_window.py > gpurun_out/${TAG}_vb_ct_window.txt 2>&1
 python experiments/misc/msm_reduce_l1_sweep.py 18 19 20 21 22 > gpurun_out/${TAG}_msm_reduce_l1_sweep.txt 2>&1
+python experiments/misc/msm_sort_hist_ab.py > gpurun_out/${TAG}_msm_sort_hist_ab.txt 2>&1
 (cd experiments/hsa_stale_mapping; [ -x repro ] || /opt/rocm/bin/hipcc -O2 -o repro repro.cpp; for v in 0 1 2 3 4 5; do timeout 200 ./repro $v 3000 2>&1 | tail -1; done) > gpurun_out/${TAG}_hsa_stale_mapping.txt 2>&1
 tail -1 gpurun_out/${TAG}_profile.log
