@@ -16,7 +16,8 @@ line; under `python -m torch.distributed.run --nproc-per-node N ... bench.py --g
                    host tail -- window sums, Horner, one inversion -- on every rank).
 --msm-partition  : terms  = rank g owns terms [g n/G, (g+1) n/G) and all their windows;
                    window = rank g owns windows g, g + G, ... of ALL terms (every rank holds the whole batch; strong scaling only).
---msm-async D    : N = 1: D MSMs in flight (jj_msm_begin / jj_msm_finish): the host tail of one overlaps the kernels of the next.
+--msm-async D    : D MSMs in flight (N = 1: jj_msm_begin / jj_msm_finish; N > 1 over RCCL with --msm-exchange c: jj_msm_allgather_begin):
+                   the exchange and the host tail of one overlap the kernels of the next.
 --msm-contexts K : N = 1: K contexts (streams + workspaces) on the one GPU, one host thread each, the step's MSMs dealt among them:
                    sustained throughput (the dependent chains of one MSM leave most of the GPU idle); `ms_per_pass` is then the
                    aggregate time per MSM, not the latency of one.
@@ -142,7 +143,7 @@ def parse():
     ap.add_argument("--decompress-flags", type=int, default=13,
                     help="jj_decompress flags: 1 ZIP-216 | 2 torsion-free (order-8 Tate pairing; JJ_TORSION_CHECK=ladder for the [r]P ladder) | 4 reject small order | 8 clear cofactor (default 13 = BASELINE config 5: decode + small-order check + mul_by_cofactor)")
     ap.add_argument("--msm-partition", default="terms", choices=["terms", "window"], help="multi-rank MSM: cut by terms or by windows (see the module docstring)")
-    ap.add_argument("--msm-async", type=int, default=1, help="N = 1 MSM workload: jobs in flight per context (1 = synchronous jj_msm calls)")
+    ap.add_argument("--msm-async", type=int, default=1, help="MSM workload: jobs in flight per context (1 = synchronous jj_msm / jj_msm_allgather calls)")
     ap.add_argument("--msm-contexts", type=int, default=1, help="N = 1 MSM workload: contexts (each with its own stream and workspaces) driven by as many host threads on the one GPU: "
                     "the latency-bound tails of one MSM overlap the sort / accumulation of another")
     ap.add_argument("--host-buffers", default=None, choices=["pageable", "pinned", "fresh", "pooled"],
@@ -570,10 +571,11 @@ def run(a):
             [t.start() for t in th]
             [t.join() for t in th]
             return outs[0]
-        if wl == "msm" and not distributed and a.msm_async > 1:
+        if wl == "msm" and a.msm_async > 1 and (not distributed or rccl_comm is not None):
             pend = []                                           # a sliding window of jobs: begin the next before finishing the oldest
-            for _ in range(passes):
-                pend.append(eng.msm_begin(scalars, points))
+            begin = eng.msm_begin if not distributed else (lambda s_, p_: eng.msm_allgather_begin(s_, p_, "window" if by_window else "terms"))
+            for _ in range(passes):                             # (distributed: jj_msm_allgather_begin -- every rank begins the same jobs in the same order)
+                pend.append(begin(scalars, points))
                 if len(pend) == a.msm_async:
                     o = eng.msm_finish(pend.pop(0))
             for j in pend:
@@ -671,7 +673,7 @@ def run(a):
         res["host_over_device_resident"] = value / dev_ref["value"]
     if wl == "msm":
         res["config"]["msm_partition"] = a.msm_partition if n_gpus > 1 else None
-        res["config"]["msm_jobs_in_flight"] = a.msm_async if not distributed else 1
+        res["config"]["msm_jobs_in_flight"] = a.msm_async if (not distributed or rccl_comm is not None) else 1
         res["config"]["msm_contexts"] = len(msm_engs)
     rc = 0
     if rank == 0:

@@ -10,6 +10,7 @@
 //   A  jj_ctx_set_comm + jj_msm_allgather                      the whole exchange behind one call
 //   B  jj_msm_partial -> ncclAllGather -> one D2H -> jj_msm_combine   the same steps spelled out (what A does inside)
 //   C  jj_msm_allgather with the WINDOW partition              every rank holds all terms and reduces windows g, g + G, ...
+//   D  jj_msm_allgather_begin / jj_msm_finish, three in flight    a stream of MSMs: gather, fold and host tail of one beside the kernels of the next
 // Inputs are the library's counter-based generators over GLOBAL term indices (jj_synth_scalars / jj_random_points), so every rank
 // builds its shard without moving data and a checker can rebuild the batch (tests/test_gpu_dist.py compares rank 0's line with the oracle).
 #include <hip/hip_runtime.h>
@@ -101,17 +102,31 @@ int main(int argc, char** argv) {
   // ---- C: window partition (every rank passes ALL terms)
   JJ(jj_msm_allgather(ctx, n, d_sall, d_pall, 1, c));
 
+  // ---- D: a stream of MSMs (here the same one `reps` times), three jobs in flight; every rank begins the same jobs in the same order
+  uint8_t d[64];
+  bool ad = true;
+  const double t1 = now();
+  {
+    std::vector<jj_msm_job*> pend;
+    for (int r = 0; r < reps + 3; r++) {
+      if (r < reps) { jj_msm_job* j = nullptr; JJ(jj_msm_allgather_begin(ctx, cnt, d_s, d_p, 0, &j)); pend.push_back(j); }
+      if (pend.size() == 3 || (r >= reps && !pend.empty())) { JJ(jj_msm_finish(pend.front(), d)); pend.erase(pend.begin()); ad = ad && memcmp(a, d, 64) == 0; }
+    }
+  }
+  const double per_job = (now() - t1) / (reps > 0 ? reps : 1);
+
   const bool ab = memcmp(a, b, 64) == 0, ac = memcmp(a, c, 64) == 0;
   if (rank == 0) {
     printf("msm_rccl: ranks=%d n=%zu result=", world, n);
     for (int i = 0; i < 64; i++) printf("%02x", a[i]);
     printf("\nmsm_rccl: allgather == partial+ncclAllGather+combine: %s; term partition == window partition: %s\n", ab ? "ok" : "MISMATCH", ac ? "ok" : "MISMATCH");
     printf("msm_rccl: %.3f ms per jj_msm_allgather (%zu terms per rank, %d ranks)\n", per_call * 1e3, cnt, world);
+    printf("msm_rccl: %.3f ms per MSM with three jj_msm_allgather_begin jobs in flight: %s\n", per_job * 1e3, ad ? "ok" : "MISMATCH");
   }
   JJ(jj_ctx_set_comm(ctx, nullptr, 0, 1, nullptr));
   jj_ctx_destroy(ctx);
   (void)hipStreamDestroy(s);
   for (void* p : {d_s, d_p, d_sall, d_pall, d_rec, d_all}) (void)hipFree(p);
   NCCL(ncclCommDestroy(comm));
-  return (ab && ac) ? 0 : 1;
+  return (ab && ac && ad) ? 0 : 1;
 }

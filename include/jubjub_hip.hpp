@@ -291,11 +291,18 @@ inline Bytes64 msm(const Context& c, const AffineBatch& points, const FrBatch& s
 
 // The same sum with the host tail of one MSM overlapping the kernels of the next (jj_msm_begin / jj_msm_finish): the job owns copies
 // of its inputs until it is finished
+struct AllRanks { bool by_windows = false; };      // MsmJob over every rank of the communicator lent with set_comm (jj_msm_allgather_begin)
 class MsmJob {
  public:
   MsmJob(const Context& c, const AffineBatch& points, const FrBatch& scalars) : c_(&c), s_(scalars.to_bytes()), p_(points.coords()) {
     if (p_.size() != s_.size()) throw Error(JJ_ERR_INVALID, "length mismatch");
     c.check(jj_msm_begin(c.raw(), p_.size(), s_.data(), p_.data(), &job_));
+  }
+  // this rank's terms of a sum over all ranks: window sums, ncclAllGather and the fold of the gathered records queued behind one another;
+  // every rank constructs the same jobs in the same order
+  MsmJob(const Context& c, const AffineBatch& my_points, const FrBatch& my_scalars, AllRanks how) : c_(&c), s_(my_scalars.to_bytes()), p_(my_points.coords()) {
+    if (p_.size() != s_.size()) throw Error(JJ_ERR_INVALID, "length mismatch");
+    c.check(jj_msm_allgather_begin(c.raw(), p_.size(), s_.data(), p_.data(), how.by_windows ? 1 : 0, &job_));
   }
   MsmJob(const MsmJob&) = delete;
   MsmJob& operator=(const MsmJob&) = delete;

@@ -51,6 +51,7 @@ _SIGS.update({
     "jj_msm_combine_dev": [_sz, _vp, _vp],
     "jj_ctx_set_comm": [_vp, C.c_int, C.c_int, _vp],
     "jj_msm_allgather": [_sz, _vp, _vp, C.c_int, _vp],
+    "jj_msm_allgather_begin": [_sz, _vp, _vp, C.c_int, C.POINTER(_vp)],
     "jj_decompress": [_sz, _vp, C.c_uint, _vp, _u8p],
     "jj_compress": [_sz, _vp, _vp],
     "jj_batch_normalize": [_sz, _vp, _vp],

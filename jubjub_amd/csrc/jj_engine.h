@@ -123,6 +123,11 @@ struct jj_msm_job {
   uint8_t* host = nullptr;      // page-locked: nrec records, REC_MAX_BYTES apart
   size_t cap = 0;
   size_t nrec = 0;
+  // a job of jj_msm_allgather_begin: this rank's record followed by the gathered ones, in device memory the JOB owns (a lane's next
+  // job must not overwrite what a finish may still have to copy)
+  void* gdev = nullptr; size_t gdev_cap = 0;
+  int gathered = 0;             // records the all_gather delivers (0: a local job)
+  bool folded = false;          // the fold kernel was queued: host holds the ONE folded record, or a zero header if the layouts differ
 };
 
 struct jj_ctx {

@@ -235,7 +235,7 @@ static int msm_job_get(jj_ctx* c, size_t nrec, jj_msm_job** out) {
     if (hipHostMalloc((void**)&j->host, want, hipHostMallocCoherent | hipHostMallocPortable) != hipSuccess) { (void)hipEventDestroy(j->ev); delete j; c->err = "hipHostMalloc failed"; return JJ_ERR_NOMEM; }
     j->cap = want;
   }
-  j->nrec = 0;
+  j->nrec = 0; j->gathered = 0; j->folded = false;
   for (size_t r = 0; r < std::max<size_t>(nrec, 1); r++) memset(j->host + r * jjhost::REC_MAX_BYTES, 0, jjhost::REC_HDR_BYTES);   // a stale header of a pooled buffer must never validate
   *out = j;
   return JJ_OK;
@@ -243,6 +243,7 @@ static int msm_job_get(jj_ctx* c, size_t nrec, jj_msm_job** out) {
 void msm_job_put(jj_ctx* c, jj_msm_job* j) {
   if (c->job_pool.size() < 8) { c->job_pool.push_back(j); return; }
   if (j->host) (void)hipHostFree(j->host);
+  if (j->gdev) (void)hipFree(j->gdev);
   (void)hipEventDestroy(j->ev);
   delete j;
 }
@@ -318,6 +319,16 @@ JJ_API int jj_msm_finish(jj_msm_job* j, void* out64) {
   if (!out64) { (void)hipEventSynchronize(j->ev); std::lock_guard<std::recursive_mutex> lk(c->mu); msm_job_put(c, j); return JJ_ERR_INVALID; }   // the job's kernels may still be writing into its buffer
   hipError_t e = hipEventSynchronize(j->ev);                       // no context lock while waiting: other threads may queue work
   jjhost::Ext total = jjhost::identity();
+  if (e == hipSuccess && j->gathered && j->folded) {
+    // a job of jj_msm_allgather_begin: the fold kernel left ONE record -- or a zero header: records of different window layouts (ranks
+    // with different term counts), which the host adds after one copy of all of them out of the job's own device buffer
+    uint32_t magic; memcpy(&magic, j->host, 4);
+    if (magic != MSM_REC_MAGIC) {
+      std::lock_guard<std::recursive_mutex> lk(c->mu);
+      e = hipMemcpy(j->host, (const uint8_t*)j->gdev + JJ_MSM_PARTIAL_BYTES, (size_t)j->gathered * JJ_MSM_PARTIAL_BYTES, hipMemcpyDeviceToHost);
+      j->nrec = (size_t)j->gathered;
+    }
+  }
   const bool ok = e == hipSuccess && jjhost::combine_records(j->host, j->nrec, jjhost::REC_MAX_BYTES, &total);
   JJ_ENTER(c);
   int rc = JJ_OK;
@@ -474,6 +485,70 @@ JJ_API int jj_msm_combine_dev(jj_ctx* c, size_t count, const void* records_dev, 
   const int rc = msm_combine_dev_locked(c, count, (const uint8_t*)records_dev, &total);
   if (rc) return rc;
   return msm_write_total(c, total, out64);
+}
+// jj_msm_allgather in two halves (as jj_msm_begin / jj_msm_finish for the one-GPU sum): everything up to the folded record is queued on
+// one of the context's lanes -- the rank's window sums, the ncclAllGather (stream-ordered like any kernel), the fold of the G records
+// into one written straight into the job's page-locked buffer -- and the call returns; jj_msm_finish waits for that job and runs the
+// single-record host tail.  With several jobs in flight the gather, the fold, the wait and the host tail of one MSM run beside the
+// kernels of the next: a rank's sustained rate is that of its kernels, not of the call's latency.
+JJ_API int jj_msm_allgather_begin(jj_ctx* c, size_t n, const void* scalars, const void* points, int partition, jj_msm_job** job) {
+  if (!c || !job || (partition != 0 && partition != 1)) return JJ_ERR_INVALID;
+  *job = nullptr;
+  JJ_ENTER(c);
+  if (!c->comm || !c->all_gather) { c->err = "jj_msm_allgather_begin: no communicator (jj_ctx_set_comm)"; return JJ_ERR_INVALID; }
+  if (n > ((size_t)1 << c->msm_pass_log2)) { c->err = "jj_msm_allgather_begin takes at most one pass of terms (2^24) per rank; cut larger inputs"; return JJ_ERR_INVALID; }
+  const int G = c->comm_nranks;
+  const int part_index = partition ? c->comm_rank : 0, part_count = partition ? G : 1;
+  jj_msm_job* j;
+  int rc = msm_job_get(c, (size_t)G, &j); if (rc) return rc;
+  const size_t need = (size_t)(G + 1) * JJ_MSM_PARTIAL_BYTES;
+  if (j->gdev_cap < need) {
+    if (j->gdev) (void)hipFree(j->gdev);
+    j->gdev = nullptr; j->gdev_cap = 0;
+    if (hipMalloc(&j->gdev, need) != hipSuccess) { (void)hipGetLastError(); msm_job_put(c, j); c->err = "hipMalloc failed"; return JJ_ERR_NOMEM; }
+    j->gdev_cap = need;
+  }
+  uint8_t* mine = (uint8_t*)j->gdev;                                // this rank's record, then the G gathered ones
+  uint8_t* all = mine + JJ_MSM_PARTIAL_BYTES;
+  int k = 0;
+  if (n && c->msm_lanes > 1 && is_device_ptr(scalars) && is_device_ptr(points)) k = (int)(c->next_lane++ % (unsigned)c->msm_lanes);
+  MsmLane* L = nullptr;
+  if ((rc = msm_lane(c, k, &L))) { msm_job_put(c, j); return rc; }
+  auto fail = [&](int code) { (void)hipStreamSynchronize(L->stream); (void)hipGetLastError(); msm_job_put(c, j); return code; };
+  hipError_t e = hipMemsetAsync(mine, 0, JJ_MSM_PARTIAL_BYTES, L->stream);
+  if (e != hipSuccess) { c->err = std::string("hipMemsetAsync failed: ") + hipGetErrorString(e); return fail(JJ_ERR_HIP); }
+  const int layout_W = n <= (size_t)c->msm_small_max ? SM_W : msm_windows_for(c, n);
+  if (n == 0 || part_index >= layout_W) {
+    // an empty shard: a valid record without windows (as jj_msm_partial writes it)
+    uint32_t hdr[MSM_REC_HDR_WORDS] = {MSM_REC_MAGIC, 2u, (uint32_t)(n == 0 ? SM_W : layout_W), 1u};
+    hdr[6] = (uint32_t)n; hdr[7] = (uint32_t)((uint64_t)n >> 32);
+    memcpy(c->host_out[c->host_out_next], hdr, 64);
+    e = hipMemcpyAsync(mine, c->host_out[c->host_out_next], 64, hipMemcpyHostToDevice, L->stream);
+    c->host_out_next = (c->host_out_next + 1) % 8;
+    if (e != hipSuccess) { c->err = std::string("hipMemcpyAsync failed: ") + hipGetErrorString(e); return fail(JJ_ERR_HIP); }
+  } else {
+    const void *ds, *dp;
+    size_t used = 0;
+    if ((rc = stage_in(c, 0, scalars, 32 * n, &ds)) || (rc = stage_in(c, 1, points, 64 * n, &dp))) return fail(rc);
+    if ((rc = msm_enqueue(c, *L, n, ds, dp, part_index, part_count, mine, &used))) return fail(rc);
+  }
+  // From here on the other ranks wait for this one: a failure below is fatal for the communicator (as with any RCCL collective)
+  const int nrc = c->all_gather(mine, all, JJ_MSM_PARTIAL_BYTES, /* ncclUint8 */ 1, c->comm, L->stream);
+  if (nrc != 0) { c->err = "ncclAllGather failed with ncclResult_t " + std::to_string(nrc); return fail(JJ_ERR_HIP); }
+  j->gathered = G;
+  if (c->msm_fold_dev && G >= c->msm_fold_min) {
+    hipLaunchKernelGGL(k_msm_fold_records, dim3(jjhost::REC_MAX_W), dim3(4 * MSM_TREE_QUADS), 0, L->stream, (const u32*)all, (u32)G, (u32)(JJ_MSM_PARTIAL_BYTES / 4), (u32*)j->host);
+    j->folded = true; j->nrec = 1;
+  } else {
+    e = hipMemcpyAsync(j->host, all, (size_t)G * JJ_MSM_PARTIAL_BYTES, hipMemcpyDeviceToHost, L->stream);
+    if (e != hipSuccess) { c->err = std::string("hipMemcpyAsync failed: ") + hipGetErrorString(e); return fail(JJ_ERR_HIP); }
+    j->nrec = (size_t)G;
+  }
+  e = hipEventRecord(j->ev, L->stream);
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e != hipSuccess) { c->err = std::string("MSM launch failed: ") + hipGetErrorString(e); return fail(JJ_ERR_HIP); }
+  *job = j;
+  return JJ_OK;
 }
 JJ_API int jj_msm_allgather(jj_ctx* c, size_t n, const void* scalars, const void* points, int partition, void* out64) {
   if (!c || !out64 || (partition != 0 && partition != 1)) return JJ_ERR_INVALID;

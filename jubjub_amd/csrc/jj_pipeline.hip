@@ -451,7 +451,7 @@ JJ_API int jj_ctx_destroy(jj_ctx* c) {
   DevBuf* all[] = {&c->in[0], &c->in[1], &c->in[2], &c->in[3], &c->out[0], &c->out[1], &c->okb, &c->ws0.ext, &c->ws0.scratch, &c->ws0.tables,
                    &c->ws_tmp[0], &c->ws_tmp[1], &c->ws_tmp[2], &c->ws_tmp[3], &c->sqrt_tabs, &c->ws0.cursor,
                    &c->pipe.wset.ext, &c->pipe.wset.scratch, &c->pipe.wset.tables, &c->pipe.wset.cursor};
-  for (jj_msm_job* j : c->job_pool) { if (j->host) (void)hipHostFree(j->host); (void)hipEventDestroy(j->ev); delete j; }
+  for (jj_msm_job* j : c->job_pool) { if (j->host) (void)hipHostFree(j->host); if (j->gdev) (void)hipFree(j->gdev); (void)hipEventDestroy(j->ev); delete j; }
   for (MsmLane& L : c->lanes) {
     if (L.owned) (void)hipStreamSynchronize(L.stream);
     DevBuf* lb[] = {&L.buf[0], &L.buf[1], &L.buf[2], &L.buf[3], &L.buf[4], &L.buf[5], &L.buf[6], &L.buf[7], &L.ctl, &L.bigpart, &L.seg, &L.rec, &L.bins};

@@ -478,6 +478,18 @@ class Engine:
         self._check(self._lib.jj_msm_allgather(self._ctx, C.c_size_t(a.n), a.ptr, p.ptr, C.c_int({"terms": 0, "window": 1}[partition]), out.ctypes.data))
         return out
 
+    def msm_allgather_begin(self, scalars, points, partition="terms"):
+        """msm_allgather in two halves (jj_msm_allgather_begin): queues this rank's window sums, the ncclAllGather and the fold of the
+        gathered records, returns a job; msm_finish(job) waits for it and runs the host tail.  With several jobs in flight the exchange
+        and the host tail of one MSM overlap the kernels of the next.  A collective: every rank begins the same jobs in the same order."""
+        a, p = _Arg(scalars, 32), _Arg(points, 64)
+        if a.n != p.n:
+            raise ValueError("length mismatch: %d vs %d" % (a.n, p.n))
+        self._bind_stream([a, p])
+        h = C.c_void_p()
+        self._check(self._lib.jj_msm_allgather_begin(self._ctx, C.c_size_t(a.n), a.ptr, p.ptr, C.c_int({"terms": 0, "window": 1}[partition]), C.byref(h)))
+        return MsmJob(h, (a.keep, p.keep))
+
     def msm_combine(self, records):
         """Second half: any number of records (count x MSM_PARTIAL_BYTES bytes) -> the 64-byte affine sum as a numpy array.  A CUDA
         tensor takes jj_msm_combine_dev (the records are added on the device, ONE record is copied to the host tail); numpy / CPU

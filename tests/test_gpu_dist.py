@@ -131,6 +131,16 @@ def test_one_rank_rccl_msm_both_exchanges(exchange):
     assert len(res["rank_ms_per_step"]["per_rank"]) == 1
 
 
+def test_one_rank_rccl_msm_jobs_in_flight():
+    """--msm-async 3 over RCCL: jj_msm_allgather_begin / jj_msm_finish -- the real ncclAllGather queued on the jobs' lanes (two streams
+    in turn on one communicator), three MSMs in flight; one rank, Pippenger size.  (G > 1 ranks: the loopback all-gather of
+    test_gpu_parity.py::test_msm_allgather_of_G_ranks_played_on_one_gpu.)"""
+    res = run_bench(["--gpus", "1", "--workload", "msm", "--log2n", "16", "--steps", "2", "--warmup", "1", "--passes", "7", "--no-cpu-baseline",
+                     "--msm-async", "3"], {"JJ_BENCH_FORCE_DIST": "1", "MASTER_PORT": str(free_port())})
+    assert res["verified"] is True and res["rccl_world_size"] == 1 and res["msm_result"] == oracle_msm(1 << 16)
+    assert res["config"]["msm_jobs_in_flight"] == 3 and "jj_msm_allgather" in res["config"]["parallelism"]
+
+
 @pytest.mark.parametrize("workload,extra", [("varbase", ["--log2n", "15", "--no-extras"]), ("fixedbase", ["--log2n", "16"]),
                                             ("decompress", ["--log2n", "16"])])
 def test_one_rank_rccl_leg_every_workload(workload, extra):

@@ -235,7 +235,7 @@ def test_msm_allgather_one_rank_rccl():
 
 def test_msm_rccl_example_one_rank(tmp_path):
     """examples/msm_rccl.cpp (one process per GPU, ncclUniqueId through a file) built against /opt/rocm's librccl and run with one
-    rank: its three ways agree and the point equals the oracle's MSM over the same synthetic terms."""
+    rank: its four ways agree and the point equals the oracle's MSM over the same synthetic terms."""
     import torch
 
     from jubjub_amd import Engine
@@ -250,6 +250,7 @@ def test_msm_rccl_example_one_rank(tmp_path):
     r = subprocess.run([str(exe), str(n), "2"], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "allgather == partial+ncclAllGather+combine: ok; term partition == window partition: ok" in r.stdout, r.stdout
+    assert "jobs in flight: ok" in r.stdout, r.stdout                     # way D: jj_msm_allgather_begin / jj_msm_finish, three in flight
     got = [ln.split("result=")[1].strip() for ln in r.stdout.splitlines() if "result=" in ln][0]
     e = Engine(0)
     SEED = 0x4A55424A5542

@@ -719,6 +719,69 @@ def test_msm_gathered_records_folded_on_the_device(monkeypatch, fold):
     e2.close()
 
 
+@pytest.mark.parametrize("G, fold_min", [(8, 8), (2, 8), (3, 2)])
+def test_msm_allgather_of_G_ranks_played_on_one_gpu(monkeypatch, G, fold_min):
+    """jj_msm_allgather and jj_msm_allgather_begin / jj_msm_finish with G > 1 ranks, which a 1-GPU box cannot hold: the context gets an
+    all-gather that plays the other ranks (tests/util.py LoopbackComm: their records, computed beforehand, land in the other slots of the
+    receive buffer, stream-ordered like RCCL's kernel).  Every rank's call must return the oracle's sum of ALL terms -- term and
+    window partition, ragged shards, device and host inputs, G records folded on the device (G >= fold_min) or added by the host,
+    three jobs with different terms in flight finished out of order, and shards of different window layouts (a 100-term rank among
+    Pippenger ranks: the fold kernel declines, the finish copies all records out of the job's own buffer)."""
+    import torch
+
+    from jubjub_amd import Engine
+    from jubjub_amd.dist import shard_bounds
+    from util import LoopbackComm
+
+    monkeypatch.setenv("JJ_MSM_FOLD_MIN", str(fold_min))
+    dev = torch.device("cuda", 0)
+    e2 = Engine(0)
+    n = 9000 * G + 5
+    batches = []
+    for k in range(3):
+        S, P = rand_scalars(4100 + k, n, full_width=True), rand_points(4200 + k, n)
+        batches.append((S, P, torch.from_numpy(S).to(dev), torch.from_numpy(P).to(dev), O.msm(S, P).reshape(64)))
+    for partition in ("terms", "window"):
+        def mine(b, g):
+            if partition == "window":
+                return b[2], b[3]
+            lo, hi = shard_bounds(n, g, G)
+            return b[2][lo:hi], b[3][lo:hi]
+
+        recs = [torch.stack([e2.msm_partial(*mine(b, g)) if partition == "terms" else e2.msm_partial(b[2], b[3], g, G) for g in range(G)]) for b in batches]
+        for rank in sorted({0, G // 2, G - 1}):
+            comm = LoopbackComm(rank, G)
+            for r in recs:
+                comm.add_round(r)
+            e2.set_comm(comm)
+            for k, b in enumerate(batches):                           # synchronous calls, one per prepared round
+                ds, dp = mine(b, rank)
+                got = e2.msm_allgather(ds, dp, partition) if k != 1 else e2.msm_allgather(ds.cpu().numpy(), dp.cpu().numpy(), partition)
+                assert (got == b[4]).all(), (partition, rank, k)
+            jobs = [e2.msm_allgather_begin(*mine(b, rank), partition) for b in batches]        # rounds 3, 4, 5 = the same three again
+            for k in (2, 0, 1):
+                assert (e2.msm_finish(jobs[k]) == batches[k][4]).all(), (partition, rank, "job", k)
+            assert comm.calls() == 6
+            e2.set_comm(None)
+            comm.close()
+    # ranks whose shards have different window layouts: rank 1 holds 100 terms (small-batch path, 64 windows), the others thousands
+    S, P, Sd, Pd, want = batches[0]
+    cuts = [0, 9000, 9100] + [9100 + (n - 9100) * g // (G - 2) for g in range(1, G - 1)] if G > 2 else [0, n - 100, n]
+    cuts = cuts[:G] + [n]
+    recs = torch.stack([e2.msm_partial(Sd[cuts[g]:cuts[g + 1]], Pd[cuts[g]:cuts[g + 1]]) for g in range(G)])
+    for rank in (0, 1):
+        comm = LoopbackComm(rank, G)
+        comm.add_round(recs)
+        e2.set_comm(comm)
+        lo, hi = cuts[rank], cuts[rank + 1]
+        assert (e2.msm_allgather(Sd[lo:hi], Pd[lo:hi]) == want).all(), ("mixed layouts", rank)
+        j = e2.msm_allgather_begin(Sd[lo:hi], Pd[lo:hi])
+        assert (e2.msm_finish(j) == want).all(), ("mixed layouts, job", rank)
+        e2.set_comm(None)
+        comm.close()
+    e2.close()
+
+
 def test_serialization_golden(eng, golden):
     encs = np.array(golden["serialization_16"]["encodings"], np.uint8)
     gen8 = eng.mul_by_cofactor(arr64([J.GENERATOR]))

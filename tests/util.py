@@ -113,3 +113,44 @@ def oracle_msm_record(S, P, part_index=0, part_count=1, W=64):
     hdr = np.array([MSM_REC_MAGIC, 2, W, 1, mask & 0xFFFFFFFF, mask >> 32, n & 0xFFFFFFFF, n >> 32], dtype="<u4")
     rec[:32] = np.frombuffer(hdr.tobytes(), np.uint8)
     return rec
+
+
+class LoopbackComm:
+    """Plays the other ranks of an RCCL communicator on ONE GPU (tools/loopback_comm.cpp) -- what Engine.set_comm takes in place of a
+    jubjub_amd.dist.RcclComm: the all-gather puts what THIS rank sends into slot `rank` and, into the other slots, the records the test
+    prepared for the other ranks (add_round: a (world, MSM_PARTIAL_BYTES) CUDA tensor per call, used in turn)."""
+
+    def __init__(self, rank, world):
+        import ctypes as C
+        import os
+        import subprocess
+
+        tools = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools")
+        so, src = os.path.join(tools, "libloopback_comm.so"), os.path.join(tools, "loopback_comm.cpp")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-shared", "-fPIC", "-o", so, src])
+        self._lib = C.CDLL(so)
+        self._lib.jj_loopback_create.restype = C.c_void_p
+        self._lib.jj_loopback_create.argtypes = [C.c_int, C.c_int]
+        self._lib.jj_loopback_set.argtypes = [C.c_void_p, C.c_uint, C.c_void_p]
+        self._lib.jj_loopback_rewind.argtypes = [C.c_void_p]
+        self._lib.jj_loopback_calls.argtypes = [C.c_void_p]
+        self._lib.jj_loopback_calls.restype = C.c_uint
+        self._lib.jj_loopback_destroy.argtypes = [C.c_void_p]
+        self.rank, self.world = int(rank), int(world)
+        self.handle = self._lib.jj_loopback_create(self.rank, self.world)
+        self.all_gather_addr = C.cast(self._lib.jj_loopback_all_gather, C.c_void_p).value
+        self._keep = []
+
+    def add_round(self, records):
+        assert records.is_cuda and records.is_contiguous() and records.shape[0] == self.world
+        assert self._lib.jj_loopback_set(self.handle, len(self._keep), records.data_ptr()) == 0
+        self._keep.append(records)
+
+    def calls(self):
+        return int(self._lib.jj_loopback_calls(self.handle))
+
+    def close(self):
+        if self.handle:
+            self._lib.jj_loopback_destroy(self.handle)
+            self.handle = None
