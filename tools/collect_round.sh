@@ -33,4 +33,6 @@ for f in gpurun_out/${TAG}_bench_host_*.json gpurun_out/${TAG}_bench_msm20_rccl1
 (echo "$HDR"; echo "# command: python experiments/misc/msm_reduce_l1_sweep.py 18 19 20 21 22"; grep -v amdgpu gpurun_out/${TAG}_msm_reduce_l1_sweep.txt) > profiles/${TAG}_msm_reduce_l1_sweep.txt
 (echo "$HDR"; echo "# command: experiments/hsa_stale_mapping/repro <variant> 3000   (six variants of a stand-alone reproducer of round 4's GPU memory fault)"; cat gpurun_out/${TAG}_hsa_stale_mapping.txt) > profiles/${TAG}_hsa_stale_mapping.txt
 (echo "$HDR"; echo "# command: python experiments/misc/msm_sort_hist_ab.py"; grep -v amdgpu gpurun_out/${TAG}_msm_sort_hist_ab.txt) > profiles/${TAG}_msm_sort_hist_ab.txt
+(echo "$HDR"; echo "# command: python experiments/misc/msm_allgather_pipeline.py 20 8   (the other seven ranks played by tools/loopback_comm.cpp)"; grep -v amdgpu gpurun_out/${TAG}_msm_allgather_pipeline.txt) > profiles/${TAG}_msm_allgather_pipeline.txt
+[ -s gpurun_out/${TAG}_bench_msm20_rccl1_async4.json ] && cp gpurun_out/${TAG}_bench_msm20_rccl1_async4.json profiles/
 python3 tools/design_numbers.py $TAG

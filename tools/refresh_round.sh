@@ -51,5 +51,7 @@ timeout 600 python tests/soak.py 240 3000 > gpurun_out/${TAG}_soak.txt 2>&1 || e
 python experiments/misc/vb_ct_window.py > gpurun_out/${TAG}_vb_ct_window.txt 2>&1
 python experiments/misc/msm_reduce_l1_sweep.py 18 19 20 21 22 > gpurun_out/${TAG}_msm_reduce_l1_sweep.txt 2>&1
 python experiments/misc/msm_sort_hist_ab.py > gpurun_out/${TAG}_msm_sort_hist_ab.txt 2>&1
+python experiments/misc/msm_allgather_pipeline.py 20 8 > gpurun_out/${TAG}_msm_allgather_pipeline.txt 2>&1     # one rank of eight with the other ranks played by tools/loopback_comm.cpp: synchronous jj_msm_allgather against jj_msm_allgather_begin jobs in flight
+JJ_BENCH_FORCE_DIST=1 python bench.py --gpus 1 --workload msm --msm-exchange c --msm-async 4 --no-cpu-baseline > gpurun_out/${TAG}_bench_msm20_rccl1_async4.json 2>/dev/null </dev/null   # the real ncclAllGather (one rank) on the jobs' lanes
 (cd experiments/hsa_stale_mapping; [ -x repro ] || /opt/rocm/bin/hipcc -O2 -o repro repro.cpp; for v in 0 1 2 3 4 5; do timeout 200 ./repro $v 3000 2>&1 | tail -1; done) > gpurun_out/${TAG}_hsa_stale_mapping.txt 2>&1
 tail -1 gpurun_out/${TAG}_profile.log
