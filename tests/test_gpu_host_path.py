@@ -212,6 +212,8 @@ for n in (0, 1, 777, 40000):
     assert (eng.msm_allgather(ds, dp, "terms") == want).all(), n
     assert (eng.msm_allgather(ds, dp, "window") == want).all(), n
     assert (eng.msm_allgather(s, p, "terms") == want).all(), n         # host arrays are staged
+    j1, j2 = eng.msm_allgather_begin(ds, dp, "terms"), eng.msm_allgather_begin(s, p, "window")     # the same in two halves, two jobs in flight
+    assert (eng.msm_finish(j2) == want).all() and (eng.msm_finish(j1) == want).all(), n
 eng.set_comm(None)
 comm.close()
 try:
