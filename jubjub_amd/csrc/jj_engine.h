@@ -216,6 +216,7 @@ struct jj_ctx {
   typedef int (*AllGatherFn)(const void*, void*, size_t, int, void*, hipStream_t);
   void* comm = nullptr; int comm_rank = 0, comm_nranks = 1; AllGatherFn all_gather = nullptr;
   DevBuf gather_dev; uint8_t* gather_host = nullptr; size_t gather_host_cap = 0;
+  bool msm_hist_lds_set = false;   // k_msm_convert_hist's LDS carve-out was requested on this context's device
   bool msm_fold_dev = true;      // gathered records are folded window by window on the device before ONE record goes to the host tail (JJ_MSM_FOLD=host: every record is copied and the host adds them)
   int msm_fold_min = 8;          // ... from this many records (JJ_MSM_FOLD_MIN, 2..4096): at 8 the two paths cost the same (57 us per call, profiles/r5_msm_partition_cost.txt), beyond it the host path grows by ~2.3 us per record while the fold stays put
   // result pool (jj_result_acquire / _release): page-locked result buffers owned by the context, handed out and taken back, so that a caller whose API

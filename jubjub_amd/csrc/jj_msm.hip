@@ -133,15 +133,16 @@ static int msm_enqueue_pippenger(jj_ctx* c, MsmLane& ln, size_t n, const void* d
   // Two-pass sort, round 5: the coarse histogram is taken by the conversion kernel itself (k_msm_convert_hist: totals per (slot, bin)), the tiles of
   // the first pass reserve their runs with one global atomic per bin: no k_msm_part_hist, no k_msm_part_plan.  JJ_MSM_SORT_HIST=separate keeps the
   // round-4 kernels (per-tile counts + a scan: the order of the entries inside a bucket is then the order of the terms).
-  // (measured, experiments/misc/msm_sort_hist_ab.py: 2^20 terms 1.26 -> 1.21 ms, 2^19 -1 %, 2^18 and 2^21 equal, 2^22 +0.7 %: from 2^22 terms the 8192 tiles' atomics on the
-  // same 2048 cursors cost more than the histogram pass they replace, so the fused form stops at 3 x 2^20 terms)
+  // (measured, experiments/misc/msm_sort_hist_ab.py, three boxes: 2^20 terms -3 ... -7 % (1.32 -> 1.24 ms), 2^19 -1 ... -4 %, 2^18 and 2^21 0 ... -2 %, 2^22 +0.7 ... -1.5 %:
+  // at 2^22 terms the 8192 tiles' atomics on the same 2048 cursors cost about what the histogram pass they replace costs, so the fused form stops at 3 x 2^20 terms)
   const bool fused_hist = two_pass && c->msm_fused_hist && Ws <= 64 && Ws * HB <= 4096 && n <= ((size_t)3 << 20);
   if (fused_hist) {
     const bool fresh = ln.bins.cap == 0;
     if ((rc = ensure(c, ln.bins, (size_t)2 * 2 * MSM_BINS_WORDS * 4))) return rc;
     if (fresh) { HIPCHK(c, hipMemsetAsync(ln.bins.p, 0, ln.bins.cap, st)); ln.bins_parity = 0; }     // afterwards every pass clears the other parity's half
-    static bool lds_set = false;
-    if (!lds_set) { HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_convert_hist), hipFuncAttributeMaxDynamicSharedMemorySize, MSM_CH_STAGE_WORDS * 4 + 16384)); lds_set = true; }      // 160 KB: the staging of sixteen waves + up to 4096 counters
+    // 160 KB: the staging of sixteen waves + up to 4096 counters.  Once per CONTEXT, with its device current: the attribute belongs to the
+    // device's copy of the kernel (jj_multi_* drives several devices from one process)
+    if (!c->msm_hist_lds_set) { HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_convert_hist), hipFuncAttributeMaxDynamicSharedMemorySize, MSM_CH_STAGE_WORDS * 4 + 16384)); c->msm_hist_lds_set = true; }
     u32* totals = (u32*)ln.bins.p + (size_t)ln.bins_parity * 2 * MSM_BINS_WORDS;
     u32* cursor = totals + MSM_BINS_WORDS;
     u32* other = (u32*)ln.bins.p + (size_t)(ln.bins_parity ^ 1) * 2 * MSM_BINS_WORDS;

@@ -468,7 +468,7 @@ class Engine:
 
     def msm_allgather(self, scalars, points, partition="terms"):
         """One MSM over all ranks of the communicator lent with set_comm, entirely behind the C ABI (jj_msm_allgather): record of
-        window sums -> ncclAllGather over xGMI -> one copy to the host -> one host tail.  partition "terms": the arrays are THIS
+        window sums -> ncclAllGather over xGMI -> the gathered records folded into one on the device (from 8 ranks; below that one copy of all of them) -> one host tail.  partition "terms": the arrays are THIS
         rank's terms; "window": ALL terms on every rank.  Returns the 64-byte affine sum as a numpy array (host) on every rank."""
         a, p = _Arg(scalars, 32), _Arg(points, 64)
         if a.n != p.n:
