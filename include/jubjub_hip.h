@@ -260,9 +260,10 @@ int jj_msm(jj_ctx*, size_t n, const void* scalars32, const void* points64, void*
  * work of one MSM plus the copy of its records into a page-locked buffer owned by the job and returns at once (device
  * pointers; host arrays are staged first); jj_msm_finish waits for THAT job only, runs the host tail and writes the 64-byte
  * result (host pointer: complete on return; device pointer: copy queued on the context's stream).  A context owns several MSM
- * lanes (streams + workspaces; JJ_MSM_LANES, default 2): jobs with device-pointer inputs alternate over them, so that the
- * latency-bound end of one MSM (fix-up, bucket reduce: a few hundred wavefronts) overlaps the sort and accumulation of the
- * next; every lane starts after the work already queued on the context's stream.  Jobs may be finished in any order, each
+ * lanes (streams of their own + workspaces; JJ_MSM_LANES, default 2; 1 = every job on the context's stream): jobs with
+ * device-pointer inputs alternate over them, so that the latency-bound end of one MSM (fix-up, bucket reduce: a few hundred
+ * wavefronts) overlaps the sort and accumulation of the next; every job starts after the work already queued on the
+ * context's stream when it was begun.  Jobs may be finished in any order, each
  * exactly once (finish releases the job, also on error).  Device input arrays must stay valid until the job is finished; every job must be finished
  * before its context is destroyed. */
 typedef struct jj_msm_job jj_msm_job;

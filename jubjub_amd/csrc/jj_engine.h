@@ -195,8 +195,8 @@ struct jj_ctx {
   size_t pipe_chunk = 0;                 // elements per pipeline chunk: 0 = per entry point (pipe_chunk_for), else JJ_PIPE_CHUNK_LOG2
   // MSM jobs (jj_msm_begin / jj_msm_finish): free list of page-locked record buffers + events
   std::vector<jj_msm_job*> job_pool;
-  MsmLane lanes[MSM_LANES_MAX];
-  int msm_lanes = 2;             // lanes that device-pointer jobs of jj_msm_begin alternate over (JJ_MSM_LANES, 1..4; memory per lane in use)
+  MsmLane lanes[MSM_LANES_MAX + 1];   // [0]: the context's launch stream (synchronous calls, host-staged inputs); [1 ..]: streams of their own for the jobs in flight
+  int msm_lanes = 2;             // lanes that device-pointer jobs of jj_msm_begin / jj_msm_allgather_begin alternate over (JJ_MSM_LANES, 1..4; memory per lane in use; 1: every job on the context's stream)
   unsigned next_lane = 0;
   uint8_t host_out[8][64];       // results on their way to a device pointer (ring: the copies are asynchronous)
   int host_out_next = 0;

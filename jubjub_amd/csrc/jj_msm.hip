@@ -201,8 +201,11 @@ static int msm_enqueue(jj_ctx* c, MsmLane& L, size_t n, const void* ds, const vo
   *rec_bytes = jjhost::rec_bytes(small ? SM_W : msm_windows_for(c, n));
   return small ? msm_enqueue_small(c, L, n, ds, dp, part_w0, part_stride, rec_dev) : msm_enqueue_pippenger(c, L, n, ds, dp, part_w0, part_stride, rec_dev);
 }
-// lane k of the context, ready for use: lane 0 follows the context's launch stream; the others own two streams, created on first
-// use, and start their work after everything already queued on the launch stream (the inputs may have been produced there)
+// lane k of the context, ready for use: lane 0 IS the context's launch stream (synchronous calls, host-staged inputs); the others own
+// their stream, created on first use, and start a job after everything already queued on the launch stream (the inputs may have been
+// produced there).  Jobs in flight (device-pointer inputs) alternate over lanes 1 .. msm_lanes and never run on lane 0: a lane that is the
+// launch stream makes every other lane's next job wait for ITS job, and the jobs then run in pairs that start together (round 5,
+// profiles/r5_msm_allgather_timeline.txt: -6 % with two or three jobs in flight once the lanes are independent)
 static int msm_lane(jj_ctx* c, int k, MsmLane** out) {
   MsmLane& L = c->lanes[k];
   if (k == 0) { L.stream = c->stream; *out = &L; return JJ_OK; }
@@ -248,8 +251,8 @@ void msm_job_put(jj_ctx* c, jj_msm_job* j) {
   (void)hipEventDestroy(j->ev);
   delete j;
 }
-// spread: device-pointer jobs alternate over the context's lanes (jj_msm_begin); otherwise lane 0 (jj_msm; host arrays are staged
-// through buffers the launch stream owns)
+// spread: device-pointer jobs alternate over the context's lanes 1 .. msm_lanes (jj_msm_begin); otherwise lane 0 (jj_msm; host arrays are
+// staged through buffers the launch stream owns; JJ_MSM_LANES=1: every job)
 int msm_begin_locked(jj_ctx* c, size_t n, const void* scalars, const void* points, int part_w0, int part_stride, bool spread, jj_msm_job** out) {
   size_t PASS = (size_t)1 << c->msm_pass_log2;
   // Host arrays of 2^19 terms and more are reduced in SEVERAL passes (one record each, one host tail): the copy of a pass's slice runs on the
@@ -264,7 +267,7 @@ int msm_begin_locked(jj_ctx* c, size_t n, const void* scalars, const void* point
   jj_msm_job* j;
   int rc = msm_job_get(c, npass, &j); if (rc) return rc;
   int k = 0;
-  if (spread && n && c->msm_lanes > 1 && is_device_ptr(scalars) && is_device_ptr(points)) k = (int)(c->next_lane++ % (unsigned)c->msm_lanes);
+  if (spread && n && c->msm_lanes > 1 && is_device_ptr(scalars) && is_device_ptr(points)) k = 1 + (int)(c->next_lane++ % (unsigned)c->msm_lanes);
   MsmLane* L = nullptr;
   if ((rc = msm_lane(c, k, &L))) { msm_job_put(c, j); return rc; }
   auto fail = [&](int code) { if (split && c->pipe.h2d) (void)hipStreamSynchronize(c->pipe.h2d); (void)hipStreamSynchronize(L->stream); (void)hipGetLastError(); msm_job_put(c, j); return code; };   // kernels may still be writing into the job's buffer
@@ -512,7 +515,7 @@ JJ_API int jj_msm_allgather_begin(jj_ctx* c, size_t n, const void* scalars, cons
   uint8_t* mine = (uint8_t*)j->gdev;                                // this rank's record, then the G gathered ones
   uint8_t* all = mine + JJ_MSM_PARTIAL_BYTES;
   int k = 0;
-  if (n && c->msm_lanes > 1 && is_device_ptr(scalars) && is_device_ptr(points)) k = (int)(c->next_lane++ % (unsigned)c->msm_lanes);
+  if (n && c->msm_lanes > 1 && is_device_ptr(scalars) && is_device_ptr(points)) k = 1 + (int)(c->next_lane++ % (unsigned)c->msm_lanes);
   MsmLane* L = nullptr;
   if ((rc = msm_lane(c, k, &L))) { msm_job_put(c, j); return rc; }
   auto fail = [&](int code) { (void)hipStreamSynchronize(L->stream); (void)hipGetLastError(); msm_job_put(c, j); return code; };
