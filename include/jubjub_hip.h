@@ -315,7 +315,7 @@ int jj_msm_allgather(jj_ctx*, size_t n, const void* scalars32, const void* point
  * the folded record lands in a page-locked buffer the job owns) and returns; jj_msm_finish (above) waits for THAT job and runs the
  * single-record host tail.  With two to four jobs in flight a rank's gather, fold, wait and host tail run beside the kernels of its
  * next MSM, so the sustained rate of the distributed sum is set by the kernels of one share (2^17 terms of a 2^20-term MSM cut
- * eight ways: 0.25-0.27 ms per MSM against 0.39 ms + the gather's latency for one synchronous call).  A collective like jj_msm_allgather:
+ * eight ways: 0.245-0.255 ms per MSM against 0.385 ms + the gather's latency for one synchronous call).  A collective like jj_msm_allgather:
  * every rank begins the same jobs in the same order (the gathers of one communicator run in the order they were queued); jobs
  * may be finished in any order, each exactly once; at most 2^24 terms per rank and job; device input arrays stay valid until the
  * job is finished. */
