@@ -127,6 +127,21 @@ def test_host_buffer_api_without_a_gpu():
     del buf
 
 
+def test_job_entry_points_refuse_null_arguments():
+    """the two-halves MSM entry points (jj_msm_begin, jj_msm_allgather_begin, jj_msm_finish) check their arguments before touching a device:
+    no context, no job slot, a partition that is neither terms nor windows -> JJ_ERR_INVALID (no crash, no CPU fallback)"""
+    from jubjub_amd import _lib
+
+    lib = _lib.load()
+    job = ctypes.c_void_p()
+    out = (ctypes.c_uint8 * 64)()
+    assert lib.jj_msm_begin(None, 0, None, None, ctypes.byref(job)) == _lib.JJ_ERR_INVALID and not job.value
+    assert lib.jj_msm_allgather_begin(None, 0, None, None, 0, ctypes.byref(job)) == _lib.JJ_ERR_INVALID and not job.value
+    assert lib.jj_msm_finish(None, out) == _lib.JJ_ERR_INVALID
+    assert lib.jj_msm_allgather(None, 0, None, None, 0, out) == _lib.JJ_ERR_INVALID
+    assert lib.jj_msm_combine_dev(None, 0, None, out) == _lib.JJ_ERR_INVALID
+
+
 def test_host_batch_chunk_schedule_properties():
     """jj_plan_host_chunks is the function run_pipelined cuts a host batch with (jj_pipeline.hip pipe_chunk_bounds): the chunks tile [0, n)
     in order, none is empty or longer than chunk + the edge, the ramp's short first and last chunk appear exactly when the batch has four
