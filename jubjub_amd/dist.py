@@ -2,9 +2,10 @@
 Multi-GPU host logic: one process per GPU (torch.distributed; backend "nccl" = RCCL on ROCm, "gloo" on CPU
 for tests).  The independent-batch workloads shard with NO data-path collective; MSM all-gathers one record of partial
 window sums per rank (JJ_MSM_PARTIAL_BYTES = 8256 bytes; elliptic-curve addition is not an RCCL reduction operator),
-copies the gathered records to the host once and every rank runs one host tail over them (jj_msm_combine).
-C / C++ / Rust callers do the same exchange without Python: jj_ctx_set_comm + jj_msm_allgather (include/jubjub_hip.h,
-examples/msm_rccl.cpp).
+folds the gathered records into one on the device (from 8 ranks; below that they are copied to the host once) and every rank runs
+one host tail (jj_msm_combine / jj_msm_combine_dev).
+C / C++ / Rust callers do the same exchange without Python: jj_ctx_set_comm + jj_msm_allgather, or in two halves for a stream of
+MSMs, jj_msm_allgather_begin + jj_msm_finish (include/jubjub_hip.h, examples/msm_rccl.cpp; Engine.msm_allgather / msm_allgather_begin).
 
 `engine` is any object with the Engine methods used here (varbase_mul, fixedbase_mul, decompress, msm,
 point_sum); production code passes jubjub_amd.Engine — the CPU tests pass an oracle-backed stand-in.
