@@ -141,7 +141,7 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="varbase workload: skip the fixed-base side measurements (clean per-kernel profiles)")
     ap.add_argument("--fb-window", type=int, default=0, help="fixed-base table: 0/7 = signed comb in LDS (default: 32 additions + 3 doublings), 6 = signed 6-bit windows in LDS (43 additions), both with the constant-time shuffle select; 8..16 = table gathered from L2 / Infinity Cache")
     ap.add_argument("--decompress-flags", type=int, default=13,
-                    help="jj_decompress flags: 1 ZIP-216 | 2 torsion-free (order-8 Tate pairing; JJ_TORSION_CHECK=ladder for the [r]P ladder) | 4 reject small order | 8 clear cofactor (default 13 = BASELINE config 5: decode + small-order check + mul_by_cofactor)")
+                    help="jj_decompress flags: 1 ZIP-216 | 2 torsion-free (order-8 Tate pairing; --opt torsion_check_ladder=1 for the [r]P ladder) | 4 reject small order | 8 clear cofactor (default 13 = BASELINE config 5: decode + small-order check + mul_by_cofactor)")
     ap.add_argument("--msm-partition", default="terms", choices=["terms", "window"], help="multi-rank MSM: cut by terms or by windows (see the module docstring)")
     ap.add_argument("--msm-async", type=int, default=1, help="MSM workload: jobs in flight per context (1 = synchronous jj_msm / jj_msm_allgather calls)")
     ap.add_argument("--msm-contexts", type=int, default=1, help="N = 1 MSM workload: contexts (each with its own stream and workspaces) driven by as many host threads on the one GPU: "
@@ -157,6 +157,8 @@ def parse():
                     help="multi-rank MSM over the nccl backend: c = the whole exchange behind the C ABI (jj_ctx_set_comm + jj_msm_allgather on an RCCL "
                          "communicator of this process's own); torch = jj_msm_partial + torch.distributed.all_gather + jj_msm_combine")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for plumbing tests)")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="jj_ctx_set_option for every context of the run (repeatable), e.g. --opt msm_lanes=1 --opt msm_front1=0; "
+                    "host_tail_scalar=1 is process-wide.  The library reads no JJ_* environment variable.")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target wall time of each CPU baseline sample")
     return ap.parse_args()
 
@@ -403,7 +405,8 @@ def run(a):
         if rank == 0:
             print("bench.py: --gpus %d but the launcher started %d rank(s); refusing to mislabel the run" % (a.gpus, world), file=sys.stderr)
         return 2
-    eng = Engine(dev_index)
+    ctx_options = {kv.split("=", 1)[0]: int(kv.split("=", 1)[1]) for kv in a.opt}
+    eng = Engine(dev_index, options=ctx_options)
 
     wl = a.workload
     log2n = a.log2n if a.log2n is not None else DEFAULT_LOG2N[wl]
@@ -538,7 +541,7 @@ def run(a):
     if wl == "msm" and not distributed and a.msm_contexts > 1:
         import threading
 
-        msm_engs += [Engine(dev_index) for _ in range(a.msm_contexts - 1)]
+        msm_engs += [Engine(dev_index, options=ctx_options) for _ in range(a.msm_contexts - 1)]
         msm_streams = [torch.cuda.Stream(dev) for _ in msm_engs]
 
     def msm_series(e, count):
@@ -665,7 +668,7 @@ def run(a):
     if host:
         res["pcie_inclusive"] = True
         res["config"]["host_buffers"] = {"pinned": "page-locked (jj_host_alloc), reused by every pass",
-                                         "pageable": "pageable numpy memory, reused by every pass; the chunks pass through the context's page-locked staging slots (bounce path; JJ_PIPE_PAGEABLE=register: arrays that consist of whole pages are page-locked in place instead)",
+                                         "pageable": "pageable numpy memory, reused by every pass; the chunks pass through the context's page-locked staging slots (bounce path; --opt pipe_pageable_register=1: arrays that consist of whole pages are page-locked in place instead)",
                                          "pooled": "inputs: pageable numpy memory, reused; RESULT: a different page-locked buffer from the library's pool for every call (jj_result_acquire; the previous call's buffer is released after the next one was acquired)",
                                          "fresh": "pageable numpy memory; the RESULT array is newly allocated (np.empty) for every call: its pages are faulted in and page-locked inside the call"}[host]
         res["config"]["result_bytes"] = out_w if wl != "msm" else 64

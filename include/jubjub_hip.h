@@ -53,6 +53,26 @@ int jj_ctx_destroy(jj_ctx* ctx);
 int jj_ctx_set_stream(jj_ctx* ctx, void* hip_stream);
 int jj_ctx_use_own_stream(jj_ctx* ctx);
 int jj_ctx_sync(jj_ctx* ctx);
+/* Options.  The library reads NO environment variable: what a caller may tune is set per context, by key, right after jj_ctx_create (before the
+ * first batch call).  No option changes WHAT an entry point computes or its timing discipline: the constant-time ladders and selects have no
+ * switch (for public scalars there are the explicit *_vartime entry points).  Unknown key or value out of range: JJ_ERR_INVALID.
+ *   msm_lanes 1..4 (2)            streams the jobs of jj_msm_begin / jj_msm_allgather_begin alternate over; 1 = every job on the context's stream
+ *                                 (jj_ctx_set_comm with more than one rank sets 1: all gathers of one communicator then go through ONE stream)
+ *   msm_fold_min 2..4096 (8)      jj_msm_allgather / _combine_dev fold the gathered records on the device from this many records
+ *   msm_fold_dev 0|1 (1)          0: the gathered records are copied to the host and added there
+ *   msm_host_split 0|1 (1)        host arrays of 2^19 terms and more in several passes, each copy beside the kernels of the pass before
+ *   msm_pass_log2 10..24 (24)     terms per Pippenger pass
+ *   result_pool_mb 0..2^20 (4096) bytes of released result buffers kept for reuse (jj_result_acquire)
+ *   torsion_check_ladder 0|1 (0)  jj_is_torsion_free / _prime_order by [r]P (the reference's definition) instead of the order-8 pairing
+ *   pipe_pageable_register 0|1 (0), pipe_copy_threads 0..64 (0 = auto), pipe_ramp 0|1 (1), pipe_prefault 0|1 (1), pipe_chunk_log2 0|8..24 (0 = per
+ *                                 entry point): the host-buffer pipeline
+ *   fixedbase_default 6|7 (7)     what window_bits = 0 means for jj_fixedbase_table_create
+ * Planner overrides, for tests and measurements (every value gives the same results): msm_windows, msm_small_max, msm_small_blk, msm_accum,
+ * msm_seg_len, msm_chunk, msm_reduce_chunk, msm_reduce_l1, msm_reduce_l2_chunk, msm_sort_hist_fused, msm_sort_two_pass, msm_front1, vb_ct_window,
+ * vb_quad_max, dec_c_mid (ranges: jj_pipeline.hip ctx_options).
+ * One process-wide option, set with ctx = NULL: host_tail_scalar 0|1 (0) -- the MSM host tail on the scalar 4 x 64-bit chain even where AVX-512 IFMA is there. */
+int jj_ctx_set_option(jj_ctx* ctx, const char* key, long long value);
+int jj_ctx_get_option(jj_ctx* ctx, const char* key, long long* value);
 const char* jj_last_error(jj_ctx* ctx);
 int jj_version(void);
 /* WnafGroup::recommended_wnaf_for_num_scalars (src/lib.rs:1320-1335) */
@@ -78,10 +98,10 @@ int jj_peak_imad32_samples(jj_ctx* ctx, int count, double* out_per_sec);
  *   - memory from jj_host_alloc, or memory registered once with jj_host_register, is used as it is: the copies run straight
  *     from and to it (2^24 fixed-base units: 0.90 of the device-resident rate, profiles/r4_pcie_inclusive.txt);
  *   - any other (pageable) array passes through page-locked staging buffers of the context, copied by a few host threads (default
- *     8, JJ_PIPE_COPY_THREADS) beside the GPU's work: within 2-3 % of the page-locked rates, nothing of the caller's is registered,
+ *     8, option pipe_copy_threads) beside the GPU's work: within 2-3 % of the page-locked rates, nothing of the caller's is registered,
  *     and a result array the caller has only just allocated costs no more than its page faults.  The GPU never touches the caller's
  *     pageable pages: arrays of 1 MB and more are not handed to the HIP runtime either (which would page-lock them itself).
- *     JJ_PIPE_PAGEABLE=register selects round 3's way instead for arrays that consist of whole pages (both ends page-aligned, 1 MB and
+ *     option pipe_pageable_register = 1 selects round 3's way instead for arrays that consist of whole pages (both ends page-aligned, 1 MB and
  *     more: page-locked in place for the call: no CPU copies, but a freshly allocated 1 GB result array then costs ~65 ms of serial page
  *     faults and pinning inside the call); all other arrays are staged in that mode too -- page-locking them in place would hand pages of
  *     neighbouring objects to the GPU as well (two GPU write faults in ~3000 randomised test rounds followed that).
@@ -107,7 +127,7 @@ int jj_host_unregister(void* p);
  * buffers, profiles/r4_bench_host_*_fresh.json); jj_result_acquire hands out a buffer of at least `bytes` bytes instead (allocated on
  * first use, recycled afterwards: the smallest free buffer that fits), the entry points recognise it as page-locked memory (copies run
  * straight into it), and jj_result_release gives it back when the caller has consumed the result -- several buffers may be out at a
- * time, so every call can return a DIFFERENT result object.  Released buffers are kept while the pool holds at most JJ_RESULT_POOL_MB
+ * time, so every call can return a DIFFERENT result object.  Released buffers are kept while the pool holds at most result_pool_mb (option)
  * (default 4096) megabytes, and freed with the context.  jj_result_release(NULL) is a no-op; a pointer the context did not hand out
  * is JJ_ERR_INVALID.  Thread-safe per context like every entry point. */
 int jj_result_acquire(jj_ctx*, size_t bytes, void** out);
@@ -115,7 +135,7 @@ int jj_result_release(jj_ctx*, void* p);
 int jj_result_pool_stats(jj_ctx*, size_t* buffers, size_t* bytes, size_t* in_use);
 /* How a host batch is cut -- pure functions of their arguments (no context, no device: the CPU-side tests call them).
  * jj_plan_host_chunks: the chunk boundaries of a pipelined host batch of n >= 1 units with chunks of `chunk` units (what the library
- * picks per entry point or JJ_PIPE_CHUNK_LOG2 sets): chunk k = [bounds[k], bounds[k + 1]), *count = entries of bounds (chunks + 1).
+ * picks per entry point or option pipe_chunk_log2 sets): chunk k = [bounds[k], bounds[k + 1]), *count = entries of bounds (chunks + 1).
  * ramp != 0: the first and the last chunk are chunk / 4 when the batch has at least four chunks of at least 2^18 units -- the first
  * copy in and the last copy out are the two transfers nothing overlaps; `quantum` (0 = none): the units one round of the kernel's
  * lanes takes, edges are whole multiples of it.  cap = 0 (bounds may be NULL) returns the count only.
@@ -181,7 +201,7 @@ int jj_point_to_niels(jj_ctx*, size_t n, const void* p, void* out96);
 int jj_is_identity(jj_ctx*, size_t n, const void* p, uint8_t* out);
 int jj_is_small_order(jj_ctx*, size_t n, const void* p, uint8_t* out);
 /* is_torsion_free: same predicate as [r]P == O (lib.rs:709-711) for points on the curve, computed with the order-8
- * Tate pairing (one exponentiation) instead of the 252-step ladder; JJ_TORSION_CHECK=ladder selects the ladder. */
+ * Tate pairing (one exponentiation) instead of the 252-step ladder; option torsion_check_ladder = 1 selects the ladder. */
 int jj_is_torsion_free(jj_ctx*, size_t n, const void* p, uint8_t* out);
 int jj_is_prime_order(jj_ctx*, size_t n, const void* p, uint8_t* out);
 int jj_is_on_curve(jj_ctx*, size_t n, const void* p, uint8_t* out);
@@ -194,18 +214,18 @@ int jj_point_sum(jj_ctx*, size_t n, const void* p, void* out64);
  * CONSTANT-TIME like the reference's ladder (conditional_select, src/lib.rs:334-343): neither the instruction stream nor any memory
  * address depends on the scalar.  Signed 3-bit windows (k' = k + sum 4 * 8^i: 84 windows tile the 252 bits, bit 252 is the recoding carry),
  * table {P, 2P, 3P, 4P}: {P, 2P} in registers, {3P, 4P} in a per-lane LDS slot that is read whole for every window; the entry is picked
- * with bit masks, the sign applied through the subtraction formulas: 85 additions + 252 doublings.  Batches up to JJ_VB_QUAD_MAX
+ * with bit masks, the sign applied through the subtraction formulas: 85 additions + 252 doublings.  Batches up to vb_quad_max
  * (32 768) units run one scalar multiplication per quad of lanes (every lane keeps its own coordinate of the four entries in
  * registers): same discipline, a third of the latency. */
 int jj_varbase_mul(jj_ctx*, size_t n, const void* scalars32, const void* points64, void* out64);
 /* same, result written as 32-byte compressed encodings (to_bytes of the product, src/lib.rs:455-464, 1419-1421) */
 int jj_varbase_mul_compressed(jj_ctx*, size_t n, const void* scalars32, const void* points64, void* out32);
-/* the name rounds 3-4 gave the constant-time ladder when it was the opt-in: the same as jj_varbase_mul, whatever JJ_VARBASE_DEFAULT says */
+/* the name rounds 3-4 gave the constant-time ladder when it was the opt-in: the same as jj_varbase_mul */
 int jj_varbase_mul_ct(jj_ctx*, size_t n, const void* scalars32, const void* points64, void* out64);
 /* VARIABLE-TIME variants for PUBLIC scalars (what rounds 1-4 shipped as jj_varbase_mul): signed 5-bit windows, the lane's table
  * {0 .. 16} P in device memory, read at a digit-dependent address: a scalar-independent instruction stream but scalar-dependent
- * memory addresses (cache timing).  About 2.5 % faster than jj_varbase_mul at 2^20 units (profiles/r5_vb_ct_window.txt).
- * JJ_VARBASE_DEFAULT=vartime makes jj_varbase_mul / _compressed take this ladder as well (A/B measurements). */
+ * memory addresses (cache timing).  About 1.6 % faster than jj_varbase_mul at 2^20 units (ratio 0.984, profiles/r5_vb_ct_window.txt).
+ * Nothing makes jj_varbase_mul / _compressed take this ladder: no option, no environment variable. */
 int jj_varbase_mul_vartime(jj_ctx*, size_t n, const void* scalars32, const void* points64, void* out64);
 int jj_varbase_mul_vartime_compressed(jj_ctx*, size_t n, const void* scalars32, const void* points64, void* out32);
 /* One scalar, many bases: out[i] = points[i] * scalar (the `Wnaf::scalar(..).base(..)` reuse pattern of the group crate,
@@ -254,13 +274,13 @@ int jj_fixedbase_composite_mul(jj_ctx*, const jj_table* t, size_t n, const void*
  * step -- adding the partial sums of each window, Horner over the windows (a chain of 252 dependent doublings) and one
  * inversion -- runs on the calling host thread, so for every n this call waits for the stream even when all pointers are
  * device pointers (the 64-byte result is then copied to out64 asynchronously).  HOST arrays of 2^19 terms and more are summed in
- * two to eight passes, the copy of each pass's slice beside the kernels of the pass before (JJ_MSM_HOST_SPLIT=0: one pass). */
+ * two to eight passes, the copy of each pass's slice beside the kernels of the pass before (option msm_host_split = 0: one pass). */
 int jj_msm(jj_ctx*, size_t n, const void* scalars32, const void* points64, void* out64);
 /* The same in two halves, so that the host tail of one MSM overlaps the kernels of the next: jj_msm_begin queues all device
  * work of one MSM plus the copy of its records into a page-locked buffer owned by the job and returns at once (device
  * pointers; host arrays are staged first); jj_msm_finish waits for THAT job only, runs the host tail and writes the 64-byte
  * result (host pointer: complete on return; device pointer: copy queued on the context's stream).  A context owns several MSM
- * lanes (streams of their own + workspaces; JJ_MSM_LANES, default 2; 1 = every job on the context's stream): jobs with
+ * lanes (streams of their own + workspaces; option msm_lanes, default 2; 1 = every job on the context's stream): jobs with
  * device-pointer inputs alternate over them, so that the latency-bound end of one MSM (fix-up, bucket reduce: a few hundred
  * wavefronts) overlaps the sort and accumulation of the next; every job starts after the work already queued on the
  * context's stream when it was begun.  Jobs may be finished in any order, each

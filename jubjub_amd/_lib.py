@@ -3,8 +3,11 @@ there is no CPU fallback in the product path."""
 import ctypes as C
 import os
 
-# (HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues, default 4; applications that drive host batches beside other HIP work export
-# GPU_MAX_HW_QUEUES=8 before the first HIP call -- include/jubjub_hip.h.  Neither the library nor this module touches the process environment.)
+# HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  A context with jobs in flight uses five streams (launch, two
+# copy streams, two MSM lanes): with four queues two of them share one and the pipelines run 1.7-2x slower (profiles/r4_pcie_inclusive.txt).  The C
+# library never touches the environment (it warns once on stderr when it creates its fifth stream with fewer than 8 queues configured); this
+# PYTHON package sets the variable, if the application has not, before the HIP runtime is loaded -- a HIP runtime variable, not a switch of ours.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("JJ_LIB_PATH") or os.path.join(HERE, "lib", "libjubjub_hip.so")   # JJ_LIB_PATH: A/B builds of the same library
@@ -83,7 +86,7 @@ EXPORTS = sorted(list(_SIGS) + ["jj_ctx_create", "jj_ctx_destroy", "jj_last_erro
                                 "jj_msm_fold_partials", "jj_msm_finish", "jj_msm_combine",
                                 "jj_host_alloc", "jj_host_free", "jj_host_register", "jj_host_unregister",
                                 "jj_result_acquire", "jj_result_release", "jj_result_pool_stats",
-                                "jj_plan_host_chunks", "jj_plan_msm_host_passes"])
+                                "jj_plan_host_chunks", "jj_plan_msm_host_passes", "jj_ctx_set_option", "jj_ctx_get_option"])
 
 _lib = None
 
@@ -165,6 +168,10 @@ def load():
     lib.jj_plan_host_chunks.argtypes = [C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(C.c_size_t), C.c_size_t, C.POINTER(C.c_size_t)]
     lib.jj_plan_msm_host_passes.restype = C.c_int
     lib.jj_plan_msm_host_passes.argtypes = [C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    lib.jj_ctx_set_option.restype = C.c_int
+    lib.jj_ctx_set_option.argtypes = [_vp, C.c_char_p, C.c_longlong]
+    lib.jj_ctx_get_option.restype = C.c_int
+    lib.jj_ctx_get_option.argtypes = [_vp, C.c_char_p, C.POINTER(C.c_longlong)]
     lib.jj_fr_char_le_bits.restype = C.c_int
     lib.jj_fr_char_le_bits.argtypes = [C.POINTER(C.c_uint8)]
     lib.jj_device_info.restype = C.c_int

@@ -149,7 +149,9 @@ struct jj_ctx {
   int msm_segments = -1;         // bucket accumulation: 1 = length-sorted segments, 0 = fixed chunks + fix-up, -1 = segments from MSM_LARGE_MIN (147 456) terms
                                  // (2-4 % faster there, slower below: more launches) (JJ_MSM_ACCUM=segments|chunks)
   int msm_seg_len = 0;           // segment length override (JJ_MSM_SEG_LEN; 0 = twice the mean bucket of the widest windows, clamped to [32, 1024])
-  int msm_chunk = 0;             // accumulation chunk override (JJ_MSM_CHUNK; 0 = scale with n)
+  int msm_chunk = 0;             // accumulation chunk override (option msm_chunk; 0 = from msm_chunk_waves)
+  int msm_sort_blocks_per_cu = 2; // one-pass sort (k_msm_front2 / k_msm_scatter2): (part, slot) blocks per CU the parts are cut for (option msm_sort_blocks_per_cu, 1..4)
+  int msm_chunk_waves = 2;       // chunked accumulation: rounds of one-wave-per-SIMD workgroups per CU the launch is sized for (option msm_chunk_waves, 1..8)
   int msm_reduce_chunk = 0;      // bucket-reduce chunk length (0 = from the bucket count, see msm_enqueue_pippenger; JJ_MSM_REDUCE_CHUNK, a power of two)
   int msm_l1_rows = -1;          // two-level bucket reduce (k_msm_reduce_l1 / _l2): rows R of the bucket matrix a level-1 lane sums (a power of two, 2..64); 0 = one level (k_msm_reduce_fold);
                                  // -1 = from the bucket count (msm_enqueue_pippenger; JJ_MSM_REDUCE_L1)
@@ -215,7 +217,9 @@ struct jj_ctx {
   // multi-rank MSM exchange (jj_ctx_set_comm / jj_msm_allgather): the caller's RCCL communicator, ncclAllGather of the library that made it
   typedef int (*AllGatherFn)(const void*, void*, size_t, int, void*, hipStream_t);
   void* comm = nullptr; int comm_rank = 0, comm_nranks = 1; AllGatherFn all_gather = nullptr;
-  DevBuf gather_dev; uint8_t* gather_host = nullptr; size_t gather_host_cap = 0;
+  DevBuf gather_dev, poison_dev; uint8_t* gather_host = nullptr; size_t gather_host_cap = 0;      // poison_dev: the all-zero record a failing rank gathers (msm_post_poison)
+  bool msm_front1 = true;          // one-pass sort: conversion + tile histograms / plan + scatter in two launches (k_msm_front1, k_msm_scatter1); false: the four launches of rounds 2-5
+  bool msm_front1_lds_set = false;
   bool msm_hist_lds_set = false;   // k_msm_convert_hist's LDS carve-out was requested on this context's device
   bool msm_fold_dev = true;      // gathered records are folded window by window on the device before ONE record goes to the host tail (JJ_MSM_FOLD=host: every record is copied and the host adds them)
   int msm_fold_min = 8;          // ... from this many records (JJ_MSM_FOLD_MIN, 2..4096): at 8 the two paths cost the same (57 us per call, profiles/r5_msm_partition_cost.txt), beyond it the host path grows by ~2.3 us per record while the fold stays put

@@ -2,7 +2,7 @@
 // AVX-512 IFMA: the four coordinates (U, V, Z, T) of the running point are the four 64-bit lanes of 256-bit vectors, a field element is
 // five 52-bit limbs (one vector per limb), and a point doubling is TWO four-lane Montgomery products -- [U U, V V, Z Z, U V], then
 // [E F, G H, F G, E H] -- instead of seven scalar 4 x 64-bit products one after the other.  ~4x the scalar chain on a Zen 5 / Ice Lake
-// core; used when the CPU has avx512ifma + avx512vl (checked at run time; JJ_HOST_TAIL=scalar forces the scalar chain).
+// core; used when the CPU has avx512ifma + avx512vl (checked at run time; jj_ctx_set_option(NULL, "host_tail_scalar", 1) forces the scalar chain).
 //
 // Form.  Montgomery radix 2^260 here, 2^256 in the records and in jj_host_tail.h.  The integers of a record are used AS THEY ARE: read
 // in this radix they are the coordinates times 2^-4, and a projective point may be scaled by any constant (U, V, Z and T by the same
@@ -280,13 +280,11 @@ JJ_IFMA static inline Ext horner(int W, const bool* have, const P4* sum) {
   st(out, acc);
   return unpack_point(out);
 }
+// jj_ctx_set_option(NULL, "host_tail_scalar", 1): the scalar 4 x 64-bit chain even where the IFMA chain is available (tests, measurements)
+inline std::atomic<int>& force_scalar() { static std::atomic<int> v{0}; return v; }
 static inline bool available() {
-  static const bool ok = [] {
-    const char* e = getenv("JJ_HOST_TAIL");
-    if (e && !strcmp(e, "scalar")) return false;
-    return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("avx512ifma");
-  }();
-  return ok;
+  static const bool ok = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("avx512ifma");
+  return ok && !force_scalar().load(std::memory_order_relaxed);
 }
 
 }  // namespace ifma

@@ -61,7 +61,7 @@ static int msm_enqueue_pippenger(jj_ctx* c, MsmLane& ln, size_t n, const void* d
   u32 L_auto = 4;
   while (L_auto < B && reduce_blocks(L_auto) > (u32)c->cus) L_auto <<= 1;
   const u32 L = std::min<u32>(c->msm_reduce_chunk ? (u32)c->msm_reduce_chunk : L_auto, B);
-  if (B % L || (L & (L - 1))) { c->err = "inconsistent MSM tuning override (JJ_MSM_REDUCE_CHUNK must be a power of two dividing the bucket count)"; return JJ_ERR_INVALID; }
+  if (B % L || (L & (L - 1))) { c->err = "inconsistent MSM tuning override (option msm_reduce_chunk must be a power of two dividing the bucket count)"; return JJ_ERR_INVALID; }
   const u32 K = B / L, nblk = std::min<u32>(MSM_TREE_QUADS, (K + MSM_TREE_QUADS - 1) / MSM_TREE_QUADS);      // workgroups of 64 quads per window, at most
   const u32 reduce_grid = reduce_blocks(L);
   int jbits = 0; while ((1u << jbits) < B) jbits++;
@@ -86,19 +86,30 @@ static int msm_enqueue_pippenger(jj_ctx* c, MsmLane& ln, size_t n, const void* d
   const size_t l1_bytes = l1_rows ? (size_t)Ws * (B / l1_rows) * ENIELS_WORDS * 4 : 0;      // one array of extended-Niels records (S, then T)
   int rc;
   DevBuf &kprime = ln.buf[0], &niels = ln.buf[1], &offb = ln.buf[2], &idx = ln.buf[3], &buckets = ln.buf[4], &ra = ln.buf[5], &tcnt = ln.buf[7];
-  u32 chunk = MSM_CHUNK_MIN;                           // 16 entries per lane up to 2^19 terms, 32 at 2^20, then proportional to n (measured)
-  while (chunk < 256 && ((size_t)chunk << 15) < n) chunk <<= 1;
-  if (n < ((size_t)1 << 15)) chunk = 8;               // small inputs (only reached with the small-batch path switched off): more lanes, shorter chains
+  // Entries per lane of the chunked accumulation (below MSM_LARGE_MIN terms; above, the segments decide).  The launch is Ws x ceil(nchunk / 256)
+  // workgroups of one wave per SIMD, and the dispatcher deals them round the CUs: what counts is how many ROUNDS of workgroups a CU gets, so the
+  // chunk is the shortest one that fits the launch into msm_chunk_waves rounds (round 6: 2^17 terms ran 16 entries in 2.9 rounds -- three -- where
+  // 24 entries in 1.9 rounds cost the same accumulation time and leave a third fewer heads to the fix-up: 353 -> 339 us per call; 2^16 terms ran
+  // 1.4 rounds, i.e. two, of 16 entries for 23 entries' worth of work).  Rounds 2-5: 16 entries up to 2^19 terms, 8 below 2^15.
+  u32 chunk = 8;
+  // Jobs in flight (lanes of their own) share the CUs with the neighbouring job's kernels, the rounds argument does not hold for them and
+  // shorter chunks interleave better: one round more (measured, four jobs in flight at 2^17 terms: 0.228-0.241 ms per MSM against 0.249-0.258).
+  { const size_t cap = (size_t)(std::max(1, c->msm_chunk_waves) + (&ln != &c->lanes[0] ? 1 : 0)) * (size_t)c->cus;
+    while (chunk < 1024 && (size_t)Ws * ((((n + chunk - 1) / chunk) + 255) / 256) > cap) chunk++; }
   if (c->msm_chunk) chunk = (u32)c->msm_chunk;
   const u32 nchunk = (u32)((n + chunk - 1) / chunk);
   const bool two_pass = B > 4096 || (B == 4096 && c->msm_two_pass != 0);      // the one-pass plan kernel covers 4096 buckets per window
   const u32 HB = B >> MSM_LO_BITS;
-  if (two_pass && HB > MSM_HB_MAX) { c->err = "MSM window layout has more coarse bins per window than the two-pass sort holds (JJ_MSM_WINDOWS must be 16..36)"; return JJ_ERR_INVALID; }
+  if (two_pass && HB > MSM_HB_MAX) { c->err = "MSM window layout has more coarse bins per window than the two-pass sort holds (option msm_windows must be 16..36)"; return JJ_ERR_INVALID; }
   const u32 ptiles = (u32)((n + MSM_P1_TILE - 1) / MSM_P1_TILE);        // the first pass of the two-pass sort orders a whole tile in LDS
   const size_t pm = (size_t)HB * ptiles;                               // runs per slot
   // one-pass sort tiles: enough (tile, window) blocks to fill the GPU, each at least 4096 terms
   const u32 ntiles = (u32)std::max<size_t>(1, std::min<size_t>((size_t)(c->cus + Ws - 1) / Ws, (n + 4095) / 4096));
   const size_t tile = (n + ntiles - 1) / ntiles;
+  // one-pass sort in two launches (round 6): counting blocks (part, slot), as many parts as give every CU one block, each part at least 4096 terms
+  const u32 f2_parts = (u32)std::max<size_t>(1, std::min<size_t>(std::min<size_t>((size_t)c->msm_sort_blocks_per_cu * c->cus / Ws, MSM_F2_PARTS_MAX), (n + 4095) / 4096));
+  const size_t f2_part_terms = (n + f2_parts - 1) / f2_parts;
+  const bool front1 = !two_pass && c->msm_front1 && B <= 4096;
   const bool use_segments = c->msm_segments == 1 || (c->msm_segments < 0 && n >= MSM_LARGE_MIN);
   // segments of at most P entries, sorted by length; P bounds the serial depth of one lane: twice the mean bucket of the widest windows
   u32 P = (u32)std::min<size_t>(SEG_PMAX, std::max<size_t>(32, 2 * n / B));
@@ -114,7 +125,7 @@ static int msm_enqueue_pippenger(jj_ctx* c, MsmLane& ln, size_t n, const void* d
   if ((rc = ensure(c, niels, n * (size_t)GNIELS_WORDS * 4))) return rc;
   if ((rc = ensure(c, offb, (size_t)Ws * (B + 1) * 4))) return rc;
   if ((rc = ensure(c, idx, n * (size_t)Ws * 4))) return rc;
-  if ((rc = ensure(c, tcnt, two_pass ? ((size_t)Ws * (2 * pm + 1)) * 4 : (size_t)Ws * ntiles * B * 4))) return rc;
+  if ((rc = ensure(c, tcnt, two_pass ? ((size_t)Ws * (2 * pm + 1)) * 4 : front1 ? (size_t)Ws * f2_parts * B * 4 : (size_t)Ws * ntiles * B * 4))) return rc;
   if ((rc = ensure(c, buckets, (size_t)EXT_AOS_WORDS * 4 * nb))) return rc;
   // ra: first the two-pass sort's records (4 + 1 bytes per entry), then the chunk heads / segment heads
   // (and, once the heads are folded in, the two arrays level 1 of the reduce hands to level 2)
@@ -163,6 +174,12 @@ static int msm_enqueue_pippenger(jj_ctx* c, MsmLane& ln, size_t n, const void* d
     hipLaunchKernelGGL(k_msm_part_scatter, dim3(ptiles, Ws), dim3(MSM_SORT_THREADS), 0, st, n, (size_t)MSM_P1_TILE, mp, (const u32*)kprime.p, (const u32*)tcs, rec, lo8, (const u32*)nullptr, (u32*)nullptr);
     if (seg_fused) hipLaunchKernelGGL(k_msm_part_sort<true>, dim3(HB, Ws), dim3(MSM_P2_THREADS), 0, st, mp, ptiles, (const u32*)tcs, (const u32*)rec, (const uint8_t*)lo8, (u32*)idx.p, off, P, ExtAoS{(u32*)buckets.p}, (u32*)ln.seg.p, (const u32*)nullptr);
     else hipLaunchKernelGGL(k_msm_part_sort<false>, dim3(HB, Ws), dim3(MSM_P2_THREADS), 0, st, mp, ptiles, (const u32*)tcs, (const u32*)rec, (const uint8_t*)lo8, (u32*)idx.p, off, P, ExtAoS{nullptr}, (u32*)nullptr, (const u32*)nullptr);
+  } else if (front1) {
+    // round 6: counting (from the raw scalars) + point conversion in one launch, plan + scatter in the next (k_msm_front2 / k_msm_scatter2); no k'
+    const size_t f2_lds = std::max<size_t>((size_t)B * 4, (size_t)MSM_F2_STAGE_WORDS * 4);
+    if (!c->msm_front1_lds_set) { HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_front2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>((size_t)4096 * 4, (size_t)MSM_F2_STAGE_WORDS * 4))); c->msm_front1_lds_set = true; }
+    hipLaunchKernelGGL(k_msm_front2, dim3(f2_parts * Ws + (unsigned)((n + MSM_F2_THREADS - 1) / MSM_F2_THREADS)), dim3(MSM_F2_THREADS), f2_lds, st, n, ds, dp, mp, (u32*)niels.p, (u32*)tcnt.p, counters, f2_parts, f2_part_terms);
+    hipLaunchKernelGGL(k_msm_scatter2, dim3(f2_parts * 8 * ((Ws + 7) / 8)), dim3(MSM_SORT_THREADS), B * 4, st, n, f2_parts, f2_part_terms, mp, ds, (const u32*)tcnt.p, off, (u32*)idx.p);
   } else {
     hipLaunchKernelGGL(k_msm_convert, dim3(blocks_for(n)), dim3(256), 0, st, n, ds, dp, mp, (u32*)kprime.p, (u32*)niels.p, 3);
     hipLaunchKernelGGL(k_msm_hist, dim3(ntiles, Ws), dim3(MSM_SORT_THREADS), B * 4, st, n, tile, mp, (const u32*)kprime.p, (u32*)tcnt.p);
@@ -183,10 +200,10 @@ static int msm_enqueue_pippenger(jj_ctx* c, MsmLane& ln, size_t n, const void* d
     merge_list = merge;
   } else {
     hipLaunchKernelGGL(k_msm_accumulate, dim3(blocks_for(nchunk), Ws), dim3(256), 0, st, n, B, chunk, nchunk, (const u32*)off, (const u32*)idx.p, (const u32*)niels.p, bk, head);
-    hipLaunchKernelGGL(k_msm_fixup, dim3(blocks_for(2 * nb)), dim3(256), 0, st, n, B, Ws, chunk, nchunk, (const u32*)off, bk, head, counters, big);
+    hipLaunchKernelGGL(k_msm_fixup, dim3(blocks_for(2 * nb)), dim3(256), 0, st, n, B, Ws, chunk, nchunk, (const u32*)off, bk, head);      // (big buckets included: no second launch)
   }
-  // (segment path: 512 workgroups, the merge list of repeated scalars is walked by the same launch)
-  hipLaunchKernelGGL(k_msm_fixup_big, dim3(merge_list ? 2u * (unsigned)c->cus : 256u), dim3(256), 0, st, counters, (const BigBucket*)big, bk, head, partial, merge_list);
+  // (segment path: 512 workgroups, the merge list of repeated scalars is walked by the same launch as the big buckets)
+  if (use_segments) hipLaunchKernelGGL(k_msm_fixup_big, dim3(2u * (unsigned)c->cus), dim3(256), 0, st, counters, (const BigBucket*)big, bk, head, partial, merge_list);
   if (l1_rows) {
     u32* SN = (u32*)ra.p; u32* TN = (u32*)((uint8_t*)ra.p + l1_bytes);        // the heads are dead: k_msm_fixup_big was their last reader
     hipLaunchKernelGGL(k_msm_reduce_l1, dim3(blocks_for((size_t)Ws << mbits)), dim3(256), 0, st, mp, mbits, bk, SN, TN);
@@ -210,6 +227,13 @@ static int msm_lane(jj_ctx* c, int k, MsmLane** out) {
   MsmLane& L = c->lanes[k];
   if (k == 0) { L.stream = c->stream; *out = &L; return JJ_OK; }
   if (!L.owned) {
+    // launch stream + two copy streams + this lane: from the second lane on the context has more streams than HIP's default of four hardware
+    // queues.  Streams that share a queue serialise (1.7-2x slower pipelines); the library does not touch the environment, it says so once.
+    if (k >= 2) {
+      static std::atomic<bool> warned{false};
+      const char* q = getenv("GPU_MAX_HW_QUEUES");
+      if ((!q || atoi(q) < 8) && !warned.exchange(true)) fprintf(stderr, "libjubjub_hip: MSM jobs in flight use 5+ streams; export GPU_MAX_HW_QUEUES=8 before the first HIP call (or set option msm_lanes=1), streams sharing a hardware queue serialise\n");
+    }
     HIPCHK(c, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
     HIPCHK(c, hipEventCreateWithFlags(&L.ready_ev, hipEventDisableTiming));
     L.owned = true;
@@ -236,7 +260,7 @@ static int msm_job_get(jj_ctx* c, size_t nrec, jj_msm_job** out) {
   if (j->cap < want) {
     if (j->host) (void)hipHostFree(j->host);
     j->host = nullptr; j->cap = 0;
-    if (hipHostMalloc((void**)&j->host, want, hipHostMallocCoherent | hipHostMallocPortable) != hipSuccess) { (void)hipEventDestroy(j->ev); delete j; c->err = "hipHostMalloc failed"; return JJ_ERR_NOMEM; }
+    if (hipHostMalloc((void**)&j->host, want, hipHostMallocCoherent | hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); if (j->gdev) (void)hipFree(j->gdev); (void)hipEventDestroy(j->ev); delete j; c->err = "hipHostMalloc failed"; return JJ_ERR_NOMEM; }
     j->cap = want;
   }
   j->nrec = 0; j->gathered = 0; j->folded = false;
@@ -328,8 +352,12 @@ JJ_API int jj_msm_finish(jj_msm_job* j, void* out64) {
     // with different term counts), which the host adds after one copy of all of them out of the job's own device buffer
     uint32_t magic; memcpy(&magic, j->host, 4);
     if (magic != MSM_REC_MAGIC) {
+      // (the context's device current, the copy on the context's own stream and a wait for THAT stream only: a blocking hipMemcpy runs on the
+      // null stream, which synchronises with every blocking stream of the process -- e.g. a caller's stream that carries the next job's gather)
       std::lock_guard<std::recursive_mutex> lk(c->mu);
-      e = hipMemcpy(j->host, (const uint8_t*)j->gdev + JJ_MSM_PARTIAL_BYTES, (size_t)j->gathered * JJ_MSM_PARTIAL_BYTES, hipMemcpyDeviceToHost);
+      e = hipSetDevice(c->device);
+      if (e == hipSuccess) e = hipMemcpyAsync(j->host, (const uint8_t*)j->gdev + JJ_MSM_PARTIAL_BYTES, (size_t)j->gathered * JJ_MSM_PARTIAL_BYTES, hipMemcpyDeviceToHost, c->own_stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(c->own_stream);
       j->nrec = (size_t)j->gathered;
     }
   }
@@ -439,15 +467,17 @@ JJ_API int jj_ctx_set_comm(jj_ctx* c, void* nccl_comm, int rank, int nranks, voi
   if (!fn) { void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL); if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL); if (h) fn = dlsym(h, "ncclAllGather"); }
   if (!fn) { c->err = "jj_ctx_set_comm: ncclAllGather not found (pass its address, or load librccl first)"; return JJ_ERR_INVALID; }
   c->comm = nccl_comm; c->comm_rank = rank; c->comm_nranks = nranks; c->all_gather = (jj_ctx::AllGatherFn)fn;
+  // With more than one rank the jobs in flight stay on ONE lane: consecutive all-gathers of one communicator are then queued on one stream, in
+  // the same order on every rank.  Gathers alternating over streams rely on RCCL ordering collectives of a communicator across streams in
+  // submission order -- seen with one rank and with the loopback stand-in only, never between GPUs (no multi-GPU box in five rounds).  A caller
+  // that has checked it on its node sets option msm_lanes back to 2..4 AFTER this call.
+  if (nranks > 1) c->msm_lanes = 1;
   return JJ_OK;
 }
-// One MSM over the terms (partition 0: each rank passes ITS terms) or the windows (partition 1: each rank passes ALL terms) of every
-// rank of the communicator: record of window sums on this device -> ncclAllGather of JJ_MSM_PARTIAL_BYTES per rank over xGMI -> ONE
-// copy of the gathered records to the host -> ONE host tail (jj_msm_combine) on every rank.  Every rank gets the same point.
 // `count` records in DEVICE memory (JJ_MSM_PARTIAL_BYTES apart: what an all_gather delivered) -> the sum of the MSMs they stand for.
-// The records are folded window by window ON THE DEVICE into one (k_msm_fold_records), that one is copied to the host (8 KB, whatever
-// count is) and takes the single-record host tail.  Records of different window layouts, or JJ_MSM_FOLD=host: all records are copied and
-// the host adds them (round 4's path).  The context's lock is held by the caller.
+// From msm_fold_min records (option, default 8) they are folded window by window ON THE DEVICE into one (k_msm_fold_records), that one is
+// copied to the host (8 KB, whatever count is) and takes the single-record host tail.  Fewer records, records of different window layouts, or
+// option msm_fold_dev = 0: all records are copied and the host adds them (round 4's path).  The context's lock is held by the caller.
 static int msm_combine_dev_locked(jj_ctx* c, size_t count, const uint8_t* recs_dev, jjhost::Ext* total) {
   *total = jjhost::identity();
   if (count == 0) return JJ_OK;
@@ -490,6 +520,21 @@ JJ_API int jj_msm_combine_dev(jj_ctx* c, size_t count, const void* records_dev, 
   if (rc) return rc;
   return msm_write_total(c, total, out64);
 }
+// A rank that fails BEFORE its all-gather (its term count is over the pass limit, a workspace cannot grow, a launch fails) must not leave the
+// other ranks waiting in theirs: it still takes part, with an all-zero record -- no valid header, so every rank's fold / host tail rejects the
+// set and every rank's call returns an error ("a gathered MSM record is damaged") instead of hanging or summing without this rank's terms.
+// Best effort: if even this gather cannot be queued, the communicator is lost, as after any failed RCCL collective.
+static void msm_post_poison(jj_ctx* c, hipStream_t st) {
+  (void)hipGetLastError();
+  if (!c->comm || !c->all_gather) return;
+  const size_t G = (size_t)c->comm_nranks;
+  if (ensure(c, c->poison_dev, (G + 1) * JJ_MSM_PARTIAL_BYTES) != JJ_OK) return;
+  uint8_t* mine = (uint8_t*)c->poison_dev.p;
+  if (hipMemsetAsync(mine, 0, JJ_MSM_PARTIAL_BYTES, st) != hipSuccess) { (void)hipGetLastError(); return; }
+  (void)c->all_gather(mine, mine + JJ_MSM_PARTIAL_BYTES, JJ_MSM_PARTIAL_BYTES, /* ncclUint8 */ 1, c->comm, st);
+  (void)hipStreamSynchronize(st);
+  (void)hipGetLastError();
+}
 // jj_msm_allgather in two halves (as jj_msm_begin / jj_msm_finish for the one-GPU sum): everything up to the folded record is queued on
 // one of the context's lanes -- the rank's window sums, the ncclAllGather (stream-ordered like any kernel), the fold of the G records
 // into one written straight into the job's page-locked buffer -- and the call returns; jj_msm_finish waits for that job and runs the
@@ -500,16 +545,17 @@ JJ_API int jj_msm_allgather_begin(jj_ctx* c, size_t n, const void* scalars, cons
   *job = nullptr;
   JJ_ENTER(c);
   if (!c->comm || !c->all_gather) { c->err = "jj_msm_allgather_begin: no communicator (jj_ctx_set_comm)"; return JJ_ERR_INVALID; }
-  if (n > ((size_t)1 << c->msm_pass_log2)) { c->err = "jj_msm_allgather_begin takes at most one pass of terms (2^24) per rank; cut larger inputs"; return JJ_ERR_INVALID; }
+  // (every failure from here to the gather posts a poison record: the other ranks are already on their way into the collective)
+  if (n > ((size_t)1 << c->msm_pass_log2)) { msm_post_poison(c, c->stream); c->err = "jj_msm_allgather_begin takes at most one pass of terms (2^24) per rank; cut larger inputs"; return JJ_ERR_INVALID; }
   const int G = c->comm_nranks;
   const int part_index = partition ? c->comm_rank : 0, part_count = partition ? G : 1;
   jj_msm_job* j;
-  int rc = msm_job_get(c, (size_t)G, &j); if (rc) return rc;
+  int rc = msm_job_get(c, (size_t)G, &j); if (rc) { const std::string keep = c->err; msm_post_poison(c, c->stream); c->err = keep; return rc; }
   const size_t need = (size_t)(G + 1) * JJ_MSM_PARTIAL_BYTES;
   if (j->gdev_cap < need) {
     if (j->gdev) (void)hipFree(j->gdev);
     j->gdev = nullptr; j->gdev_cap = 0;
-    if (hipMalloc(&j->gdev, need) != hipSuccess) { (void)hipGetLastError(); msm_job_put(c, j); c->err = "hipMalloc failed"; return JJ_ERR_NOMEM; }
+    if (hipMalloc(&j->gdev, need) != hipSuccess) { (void)hipGetLastError(); msm_job_put(c, j); msm_post_poison(c, c->stream); c->err = "hipMalloc failed"; return JJ_ERR_NOMEM; }
     j->gdev_cap = need;
   }
   uint8_t* mine = (uint8_t*)j->gdev;                                // this rank's record, then the G gathered ones
@@ -517,8 +563,9 @@ JJ_API int jj_msm_allgather_begin(jj_ctx* c, size_t n, const void* scalars, cons
   int k = 0;
   if (n && c->msm_lanes > 1 && is_device_ptr(scalars) && is_device_ptr(points)) k = 1 + (int)(c->next_lane++ % (unsigned)c->msm_lanes);
   MsmLane* L = nullptr;
-  if ((rc = msm_lane(c, k, &L))) { msm_job_put(c, j); return rc; }
-  auto fail = [&](int code) { (void)hipStreamSynchronize(L->stream); (void)hipGetLastError(); msm_job_put(c, j); return code; };
+  if ((rc = msm_lane(c, k, &L))) { const std::string keep = c->err; msm_job_put(c, j); msm_post_poison(c, c->stream); c->err = keep; return rc; }
+  bool gathered = false;          // a failure before the gather posts the poison record in its place
+  auto fail = [&](int code) { const std::string keep = c->err; (void)hipStreamSynchronize(L->stream); (void)hipGetLastError(); if (!gathered) msm_post_poison(c, L->stream); msm_job_put(c, j); c->err = keep; return code; };
   hipError_t e = hipMemsetAsync(mine, 0, JJ_MSM_PARTIAL_BYTES, L->stream);
   if (e != hipSuccess) { c->err = std::string("hipMemsetAsync failed: ") + hipGetErrorString(e); return fail(JJ_ERR_HIP); }
   const int layout_W = n <= (size_t)c->msm_small_max ? SM_W : msm_windows_for(c, n);
@@ -536,8 +583,8 @@ JJ_API int jj_msm_allgather_begin(jj_ctx* c, size_t n, const void* scalars, cons
     if ((rc = stage_in(c, 0, scalars, 32 * n, &ds)) || (rc = stage_in(c, 1, points, 64 * n, &dp))) return fail(rc);
     if ((rc = msm_enqueue(c, *L, n, ds, dp, part_index, part_count, mine, &used))) return fail(rc);
   }
-  // From here on the other ranks wait for this one: a failure below is fatal for the communicator (as with any RCCL collective)
   const int nrc = c->all_gather(mine, all, JJ_MSM_PARTIAL_BYTES, /* ncclUint8 */ 1, c->comm, L->stream);
+  gathered = true;                // (a failure of the collective itself is fatal for the communicator, as with any RCCL collective)
   if (nrc != 0) { c->err = "ncclAllGather failed with ncclResult_t " + std::to_string(nrc); return fail(JJ_ERR_HIP); }
   j->gathered = G;
   if (c->msm_fold_dev && G >= c->msm_fold_min) {
@@ -554,16 +601,19 @@ JJ_API int jj_msm_allgather_begin(jj_ctx* c, size_t n, const void* scalars, cons
   *job = j;
   return JJ_OK;
 }
+// One MSM over the terms (partition 0: each rank passes ITS terms) or the windows (partition 1: each rank passes ALL terms) of every
+// rank of the communicator: record of window sums on this device -> ncclAllGather of JJ_MSM_PARTIAL_BYTES per rank over xGMI -> fold on
+// the device (from msm_fold_min records) or ONE copy of the gathered records -> ONE host tail on every rank.  Every rank gets the same point.
 JJ_API int jj_msm_allgather(jj_ctx* c, size_t n, const void* scalars, const void* points, int partition, void* out64) {
   if (!c || !out64 || (partition != 0 && partition != 1)) return JJ_ERR_INVALID;
   JJ_ENTER(c);                                                       // held through the gather and the host tail (jj_msm_partial re-enters it: the mutex is recursive)
   if (!c->comm || !c->all_gather) { c->err = "jj_msm_allgather: no communicator (jj_ctx_set_comm)"; return JJ_ERR_INVALID; }
   const int G = c->comm_nranks;
   int rc;
-  if ((rc = ensure(c, c->gather_dev, (size_t)(G + 1) * JJ_MSM_PARTIAL_BYTES))) return rc;
+  if ((rc = ensure(c, c->gather_dev, (size_t)(G + 1) * JJ_MSM_PARTIAL_BYTES))) { const std::string keep = c->err; msm_post_poison(c, c->stream); c->err = keep; return rc; }
   uint8_t* mine = (uint8_t*)c->gather_dev.p;                       // this rank's record, then the G gathered ones
   uint8_t* all = mine + JJ_MSM_PARTIAL_BYTES;
-  if ((rc = jj_msm_partial(c, n, scalars, points, partition ? c->comm_rank : 0, partition ? G : 1, mine))) return rc;
+  if ((rc = jj_msm_partial(c, n, scalars, points, partition ? c->comm_rank : 0, partition ? G : 1, mine))) { const std::string keep = c->err; msm_post_poison(c, c->stream); c->err = keep; return rc; }
   const int nrc = c->all_gather(mine, all, JJ_MSM_PARTIAL_BYTES, /* ncclUint8 */ 1, c->comm, c->stream);
   if (nrc != 0) { c->err = "ncclAllGather failed with ncclResult_t " + std::to_string(nrc); return JJ_ERR_HIP; }
   jjhost::Ext total;

@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(MSM_CH_THREADS) k_msm_convert_hist(size_t n, c
           if (a) atomicAdd(&hist[(u32)sl * HB + ((a - 1) >> 8)], 1u);
           sl++; next_slot_window += mp.wstride;
         }
-        _Pragma("unroll") for (int j = 0; j < 7; j++) sh[j] = (u32)(((((u64)sh[j + 1]) << 32) | sh[j]) >> width);
+        _Pragma("unroll") for (int j = 0; j < 7; j++) sh[j] = __builtin_amdgcn_alignbit(sh[j + 1], sh[j], (u32)width);      // (a 64-bit shift by a run-time amount is quarter-rate)
         sh[7] >>= width;
       }
       const ANiels t = Curve::to_niels(load_affine(points, i));
@@ -419,6 +419,138 @@ __global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_scatter(size_t n, size
       const size_t i = i0 + (size_t)q * MSM_SORT_THREADS;
       a[q] = 0; neg[q] = 0;
       if (i < hi) a[q] = msm_digit_wm(kp, n, i, mp, w, neg[q]);
+    }
+    u32 slot[MSM_SORT_UNROLL];
+    _Pragma("unroll") for (int q = 0; q < MSM_SORT_UNROLL; q++) slot[q] = a[q] ? atomicAdd(&msm_lds[a[q] - 1], 1u) : 0u;
+    _Pragma("unroll") for (int q = 0; q < MSM_SORT_UNROLL; q++) if (a[q]) idx[slot[q]] = (u32)(i0 + (size_t)q * MSM_SORT_THREADS) | (neg[q] << 31);
+  }
+}
+// ---- One-pass sort in TWO launches (round 6; 2^14 .. 147 456 terms, windows of 11 bits).  Conversion, histogram, plan and scatter were four
+// launches of 6-30 us each, shorter than the host's launch interval: up to 35-40 us of the 2^17-term call were an idle GPU between them.
+// LDS atomics run at about ONE LANE PER CLOCK PER CU (k_msm_hist: 3.0 M in 4.5 us on 256 CUs; a first fused kernel that counted on 64 CUs took
+// 18 us), so the counting keeps the decomposition of k_msm_hist -- block (part, slot), every CU counts -- and what goes is the pass that
+// produced its input: the blocks read the RAW scalars and recode them on the fly (two 16-byte loads and an eight-word carry chain per term, 23
+// times over, out of L2: the 4 MB of scalars are read once per XCD from memory), k' is never written.
+//   k_msm_front2   : workgroups [0, nparts Ws): block (part, slot) counts the part's entries per bucket of the slot's window in LDS ->
+//                    tc[slot][part][bucket]; the workgroups after them convert 1024 points each to affine-Niels records (per-wave staging as
+//                    k_msm_convert, half a wave at a time).  Two workgroups fit a CU: counting (LDS-atomic-bound) and conversion (VALU) overlap.
+//   k_msm_scatter2 : block (part, slot) forms what k_msm_plan left in memory itself: every thread sums its bucket's counts over the parts
+//                    (nparts coalesced rows) -> bucket totals and the part's prefix, one workgroup scan -> off (written by part 0), LDS
+//                    cursors, then the scatter of k_msm_scatter over the part's terms, digits from the raw scalars again.  The runs of a
+//                    bucket are in part order.
+constexpr int MSM_F2_THREADS = 512, MSM_F2_PARTS_MAX = 64;         // 512: counting and conversion workgroups both spread over all CUs (2^17 terms: 253 + 256 of them)
+constexpr int MSM_F2_STAGE_WORDS = (MSM_F2_THREADS / 64) * 32 * (GNIELS_WORDS / 4 + 1) * 4;      // 32 entries per wave at a time: 36 864 bytes
+// digit of window w (wave-uniform) of k' = k + recode, k read from the caller's scalar array
+static JJ_DEV u32 msm_digit_scalar(const void* scalars, size_t i, const MsmParams& mp, int w, u32& neg) {
+  u32 k[8];
+  load8(k, scalars, i);
+  msm_recode(k, mp);
+  const int bit = msm_win_start(mp, w), width = msm_win_width(mp, w), wi = bit >> 5, sh = bit & 31;
+  u32 lo, hi;
+  switch (wi) {                                     // uniform over the workgroup
+    case 0: lo = k[0]; hi = k[1]; break;
+    case 1: lo = k[1]; hi = k[2]; break;
+    case 2: lo = k[2]; hi = k[3]; break;
+    case 3: lo = k[3]; hi = k[4]; break;
+    case 4: lo = k[4]; hi = k[5]; break;
+    case 5: lo = k[5]; hi = k[6]; break;
+    case 6: lo = k[6]; hi = k[7]; break;
+    default: lo = k[7]; hi = 0; break;
+  }
+  return msm_digit_raw(__builtin_amdgcn_alignbit(hi, lo, (u32)sh) & ((1u << width) - 1u), mp, w, width, neg);
+}
+__global__ void __launch_bounds__(MSM_F2_THREADS) k_msm_front2(size_t n, const void* scalars, const void* points, MsmParams mp, u32* niels, u32* tc /* [Ws][nparts][B] */,
+                                                               u32* counters, u32 nparts, size_t part_terms) {
+  constexpr int PIECES = GNIELS_WORDS / 4, ROW = PIECES + 1;
+  extern __shared__ __attribute__((aligned(16))) u32 f2_lds[];
+  if (blockIdx.x == 0 && threadIdx.x < MSM_COUNTER_WORDS) counters[threadIdx.x] = 0;                 // (k_msm_plan's job on the four-launch path)
+  const u32 nhist = nparts * (u32)mp.Ws;
+  if (blockIdx.x >= nhist) {
+    // ---- points: 64 entries per wave, staged and stored 32 at a time (the staging area is the wave's own: no workgroup barrier)
+    const u32 lane = threadIdx.x & 63u;
+    uint4* my = reinterpret_cast<uint4*>(f2_lds) + (size_t)(threadIdx.x >> 6) * 32 * ROW;
+    const size_t i = (size_t)(blockIdx.x - nhist) * MSM_F2_THREADS + threadIdx.x;
+    u32 wv[GNIELS_WORDS];
+    if (i < n) {
+      const ANiels t = Curve::to_niels(load_affine(points, i));
+      _Pragma("unroll") for (int l = 0; l < NL; l++) { wv[l] = t.vpu.l[l]; wv[NL + l] = t.vmu.l[l]; wv[2 * NL + l] = t.t2d.l[l]; }
+      _Pragma("unroll") for (int l = ANIELS_WORDS - 1; l < GNIELS_WORDS; l++) wv[l] = 0;
+    }
+    const size_t r0 = (size_t)(blockIdx.x - nhist) * MSM_F2_THREADS + (threadIdx.x & ~63u);      // first entry of this wave
+    _Pragma("unroll") for (u32 h = 0; h < 2; h++) {
+      if ((lane >> 5) == h && i < n) { _Pragma("unroll") for (int v = 0; v < PIECES; v++) my[(lane & 31u) * ROW + v] = make_uint4(wv[4 * v], wv[4 * v + 1], wv[4 * v + 2], wv[4 * v + 3]); }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      uint4* out = reinterpret_cast<uint4*>(niels + (r0 + 32 * h) * GNIELS_WORDS);
+      _Pragma("unroll") for (int cpc = 0; cpc < PIECES / 2; cpc++) {
+        const u32 q = (u32)cpc * 64u + lane, rec = q / PIECES, piece = q % PIECES;
+        if (r0 + 32 * h + rec < n) out[q] = my[rec * ROW + piece];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    return;
+  }
+  // ---- counting: block (part, slot)
+  const u32 s = blockIdx.x / nparts, part = blockIdx.x - s * nparts;
+  const int w = msm_slot_window(mp, (int)s);
+  for (u32 b = threadIdx.x; b < mp.B; b += MSM_F2_THREADS) f2_lds[b] = 0;
+  __syncthreads();
+  const size_t lo = (size_t)part * part_terms, hi = lo + part_terms < n ? lo + part_terms : n;
+  for (size_t i0 = lo + threadIdx.x; i0 < hi; i0 += MSM_SORT_UNROLL * MSM_F2_THREADS) {
+    u32 a[MSM_SORT_UNROLL];
+    _Pragma("unroll") for (int q = 0; q < MSM_SORT_UNROLL; q++) {
+      const size_t i = i0 + (size_t)q * MSM_F2_THREADS;
+      u32 neg; a[q] = i < hi ? msm_digit_scalar(scalars, i, mp, w, neg) : 0u;
+    }
+    _Pragma("unroll") for (int q = 0; q < MSM_SORT_UNROLL; q++) if (a[q]) atomicAdd(&f2_lds[a[q] - 1], 1u);
+  }
+  __syncthreads();
+  u32* out = tc + ((size_t)s * nparts + part) * mp.B;
+  for (u32 b = threadIdx.x; b < mp.B; b += MSM_F2_THREADS) out[b] = f2_lds[b];
+}
+// (Staging the part's entries through LDS and copying them out run by run, as k_msm_part_scatter does, was measured and dropped: 29-36 us
+// against 31 for the direct stores below -- with ~11 entries per run the copy-out saves few transactions and the block pays a second scan
+// and two more barriers.)
+__global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_scatter2(size_t n, u32 nparts, size_t part_terms, MsmParams mp, const void* scalars, const u32* tc, u32* off, u32* idx) {
+  extern __shared__ u32 msm_lds[];
+  __shared__ u32 part_s[17];
+  const u32 xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+  const int s = (int)((j / nparts) * 8 + xcd);                 // a window's parts on ONE XCD (as k_msm_scatter)
+  const u32 part = j % nparts;
+  if (s >= mp.Ws) return;
+  const int w = msm_slot_window(mp, s);
+  const u32 B = mp.B;
+  const u32 bper = (B + 1023u) / 1024u, b0 = threadIdx.x * bper;             // consecutive buckets per thread (B <= 4096)
+  const u32* rows = tc + (size_t)s * nparts * B;
+  u32 tot[MSM_PLAN_PER], pre[MSM_PLAN_PER], sum = 0;
+  _Pragma("unroll") for (int q = 0; q < MSM_PLAN_PER; q++) {
+    tot[q] = 0; pre[q] = 0;
+    if ((u32)q < bper && b0 + q < B) {
+      _Pragma("unroll 8") for (u32 t = 0; t < nparts; t++) { const u32 c = rows[(size_t)t * B + b0 + q]; tot[q] += c; pre[q] += t < part ? c : 0u; }
+    }
+    sum += tot[q];
+  }
+  u32 total;
+  u32 run = (u32)((size_t)s * n) + block_exclusive_scan_1024(sum, part_s, &total);
+  u32* o = off + (size_t)s * (B + 1);
+  _Pragma("unroll") for (int q = 0; q < MSM_PLAN_PER; q++) {
+    if ((u32)q >= bper || b0 + q >= B) break;
+    if (part == 0) o[b0 + q] = run;
+    msm_lds[b0 + q] = run + pre[q];
+    run += tot[q];
+  }
+  if (part == 0 && threadIdx.x == 0) o[B] = (u32)((size_t)s * n) + total;
+  __syncthreads();
+  const size_t lo = (size_t)part * part_terms, hi = lo + part_terms < n ? lo + part_terms : n;
+  for (size_t i0 = lo + threadIdx.x; i0 < hi; i0 += MSM_SORT_UNROLL * MSM_SORT_THREADS) {
+    u32 a[MSM_SORT_UNROLL], neg[MSM_SORT_UNROLL];
+    _Pragma("unroll") for (int q = 0; q < MSM_SORT_UNROLL; q++) {
+      const size_t i = i0 + (size_t)q * MSM_SORT_THREADS;
+      a[q] = 0; neg[q] = 0;
+      if (i < hi) a[q] = msm_digit_scalar(scalars, i, mp, w, neg[q]);
     }
     u32 slot[MSM_SORT_UNROLL];
     _Pragma("unroll") for (int q = 0; q < MSM_SORT_UNROLL; q++) slot[q] = a[q] ? atomicAdd(&msm_lds[a[q] - 1], 1u) : 0u;
@@ -725,36 +857,60 @@ static JJ_DEV Ext pair_partner(const Ext& e) {      // the point held by the oth
   }
   return r;
 }
-__global__ void __launch_bounds__(256) k_msm_fixup(size_t n, u32 B, u32 Ws, u32 chunk, u32 nchunk, const u32* off, ExtAoS buckets, ExtAoS head, u32* counters, BigBucket* big) {
+// A bucket with more than FIXUP_SERIAL_MAX heads (repeated scalars) is not walked by its pair: the WHOLE WAVE takes it afterwards -- lane l
+// adds up heads t_first + l, + 64, ..., six butterfly steps over the lanes (ds_bpermute) fold the 64 partial sums, lane 0 adds the bucket's
+// own run and stores.  (Until round 6 such buckets went to a work list for a second launch, k_msm_fixup_big: 5 us per call for a list that is
+// empty unless scalars repeat.  The segment path of large inputs still uses that kernel for its merge list.)
+static JJ_DEV Ext wave_xor_partner(const Ext& e, int d) {
+  Ext r;
+  _Pragma("unroll") for (int l = 0; l < NL; l++) {
+    r.u.l[l] = (u32)__shfl_xor((int)e.u.l[l], d, 64); r.v.l[l] = (u32)__shfl_xor((int)e.v.l[l], d, 64); r.z.l[l] = (u32)__shfl_xor((int)e.z.l[l], d, 64);
+    r.t1.l[l] = (u32)__shfl_xor((int)e.t1.l[l], d, 64); r.t2.l[l] = (u32)__shfl_xor((int)e.t2.l[l], d, 64);
+  }
+  return r;
+}
+__global__ void __launch_bounds__(256) k_msm_fixup(size_t n, u32 B, u32 Ws, u32 chunk, u32 nchunk, const u32* off, ExtAoS buckets, ExtAoS head) {
   const size_t g = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
-  const u32 half = threadIdx.x & 1u;
-  if (g >= (size_t)Ws * B) return;
-  const u32 s = (u32)(g / B), j = (u32)(g % B);
-  const u32* o = off + (size_t)s * (B + 1);
-  const u32 base = (u32)(s * n), lo = o[j] - base, hi = o[j + 1] - base;
-  if (lo == hi) { if (half == 0) aos_put_ext(buckets, g, Curve::identity()); return; }
-  const size_t t_first = (size_t)s * nchunk + lo / chunk + 1, t_last = (size_t)s * nchunk + (hi - 1) / chunk;
-  if (t_first > t_last) return;
-  if (t_last - t_first + 1 > FIXUP_SERIAL_MAX) {
-    u32 slot = half == 0 ? atomicAdd(&counters[2], 1u) : 0u;
-    slot = (u32)__shfl((int)slot, (int)(threadIdx.x & 62u), 64);          // the even lane's slot
-    if (slot < FIXUP_BIG_MAX) {
-      if (half == 0) { big[slot].bucket = (u32)g; big[slot].t_first = (u32)t_first; big[slot].t_last = (u32)t_last; big[slot].pad = 0; }
-      return;
+  const u32 half = threadIdx.x & 1u, lane = threadIdx.x & 63u;
+  size_t t_first = 1, t_last = 0;                             // no heads
+  if (g < (size_t)Ws * B) {
+    const u32 s = (u32)(g / B), j = (u32)(g % B);
+    const u32* o = off + (size_t)s * (B + 1);
+    const u32 base = (u32)(s * n), lo = o[j] - base, hi = o[j + 1] - base;
+    if (lo == hi) { if (half == 0) aos_put_ext(buckets, g, Curve::identity()); }
+    else { t_first = (size_t)s * nchunk + lo / chunk + 1; t_last = (size_t)s * nchunk + (hi - 1) / chunk; }
+  }
+  const bool some = t_first <= t_last, big = some && t_last - t_first + 1 > FIXUP_SERIAL_MAX;
+  if (some && !big) {
+    // even lane: the bucket's own first run + heads t_first, t_first + 2, ...; odd lane: heads t_first + 1, t_first + 3, ...
+    Ext acc = half == 0 ? aos_ext(buckets, g) : Curve::identity();
+    size_t t = t_first + half;
+    Ext nx = aos_ext(head, t <= t_last ? t : t_last);
+    #pragma unroll 1
+    for (; t <= t_last; t += 2) {
+      const Ext cur = nx;
+      if (t + 2 <= t_last) nx = aos_ext(head, t + 2);
+      acc = Curve::add(acc, Curve::to_niels(cur));
     }
+    acc = Curve::add(acc, Curve::to_niels(pair_partner(acc)));
+    if (half == 0) aos_put_ext(buckets, g, acc);
   }
-  // even lane: the bucket's own first run + heads t_first, t_first + 2, ...; odd lane: heads t_first + 1, t_first + 3, ...
-  Ext acc = half == 0 ? aos_ext(buckets, g) : Curve::identity();
-  size_t t = t_first + half;
-  Ext nx = aos_ext(head, t <= t_last ? t : t_last);
+  unsigned long long todo = __ballot(big && half == 0);
   #pragma unroll 1
-  for (; t <= t_last; t += 2) {
-    const Ext cur = nx;
-    if (t + 2 <= t_last) nx = aos_ext(head, t + 2);
-    acc = Curve::add(acc, Curve::to_niels(cur));
+  while (todo) {                                              // uniform over the wave
+    const int src = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    const size_t gb = ((size_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u) + (u32)src) >> 1;
+    const u32 tf_lo = (u32)__shfl((int)(u32)t_first, src, 64), tf_hi = (u32)__shfl((int)(u32)(t_first >> 32), src, 64);
+    const u32 tl_lo = (u32)__shfl((int)(u32)t_last, src, 64), tl_hi = (u32)__shfl((int)(u32)(t_last >> 32), src, 64);
+    const size_t tf = ((size_t)tf_hi << 32) | tf_lo, tl = ((size_t)tl_hi << 32) | tl_lo;
+    Ext acc = Curve::identity();
+    #pragma unroll 1
+    for (size_t t = tf + lane; t <= tl; t += 64) acc = Curve::add(acc, Curve::to_niels(aos_ext(head, t)));
+    #pragma unroll 1
+    for (int d = 32; d >= 1; d >>= 1) acc = Curve::add(acc, Curve::to_niels(wave_xor_partner(acc, d)));
+    if (lane == 0) { acc = Curve::add(acc, Curve::to_niels(aos_ext(buckets, gb))); aos_put_ext(buckets, gb, acc); }
   }
-  acc = Curve::add(acc, Curve::to_niels(pair_partner(acc)));
-  if (half == 0) aos_put_ext(buckets, g, acc);
 }
 // ---- Segment-sorted accumulation (large inputs).  Every non-empty bucket is cut into segments of at most P entries, the
 // segments are counting-sorted by length (longest first), and each lane adds up one segment: lanes of a wave run the

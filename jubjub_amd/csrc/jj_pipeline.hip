@@ -380,6 +380,86 @@ JJ_API int jj_recommended_wnaf_for_num_scalars(size_t num_scalars) {
   return ret;
 }
 
+// ---- options (jj_ctx_set_option).  The library reads NO environment variable of its own: what rounds 2-5 took from JJ_* variables is set per context,
+// by key, through the C ABI -- and nothing here can change the timing discipline of an entry point (the constant-time ladders and selects have no switch).
+struct CtxOption { const char* key; long long lo, hi; void (*set)(jj_ctx*, long long); long long (*get)(const jj_ctx*); };
+#define JJ_OPT(key, lo, hi, field, type) {key, lo, hi, [](jj_ctx* c, long long v) { c->field = (type)v; }, [](const jj_ctx* c) { return (long long)c->field; }}
+static const CtxOption* ctx_options() {
+  static const CtxOption table[] = {
+    // what a caller may legitimately need
+    JJ_OPT("msm_lanes", 1, MSM_LANES_MAX, msm_lanes, int),                   // streams the jobs in flight alternate over (1: every job on the context's stream)
+    JJ_OPT("msm_fold_min", 2, 4096, msm_fold_min, int),                      // gathered records are folded on the device from this many
+    JJ_OPT("msm_fold_dev", 0, 1, msm_fold_dev, bool),                        // 0: every gathered record is copied and the host adds them
+    JJ_OPT("msm_host_split", 0, 1, msm_host_split, bool),                    // host arrays of 2^19+ terms in several passes, copies beside kernels
+    JJ_OPT("msm_pass_log2", 10, 24, msm_pass_log2, int),                     // terms per Pippenger pass
+    {"result_pool_mb", 0, 1 << 20, [](jj_ctx* c, long long v) { c->result_pool_keep = (size_t)v << 20; }, [](const jj_ctx* c) { return (long long)(c->result_pool_keep >> 20); }},
+    JJ_OPT("torsion_check_ladder", 0, 1, torsion_ladder, bool),              // subgroup test by [r]P (the reference's definition) instead of the pairing
+    {"pipe_pageable_register", 0, 1, [](jj_ctx* c, long long v) { c->pipe_bounce = v == 0; }, [](const jj_ctx* c) { return (long long)!c->pipe_bounce; }},
+    JJ_OPT("pipe_copy_threads", 0, 64, pipe_copy_threads, int),
+    JJ_OPT("pipe_ramp", 0, 1, pipe_ramp, bool),
+    JJ_OPT("pipe_prefault", 0, 1, pipe_prefault, bool),
+    {"pipe_chunk_log2", 0, 24, [](jj_ctx* c, long long v) { c->pipe_chunk = v >= 8 ? (size_t)1 << v : 0; }, [](const jj_ctx* c) { long long l = 0; while (((size_t)1 << l) < c->pipe_chunk) l++; return c->pipe_chunk ? l : 0LL; }},
+    {"fixedbase_default", 6, 7, [](jj_ctx* c, long long v) { c->fb_default_kind = (int)v; }, [](const jj_ctx* c) { return (long long)c->fb_default_kind; }},
+    // planner overrides (tests and measurements; every value gives the same results)
+    JJ_OPT("msm_windows", 0, MSM_WINDOWS_MAX, msm_windows, int),             // 0 = from n; else 16..36
+    JJ_OPT("msm_small_max", 0, 1 << 20, msm_small_max, int),
+    JJ_OPT("msm_small_blk", 1, MSM_SMALL_BLK_MAX, msm_small_blk, int),
+    JJ_OPT("msm_accum", -1, 1, msm_segments, int),                           // 1 = length-sorted segments, 0 = chunks + fix-up, -1 = by size
+    JJ_OPT("msm_seg_len", 0, 1024, msm_seg_len, int),
+    JJ_OPT("msm_chunk", 0, 1024, msm_chunk, int),
+    JJ_OPT("msm_chunk_waves", 1, 8, msm_chunk_waves, int),
+    JJ_OPT("msm_sort_blocks_per_cu", 1, 4, msm_sort_blocks_per_cu, int),
+    JJ_OPT("msm_reduce_chunk", 0, 256, msm_reduce_chunk, int),
+    JJ_OPT("msm_reduce_l1", -1, 64, msm_l1_rows, int),
+    JJ_OPT("msm_reduce_l2_chunk", 0, 64, msm_l2_chunk, int),
+    JJ_OPT("msm_sort_hist_fused", 0, 1, msm_fused_hist, bool),
+    JJ_OPT("msm_sort_two_pass", -1, 1, msm_two_pass, int),
+    JJ_OPT("msm_front1", 0, 1, msm_front1, bool),
+    JJ_OPT("vb_ct_window", 2, 3, vb_ct_window, int),
+    JJ_OPT("vb_quad_max", 0, 1 << 20, vb_quad_max, int),
+    JJ_OPT("dec_c_mid", 8, 16, dec_c_mid, int),
+    {nullptr, 0, 0, nullptr, nullptr}};
+  return table;
+}
+#undef JJ_OPT
+static int ctx_option_apply(jj_ctx* c, const CtxOption* o, long long v) {
+  const auto pow2 = [](long long x) { return x > 0 && (x & (x - 1)) == 0; };
+  if (v < o->lo || v > o->hi) return JJ_ERR_INVALID;
+  const std::string k = o->key;
+  if (k == "msm_windows" && v != 0 && v < MSM_WINDOWS_MIN) return JJ_ERR_INVALID;
+  if (k == "msm_seg_len" && v != 0 && v < 8) return JJ_ERR_INVALID;
+  if (k == "msm_chunk" && v != 0 && v < 8) return JJ_ERR_INVALID;
+  if ((k == "msm_reduce_chunk" || k == "msm_reduce_l2_chunk") && v != 0 && (v < 2 || !pow2(v))) return JJ_ERR_INVALID;
+  if (k == "msm_reduce_l1" && v > 0 && (v < 2 || !pow2(v))) return JJ_ERR_INVALID;
+  if (k == "dec_c_mid" && v != 8 && v != 16) return JJ_ERR_INVALID;
+  if (k == "pipe_chunk_log2" && v != 0 && v < 8) return JJ_ERR_INVALID;
+  o->set(c, v);
+  return JJ_OK;
+}
+// key == "host_tail_scalar" with ctx == NULL is the one process-wide option (the host tail of jj_msm_combine has no context)
+JJ_API int jj_ctx_set_option(jj_ctx* c, const char* key, long long value) {
+  if (!key) return JJ_ERR_INVALID;
+  if (!strcmp(key, "host_tail_scalar")) { if (value != 0 && value != 1) return JJ_ERR_INVALID; jjhost::ifma::force_scalar().store((int)value); return JJ_OK; }
+  if (!c) return JJ_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  for (const CtxOption* o = ctx_options(); o->key; o++) if (!strcmp(o->key, key)) {
+    const int rc = ctx_option_apply(c, o, value);
+    if (rc) c->err = std::string("jj_ctx_set_option: value out of range for ") + key + " (" + std::to_string(o->lo) + " .. " + std::to_string(o->hi) + ")";
+    return rc;
+  }
+  c->err = std::string("jj_ctx_set_option: unknown key ") + key;
+  return JJ_ERR_INVALID;
+}
+JJ_API int jj_ctx_get_option(jj_ctx* c, const char* key, long long* value) {
+  if (!key || !value) return JJ_ERR_INVALID;
+  if (!strcmp(key, "host_tail_scalar")) { *value = jjhost::ifma::force_scalar().load(); return JJ_OK; }
+  if (!c) return JJ_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  for (const CtxOption* o = ctx_options(); o->key; o++) if (!strcmp(o->key, key)) { *value = o->get(c); return JJ_OK; }
+  c->err = std::string("jj_ctx_get_option: unknown key ") + key;
+  return JJ_ERR_INVALID;
+}
+
 JJ_API int jj_ctx_create(int device, jj_ctx** out) {
   if (!out) return JJ_ERR_INVALID;
   *out = nullptr;
@@ -406,40 +486,20 @@ JJ_API int jj_ctx_create(int device, jj_ctx** out) {
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(JJ_ERR_HIP);
   if (hipEventCreateWithFlags(&c->order_ev, hipEventDisableTiming) != hipSuccess) return fail(JJ_ERR_HIP);
   c->stream = c->own_stream;
-  if (const char* e = getenv("JJ_DEC_C_MID")) { int v = atoi(e); if (v == 8 || v == 16) c->dec_c_mid = v; }
-  if (const char* e = getenv("JJ_PIPE_PAGEABLE")) c->pipe_bounce = strcmp(e, "register") != 0;
-  if (const char* e = getenv("JJ_RESULT_POOL_MB")) { long v = atol(e); if (v >= 0 && v <= (1L << 20)) c->result_pool_keep = (size_t)v << 20; }
-  if (const char* e = getenv("JJ_PIPE_COPY_THREADS")) { int v = atoi(e); if (v >= 0 && v <= 64) c->pipe_copy_threads = v; }
-  if (const char* e = getenv("JJ_PIPE_RAMP")) c->pipe_ramp = atoi(e) != 0;
-  if (const char* e = getenv("JJ_PIPE_PREFAULT")) c->pipe_prefault = atoi(e) != 0;
-#ifdef JJ_EXPERIMENTS      // experiment-only knobs: not read by the shipped library (JJ_PIPE_STREAMS=2 is 1.7x slower, =3 equals the default: jj_engine.h pipe_mode)
-  if (const char* e = getenv("JJ_PIPE_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= 3) c->pipe_mode = v; }
+#ifdef JJ_EXPERIMENTS
+  // Probe builds only (-DJJ_EXPERIMENTS, tools/ and experiments/): every option of jj_ctx_set_option can be preset as JJ_<KEY>, and the
+  // switches that change the TIMING DISCIPLINE of an entry point exist here and nowhere else.  The shipped library reads no JJ_* variable.
+  for (const CtxOption* o = ctx_options(); o->key; o++) {
+    std::string name = "JJ_";
+    for (const char* q = o->key; *q; q++) name += (char)toupper((unsigned char)*q);
+    if (const char* e = getenv(name.c_str())) { if (ctx_option_apply(c, o, atoll(e)) != JJ_OK) fprintf(stderr, "libjubjub_hip: %s=%s ignored (valid: %lld..%lld)\n", name.c_str(), e, (long long)o->lo, (long long)o->hi); }
+  }
+  if (const char* e = getenv("JJ_PIPE_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= 3) c->pipe_mode = v; }      // =2 is 1.7x slower, =3 equals the default: jj_engine.h pipe_mode
   if (const char* e = getenv("JJ_FB_GATHER_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) c->fb_gather_blocks_per_cu = v; }
   if (const char* e = getenv("JJ_VB_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) c->vb_blocks_per_cu = v; }
+  if (const char* e = getenv("JJ_VARBASE_DEFAULT")) c->vb_default_ct = strcmp(e, "vartime") != 0;          // A/B only: jj_varbase_mul takes the table ladder
+  if (const char* e = getenv("JJ_FIXEDBASE_SELECT")) c->fb_const_time = strcmp(e, "gather") != 0;         // A/B only: per-lane LDS gather instead of the shuffle select
 #endif
-  if (const char* e = getenv("JJ_PIPE_CHUNK_LOG2")) { int v = atoi(e); if (v >= 8 && v <= 24) c->pipe_chunk = (size_t)1 << v; }   // overrides the per-entry-point chunk
-  if (const char* e = getenv("JJ_MSM_WINDOWS")) { int v = atoi(e); if (v >= MSM_WINDOWS_MIN && v <= MSM_WINDOWS_MAX) c->msm_windows = v; else fprintf(stderr, "libjubjub_hip: JJ_MSM_WINDOWS=%s ignored (valid: %d..%d)\n", e, MSM_WINDOWS_MIN, MSM_WINDOWS_MAX); }
-  if (const char* e = getenv("JJ_MSM_HOST_SPLIT")) c->msm_host_split = atoi(e) != 0;
-  if (const char* e = getenv("JJ_MSM_FOLD")) c->msm_fold_dev = strcmp(e, "host") != 0;
-  if (const char* e = getenv("JJ_MSM_FOLD_MIN")) { int v = atoi(e); if (v >= 2 && v <= 4096) c->msm_fold_min = v; }
-  if (const char* e = getenv("JJ_MSM_LANES")) { int v = atoi(e); if (v >= 1 && v <= MSM_LANES_MAX) c->msm_lanes = v; }
-  if (const char* e = getenv("JJ_MSM_SMALL_BLK")) { int v = atoi(e); if (v >= 1 && v <= MSM_SMALL_BLK_MAX) c->msm_small_blk = v; }
-  if (const char* e = getenv("JJ_MSM_SMALL_MAX")) { int v = atoi(e); if (v >= 0 && v <= (1 << 20)) c->msm_small_max = v; }
-  if (const char* e = getenv("JJ_MSM_ACCUM")) c->msm_segments = strcmp(e, "chunks") == 0 ? 0 : strcmp(e, "segments") == 0 ? 1 : -1;
-  if (const char* e = getenv("JJ_MSM_SEG_LEN")) c->msm_seg_len = atoi(e);
-  if (const char* e = getenv("JJ_MSM_CHUNK")) { int v = atoi(e); if (v >= 8 && v <= 1024) c->msm_chunk = v; }
-  if (const char* e = getenv("JJ_MSM_REDUCE_CHUNK")) { int v = atoi(e); if (v >= 2 && v <= 256 && (v & (v - 1)) == 0) c->msm_reduce_chunk = v; }
-  if (const char* e = getenv("JJ_MSM_REDUCE_L1")) { int v = atoi(e); if (v == 0 || (v >= 2 && v <= 64 && (v & (v - 1)) == 0)) c->msm_l1_rows = v; }
-  if (const char* e = getenv("JJ_MSM_REDUCE_L2_CHUNK")) { int v = atoi(e); if (v >= 2 && v <= 64 && (v & (v - 1)) == 0) c->msm_l2_chunk = v; }
-  if (const char* e = getenv("JJ_MSM_SORT_HIST")) c->msm_fused_hist = strcmp(e, "separate") != 0;
-  if (const char* e = getenv("JJ_MSM_SORT")) c->msm_two_pass = !strcmp(e, "2pass") ? 1 : (!strcmp(e, "1pass") ? 0 : -1);
-  if (const char* e = getenv("JJ_MSM_PASS_LOG2")) { int v = atoi(e); if (v >= 10 && v <= 24) c->msm_pass_log2 = v; }
-  if (const char* e = getenv("JJ_VARBASE_DEFAULT")) c->vb_default_ct = strcmp(e, "vartime") != 0;
-  if (const char* e = getenv("JJ_VB_CT_WINDOW")) { int v = atoi(e); if (v == 2 || v == 3) c->vb_ct_window = v; }
-  if (const char* e = getenv("JJ_VB_QUAD_MAX")) { int v = atoi(e); if (v >= 0 && v <= (1 << 20)) c->vb_quad_max = v; }
-  if (const char* e = getenv("JJ_TORSION_CHECK")) c->torsion_ladder = strcmp(e, "ladder") == 0;
-  if (const char* e = getenv("JJ_FIXEDBASE_SELECT")) c->fb_const_time = strcmp(e, "gather") != 0;
-  if (const char* e = getenv("JJ_FIXEDBASE_DEFAULT")) { int v = atoi(e); if (v == 6 || v == 7) c->fb_default_kind = v; }
   { const int rc = jj_batch_init(c); if (rc) return fail(rc); }       // LDS carve-outs of the fixed-base kernels, square-root tables (jj_abi.hip)
   *out = c;
   return JJ_OK;
@@ -466,6 +526,7 @@ JJ_API int jj_ctx_destroy(jj_ctx* c) {
   for (int i = 0; i < 3; i++) { if (c->stage_in[i]) (void)hipHostFree(c->stage_in[i]); if (c->stage_out[i]) (void)hipHostFree(c->stage_out[i]); if (c->ev_stage[i]) (void)hipEventDestroy(c->ev_stage[i]); }
   for (auto& b : c->result_pool) (void)hipHostFree(b.p);
   if (c->gather_dev.p) (void)hipFree(c->gather_dev.p);
+  if (c->poison_dev.p) (void)hipFree(c->poison_dev.p);
   if (c->gather_host) (void)hipHostFree(c->gather_host);
   if (c->pipe.ready) {
     for (int i = 0; i < 2; i++) {

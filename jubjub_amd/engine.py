@@ -96,7 +96,9 @@ class MsmJob:
 
 
 class Engine:
-    def __init__(self, device=0):
+    def __init__(self, device=0, options=None):
+        """options: {key: int} for jj_ctx_set_option (include/jubjub_hip.h lists the keys), applied before the first call.  Neither this class nor
+        the library reads JJ_* environment variables."""
         self._mu = threading.RLock()      # stream selection + call form one critical section per Engine (see _locked below)
         self._lib = _lib.load()
         ctx = C.c_void_p()
@@ -107,6 +109,8 @@ class Engine:
                 device, rc, "no gfx950 GPU visible; there is no CPU fallback" if rc == _lib.JJ_ERR_NODEVICE else "HIP error"))
         self._ctx = ctx
         self.device = int(device)
+        for key, value in (options or {}).items():
+            self.set_option(key, value)
 
     # -------------------------------------------------------------- plumbing
     def close(self):
@@ -126,6 +130,22 @@ class Engine:
 
     def sync(self):
         self._check(self._lib.jj_ctx_sync(self._ctx))
+
+    def set_option(self, key, value):
+        """jj_ctx_set_option: per-context tuning by key ("msm_lanes", "msm_fold_min", ...); "host_tail_scalar" is process-wide."""
+        if key == "host_tail_scalar":
+            rc = self._lib.jj_ctx_set_option(None, key.encode(), int(value))
+            if rc:
+                raise JubjubError("jj_ctx_set_option(%s=%r) failed with %d" % (key, value, rc))
+            return
+        self._check(self._lib.jj_ctx_set_option(self._ctx, key.encode(), int(value)))
+
+    def get_option(self, key):
+        v = C.c_longlong()
+        rc = self._lib.jj_ctx_get_option(None if key == "host_tail_scalar" else self._ctx, key.encode(), C.byref(v))
+        if rc:
+            raise JubjubError("jj_ctx_get_option(%s) failed with %d" % (key, rc))
+        return v.value
 
     def device_info(self):
         out = (C.c_int64 * 4)()
@@ -440,8 +460,11 @@ class Engine:
         if job._h is None:
             raise JubjubError("MSM job already finished")
         out = np.empty((64,), np.uint8)
-        h, job._h, job._keep = job._h, None, None
-        self._check(self._lib.jj_msm_finish(h, out.ctypes.data))
+        h, job._h = job._h, None
+        try:
+            self._check(self._lib.jj_msm_finish(h, out.ctypes.data))      # waits for the job's kernels: they run on a lane no other stream is ordered with ...
+        finally:
+            job._keep = None                                              # ... so the inputs are released only now (a caching allocator could hand the block on at once)
         return out
 
     def msm_partial(self, scalars, points, part_index=0, part_count=1):

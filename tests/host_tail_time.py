@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Time of the MSM host tail (jj_msm_combine: window sums of `records` records added window by window, Horner over the windows, one inversion)
 on this host's CPU, per window layout W (16: 2^20 terms and more, 17, 23: Pippenger below, 64: small batches) -- no GPU involved.
-JJ_HOST_TAIL=scalar forces the scalar 4 x 64-bit chain; the default takes the AVX-512 IFMA chain when the CPU has it.
-Usage: python tests/host_tail_time.py [records ...]"""
+`scalar` as the first argument forces the scalar 4 x 64-bit chain (jj_ctx_set_option(NULL, "host_tail_scalar", 1)); the default takes the AVX-512 IFMA
+chain when the CPU has it.
+Usage: python tests/host_tail_time.py [scalar] [records ...]"""
 import ctypes
 import os
 import sys
@@ -18,9 +19,14 @@ from oracle import c_oracle as O  # noqa: E402
 from util import oracle_msm_record, rand_points, rand_scalars  # noqa: E402
 
 lib = _lib.load()
-counts = [int(a) for a in sys.argv[1:]] or [1, 8]
+args = sys.argv[1:]
+scalar = bool(args) and args[0] == "scalar"
+if scalar:
+    args = args[1:]
+    assert lib.jj_ctx_set_option(None, b"host_tail_scalar", 1) == 0
+counts = [int(a) for a in args] or [1, 8]
 flags = [w for w in open("/proc/cpuinfo").read().split("flags", 1)[1].split("\n", 1)[0].split() if w in ("avx512ifma", "avx512vl", "adx", "bmi2")]
-print("# cpu: %s | %s | JJ_HOST_TAIL=%s" % ([ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")][0], " ".join(sorted(flags)), os.environ.get("JJ_HOST_TAIL", "(default)")))
+print("# cpu: %s | %s | host tail: %s" % ([ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")][0], " ".join(sorted(flags)), "scalar chain (forced)" if scalar else "default"))
 for G in counts:
     for W in (16, 17, 23, 64):
         n = 24 * G

@@ -18,17 +18,10 @@ from util import pt64  # noqa: E402
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 SEED0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 eng = Engine(0)
-os.environ["JJ_MSM_SMALL_MAX"] = "0"
-os.environ["JJ_MSM_ACCUM"] = "segments"      # second context: the large-input MSM accumulation scheme forced on small inputs
-os.environ["JJ_VB_QUAD_MAX"] = "0"           # ... and the per-lane var-base kernel instead of the per-quad one
-eng_alt = Engine(0)
-del os.environ["JJ_MSM_ACCUM"], os.environ["JJ_VB_QUAD_MAX"], os.environ["JJ_MSM_SMALL_MAX"]
-eng_wide = []                                # Pippenger with 16 / 19 / 23 windows (two-pass and one-pass sort) forced on every size
-os.environ["JJ_MSM_SMALL_MAX"] = "0"
-for nwin_msm in (16, 19, 23):
-    os.environ["JJ_MSM_WINDOWS"] = str(nwin_msm)
-    eng_wide.append(Engine(0))
-del os.environ["JJ_MSM_WINDOWS"], os.environ["JJ_MSM_SMALL_MAX"]
+# second context: the large-input MSM accumulation scheme forced on small inputs, and the per-lane var-base kernel instead of the per-quad one
+eng_alt = Engine(0, options={"msm_small_max": 0, "msm_accum": 1, "vb_quad_max": 0})
+# Pippenger with 16 / 19 / 23 windows (two-pass and one-pass sort) forced on every size
+eng_wide = [Engine(0, options={"msm_small_max": 0, "msm_windows": nwin_msm}) for nwin_msm in (16, 19, 23)]
 base = pt64(J.GENERATOR)
 G8 = J.scalar_mul_fast(J.GENERATOR, J.R_MOD)             # order-8 component of the generator
 TORS = np.stack([pt64(J.scalar_mul_fast(G8, j) if j else J.AFFINE_IDENTITY) for j in range(8)])

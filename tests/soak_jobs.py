@@ -31,9 +31,7 @@ t_end, rnd, jobs_done = time.time() + budget, 0, 0
 while time.time() < t_end:
     rng = np.random.default_rng(SEED0 + rnd)
     lanes = int(rng.integers(1, 5))
-    os.environ["JJ_MSM_LANES"] = str(lanes)
-    eng = Engine(0)
-    del os.environ["JJ_MSM_LANES"]
+    eng = Engine(0, options={"msm_lanes": lanes})
     depth = int(rng.integers(1, 7))
     G = int(rng.choice([0, 0, 2, 3, 8]))                        # 0: one-GPU jobs; else the distributed halves with G ranks played on this GPU
     njobs = int(rng.integers(3, 10))

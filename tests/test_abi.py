@@ -285,3 +285,19 @@ def test_gpu_tests_fail_not_skip_on_a_broken_gpu_box(monkeypatch):
     monkeypatch.setattr(_lib, "load", boom)
     assert conftest.gpu_state()[0] == "broken"
     monkeypatch.setattr(conftest, "_GPU_STATE", None)              # leave no cached verdict behind for the other tests
+
+
+def test_shipped_library_reads_no_jj_environment_variable():
+    """Round 5's library read 34 JJ_* variables, two of which turned constant-time entry points into variable-time ones.  The shipped library
+    now holds no such name at all (options go through jj_ctx_set_option; experiment switches exist in -DJJ_EXPERIMENTS probe builds only)."""
+    import re
+    import subprocess
+
+    from jubjub_amd import _lib
+
+    blob = open(_lib.LIB_PATH, "rb").read()
+    names = sorted(set(m.decode() for m in re.findall(rb"JJ_[A-Z0-9_]{3,}", blob)) - {"JJ_MSM_PARTIAL_BYTES"})      # (a constant's name inside HIPCHK messages)
+    assert names == [], names
+    src = "".join(open(os.path.join(ROOT, "jubjub_amd", "csrc", f)).read() for f in sorted(os.listdir(os.path.join(ROOT, "jubjub_amd", "csrc"))))
+    outside = re.sub(r"#ifdef JJ_EXPERIMENTS.*?#e(?:lse|ndif)", "", src, flags=re.S)
+    assert re.findall(r'getenv\("(\w+)"\)', outside) == ["GPU_MAX_HW_QUEUES"]        # a HIP runtime variable, read for a one-time warning only

@@ -137,11 +137,11 @@ def test_msm_combine_scalar_and_ifma_chains_agree():
     import sys
 
     code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from jubjub_amd import _lib\nassert _lib.load().jj_ctx_set_option(None, b'host_tail_scalar', int(sys.argv[1] == 'scalar')) == 0\n"
             "import test_dist_cpu as T\nT.test_msm_combine_host_only()\nT._combine_random_records()\nprint('COMBINE OK')\n") % (
                 os.path.dirname(os.path.abspath(__file__)), os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
     for mode in ("scalar", "auto"):
-        env = dict(os.environ, JJ_HOST_TAIL=mode)
-        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+        r = subprocess.run([sys.executable, "-c", code, mode], capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and "COMBINE OK" in r.stdout, (mode, r.stdout[-2000:], r.stderr[-2000:])
 
 

@@ -143,8 +143,9 @@ def test_subgroup_check_2p20(env, monkeypatch):
     tf = eng.predicate("is_torsion_free", P)
     want = (torch.arange(n, device=dev) % 8 == 0)
     assert bool((tf.bool() == want).all())
-    monkeypatch.setenv("JJ_TORSION_CHECK", "ladder")
-    e2 = Engine(0)
+    opts = {}
+    opts['torsion_check_ladder'] = 1
+    e2 = Engine(0, options=opts)
     m = 1 << 17
     assert bool((e2.predicate("is_torsion_free", P[:m]) == tf[:m]).all())
     e2.close()

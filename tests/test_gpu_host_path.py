@@ -142,9 +142,10 @@ def test_pageable_arrays_page_locked_in_place(monkeypatch):
 
     from jubjub_amd import Engine
 
-    monkeypatch.setenv("JJ_PIPE_PAGEABLE", "register")
-    monkeypatch.setenv("JJ_PIPE_RAMP", "0")
-    e = Engine(0)
+    opts = {}
+    opts['pipe_pageable_register'] = 1
+    opts['pipe_ramp'] = 0
+    e = Engine(0, options=opts)
     for n in (1 << 21, N_PIPE, (1 << 20) + 5):                  # all arrays registered | all staged | points + result registered, scalars staged
         s, p = _inputs(n, 77)
         out = e.varbase_mul(s, p)                               # a new numpy result array
@@ -263,20 +264,24 @@ def test_msm_rccl_example_one_rank(tmp_path):
 
 
 # ------------------------------------------------------------------------------------------------ ADVICE r3 regressions
-def test_msm_windows_override_out_of_range_is_ignored(monkeypatch, capfd):
-    """JJ_MSM_WINDOWS below 16 would need more than 128 coarse bins per window in the two-pass sort (LDS overrun): the override is
-    ignored with a warning and the MSM is still right."""
+def test_msm_windows_override_out_of_range_is_refused():
+    """msm_windows below 16 would need more than 128 coarse bins per window in the two-pass sort (LDS overrun): jj_ctx_set_option refuses the
+    value (JJ_ERR_INVALID, the range in jj_last_error), the context keeps its planner and the MSM is still right."""
     from jubjub_amd import Engine
+    from jubjub_amd.engine import JubjubError
 
-    monkeypatch.setenv("JJ_MSM_WINDOWS", "12")
-    monkeypatch.setenv("JJ_MSM_SMALL_MAX", "0")
-    e = Engine(0)
+    e = Engine(0, options={"msm_small_max": 0})
+    for bad in (12, 15, 37, -1):
+        with pytest.raises(JubjubError, match="out of range"):
+            e.set_option("msm_windows", bad)
+    with pytest.raises(JubjubError, match="unknown key"):
+        e.set_option("varbase_default", 0)                      # no option reaches the timing discipline of an entry point
+    assert e.get_option("msm_windows") == 0 and e.get_option("msm_small_max") == 0
     n = 70000
     s, p = rand_scalars(8, n), rand_points(9, n)
     got = e.msm(s, p)
     e.close()
     assert (got == O.msm(s, p).reshape(64)).all()
-    assert "JJ_MSM_WINDOWS=12 ignored" in capfd.readouterr().err
 
 
 def test_msm_window_partition_with_more_parts_than_windows(eng):
@@ -368,8 +373,9 @@ def test_msm_host_arrays_reduced_in_overlapped_passes(n, monkeypatch):
     rec = e.msm_partial(hs, hp, 0, 1)
     assert (e.msm_combine(rec[None]) == want).all()
     e.close()
-    monkeypatch.setenv("JJ_MSM_HOST_SPLIT", "0")
-    e = Engine(0)
+    opts = {}
+    opts['msm_host_split'] = 0
+    e = Engine(0, options=opts)
     assert (e.msm(s, p) == want).all()
     e.close()
 
@@ -381,11 +387,12 @@ def test_msm_host_arrays_more_passes_than_eight(monkeypatch):
     import torch
     from jubjub_amd import Engine
 
-    monkeypatch.setenv("JJ_MSM_PASS_LOG2", "18")
+    opts = {}
+    opts['msm_pass_log2'] = 18
     n = 3 * (1 << 19) + 5
     s, p = rand_scalars(71, n), rand_points(72, n)
     want = O.msm_pippenger(s, p).reshape(64)
-    e = Engine(0)
+    e = Engine(0, options=opts)
     assert (e.msm(s, p) == want).all()
     hs, hp = e.host_alloc((n, 32)), e.host_alloc((n, 64))
     hs[:], hp[:] = s, p

@@ -129,8 +129,9 @@ def test_torsion_free_pairing_vs_reference_ladder(eng, golden, monkeypatch):
     assert 0 < int(want.sum()) < len(P)
     assert (eng.predicate("is_torsion_free", P) == want).all()
     assert (eng.predicate("is_prime_order", P) == O.predicate("is_prime_order", P)).all()
-    monkeypatch.setenv("JJ_TORSION_CHECK", "ladder")
-    e2 = Engine(0)
+    opts = {}
+    opts['torsion_check_ladder'] = 1
+    e2 = Engine(0, options=opts)
     assert (e2.predicate("is_torsion_free", P) == want).all()
     enc = O.compress(P)
     for flags in (1 | 2, 1 | 2 | 4 | 8):
@@ -164,8 +165,9 @@ def test_varbase_per_lane_and_per_quad_kernels(golden, monkeypatch):
     Pn = np.concatenate([Pn, rand_points(52, 1500)])
     want = O.varbase_mul(S, Pn)
     for quad_max in ("0", "1048576"):
-        monkeypatch.setenv("JJ_VB_QUAD_MAX", quad_max)
-        e2 = Engine(0)
+        opts = {}
+        opts['vb_quad_max'] = int(quad_max)
+        e2 = Engine(0, options=opts)
         assert (e2.varbase_mul(S, Pn) == want).all(), quad_max                     # constant-time: k_varbase_ct3 / k_varbase_ct_quad
         assert (e2.varbase_mul_vartime(S, Pn) == want).all(), quad_max             # table ladder: k_varbase / k_varbase_quad
         assert (e2.varbase_mul_vartime_compressed(S, Pn) == O.compress(want)).all(), quad_max
@@ -185,9 +187,10 @@ def test_varbase_constant_time_ladder(golden, monkeypatch, window, quad_max):
     multiplication per quad of lanes (k_varbase_ct_quad: every lane keeps its own coordinate of {P .. 4P} in registers); 0: one per lane."""
     from jubjub_amd import Engine
 
-    monkeypatch.setenv("JJ_VB_CT_WINDOW", window)
-    monkeypatch.setenv("JJ_VB_QUAD_MAX", quad_max)
-    eng = Engine(0)
+    opts = {}
+    opts['vb_ct_window'] = int(window)
+    opts['vb_quad_max'] = int(quad_max)
+    eng = Engine(0, options=opts)
     pts = np.concatenate([rand_points(3, 8), torsion_points(golden), arr64([J.GENERATOR, J.AFFINE_IDENTITY])])
     S = np.stack([b32(k) for k in EDGE_SCALARS for _ in pts])
     Pn = np.stack([p for _ in EDGE_SCALARS for p in pts])
@@ -236,8 +239,9 @@ def test_varbase_shared_scalar_kernel_large_ragged_batch(eng, golden, monkeypatc
     address, its digits live in scalar registers); ragged batch sizes exercise the waves' work cursor"""
     from jubjub_amd import Engine
 
-    monkeypatch.setenv("JJ_VB_QUAD_MAX", "0")                # every size through the per-lane kernels
-    e2 = Engine(0)
+    opts = {}
+    opts['vb_quad_max'] = 0                # every size through the per-lane kernels
+    e2 = Engine(0, options=opts)
     pts = np.concatenate([rand_points(93, 40001 - 10), torsion_points(golden), arr64([J.GENERATOR, J.AFFINE_IDENTITY])])
     for k in (to_int(rand_scalars(94, 1, full_width=True)[0]), R - 1):
         S = np.repeat(b32(k)[None, :], len(pts), axis=0)
@@ -282,15 +286,14 @@ def test_fixedbase(eng):
         eng.fixedbase_table(pt64(J.GENERATOR), 5)
 
 
-@pytest.mark.parametrize("select", ["shuffle", "gather"])
-def test_fixedbase_signed_comb(monkeypatch, golden, select):
+def test_fixedbase_signed_comb(golden):
     """k_fixedbase_comb (8 teeth, 8 column blocks, 32 additions + 3 doublings; even scalars take the last entry from T_0 -+ B):
     every parity / sign class of the last column, scalars whose comb columns are all +, all -, alternating, 0, 1, 2, r - 1, r,
     2^252 - 1, top bits set; bases of every kind (generator, prime-order, 8-torsion, order 2, identity); ragged waves; the
-    constant-time shuffle select and the per-lane LDS gather; and the chained (multi-base) form."""
+    the constant-time shuffle select (the per-lane LDS gather exists in -DJJ_EXPERIMENTS probe builds only: tools/fixedbase_floor.sh); and the
+    chained (multi-base) form."""
     from jubjub_amd import Engine
 
-    monkeypatch.setenv("JJ_FIXEDBASE_SELECT", select)
     e2 = Engine(0)
     comb = [0, 1, 2, 3, 4, (1 << 252) - 1, (1 << 252) - 2, 1 << 251, (1 << 251) + 1, sum(1 << (32 * i) for i in range(8)) & ((1 << 252) - 1), sum(1 << (32 * i + 1) for i in range(8)) & ((1 << 252) - 1), sum(0x88888888 << (32 * i) for i in range(8)) & ((1 << 252) - 1),
             int("5" * 63, 16), int("a" * 62, 16), (1 << 224) - 1, 1 << 224, (1 << 224) + 2, (1 << 32) - 1, 1 << 32, (1 << 31) | 1, R - 1, R, R + 1, 8 * R - 1]
@@ -375,8 +378,9 @@ def test_msm_small_batch_path_and_pippenger_on_the_same_inputs(monkeypatch, smal
     Pippenger, each forced over every size: ragged sizes around the 128-quad workgroups, edge scalars, identity / torsion points."""
     from jubjub_amd import Engine
 
-    monkeypatch.setenv("JJ_MSM_SMALL_MAX", small_max)
-    e2 = Engine(0)
+    opts = {}
+    opts['msm_small_max'] = int(small_max)
+    e2 = Engine(0, options=opts)
     for n in (1, 2, 33, 127, 128, 129, 511, 513, 700, 1025, 4097, 40000):
         S = rand_scalars(112 + n, n, full_width=True)
         P = rand_points(113 + n, n, subgroup=(n % 2 == 0))
@@ -399,10 +403,11 @@ def test_msm_both_accumulation_schemes(monkeypatch, mode):
     forced in turn on the same inputs, including skewed digit distributions and short segments."""
     from jubjub_amd import Engine
 
-    monkeypatch.setenv("JJ_MSM_ACCUM", mode)
-    monkeypatch.setenv("JJ_MSM_SEG_LEN", "8")
-    monkeypatch.setenv("JJ_MSM_SMALL_MAX", "0")
-    e2 = Engine(0)
+    opts = {}
+    opts['msm_accum'] = {"segments": 1, "chunks": 0}[mode]
+    opts['msm_seg_len'] = 8
+    opts['msm_small_max'] = 0
+    e2 = Engine(0, options=opts)
     for n in (1, 5, 300, 4099, 70000):
         S = rand_scalars(212 + n, n, full_width=True)
         P = rand_points(213 + n, n)
@@ -460,10 +465,11 @@ def test_msm_window_counts_both_sorts(monkeypatch, window, sort):
     ragged sizes, a bin far larger than the LDS stage (equal scalars), zero digits, the largest top-window digit."""
     from jubjub_amd import Engine
 
-    monkeypatch.setenv("JJ_MSM_WINDOWS", str(window))
-    monkeypatch.setenv("JJ_MSM_SORT", sort)
-    monkeypatch.setenv("JJ_MSM_SMALL_MAX", "0")
-    e2 = Engine(0)
+    opts = {}
+    opts['msm_windows'] = window
+    opts['msm_sort_two_pass'] = {"2pass": 1, "1pass": 0}[sort]
+    opts['msm_small_max'] = 0
+    e2 = Engine(0, options=opts)
     for n in (1, 2, 300, 8191, 8193, 30000):
         S = rand_scalars(512 + n + window, n, full_width=True)
         P = rand_points(513 + n, n, subgroup=(n % 2 == 0))
@@ -492,12 +498,13 @@ def test_msm_two_level_bucket_reduce(monkeypatch, window, rows, l2chunk):
     ragged sizes, equal scalars (one bucket per window holds everything), zero digits and the largest top-window digit."""
     from jubjub_amd import Engine
 
-    monkeypatch.setenv("JJ_MSM_WINDOWS", str(window))
-    monkeypatch.setenv("JJ_MSM_REDUCE_L1", str(rows))
+    opts = {}
+    opts['msm_windows'] = window
+    opts['msm_reduce_l1'] = rows
     if l2chunk:
-        monkeypatch.setenv("JJ_MSM_REDUCE_L2_CHUNK", str(l2chunk))
-    monkeypatch.setenv("JJ_MSM_SMALL_MAX", "0")
-    e2 = Engine(0)
+        opts['msm_reduce_l2_chunk'] = l2chunk
+    opts['msm_small_max'] = 0
+    e2 = Engine(0, options=opts)
     for n in (1, 2, 301, 30011):
         S = rand_scalars(1512 + n + window, n, full_width=True)
         P = rand_points(1513 + n, n, subgroup=(n % 2 == 0))
@@ -530,10 +537,11 @@ def test_msm_two_pass_sort_histogram_modes(monkeypatch, mode, window):
     the 1024-term and 4096-term workgroups and the 8192-term tiles, a window partition (slots != windows), equal scalars (one bin holds every entry), zeros."""
     from jubjub_amd import Engine
 
-    monkeypatch.setenv("JJ_MSM_SORT_HIST", mode)
-    monkeypatch.setenv("JJ_MSM_WINDOWS", str(window))
-    monkeypatch.setenv("JJ_MSM_SMALL_MAX", "0")
-    e2 = Engine(0)
+    opts = {}
+    opts['msm_sort_hist_fused'] = {"separate": 0, "fused": 1}[mode]
+    opts['msm_windows'] = window
+    opts['msm_small_max'] = 0
+    e2 = Engine(0, options=opts)
     for n in (1, 1023, 1025, 4097, 8191, 8193, 50021):
         S = rand_scalars(3512 + n + window, n, full_width=True)
         P = rand_points(3513 + n, n, subgroup=(n % 2 == 0))
@@ -557,8 +565,9 @@ def test_msm_back_to_back_sizes(monkeypatch):
     before it, including the LDS-staged conversion's ragged last workgroup (n not a multiple of 64)."""
     from jubjub_amd import Engine
 
-    monkeypatch.setenv("JJ_MSM_SMALL_MAX", "0")
-    e2 = Engine(0)
+    opts = {}
+    opts['msm_small_max'] = 0
+    e2 = Engine(0, options=opts)
     for n in (1, 300, 5000, 40000, 2000, 40001, 63, 65):
         S = rand_scalars(712 + n, n, full_width=True)
         P = rand_points(713 + n, n)
@@ -570,8 +579,9 @@ def test_msm_multipass(monkeypatch):
     """Inputs larger than one Pippenger pass are folded pass by pass (pass size shrunk here via the env knob)."""
     from jubjub_amd import Engine
 
-    monkeypatch.setenv("JJ_MSM_PASS_LOG2", "12")
-    e2 = Engine(0)
+    opts = {}
+    opts['msm_pass_log2'] = 12
+    e2 = Engine(0, options=opts)
     n = 10000
     S, P = rand_scalars(41, n, full_width=True), rand_points(42, n)
     assert (e2.msm(S, P) == O.msm(S, P)).all()
@@ -617,9 +627,10 @@ def test_msm_jobs_over_several_lanes(monkeypatch, lanes):
 
     from jubjub_amd import Engine
 
-    monkeypatch.setenv("JJ_MSM_LANES", lanes)
-    monkeypatch.setenv("JJ_MSM_PASS_LOG2", "16")
-    e2 = Engine(0)
+    opts = {}
+    opts['msm_lanes'] = int(lanes)
+    opts['msm_pass_log2'] = 16
+    e2 = Engine(0, options=opts)
     dev = torch.device("cuda", 0)
     sizes = (700, 40000, 5, 20000, 70000, 300, 100000, 17000, 33000)
     data = [(rand_scalars(1200 + n, n, full_width=True), rand_points(1201 + n, n)) for n in sizes]
@@ -687,9 +698,10 @@ def test_msm_gathered_records_folded_on_the_device(monkeypatch, fold):
     from jubjub_amd import Engine, _lib
     from jubjub_amd.dist import shard_bounds
 
-    monkeypatch.setenv("JJ_MSM_FOLD", fold)
-    monkeypatch.setenv("JJ_MSM_FOLD_MIN", "2")                       # (the default folds on the device from 8 records)
-    e2 = Engine(0)
+    opts = {}
+    opts['msm_fold_dev'] = {"host": 0, "device": 1}[fold]
+    opts['msm_fold_min'] = 2                       # (the default folds on the device from 8 records)
+    e2 = Engine(0, options=opts)
     dev = torch.device("cuda", 0)
     n = 70000
     S, P = rand_scalars(2950, n, full_width=True), rand_points(2951, n)
@@ -733,9 +745,10 @@ def test_msm_allgather_of_G_ranks_played_on_one_gpu(monkeypatch, G, fold_min):
     from jubjub_amd.dist import shard_bounds
     from util import LoopbackComm
 
-    monkeypatch.setenv("JJ_MSM_FOLD_MIN", str(fold_min))
+    opts = {}
+    opts['msm_fold_min'] = fold_min
     dev = torch.device("cuda", 0)
-    e2 = Engine(0)
+    e2 = Engine(0, options=opts)
     n = 9000 * G + 5
     batches = []
     for k in range(3):
@@ -896,8 +909,9 @@ def test_host_buffer_pipeline(monkeypatch):
     result must equal the oracle (small chunks, many slots reuses, ragged tail) for every pipelined entry point."""
     from jubjub_amd import Engine
 
-    monkeypatch.setenv("JJ_PIPE_CHUNK_LOG2", "10")
-    e2 = Engine(0)
+    opts = {}
+    opts['pipe_chunk_log2'] = 10
+    e2 = Engine(0, options=opts)
     for n in (2048, 2049, 5000, 7 * 1024 + 1):
         S, P = rand_scalars(60 + n, n, full_width=True), rand_points(61 + n, n)
         want = O.varbase_mul(S, P)
@@ -1071,3 +1085,93 @@ def test_config0_shape_on_the_gpu(eng):
     assert (eng.field_binary("fq", "mul", a, b) == O.field_op(O.FQ, "mul", a, b)[0]).all()
     pts = rand_points(1025, 1024)
     assert (eng.point_double(pts) == O.point_op("double", pts)).all()
+
+
+@pytest.mark.parametrize("fold_min", [2, 8])
+def test_msm_allgather_failing_rank_posts_a_poison_record(fold_min):
+    """A rank that fails BEFORE its all-gather (here: more terms than one pass takes) must not leave the others waiting in theirs: it still
+    gathers -- an all-zero record -- and returns its error; every healthy rank's fold / host tail rejects the set ("damaged"), so every
+    rank of the collective reports a failure instead of hanging or summing without the lost terms.  The communicator stays usable.
+    (Ranks played on one GPU by tests/util.py LoopbackComm, which counts the gathers.)"""
+    import torch
+
+    from jubjub_amd import Engine
+    from jubjub_amd.engine import JubjubError
+    from util import LoopbackComm
+
+    G, n = 4, 3000
+    dev = torch.device("cuda", 0)
+    S, P = rand_scalars(6100, G * n, full_width=True), rand_points(6200, G * n)
+    Sd, Pd = torch.from_numpy(S).to(dev), torch.from_numpy(P).to(dev)
+    good = Engine(0, options={"msm_fold_min": fold_min})
+    recs = torch.stack([good.msm_partial(Sd[g * n:(g + 1) * n], Pd[g * n:(g + 1) * n]) for g in range(G)])
+    # the failing rank (1): its pass limit is below its term count
+    bad = Engine(0, options={"msm_pass_log2": 10})
+    comm = LoopbackComm(1, G)
+    comm.add_round(recs)
+    bad.set_comm(comm)
+    with pytest.raises(JubjubError, match="at most one pass"):
+        bad.msm_allgather(Sd[n:2 * n], Pd[n:2 * n])
+    assert comm.calls() == 1                                       # it took part in the collective all the same
+    with pytest.raises(JubjubError, match="at most one pass"):
+        bad.msm_allgather_begin(Sd[n:2 * n], Pd[n:2 * n])
+    assert comm.calls() == 2
+    bad.set_comm(None)
+    comm.close()
+    bad.close()
+    # a healthy rank (0) of the same collective: rank 1's slot holds the poison record
+    poisoned = recs.clone()
+    poisoned[1].zero_()
+    comm = LoopbackComm(0, G)
+    comm.add_round(poisoned)
+    comm.add_round(poisoned)
+    comm.add_round(recs)
+    good.set_comm(comm)
+    assert good.get_option("msm_lanes") == 1                       # several ranks: all gathers of the communicator on one stream
+    with pytest.raises(JubjubError, match="damaged"):
+        good.msm_allgather(Sd[:n], Pd[:n])
+    job = good.msm_allgather_begin(Sd[:n], Pd[:n])
+    with pytest.raises(JubjubError, match="damaged"):
+        good.msm_finish(job)
+    assert (good.msm_allgather(Sd[:n], Pd[:n]) == O.msm(S, P).reshape(64)).all()      # the next collective of the same communicator is fine
+    assert comm.calls() == 3
+    good.set_comm(None)
+    good.set_option("msm_lanes", 3)                                # a caller that has checked multi-stream gathers on its node may go back
+    assert good.get_option("msm_lanes") == 3
+    comm.close()
+    good.close()
+
+
+def test_options_by_key_and_no_environment(monkeypatch):
+    """jj_ctx_set_option / jj_ctx_get_option: every documented key round-trips, ranges are enforced, and the variables rounds 2-5 read from the
+    environment -- among them the two that switched the TIMING DISCIPLINE of an entry point -- change nothing: the context created under them
+    has the default options and its constant-time entry points give the oracle's results."""
+    from jubjub_amd import Engine
+    from jubjub_amd.engine import JubjubError
+
+    for k, v in {"JJ_VARBASE_DEFAULT": "vartime", "JJ_FIXEDBASE_SELECT": "gather", "JJ_MSM_LANES": "4", "JJ_MSM_WINDOWS": "30", "JJ_MSM_SMALL_MAX": "0",
+                 "JJ_TORSION_CHECK": "ladder", "JJ_MSM_FOLD_MIN": "2", "JJ_VB_QUAD_MAX": "0"}.items():
+        monkeypatch.setenv(k, v)
+    e = Engine(0)
+    defaults = {"msm_lanes": 2, "msm_windows": 0, "msm_small_max": 1 << 14, "torsion_check_ladder": 0, "msm_fold_min": 8, "vb_quad_max": 32768, "msm_front1": 1,
+                "msm_chunk_waves": 2, "fixedbase_default": 7, "pipe_pageable_register": 0, "msm_fold_dev": 1, "msm_host_split": 1, "msm_pass_log2": 24}
+    for k, v in defaults.items():
+        assert e.get_option(k) == v, k
+    for k, v in {"msm_lanes": 4, "msm_fold_min": 2, "msm_windows": 23, "result_pool_mb": 16, "pipe_chunk_log2": 12, "msm_reduce_l1": 8, "msm_accum": -1}.items():
+        e.set_option(k, v)
+        assert e.get_option(k) == v, k
+    for k, v in {"msm_lanes": 5, "msm_fold_min": 1, "msm_reduce_l1": 3, "dec_c_mid": 12, "msm_chunk": 4, "pipe_chunk_log2": 5}.items():
+        with pytest.raises(JubjubError, match="out of range"):
+            e.set_option(k, v)
+    for k in ("varbase_default", "fixedbase_select", "JJ_MSM_LANES", ""):
+        with pytest.raises(JubjubError, match="unknown key"):
+            e.set_option(k, 1)
+    e.close()
+    e = Engine(0)
+    S, P = rand_scalars(6300, 700, full_width=True), rand_points(6301, 700)
+    assert (e.varbase_mul(S, P) == O.varbase_mul(S, P)).all()
+    tab = e.fixedbase_table(pt64(J.GENERATOR), 0)
+    assert (e.fixedbase_mul(tab, S) == O.fixedbase_mul(S, pt64(J.GENERATOR))).all()
+    tab.close()
+    assert (e.msm(S, P) == O.msm(S, P).reshape(64)).all()
+    e.close()

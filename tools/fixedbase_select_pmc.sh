@@ -1,7 +1,11 @@
 #!/bin/bash
 # LDS counters of the fixed-base comb with the shuffle select (ds_bpermute, the default) and with the per-lane LDS gather: how busy the LDS
 # unit is, and how many of its cycles are bank / address conflicts of the secret-index-dependent lane pattern.  Runs on the GPU box.
+# The gather select exists in -DJJ_EXPERIMENTS builds only (the shipped library has no switch that reaches the timing discipline): build the probe
+# library first (CPU): python tools/fixedbase_floor.py build
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"; export TMPDIR=/tmp; cd "$ROOT"
+export JJ_LIB_PATH="$ROOT/experiments/probe_lib/libjj_experiments.so"
+[ -f "$JJ_LIB_PATH" ] || { echo "build the probe library first: python tools/fixedbase_floor.py build"; exit 1; }
 D=gpurun_out/pmc_lds; rm -rf $D; mkdir -p $D
 for sel in shuffle gather; do
   for set in "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_INST_LEVEL_LDS" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY" "SQ_LDS_IDX_ACTIVE SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL"; do

@@ -1,14 +1,13 @@
 #!/bin/bash
 # Runs ON THE GPU BOX: start / end of every kernel of ONE MSM call (the last of a short bench run) under rocprofv3 --kernel-trace:
-# where the time of a call goes between the kernels.   bash tools/msm_timeline.sh <log2n> [env assignments...]  -> gpurun_out/msm<log2n>_timeline.txt (stdout too)
+# where the time of a call goes between the kernels.   bash tools/msm_timeline.sh <log2n> [bench.py arguments, e.g. --opt msm_front1=0 ...]  -> gpurun_out/msm<log2n>_timeline.txt (stdout too)
 LOG2N=$1; shift
-for kv in "$@"; do export "$kv"; done
 cd "$(dirname "$0")/.."
 R=$PWD
 export TMPDIR=/tmp
 D=$R/gpurun_out/prof_tl_msm$LOG2N
 rm -rf $D
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace -d $D -o msm -- python $R/bench.py --workload msm --log2n $LOG2N --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $D.log 2>&1)
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace -d $D -o msm -- python $R/bench.py --workload msm --log2n $LOG2N --steps 3 --warmup 1 --no-cpu-baseline --no-extras "$@" > $D.log 2>&1)
 python3 - "$LOG2N" "$D" <<'PY' | tee gpurun_out/msm${LOG2N}_timeline.txt
 import glob, os, sqlite3, sys
 lg, d = sys.argv[1:3]

@@ -30,12 +30,12 @@ for hb in pinned pageable; do
   line decompress_$hb --workload decompress --host-buffers $hb
 done
 # pageable arrays page-locked in place for the call (round 3's way) instead of the bounce path through the context's staging buffers
-JJ_PIPE_PAGEABLE=register line fixedbase_pageable_register --workload fixedbase --host-buffers pageable
-JJ_PIPE_PAGEABLE=register line decompress_pageable_register --workload decompress --host-buffers pageable
+line fixedbase_pageable_register --opt pipe_pageable_register=1 --workload fixedbase --host-buffers pageable
+line decompress_pageable_register --opt pipe_pageable_register=1 --workload decompress --host-buffers pageable
 # a caller that allocates a NEW result array per call (vec![0u8; 64 * n]): bounce (default) and in-place page-locking with / without the pre-fault
 line fixedbase_fresh --workload fixedbase --host-buffers fresh
-JJ_PIPE_PAGEABLE=register line fixedbase_fresh_register --workload fixedbase --host-buffers fresh
-JJ_PIPE_PAGEABLE=register JJ_PIPE_PREFAULT=0 line fixedbase_fresh_register_noprefault --workload fixedbase --host-buffers fresh
+line fixedbase_fresh_register --opt pipe_pageable_register=1 --workload fixedbase --host-buffers fresh
+line fixedbase_fresh_register_noprefault --opt pipe_pageable_register=1 --opt pipe_prefault=0 --workload fixedbase --host-buffers fresh
 line decompress_fresh --workload decompress --host-buffers fresh
 line varbase_fresh --workload varbase --host-buffers fresh
 # ... and the same caller taking its result buffers from the library's pool (jj_result_acquire / _release, round 5): a DIFFERENT page-locked buffer per call
@@ -48,9 +48,9 @@ for hb in pinned pageable; do
   line msm20_$hb --workload msm --host-buffers $hb
   line msm22_$hb --workload msm --log2n 22 --host-buffers $hb
 done
-JJ_MSM_HOST_SPLIT=0 line msm20_pinned_one_pass --workload msm --host-buffers pinned
-JJ_MSM_HOST_SPLIT=0 line msm22_pinned_one_pass --workload msm --log2n 22 --host-buffers pinned
+line msm20_pinned_one_pass --opt msm_host_split=0 --workload msm --host-buffers pinned
+line msm22_pinned_one_pass --opt msm_host_split=0 --workload msm --log2n 22 --host-buffers pinned
 # uniform chunks (no short first / last chunk)
-JJ_PIPE_RAMP=0 line fixedbase_pinned_uniform_chunks --workload fixedbase --host-buffers pinned
-JJ_PIPE_RAMP=0 line decompress_pinned_uniform_chunks --workload decompress --host-buffers pinned
+line fixedbase_pinned_uniform_chunks --opt pipe_ramp=0 --workload fixedbase --host-buffers pinned
+line decompress_pinned_uniform_chunks --opt pipe_ramp=0 --workload decompress --host-buffers pinned
 cat $OUT

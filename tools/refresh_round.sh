@@ -43,8 +43,8 @@ bash tools/stall_pmc.sh > gpurun_out/${TAG}_stall_pmc.txt 2>&1
 (./experiments/lds_probe/energy_probe; ./experiments/lds_probe/probe) > gpurun_out/${TAG}_issue_energy_probe.txt 2>&1
 JJ_BENCH_FORCE_DIST=1 python bench.py --gpus 1 --workload msm --msm-exchange c --no-cpu-baseline > gpurun_out/${TAG}_bench_msm20_rccl1.json 2>/dev/null </dev/null   # one rank over RCCL, the exchange behind the C ABI
 python bench.py --workload msm > gpurun_out/${TAG}_bench_msm20_cpu.json 2>/dev/null                                                   # with the CPU baseline: naive fold + bucket method
-(python tests/host_tail_time.py 1 8; JJ_HOST_TAIL=scalar python tests/host_tail_time.py 1 8) > gpurun_out/${TAG}_host_tail.txt 2>&1     # MSM host tail on the box's CPU: AVX-512 IFMA chain | scalar chain
-for m in auto scalar auto scalar; do JJ_HOST_TAIL=$m python bench.py --workload msm --log2n 17 --steps 10 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('JJ_HOST_TAIL=$m  msm 2^17: %.4f ms per call (kernels %.4f ms), verified %s' % (d['config']['ms_per_pass'], d['roofline']['kernel_ms'], d['verified']))"; done >> gpurun_out/${TAG}_host_tail.txt 2>&1
+(python tests/host_tail_time.py 1 8; python tests/host_tail_time.py scalar 1 8) > gpurun_out/${TAG}_host_tail.txt 2>&1     # MSM host tail on the box's CPU: AVX-512 IFMA chain | scalar chain
+for m in 0 1 0 1; do python bench.py --opt host_tail_scalar=$m --workload msm --log2n 17 --steps 10 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('host_tail_scalar=$m  msm 2^17: %.4f ms per call (kernels %.4f ms), verified %s' % (d['config']['ms_per_pass'], d['roofline']['kernel_ms'], d['verified']))"; done >> gpurun_out/${TAG}_host_tail.txt 2>&1
 timeout 300 python tests/soak_host.py 120 > gpurun_out/${TAG}_soak_host.txt 2>&1 || echo "HOST SOAK FAILED" >> gpurun_out/${TAG}_soak_host.txt
 timeout 600 python tests/soak.py 240 3000 > gpurun_out/${TAG}_soak.txt 2>&1 || echo "SOAK FAILED" >> gpurun_out/${TAG}_soak.txt
 # round 5: constant-time ladder window widths against the table ladder; the two-level bucket reduce's sweep; the stand-alone fault reproducer
