@@ -449,11 +449,44 @@ def run(a):
         points = None
 
     rccl_comm = None
+    exchange_fallback = None
     if wl == "msm" and distributed and a.backend == "nccl" and a.msm_exchange == "c":
+        # the exchange behind the C ABI on a communicator of this process's own.  It is set up and TRIED ONCE on a small slice against the
+        # torch.distributed exchange of the same records; if any rank fails (library, communicator, the all-gather itself) or the two disagree,
+        # EVERY rank falls back to --msm-exchange torch and the line says why ("msm_exchange_fallback"): the run still has to verify.
         from jubjub_amd.dist import RcclComm
 
-        rccl_comm = RcclComm(rank, world)          # this process's own communicator; the ncclUniqueId travels over torch.distributed
-        eng.set_comm(rccl_comm)
+        err = None
+        try:
+            if os.environ.get("JJ_BENCH_BREAK_C_EXCHANGE") == str(rank):       # tests: this rank's set-up fails
+                raise RuntimeError("JJ_BENCH_BREAK_C_EXCHANGE")
+            rccl_comm = RcclComm(rank, world)      # the ncclUniqueId travels over torch.distributed; a rank that cannot load RCCL fails all of them
+            eng.set_comm(rccl_comm)
+        except Exception as e:                     # noqa: BLE001 -- whatever went wrong is the reason recorded
+            err = "%s: %s" % (type(e).__name__, e)
+        every = [None] * world
+        dist.all_gather_object(every, err)
+        if not any(every):
+            k = min(n, 4096)
+            try:
+                got = np.asarray(eng.msm_allgather(scalars[:k], points[:k], "window" if by_window else "terms")).tobytes()
+                rec = eng.msm_partial(scalars[:k], points[:k], rank, world) if by_window else eng.msm_partial(scalars[:k], points[:k])
+                recs = [torch.empty_like(rec) for _ in range(world)]
+                dist.all_gather(recs, rec)
+                want = np.asarray(eng.msm_combine(torch.stack(recs))).tobytes()
+                if got != want:
+                    err = "trial MSM over the C exchange differs from the torch.distributed exchange"
+            except Exception as e:                 # noqa: BLE001
+                err = "%s: %s" % (type(e).__name__, e)
+            dist.all_gather_object(every, err)
+        bad = [(r, e) for r, e in enumerate(every) if e]
+        if bad:
+            exchange_fallback = "rank %d: %s" % bad[0]
+            if rccl_comm is not None:
+                eng.set_comm(None)
+                rccl_comm = None                   # (not destroyed: ncclCommDestroy of a half-working communicator may itself wait for the others)
+            if rank == 0:
+                print("bench.py: C-level MSM exchange unavailable (%s); falling back to --msm-exchange torch" % exchange_fallback, file=sys.stderr)
     host = a.host_buffers
     if host and (distributed or (wl == "msm" and (host in ("fresh", "pooled") or a.msm_async > 1 or a.msm_contexts > 1))):
         if rank == 0:
@@ -662,6 +695,7 @@ def run(a):
             "parallelism": ("window partition: rank g owns windows g, g + G, ... of all terms" if by_window else "contiguous shards, one process per GPU") +
                            ("; all_gather of one 8 KB record of window sums per rank (%s%s), one host tail" % (a.backend, ", behind the C ABI: jj_msm_allgather on this process's own RCCL communicator" if rccl_comm is not None else "") if wl == "msm" else "; no data-path collective")},
         "rccl_world_size": dist.get_world_size() if distributed else 1,
+        "msm_exchange_fallback": exchange_fallback,
         # each rank's own time per step before the closing barrier (ms_per_step is the max over ranks, barrier included): stragglers show here
         "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "per_rank": rank_ms},
     }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Mid-size MSMs (2^15 ... 2^19 terms: config 4's per-rank shares): wall time per synchronous jj_msm call for every window count x level-1 rows of the
 bucket reduce x accumulation form, each forced in turn on the same device-resident inputs and checked against the default configuration's point.
-The planner's choice (jj_msm.hip msm_windows_for: 23 windows below 147 456 terms, 17 from there, 16 from 2^20; two-level reduce from 16 384
+The planner's choice (jj_msm.hip msm_windows_for: 23 windows below 147 456 terms, 17 from there, 16 from 2^18 (2^20 until round 6); two-level reduce from 16 384
 buckets per window) dates from round 3, before the two-level reduce existed.
    python experiments/misc/msm_mid_sweep.py [log2n ...]"""
 import os

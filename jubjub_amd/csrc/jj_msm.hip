@@ -25,10 +25,11 @@ constexpr size_t MSM_LARGE_MIN = (size_t)9 << 14;
 static int msm_windows_for(jj_ctx* c, size_t n) {
   if (c->msm_windows >= MSM_WINDOWS_MIN && c->msm_windows <= MSM_WINDOWS_MAX) return c->msm_windows;
   // measured (experiments/misc/msm_sweep*.sh, profiles/r3_msm_window_sweep.txt, r3_msm_reduce_grid.txt): 16 windows (13 of 16 bits, 3 of
-  // 15) from 2^20 terms; 17 windows (15 of 15 bits, 2 of 14: half the buckets, so the bucket reduce is 145 us instead of 210, for
-  // 6 % more additions) from MSM_LARGE_MIN terms; below, 23 windows of 11 bits: wider windows cut the additions but their buckets (4096+ per
-  // window) make the fix-up and reduce chains longer than the additions they save
-  return n >= ((size_t)1 << 20) ? 16 : n >= MSM_LARGE_MIN ? 17 : 23;
+  // 15) from 2^18 terms (round 6; from 2^20 before: with the two-level reduce -- 8 level-1 rows -- the 2^15 buckets per window no longer cost
+  // a 210 us chain, and 16 windows beat 17 by 0.5 % at 2^18 and 2 % at 2^19 terms, profiles/r5_msm_mid_sweep.txt); 17 windows (15 of 15 bits,
+  // 2 of 14: half the buckets for 6 % more additions) from MSM_LARGE_MIN terms; below, 23 windows of 11 bits: wider windows cut the additions
+  // but their buckets (4096+ per window) make the fix-up and reduce chains longer than the additions they save
+  return n >= ((size_t)1 << 18) ? 16 : n >= MSM_LARGE_MIN ? 17 : 23;
 }
 // counters (MSM_COUNTER_WORDS words, cleared by the first kernel of a pass) | big-bucket work list | workgroup partial sums
 constexpr size_t MSM_BIG_OFF = 512, MSM_PART_OFF = MSM_BIG_OFF + sizeof(BigBucket) * FIXUP_BIG_MAX;

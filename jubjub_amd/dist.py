@@ -93,31 +93,46 @@ class RcclComm:
     the communicator, because the two must come from the same library instance.
     The current HIP device (torch.cuda.set_device) must be this rank's GPU when the communicator is created."""
 
-    def __init__(self, rank, world, broadcast=None, lib_path=None):
+    def __init__(self, rank, world, broadcast=None, lib_path=None, agree=None):
+        """`agree` (a callable: this rank's error text or None -> the list of every rank's) makes the set-up fail on ALL ranks when it
+        fails on one, BEFORE the collective ncclCommInitRank could leave the healthy ranks waiting for the broken one (default:
+        torch.distributed.all_gather_object; not called for world == 1)."""
         import ctypes as C
 
         self.rank, self.world = int(rank), int(world)
-        self._lib = C.CDLL(lib_path or self._find_library())
+        self.handle = None
 
         class UniqueId(C.Structure):
             _fields_ = [("internal", C.c_char * 128)]
 
-        self._lib.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
-        self._lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
-        self._lib.ncclCommDestroy.argtypes = [C.c_void_p]
-        self._lib.ncclGetErrorString.restype = C.c_char_p
+        # stage 1, local: the library, its symbols and (rank 0) the id -- nothing here waits for another rank
+        err, raw = None, None
         uid = UniqueId()
-        raw = None
-        if self.rank == 0:
-            self._ok(self._lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
-            raw = C.string_at(C.addressof(uid), 128)
+        try:
+            self._lib = C.CDLL(lib_path or self._find_library())
+            self._lib.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
+            self._lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+            self._lib.ncclCommDestroy.argtypes = [C.c_void_p]
+            self._lib.ncclGetErrorString.restype = C.c_char_p
+            self.all_gather_addr = C.cast(self._lib.ncclAllGather, C.c_void_p).value
+            if self.rank == 0:
+                self._ok(self._lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+                raw = C.string_at(C.addressof(uid), 128)
+        except (OSError, AttributeError, RuntimeError) as e:
+            err = "%s: %s" % (type(e).__name__, e)
+        # stage 2: every rank learns whether every rank got this far (the broadcast below is only entered when all did)
         if self.world > 1:
+            errs = (agree or self._torch_agree)(err)
+            bad = [(r, e) for r, e in enumerate(errs) if e]
+            if bad:
+                raise RuntimeError("RCCL set-up failed on rank %d: %s" % bad[0])
             raw = (broadcast or self._torch_broadcast)(raw)
+        elif err:
+            raise RuntimeError("RCCL set-up failed: " + err)
         C.memmove(C.addressof(uid), raw, 128)
         h = C.c_void_p()
         self._ok(self._lib.ncclCommInitRank(C.byref(h), self.world, uid, self.rank), "ncclCommInitRank")
         self.handle = h.value
-        self.all_gather_addr = C.cast(self._lib.ncclAllGather, C.c_void_p).value
 
     @staticmethod
     def _find_library():
@@ -141,6 +156,14 @@ class RcclComm:
         box = [raw]
         dist.broadcast_object_list(box, src=0)
         return box[0]
+
+    @staticmethod
+    def _torch_agree(err):
+        import torch.distributed as dist
+
+        every = [None] * dist.get_world_size()
+        dist.all_gather_object(every, err)
+        return every
 
     def _ok(self, rc, what):
         if rc != 0:

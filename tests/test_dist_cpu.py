@@ -217,3 +217,21 @@ def test_msm_combine_host_only():
     bad = oracle_msm_record(S, P)
     bad[64 + 31] = 0xFF                                                                    # a coordinate >= q
     assert combine([bad])[0] != 0
+
+
+def test_rccl_comm_setup_fails_on_every_rank_before_any_collective():
+    """RcclComm: a rank that cannot load RCCL (or get the id) must fail the set-up on ALL ranks before the collective ncclCommInitRank
+    could leave the healthy ones waiting -- the `agree` step carries every rank's error text, the id broadcast is entered only when
+    nobody failed (bench.py then falls back to the torch.distributed exchange)"""
+    from jubjub_amd.dist import RcclComm
+
+    calls = []
+    with pytest.raises(RuntimeError, match="rank 0: OSError: boom"):          # a healthy rank 1 learns of rank 0's failure
+        RcclComm(1, 2, agree=lambda e: (calls.append(e), ["OSError: boom", e])[1], broadcast=lambda raw: calls.append("broadcast"))
+    assert calls == [None]
+    calls.clear()
+    with pytest.raises(RuntimeError, match="rank 0: OSError"):                # the broken rank itself still takes part in the agreement
+        RcclComm(0, 2, lib_path="/nonexistent/librccl.so", agree=lambda e: (calls.append(e), [e, None])[1], broadcast=lambda raw: calls.append("broadcast"))
+    assert len(calls) == 1 and calls[0].startswith("OSError")
+    with pytest.raises(RuntimeError, match="RCCL set-up failed"):
+        RcclComm(0, 1, lib_path="/nonexistent/librccl.so")

@@ -157,6 +157,34 @@ def test_one_rank_rccl_leg_every_workload(workload, extra):
     assert 0 < res["roofline"]["frac_nominal"] < res["roofline"]["frac_at_peak_min"] * 1.2
 
 
+def test_c_exchange_failure_falls_back_to_torch_exchange():
+    """a rank whose C-level exchange cannot be set up (here: forced) takes EVERY rank to --msm-exchange torch; the line says why and
+    still verifies -- the driver's first real N > 1 run of config 4 must not end rc != 0 for plumbing reasons"""
+    res = run_bench(["--gpus", "1", "--workload", "msm", "--log2n", "16", "--steps", "2", "--warmup", "1", "--passes", "2", "--no-cpu-baseline",
+                     "--msm-async", "2"], {"JJ_BENCH_FORCE_DIST": "1", "MASTER_PORT": str(free_port()), "JJ_BENCH_BREAK_C_EXCHANGE": "0"})
+    assert res["verified"] is True and res["msm_result"] == oracle_msm(1 << 16)
+    assert "JJ_BENCH_BREAK_C_EXCHANGE" in res["msm_exchange_fallback"] and "jj_msm_allgather" not in res["config"]["parallelism"]
+    assert res["config"]["msm_jobs_in_flight"] == 1
+    ok = run_bench(["--gpus", "1", "--workload", "msm", "--log2n", "12", "--steps", "1", "--warmup", "1", "--passes", "2", "--no-cpu-baseline"],
+                   {"JJ_BENCH_FORCE_DIST": "1", "MASTER_PORT": str(free_port())})
+    assert ok["msm_exchange_fallback"] is None and "jj_msm_allgather" in ok["config"]["parallelism"]
+
+
+def test_eight_stacked_ranks_msm_strong_scaling_and_independent_shards():
+    """the driver's widest launch, `--gpus 8`, with the eight ranks stacked on GPU 0 over gloo: config 4's shape (2^14 terms cut in eight,
+    eight records gathered, one host tail) and one independent-shard workload; shard bounds, the per-rank times and the verdict come from
+    all eight"""
+    res = run_bench(["--gpus", "8", "--workload", "msm", "--scaling", "strong", "--log2n", "14", "--steps", "2", "--warmup", "1",
+                     "--passes", "2", "--backend", "gloo", "--no-cpu-baseline"], {"JJ_BENCH_FORCE_DEVICE": "0"}, timeout=900)
+    assert res["n_gpus"] == 8 and res["scaling"] == "strong" and res["verified"] is True and res["rccl_world_size"] == 8
+    assert res["config"]["units_per_step"] == 2 * (1 << 14) and res["msm_result"] == oracle_msm(1 << 14)
+    assert len(res["rank_ms_per_step"]["per_rank"]) == 8
+    res = run_bench(["--gpus", "8", "--workload", "fixedbase", "--log2n", "13", "--steps", "2", "--warmup", "1", "--backend", "gloo",
+                     "--no-cpu-baseline"], {"JJ_BENCH_FORCE_DEVICE": "0"}, timeout=900)
+    assert res["n_gpus"] == 8 and res["scaling"] == "weak" and res["verified"] is True
+    assert res["config"]["units_per_step"] == 8 * (1 << 13) * res["config"]["passes_per_step"] and len(res["rank_ms_per_step"]["per_rank"]) == 8
+
+
 @pytest.mark.parametrize("kind", ["pinned", "pageable", "pooled"])
 def test_bench_host_buffers_line(kind):
     """--host-buffers: the timed region is the C-ABI call on host arrays; the line carries roofline.pcie and is verified"""
