@@ -68,7 +68,7 @@ int jj_ctx_sync(jj_ctx* ctx);
  *                                 entry point): the host-buffer pipeline
  *   fixedbase_default 6|7 (7)     what window_bits = 0 means for jj_fixedbase_table_create
  * Planner overrides, for tests and measurements (every value gives the same results): msm_windows, msm_small_max, msm_small_blk, msm_accum,
- * msm_seg_len, msm_chunk, msm_reduce_chunk, msm_reduce_l1, msm_reduce_l2_chunk, msm_sort_hist_fused, msm_sort_two_pass, msm_front1, vb_ct_window,
+ * msm_seg_len, msm_chunk, msm_reduce_chunk, msm_reduce_l1, msm_reduce_l2_chunk, msm_sort_hist_fused, msm_sort_two_pass, msm_front1, msm_acc_lds, vb_ct_window,
  * vb_quad_max, dec_c_mid (ranges: jj_pipeline.hip ctx_options).
  * One process-wide option, set with ctx = NULL: host_tail_scalar 0|1 (0) -- the MSM host tail on the scalar 4 x 64-bit chain even where AVX-512 IFMA is there. */
 int jj_ctx_set_option(jj_ctx* ctx, const char* key, long long value);

@@ -220,6 +220,7 @@ struct jj_ctx {
   DevBuf gather_dev, poison_dev; uint8_t* gather_host = nullptr; size_t gather_host_cap = 0;      // poison_dev: the all-zero record a failing rank gathers (msm_post_poison)
   bool msm_front1 = true;          // one-pass sort: conversion + tile histograms / plan + scatter in two launches (k_msm_front1, k_msm_scatter1); false: the four launches of rounds 2-5
   bool msm_front1_lds_set = false;
+  bool msm_acc_lds = true;         // chunked accumulation: the slot's bucket offsets staged in LDS (k_msm_accumulate<true>); false: read from memory (rounds 2-5)
   bool msm_hist_lds_set = false;   // k_msm_convert_hist's LDS carve-out was requested on this context's device
   bool msm_fold_dev = true;      // gathered records are folded window by window on the device before ONE record goes to the host tail (JJ_MSM_FOLD=host: every record is copied and the host adds them)
   int msm_fold_min = 8;          // ... from this many records (JJ_MSM_FOLD_MIN, 2..4096): at 8 the two paths cost the same (57 us per call, profiles/r5_msm_partition_cost.txt), beyond it the host path grows by ~2.3 us per record while the fold stays put

@@ -200,7 +200,8 @@ static int msm_enqueue_pippenger(jj_ctx* c, MsmLane& ln, size_t n, const void* d
     hipLaunchKernelGGL(k_msm_accumulate_seg, dim3(blocks_for(max_segs)), dim3(256), 0, st, (const u32*)(soff + (P + 1)), (const Seg*)seg, (const u32*)idx.p, (const u32*)niels.p, bk, head);
     merge_list = merge;
   } else {
-    hipLaunchKernelGGL(k_msm_accumulate, dim3(blocks_for(nchunk), Ws), dim3(256), 0, st, n, B, chunk, nchunk, (const u32*)off, (const u32*)idx.p, (const u32*)niels.p, bk, head);
+    if (B <= MSM_ACC_LDS_BUCKETS && c->msm_acc_lds) hipLaunchKernelGGL(k_msm_accumulate<true>, dim3(blocks_for(nchunk), Ws), dim3(256), (B + 1) * 4, st, n, B, chunk, nchunk, (const u32*)off, (const u32*)idx.p, (const u32*)niels.p, bk, head);
+    else hipLaunchKernelGGL(k_msm_accumulate<false>, dim3(blocks_for(nchunk), Ws), dim3(256), 0, st, n, B, chunk, nchunk, (const u32*)off, (const u32*)idx.p, (const u32*)niels.p, bk, head);
     hipLaunchKernelGGL(k_msm_fixup, dim3(blocks_for(2 * nb)), dim3(256), 0, st, n, B, Ws, chunk, nchunk, (const u32*)off, bk, head);      // (big buckets included: no second launch)
   }
   // (segment path: 512 workgroups, the merge list of repeated scalars is walked by the same launch as the big buckets)

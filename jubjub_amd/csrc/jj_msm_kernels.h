@@ -795,21 +795,33 @@ __global__ void __launch_bounds__(MSM_P2_THREADS) k_msm_part_sort(MsmParams mp, 
 // bucket start is written to buckets[s B + b]; the run a chunk inherits from the previous chunk goes to head[s nchunk + t] and is
 // merged by k_msm_fixup.
 constexpr int MSM_CHUNK_MIN = 16;
+// OFF_LDS (round 6; windows of at most MSM_ACC_LDS_BUCKETS buckets, i.e. every layout the chunked path is planned for): the slot's B + 1 bucket
+// offsets are staged in LDS first.  The lane's first bucket is then found by a binary search over LDS (ten dependent reads of ~0.1 us instead of
+// ten dependent global loads of ~0.8 us at the head of every lane's chain), and a lane that crosses into the next bucket -- some lane of a wave
+// does in four iterations of ten at 128 entries per bucket -- no longer stalls its wave on a global load in the middle of the addition chain.
+constexpr u32 MSM_ACC_LDS_BUCKETS = 8192;
+template <bool OFF_LDS>
 __global__ void __launch_bounds__(256) k_msm_accumulate(size_t n, u32 B, u32 chunk, u32 nchunk, const u32* off, const u32* idx, const u32* niels, ExtAoS buckets, ExtAoS head) {
+  extern __shared__ __attribute__((aligned(16))) u32 acc_off[];
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const u32 s = blockIdx.y;
-  const u32* o = off + (size_t)s * (B + 1);
-  const size_t M = o[B];                                    // end of the slot's entries
+  const u32* og = off + (size_t)s * (B + 1);
+  if constexpr (OFF_LDS) {
+    for (u32 k = threadIdx.x; k <= B; k += 256) acc_off[k] = og[k];
+    __syncthreads();
+  }
+  auto o = [&](size_t k) -> u32 { if constexpr (OFF_LDS) return acc_off[k]; else return og[k]; };
+  const size_t M = o(B);                                    // end of the slot's entries
   const size_t start = (size_t)s * n + t * chunk;
   if (t >= nchunk || start >= M) return;
   const size_t end = start + chunk < M ? start + chunk : M;
   // bucket containing `start`: largest b with o[b] <= start
   size_t lo = 0, hi = B;
-  while (hi - lo > 1) { const size_t mid = (lo + hi) >> 1; if (o[mid] <= start) lo = mid; else hi = mid; }
+  while (hi - lo > 1) { const size_t mid = (lo + hi) >> 1; if (o(mid) <= start) lo = mid; else hi = mid; }
   size_t b = lo;
-  u32 nxt = o[b + 1];
-  while (nxt <= start) { b++; nxt = o[b + 1]; }          // skip empty buckets that share the offset
-  bool inherited = o[b] < start;                            // first run continues a bucket begun in an earlier chunk
+  u32 nxt = o(b + 1);
+  while (nxt <= start) { b++; nxt = o(b + 1); }          // skip empty buckets that share the offset
+  bool inherited = o(b) < start;                            // first run continues a bucket begun in an earlier chunk
   Ext acc = Curve::identity();
   bool any = false;
   const size_t bk0 = (size_t)s * B, hd = (size_t)s * nchunk + t;
@@ -823,7 +835,7 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(size_t n, u32 B, u32 chu
     if (pos >= nxt) {
       if (inherited) { aos_put_ext(head, hd, acc); inherited = false; } else if (any) aos_put_ext(buckets, bk0 + b, acc);
       acc = Curve::identity(); any = false;
-      do { b++; nxt = o[b + 1]; } while (nxt <= pos);
+      do { b++; nxt = o(b + 1); } while (nxt <= pos);
     }
     const ANiels p_next = lds_aniels(niels + (size_t)(e_next & 0x7fffffffu) * GNIELS_WORDS);
     const u32 e_next2 = pos + 2 < end ? idx[pos + 2] : e_next;

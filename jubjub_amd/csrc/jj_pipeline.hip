@@ -415,6 +415,7 @@ static const CtxOption* ctx_options() {
     JJ_OPT("msm_sort_hist_fused", 0, 1, msm_fused_hist, bool),
     JJ_OPT("msm_sort_two_pass", -1, 1, msm_two_pass, int),
     JJ_OPT("msm_front1", 0, 1, msm_front1, bool),
+    JJ_OPT("msm_acc_lds", 0, 1, msm_acc_lds, bool),
     JJ_OPT("vb_ct_window", 2, 3, vb_ct_window, int),
     JJ_OPT("vb_quad_max", 0, 1 << 20, vb_quad_max, int),
     JJ_OPT("dec_c_mid", 8, 16, dec_c_mid, int),

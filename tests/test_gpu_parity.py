@@ -397,14 +397,17 @@ def test_msm_small_batch_path_and_pippenger_on_the_same_inputs(monkeypatch, smal
     e2.close()
 
 
-@pytest.mark.parametrize("mode", ["segments", "chunks"])
+@pytest.mark.parametrize("mode", ["segments", "chunks", "chunks-offsets-in-memory"])
 def test_msm_both_accumulation_schemes(monkeypatch, mode):
-    """Bucket accumulation by length-sorted segments (default from 147 456 terms) and by fixed chunks + fix-up (below),
-    forced in turn on the same inputs, including skewed digit distributions and short segments."""
+    """Bucket accumulation by length-sorted segments (default from 147 456 terms) and by fixed chunks + fix-up (below; the bucket offsets
+    staged in LDS, round 6, or read from memory as in rounds 2-5), forced in turn on the same inputs, including skewed digit distributions
+    and short segments."""
     from jubjub_amd import Engine
 
     opts = {}
-    opts['msm_accum'] = {"segments": 1, "chunks": 0}[mode]
+    opts['msm_accum'] = {"segments": 1, "chunks": 0, "chunks-offsets-in-memory": 0}[mode]
+    if mode == "chunks-offsets-in-memory":
+        opts['msm_acc_lds'] = 0
     opts['msm_seg_len'] = 8
     opts['msm_small_max'] = 0
     e2 = Engine(0, options=opts)
@@ -1153,7 +1156,7 @@ def test_options_by_key_and_no_environment(monkeypatch):
                  "JJ_TORSION_CHECK": "ladder", "JJ_MSM_FOLD_MIN": "2", "JJ_VB_QUAD_MAX": "0"}.items():
         monkeypatch.setenv(k, v)
     e = Engine(0)
-    defaults = {"msm_lanes": 2, "msm_windows": 0, "msm_small_max": 1 << 14, "torsion_check_ladder": 0, "msm_fold_min": 8, "vb_quad_max": 32768, "msm_front1": 1,
+    defaults = {"msm_lanes": 2, "msm_windows": 0, "msm_small_max": 1 << 14, "torsion_check_ladder": 0, "msm_fold_min": 8, "vb_quad_max": 32768, "msm_front1": 1, "msm_acc_lds": 1,
                 "msm_chunk_waves": 2, "fixedbase_default": 7, "pipe_pageable_register": 0, "msm_fold_dev": 1, "msm_host_split": 1, "msm_pass_log2": 24}
     for k, v in defaults.items():
         assert e.get_option(k) == v, k
