@@ -2,7 +2,7 @@
 """One rank's share of a 2^log2n-term MSM cut G ways, on ONE GPU: by terms (all windows of n / G terms) and by
 windows (windows g, g + G, ... of all n terms), device work only (jj_msm_partial, record left on the device) and with the host tail
 of one record; plus what every rank runs after the all_gather: the G records folded on the device + one 8 KB copy + the host tail of
-one record (jj_msm_combine_dev, round 5) against round 4's copy of all G records + the host's additions (JJ_MSM_FOLD=host); and the
+one record (jj_msm_combine_dev, round 5) against round 4's copy of all G records + the host's additions (option msm_fold_dev = 0); and the
 HYBRID partitions (terms / a  x  windows / b with a b = G: rank (i, j) reduces windows j, j + b, ... of term slice i).
   python experiments/misc/msm_partition_cost.py [log2n] [G]"""
 import os
@@ -61,10 +61,9 @@ recs_w = torch.stack([eng.msm_partial(S, P, g, G) for g in range(G)])
 want = eng.msm(S, P).cpu().numpy()
 assert (eng.msm_combine(recs_t) == want).all() and (eng.msm_combine(recs_w) == want).all()
 print("  %d gathered records folded on the device + 8 KB copy + host tail of ONE record : terms %.3f / %.3f   windows %.3f / %.3f" % ((G,) + timed(lambda: eng.msm_combine(recs_t)) + timed(lambda: eng.msm_combine(recs_w))))
-os.environ["JJ_MSM_FOLD"] = "host"
-eng_h = Engine(0)
+eng_h = Engine(0, options={"msm_fold_dev": 0})
 assert (eng_h.msm_combine(recs_t) == want).all()
-print("  round 4: copy of all %d records to the host + the host adds them (JJ_MSM_FOLD=host)     : terms %.3f / %.3f   windows %.3f / %.3f" % ((G,) + timed(lambda: eng_h.msm_combine(recs_t)) + timed(lambda: eng_h.msm_combine(recs_w))))
+print("  round 4: copy of all %d records to the host + the host adds them (option msm_fold_dev = 0)     : terms %.3f / %.3f   windows %.3f / %.3f" % ((G,) + timed(lambda: eng_h.msm_combine(recs_t)) + timed(lambda: eng_h.msm_combine(recs_w))))
 ht, hw = recs_t.cpu().numpy(), recs_w.cpu().numpy()
 print("  host tail alone (records already on the host)          : terms %.3f / %.3f   windows %.3f / %.3f" % (timed(lambda: eng.msm_combine(ht)) + timed(lambda: eng.msm_combine(hw))))
 print("  both partitions give the point of the one-GPU MSM: ok")

@@ -11,16 +11,14 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from jubjub_amd import Engine  # noqa: E402
 
-KEYS = ("JJ_MSM_WINDOWS", "JJ_MSM_REDUCE_L1", "JJ_MSM_REDUCE_L2_CHUNK")
-CFG = [("W16 one-level", {"JJ_MSM_WINDOWS": "16", "JJ_MSM_REDUCE_L1": "0"}),
-       ("W17 one-level", {"JJ_MSM_WINDOWS": "17", "JJ_MSM_REDUCE_L1": "0"}),
+# (round 6: context options instead of environment variables)
+CFG = [("W16 one-level", {"msm_windows": 16, "msm_reduce_l1": 0}),
+       ("W17 one-level", {"msm_windows": 17, "msm_reduce_l1": 0}),
        ("default", {})]
-for W in ("16", "17"):
-    for R in ("4", "8"):
-        CFG.append(("W%s R%s" % (W, R), {"JJ_MSM_WINDOWS": W, "JJ_MSM_REDUCE_L1": R}))
+for W in (16, 17):
+    for R in (4, 8):
+        CFG.append(("W%d R%d" % (W, R), {"msm_windows": W, "msm_reduce_l1": R}))
 sizes = [int(a) for a in sys.argv[1:]] or [18, 19, 20, 21, 22]
-for k in KEYS:
-    os.environ.pop(k, None)
 base = Engine(0)
 for lg in sizes:
     n = 1 << lg
@@ -28,10 +26,7 @@ for lg in sizes:
     P = base.random_points(n, 7, 0, subgroup=False, device="cuda:0")
     want = base.msm(S, P).cpu()
     for name, env in CFG:
-        for k in KEYS:
-            os.environ.pop(k, None)
-        os.environ.update(env)
-        eng = Engine(0)
+        eng = Engine(0, options=env)
         for _ in range(3):
             got = eng.msm(S, P)
         torch.cuda.synchronize()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Two-pass sort of the MSM: coarse histogram inside the conversion kernel + atomic run reservation (round 5 default) against the separate histogram and plan
-kernels of round 4 (JJ_MSM_SORT_HIST=separate): wall time per call, alternating, same inputs, results compared.   python experiments/misc/msm_sort_hist_ab.py [log2n ...]"""
+kernels of round 4 (option msm_sort_hist_fused = 0): wall time per call, alternating, same inputs, results compared.   python experiments/misc/msm_sort_hist_ab.py [log2n ...]"""
 import os
 import sys
 import time
@@ -11,10 +11,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from jubjub_amd import Engine  # noqa: E402
 
 sizes = [int(a) for a in sys.argv[1:]] or [18, 19, 20, 21, 22]
-os.environ.pop("JJ_MSM_SORT_HIST", None)
 fused = Engine(0)
-os.environ["JJ_MSM_SORT_HIST"] = "separate"
-sep = Engine(0)
+sep = Engine(0, options={"msm_sort_hist_fused": 0})        # round 6: a context option (was JJ_MSM_SORT_HIST=separate)
 for lg in sizes:
     n = 1 << lg
     S = fused.synth_scalars(n, 7, 0, device="cuda:0")

@@ -1,5 +1,5 @@
 import os, sys, time, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from jubjub_amd import Engine
 n = 1 << 20
 base = Engine(0)
@@ -13,9 +13,8 @@ def t(fn, reps=8):
     ts.sort(); return ts[len(ts)//2]
 d = t(lambda: base.varbase_mul_vartime(S, P))
 print("table ladder (jj_varbase_mul_vartime)  %.3f ms  %.1f M/s" % (d*1e3, n/d/1e6))
-for w in ("2", "3"):
-    os.environ["JJ_VB_CT_WINDOW"] = w
-    e = Engine(0)
+for w in (2, 3):
+    e = Engine(0, options={"vb_ct_window": w})          # round 6: a context option (was JJ_VB_CT_WINDOW)
     got = e.varbase_mul_ct(S, P)
     c = t(lambda: e.varbase_mul_ct(S, P))
     print("ct window %s     %.3f ms  %.1f M/s  ratio %.3f  equal %s" % (w, c*1e3, n/c/1e6, d/c, bool(torch.equal(got, want))))

@@ -30,19 +30,16 @@ while time.time() < t_end:
     rng = np.random.default_rng(SEED0 + rnd)
     env = {}
     if rng.integers(0, 2):
-        env["JJ_PIPE_CHUNK_LOG2"] = str(int(rng.integers(14, 20)))
+        env["pipe_chunk_log2"] = int(rng.integers(14, 20))
     if rng.integers(0, 3) == 0 or os.environ.get("SOAK_FORCE_REGISTER"):
-        env["JJ_PIPE_PAGEABLE"] = "register"
+        env["pipe_pageable_register"] = 1
     if rng.integers(0, 3) == 0:
-        env["JJ_PIPE_RAMP"] = "0"
+        env["pipe_ramp"] = 0
     if rng.integers(0, 2):
-        env["JJ_PIPE_COPY_THREADS"] = str(int(rng.integers(1, 9)))
+        env["pipe_copy_threads"] = int(rng.integers(1, 9))
     if rng.integers(0, 4) == 0:
-        env["JJ_MSM_HOST_SPLIT"] = "0"
-    os.environ.update(env)
-    eng = Engine(0)
-    for k in env:
-        del os.environ[k]
+        env["msm_host_split"] = 0
+    eng = Engine(0, options=env)                     # round 6: context options (jj_ctx_set_option); the library reads no environment variable
     n = int(rng.choice([(1 << 18) + int(rng.integers(-3, 4)), int(rng.integers(1 << 16, 1 << 21)), (1 << 20) + int(rng.integers(-70000, 70000))]))
 
     pooled = []                                      # result buffers from the library's pool (jj_result_acquire), released at the end of the round

@@ -1,13 +1,13 @@
 #!/bin/bash
 # Runs LOCALLY after tools/refresh_round.sh came back through gpurun_out/: copies the round's evidence into profiles/.
 set -e
-TAG=${1:-r5}
+TAG=${1:-r6}
 cd "$(dirname "$0")/.."
 for f in gpurun_out/profiles_$TAG/*; do
   b=$(basename $f)
   case $b in ${TAG}_*_kernel_stats.txt|${TAG}_*_pmc.txt|${TAG}_*_bench.json|traffic.json|${TAG}_kernel_resources.txt|${TAG}_instr_mix.txt) cp $f profiles/;; esac
 done
-for f in default dec1 dec3 msm20 msm22 msm17 msm20_async2 msm17_async2 msm17_async4 msm20_async4 msm17_ctx2 msm17_ctx4 msm20_ctx2 msm10 fb16 fb6; do cp gpurun_out/${TAG}_bench_$f.json profiles/${TAG}_bench_$f.json; done
+for f in default dec1 dec3 msm20 msm22 msm17 msm18 msm19 msm20_async2 msm17_async2 msm17_async4 msm20_async4 msm17_ctx2 msm17_ctx4 msm20_ctx2 msm10 fb16 fb6; do cp gpurun_out/${TAG}_bench_$f.json profiles/${TAG}_bench_$f.json; done
 BID=$(python3 -c "import json; print(json.load(open('profiles/traffic.json'))['build_id'])")
 HDR="# commit $(cat profiles/BUILD_COMMIT) | build_id $BID | MI355X gfx950"
 cp gpurun_out/${TAG}_msm17_kernel_stats.txt profiles/${TAG}_msm17_kernel_stats.txt
@@ -31,8 +31,11 @@ for f in gpurun_out/${TAG}_bench_host_*.json gpurun_out/${TAG}_bench_msm20_rccl1
 (echo "$HDR"; echo "# command: python tests/soak_host.py 120"; grep -v amdgpu gpurun_out/${TAG}_soak_host.txt | tail -4) > profiles/${TAG}_soak_host.txt
 (echo "$HDR"; echo "# command: python experiments/misc/vb_ct_window.py   (2^20 units: the table ladder, the constant-time ladder with signed 2-bit and 3-bit windows)"; grep -v amdgpu gpurun_out/${TAG}_vb_ct_window.txt) > profiles/${TAG}_vb_ct_window.txt
 (echo "$HDR"; echo "# command: python experiments/misc/msm_reduce_l1_sweep.py 18 19 20 21 22"; grep -v amdgpu gpurun_out/${TAG}_msm_reduce_l1_sweep.txt) > profiles/${TAG}_msm_reduce_l1_sweep.txt
-(echo "$HDR"; echo "# command: experiments/hsa_stale_mapping/repro <variant> 3000   (six variants of a stand-alone reproducer of round 4's GPU memory fault)"; cat gpurun_out/${TAG}_hsa_stale_mapping.txt) > profiles/${TAG}_hsa_stale_mapping.txt
 (echo "$HDR"; echo "# command: python experiments/misc/msm_sort_hist_ab.py"; grep -v amdgpu gpurun_out/${TAG}_msm_sort_hist_ab.txt) > profiles/${TAG}_msm_sort_hist_ab.txt
 (echo "$HDR"; echo "# command: python experiments/misc/msm_allgather_pipeline.py 20 8   (the other seven ranks played by tools/loopback_comm.cpp)"; grep -v amdgpu gpurun_out/${TAG}_msm_allgather_pipeline.txt) > profiles/${TAG}_msm_allgather_pipeline.txt
 [ -s gpurun_out/${TAG}_bench_msm20_rccl1_async4.json ] && cp gpurun_out/${TAG}_bench_msm20_rccl1_async4.json profiles/
+(echo "$HDR"; grep -v amdgpu gpurun_out/${TAG}_peak_clock.txt) > profiles/${TAG}_peak_clock.txt
+(echo "$HDR"; echo "# command: bench.py --opt <key>=<0|1> --workload msm --log2n 17 --steps 10 --warmup 3, alternating (msm_front1=0: the four-launch front end of round 5; msm_acc_lds=0: bucket offsets read from global memory)"; cat gpurun_out/${TAG}_msm17_ab.txt) > profiles/${TAG}_msm17_ab.txt
+(echo "$HDR"; echo "# command: bench.py --opt msm_windows=<16|17> --workload msm --log2n <18|19> --steps 10 --warmup 3, alternating (16 = the planner's choice from 2^18 terms since round 6)"; cat gpurun_out/${TAG}_msm_windows_ab.txt) > profiles/${TAG}_msm_windows_ab.txt
+(echo "$HDR"; echo "# command: python tests/soak_jobs.py 180 9000"; grep -v amdgpu gpurun_out/${TAG}_soak_jobs.txt | tail -4) > profiles/${TAG}_soak_jobs.txt
 python3 tools/design_numbers.py $TAG

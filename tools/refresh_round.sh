@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX (through gpurun): the whole evidence set of a round at one build.
 #   gpurun -- 'bash tools/refresh_round.sh r3'     then locally: bash tools/collect_round.sh r3
 set -e
-TAG=${1:-r5}
+TAG=${1:-r6}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 export GPU_MAX_HW_QUEUES=8        # the host-buffer pipeline beside torch's streams (include/jubjub_hip.h: the application sets it, not the library)
@@ -14,6 +14,8 @@ python bench.py --workload decompress --decompress-flags 3 --no-cpu-baseline > g
 python bench.py --workload msm --log2n 22 --no-cpu-baseline > gpurun_out/${TAG}_bench_msm22.json 2>/dev/null
 python bench.py --workload msm --no-cpu-baseline > gpurun_out/${TAG}_bench_msm20.json 2>/dev/null      # without the profiler's per-dispatch overhead
 python bench.py --workload msm --log2n 17 --no-cpu-baseline > gpurun_out/${TAG}_bench_msm17.json 2>/dev/null
+python bench.py --workload msm --log2n 18 --no-cpu-baseline > gpurun_out/${TAG}_bench_msm18.json 2>/dev/null
+python bench.py --workload msm --log2n 19 --no-cpu-baseline > gpurun_out/${TAG}_bench_msm19.json 2>/dev/null
 python bench.py --workload msm --msm-async 2 --no-cpu-baseline > gpurun_out/${TAG}_bench_msm20_async2.json 2>/dev/null   # two jobs in flight over the context's two lanes (jj_msm_begin / _finish)
 python bench.py --workload msm --log2n 17 --msm-async 2 --no-cpu-baseline > gpurun_out/${TAG}_bench_msm17_async2.json 2>/dev/null
 python bench.py --workload msm --log2n 17 --msm-async 4 --no-cpu-baseline > gpurun_out/${TAG}_bench_msm17_async4.json 2>/dev/null
@@ -53,5 +55,10 @@ python experiments/misc/msm_reduce_l1_sweep.py 18 19 20 21 22 > gpurun_out/${TAG
 python experiments/misc/msm_sort_hist_ab.py > gpurun_out/${TAG}_msm_sort_hist_ab.txt 2>&1
 python experiments/misc/msm_allgather_pipeline.py 20 8 > gpurun_out/${TAG}_msm_allgather_pipeline.txt 2>&1     # one rank of eight with the other ranks played by tools/loopback_comm.cpp: synchronous jj_msm_allgather against jj_msm_allgather_begin jobs in flight
 JJ_BENCH_FORCE_DIST=1 python bench.py --gpus 1 --workload msm --msm-exchange c --msm-async 4 --no-cpu-baseline > gpurun_out/${TAG}_bench_msm20_rccl1_async4.json 2>/dev/null </dev/null   # the real ncclAllGather (one rank) on the jobs' lanes
-(cd experiments/hsa_stale_mapping; [ -x repro ] || /opt/rocm/bin/hipcc -O2 -o repro repro.cpp; for v in 0 1 2 3 4 5; do timeout 200 ./repro $v 3000 2>&1 | tail -1; done) > gpurun_out/${TAG}_hsa_stale_mapping.txt 2>&1
+# round 6: clock and issue rate of the roofline denominator beside the ladder; the 2^17-term MSM's two-launch front end and the
+# LDS-staged bucket offsets against the round-5 forms (alternating bench runs); window count at 2^18 / 2^19 terms; the jobs-in-flight soak
+bash tools/peak_clock.sh > gpurun_out/${TAG}_peak_clock.log 2>&1; cp gpurun_out/peak_clock.txt gpurun_out/${TAG}_peak_clock.txt
+for o in "msm_front1=1" "msm_front1=0" "msm_front1=1" "msm_front1=0" "msm_acc_lds=1" "msm_acc_lds=0" "msm_acc_lds=1" "msm_acc_lds=0"; do python bench.py --opt $o --workload msm --log2n 17 --steps 10 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$o  msm 2^17: %.4f ms per call, verified %s' % (d['config']['ms_per_pass'], d['verified']))"; done > gpurun_out/${TAG}_msm17_ab.txt 2>&1
+for lg in 18 19; do for w in 16 17 16 17; do python bench.py --opt msm_windows=$w --workload msm --log2n $lg --steps 10 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('msm_windows=$w  msm 2^$lg: %.4f ms per call, verified %s' % (d['config']['ms_per_pass'], d['verified']))"; done; done > gpurun_out/${TAG}_msm_windows_ab.txt 2>&1
+timeout 400 python tests/soak_jobs.py 180 9000 > gpurun_out/${TAG}_soak_jobs.txt 2>&1 || echo "JOBS SOAK FAILED" >> gpurun_out/${TAG}_soak_jobs.txt
 tail -1 gpurun_out/${TAG}_profile.log
