@@ -27,7 +27,7 @@ for f in gpurun_out/${TAG}_bench_host_*.json gpurun_out/${TAG}_bench_msm20_rccl1
 (echo "$HDR"; grep -v amdgpu gpurun_out/${TAG}_fixedbase_select_pmc.txt) > profiles/${TAG}_fixedbase_select_pmc.txt
 [ -s gpurun_out/${TAG}_stall_pmc.txt ] && (echo "$HDR"; echo "# command: bash tools/stall_pmc.sh"; grep -v amdgpu gpurun_out/${TAG}_stall_pmc.txt) > profiles/${TAG}_stall_pmc.txt
 (echo "$HDR"; echo "# command: ./experiments/lds_probe/energy_probe ; ./experiments/lds_probe/probe"; cat gpurun_out/${TAG}_issue_energy_probe.txt) > profiles/${TAG}_issue_energy_probe.txt
-(echo "$HDR"; echo "# command: python tests/host_tail_time.py 1 8 (default, then `scalar`: the scalar chain forced); then bench.py --workload msm --log2n 17 with the two chains in turn"; grep -v amdgpu gpurun_out/${TAG}_host_tail.txt) > profiles/${TAG}_host_tail.txt
+(echo "$HDR"; echo "# command: python tests/host_tail_time.py 1 8 (default, then scalar: the scalar chain forced); then bench.py --workload msm --log2n 17 with the two chains in turn"; grep -v amdgpu gpurun_out/${TAG}_host_tail.txt) > profiles/${TAG}_host_tail.txt
 (echo "$HDR"; echo "# command: python tests/soak_host.py 120"; grep -v amdgpu gpurun_out/${TAG}_soak_host.txt | tail -4) > profiles/${TAG}_soak_host.txt
 (echo "$HDR"; echo "# command: python experiments/misc/vb_ct_window.py   (2^20 units: the table ladder, the constant-time ladder with signed 2-bit and 3-bit windows)"; grep -v amdgpu gpurun_out/${TAG}_vb_ct_window.txt) > profiles/${TAG}_vb_ct_window.txt
 (echo "$HDR"; echo "# command: python experiments/misc/msm_reduce_l1_sweep.py 18 19 20 21 22"; grep -v amdgpu gpurun_out/${TAG}_msm_reduce_l1_sweep.txt) > profiles/${TAG}_msm_reduce_l1_sweep.txt

@@ -32,5 +32,15 @@ for v in ("two_rounds", "one_round", "no_select"):
     g = lambda k: vals.get(k, float("nan"))
     print("%-11s %9.1f %9.3f %8.4f | %12.4g %12.4g %9.3f | %11.4g %11.4g %12.4g %12.4g" % (v, d["value"] / 1e6, d["roofline"]["kernel_ms"], d["roofline"]["frac"], g("SQ_INSTS_VALU"), g("SQ_BUSY_CYCLES"),
           g("SQ_INSTS_VALU") / g("SQ_BUSY_CYCLES") / 8, g("SQ_INSTS_LDS"), g("SQ_ACTIVE_INST_LDS"), g("SQ_LDS_BANK_CONFLICT"), g("SQ_LDS_ADDR_CONFLICT")))
+print("# round 6 (VERDICT r5 next #7): where the waves' cycles go -- fractions of SQ_WAVE_CYCLES (summed over the resident waves): waiting for anything, waiting for an instruction to issue, waiting on an LDS instruction")
+print("%-11s %12s %10s %14s %14s" % ("variant", "wave cycles", "WAIT_ANY", "WAIT_INST_ANY", "WAIT_INST_LDS"))
+for v in ("two_rounds", "one_round", "no_select"):
+    vals = {}
+    for f in sorted(glob.glob("gpurun_out/pmc_fbfloor/%s_*/**/*counter_collection.csv" % v, recursive=True)):
+        for r in csv.DictReader(open(f)):
+            if "k_fixedbase_comb" in r.get("Kernel_Name", ""):
+                vals[r["Counter_Name"]] = float(r["Counter_Value"])
+    g = lambda k: vals.get(k, float("nan"))
+    print("%-11s %12.4g %10.3f %14.3f %14.3f" % (v, g("SQ_WAVE_CYCLES"), g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"), g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES"), g("SQ_WAIT_INST_LDS") / g("SQ_WAVE_CYCLES")))
 print("# frac of the probes uses the shipped kernel's credited work (31 108 IMAD32 per unit): the additions and doublings are all there, only the entry is the wrong one")
 PY
