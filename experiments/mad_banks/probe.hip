@@ -47,7 +47,7 @@ int main() {
   hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
   const int cus = p.multiProcessorCount;
   uint32_t* out; hipMalloc(&out, (size_t)cus * 8 * 256 * 4);
-  for (int wps : {8, 1, 2}) {
+  for (int wps : {8, 1, 2, 3, 4}) {
     const int blocks = cus * wps, iters = 4096 * 8 / wps;
     printf("# %d wave(s) per SIMD\n", wps);
     run("base", k_base, blocks, out, iters, "a bank 2, b bank 3, accumulator pairs alternate (0,1)/(2,3)");

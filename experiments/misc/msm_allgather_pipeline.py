@@ -67,16 +67,20 @@ for depth in (1, 2, 4):
 for rank in (0, G - 1):
     comm = LoopbackComm(rank, G)
     comm.add_round(recs)
-    eng.set_comm(comm)
     s, p = S[rank * m:(rank + 1) * m], P[rank * m:(rank + 1) * m]
-    for depth in (1, 2, 3, 4):
-        if depth == 1:
-            med, lo, out = series(lambda: eng.msm_allgather(s, p), lambda o: o, 1)
-        else:
-            med, lo, out = series(lambda: eng.msm_allgather_begin(s, p), eng.msm_finish, depth)
-        assert (out == want).all()
-        print("  rank %d of %d: 2^%d terms + gather of %d records + fold + host tail, %d in flight : %.3f / %.3f   (x%.2f of one GPU synchronous, x%.2f of one GPU with 4 in flight)" % (
-            rank, G, log2n - (G.bit_length() - 1), G, depth, med, lo, one[1] / med, one[4] / med))
-    eng.set_comm(None)
+    # round 6: a context with several ranks starts with ONE lane (every gather of the communicator on one stream); a caller that has checked
+    # multi-stream gathers on its node sets msm_lanes back after jj_ctx_set_comm -- both are measured
+    for lanes in (1, 3):
+        eng.set_comm(comm)
+        eng.set_option("msm_lanes", lanes)
+        for depth in ((1, 2, 4) if lanes == 1 else (2, 3, 4, 6)):
+            if depth == 1:
+                med, lo, out = series(lambda: eng.msm_allgather(s, p), lambda o: o, 1)
+            else:
+                med, lo, out = series(lambda: eng.msm_allgather_begin(s, p), eng.msm_finish, depth)
+            assert (out == want).all()
+            print("  rank %d of %d, msm_lanes %d: 2^%d terms + gather of %d records + fold + host tail, %d in flight : %.3f / %.3f   (x%.2f of one GPU synchronous, x%.2f of one GPU with 4 in flight)" % (
+                rank, G, lanes, log2n - (G.bit_length() - 1), G, depth, med, lo, one[1] / med, one[4] / med))
+        eng.set_comm(None)
     comm.close()
 eng.close()

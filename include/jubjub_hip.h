@@ -56,7 +56,7 @@ int jj_ctx_sync(jj_ctx* ctx);
 /* Options.  The library reads NO environment variable: what a caller may tune is set per context, by key, right after jj_ctx_create (before the
  * first batch call).  No option changes WHAT an entry point computes or its timing discipline: the constant-time ladders and selects have no
  * switch (for public scalars there are the explicit *_vartime entry points).  Unknown key or value out of range: JJ_ERR_INVALID.
- *   msm_lanes 1..4 (2)            streams the jobs of jj_msm_begin / jj_msm_allgather_begin alternate over; 1 = every job on the context's stream
+ *   msm_lanes 1..4 (3)            streams the jobs of jj_msm_begin / jj_msm_allgather_begin alternate over; 1 = every job on the context's stream
  *                                 (jj_ctx_set_comm with more than one rank sets 1: all gathers of one communicator then go through ONE stream)
  *   msm_fold_min 2..4096 (8)      jj_msm_allgather / _combine_dev fold the gathered records on the device from this many records
  *   msm_fold_dev 0|1 (1)          0: the gathered records are copied to the host and added there
@@ -280,7 +280,7 @@ int jj_msm(jj_ctx*, size_t n, const void* scalars32, const void* points64, void*
  * work of one MSM plus the copy of its records into a page-locked buffer owned by the job and returns at once (device
  * pointers; host arrays are staged first); jj_msm_finish waits for THAT job only, runs the host tail and writes the 64-byte
  * result (host pointer: complete on return; device pointer: copy queued on the context's stream).  A context owns several MSM
- * lanes (streams of their own + workspaces; option msm_lanes, default 2; 1 = every job on the context's stream): jobs with
+ * lanes (streams of their own + workspaces; option msm_lanes, default 3 (two until round 6; with three or more jobs in flight the third lane returns 10 % at 2^17 terms); 1 = every job on the context's stream): jobs with
  * device-pointer inputs alternate over them, so that the latency-bound end of one MSM (fix-up, bucket reduce: a few hundred
  * wavefronts) overlaps the sort and accumulation of the next; every job starts after the work already queued on the
  * context's stream when it was begun.  Jobs may be finished in any order, each

@@ -198,7 +198,7 @@ struct jj_ctx {
   // MSM jobs (jj_msm_begin / jj_msm_finish): free list of page-locked record buffers + events
   std::vector<jj_msm_job*> job_pool;
   MsmLane lanes[MSM_LANES_MAX + 1];   // [0]: the context's launch stream (synchronous calls, host-staged inputs); [1 ..]: streams of their own for the jobs in flight
-  int msm_lanes = 2;             // lanes that device-pointer jobs of jj_msm_begin / jj_msm_allgather_begin alternate over (JJ_MSM_LANES, 1..4; memory per lane in use; 1: every job on the context's stream)
+  int msm_lanes = 3;             // lanes that device-pointer jobs of jj_msm_begin / jj_msm_allgather_begin alternate over (option msm_lanes, 1..4; round 6: three -- with three or more jobs in flight 2^17 terms 0.245 -> 0.221 ms per MSM, 2^18 0.385 -> 0.370, 2^20 equal, four lanes no better: profiles/r6_msm_lanes.txt; memory per lane in use; 1: every job on the context's stream)
   unsigned next_lane = 0;
   uint8_t host_out[8][64];       // results on their way to a device pointer (ring: the copies are asynchronous)
   int host_out_next = 0;

@@ -1156,7 +1156,7 @@ def test_options_by_key_and_no_environment(monkeypatch):
                  "JJ_TORSION_CHECK": "ladder", "JJ_MSM_FOLD_MIN": "2", "JJ_VB_QUAD_MAX": "0"}.items():
         monkeypatch.setenv(k, v)
     e = Engine(0)
-    defaults = {"msm_lanes": 2, "msm_windows": 0, "msm_small_max": 1 << 14, "torsion_check_ladder": 0, "msm_fold_min": 8, "vb_quad_max": 32768, "msm_front1": 1, "msm_acc_lds": 1,
+    defaults = {"msm_lanes": 3, "msm_windows": 0, "msm_small_max": 1 << 14, "torsion_check_ladder": 0, "msm_fold_min": 8, "vb_quad_max": 32768, "msm_front1": 1, "msm_acc_lds": 1,
                 "msm_chunk_waves": 2, "fixedbase_default": 7, "pipe_pageable_register": 0, "msm_fold_dev": 1, "msm_host_split": 1, "msm_pass_log2": 24}
     for k, v in defaults.items():
         assert e.get_option(k) == v, k
