@@ -708,6 +708,18 @@ def run(a):
         res["config"]["result_bytes"] = out_w if wl != "msm" else 64
         res["device_resident"] = dev_ref
         res["host_over_device_resident"] = value / dev_ref["value"]
+    if wl == "msm" and not distributed and not host and a.msm_async <= 1 and len(msm_engs) == 1:
+        # The timed region carries the HIP events the roofline's kernel_ms comes from: three hipEventRecord per call, which a 0.1-0.4 ms call feels.
+        # The same synchronous call without them, after the timed region (not `value`): what a caller of jj_msm sees.
+        one_pass(); torch.cuda.synchronize(dev)
+        reps = max(8, min(passes * a.steps, 200))
+        ts = []
+        for _ in range(reps):
+            t1 = time.perf_counter(); one_pass(); ts.append(time.perf_counter() - t1)
+        torch.cuda.synchronize(dev)
+        ts.sort()
+        res["config"]["ms_per_call_without_events"] = {"median": ts[len(ts) // 2] * 1e3, "min": ts[0] * 1e3, "calls": reps,
+                                                        "note": "jj_msm on the same device-resident inputs, profiling events off, wall time of each call through the Python mirror (host tail done when it returns; the 64 result bytes go to a new device tensor by a queued copy)"}
     if wl == "msm":
         res["config"]["msm_partition"] = a.msm_partition if n_gpus > 1 else None
         res["config"]["msm_jobs_in_flight"] = a.msm_async if (not distributed or rccl_comm is not None) else 1
@@ -749,6 +761,10 @@ def run(a):
             # data-sheet ceiling instead (1024 SIMDs x 16 lanes x 2.4 GHz), which no sustained integer load reaches on this part
             "peak_samples": {"before": [x / 1e12 for x in peak_before], "after": [x / 1e12 for x in peak_after], "median": peak / 1e12,
                              "min": samples[0] / 1e12, "max": samples[-1] / 1e12, "spread": (samples[-1] - samples[0]) / peak},
+            # which peak `frac` uses, and why it is 10 % under the data-sheet product (round 6, profiles/r6_peak_clock.txt + r6_mad_banks.txt: one rocprofv3
+            # pass with GRBM_GUI_ACTIVE / SQ_INSTS_VALU over k_peak_mad and k_varbase_ct3 in one process)
+            "peak_kind": "measured: median of 5 + 5 launches of k_peak_mad (a pure v_mad_u64_u32 stream, 8 waves per SIMD) around the timed region; frac_nominal = the same work over 1024 SIMDs x 16 lanes x 2.4 GHz",
+            "peak_attribution": "measured / nominal ~ 0.90 = clock 2.25-2.27 GHz of 2.4 under this load (0.94) x one multiply-add per 4.35 cycles per SIMD instead of 4 (0.92; independent of VGPR banks, operand kind and signedness; 5.2 cycles for a lone wave per SIMD, 4.4 for two); the ladder itself issues one VALU instruction per 4.08 cycles at 2.26 GHz",
             "frac_at_peak_max": achieved / samples[-1], "frac_at_peak_min": achieved / samples[0],
             "peak_nominal": NOMINAL_PEAK_IMAD32 / 1e12, "frac_nominal": achieved / NOMINAL_PEAK_IMAD32,
             "frac_min": (n * work_main / (min(main_ms) * 1e-3) / peak) if main_ms and len(msm_engs) == 1 else None,     # the fastest dispatch of the timed region

@@ -224,7 +224,7 @@ int jj_varbase_mul_compressed(jj_ctx*, size_t n, const void* scalars32, const vo
 int jj_varbase_mul_ct(jj_ctx*, size_t n, const void* scalars32, const void* points64, void* out64);
 /* VARIABLE-TIME variants for PUBLIC scalars (what rounds 1-4 shipped as jj_varbase_mul): signed 5-bit windows, the lane's table
  * {0 .. 16} P in device memory, read at a digit-dependent address: a scalar-independent instruction stream but scalar-dependent
- * memory addresses (cache timing).  About 1.6 % faster than jj_varbase_mul at 2^20 units (ratio 0.984, profiles/r5_vb_ct_window.txt).
+ * memory addresses (cache timing).  1.6-4.5 % faster than jj_varbase_mul at 2^20 units depending on the box (ratios 0.984 and 0.955: profiles/r5_vb_ct_window.txt, r6_vb_ct_window.txt).
  * Nothing makes jj_varbase_mul / _compressed take this ladder: no option, no environment variable. */
 int jj_varbase_mul_vartime(jj_ctx*, size_t n, const void* scalars32, const void* points64, void* out64);
 int jj_varbase_mul_vartime_compressed(jj_ctx*, size_t n, const void* scalars32, const void* points64, void* out32);

@@ -210,7 +210,7 @@ static int varbase_api(jj_ctx* c, size_t n, const void* scalars, const void* poi
 // ExtendedPoint * Fr (reference src/lib.rs:873-879 -> 357-379): the reference's ladder is constant-time (conditional_select, 334-343), and so is
 // the default here (round 5): signed 3-bit windows, mask selects, no table in memory (k_varbase_ct3; one scalar multiplication per quad of lanes up
 // to JJ_VB_QUAD_MAX units: k_varbase_ct_quad).  The _vartime entry points keep the per-lane window table in memory and signed 5-bit windows
-// (digit-dependent addresses): ~2.5 % faster at 2^20 units, for public scalars.
+// (digit-dependent addresses): 1.6-4.5 % faster at 2^20 units depending on the box (profiles/r5_vb_ct_window.txt: ratio 0.984, r6_vb_ct_window.txt: 0.955), for public scalars.
 JJ_API int jj_varbase_mul(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out) { return varbase_api(c, n, scalars, points, out, 0, c && c->vb_default_ct); }
 JJ_API int jj_varbase_mul_compressed(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out32) { return varbase_api(c, n, scalars, points, out32, 1, c && c->vb_default_ct); }
 JJ_API int jj_varbase_mul_ct(jj_ctx* c, size_t n, const void* scalars, const void* points, void* out) { return varbase_api(c, n, scalars, points, out, 0, true); }      // (the name rounds 3-4 gave the opt-in; always constant-time)

@@ -209,7 +209,7 @@ struct jj_ctx {
   bool torsion_ladder = false;   // subgroup test: false = Tate pairing (k_torsion_free), true = multiply by r (reference definition)
   bool fb_const_time = true;     // fixed-base window select: true = lane-staged + ds_bpermute shuffle, false = per-lane LDS gather
   int fb_default_kind = 7;       // what window_bits = 0 means: 7 = signed comb (32 additions + 3 doublings), 6 = signed 6-bit windows (43 additions); JJ_FIXEDBASE_DEFAULT
-  bool vb_default_ct = true;     // jj_varbase_mul / _compressed run the constant-time ladder (JJ_VARBASE_DEFAULT=vartime: the table ladder, as rounds 1-4)
+  bool vb_default_ct = true;     // jj_varbase_mul / _compressed run the constant-time ladder (always, in the shipped library; -DJJ_EXPERIMENTS probe builds read JJ_VARBASE_DEFAULT=vartime for A/B runs of the table ladder)
   int vb_ct_window = 3;          // constant-time ladder: signed window width, 3 (k_varbase_ct3) or 2 (k_varbase_ct); JJ_VB_CT_WINDOW
   int vb_quad_max = 32768;       // batches up to this size run one scalar-mul per quad of lanes (JJ_VB_QUAD_MAX; 0 = never)
   int fb_gather_blocks_per_cu = 3;   // wide-window fixed-base kernel: resident blocks of 256 per CU (JJ_FB_GATHER_BLOCKS_PER_CU)
