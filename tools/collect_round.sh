@@ -38,4 +38,7 @@ for f in gpurun_out/${TAG}_bench_host_*.json gpurun_out/${TAG}_bench_msm20_rccl1
 (echo "$HDR"; echo "# command: bench.py --opt <key>=<0|1> --workload msm --log2n 17 --steps 10 --warmup 3, alternating (msm_front1=0: the four-launch front end of round 5; msm_acc_lds=0: bucket offsets read from global memory)"; cat gpurun_out/${TAG}_msm17_ab.txt) > profiles/${TAG}_msm17_ab.txt
 (echo "$HDR"; echo "# command: bench.py --opt msm_windows=<16|17> --workload msm --log2n <18|19> --steps 10 --warmup 3, alternating (16 = the planner's choice from 2^18 terms since round 6)"; cat gpurun_out/${TAG}_msm_windows_ab.txt) > profiles/${TAG}_msm_windows_ab.txt
 (echo "$HDR"; echo "# command: python tests/soak_jobs.py 180 9000"; grep -v amdgpu gpurun_out/${TAG}_soak_jobs.txt | tail -4) > profiles/${TAG}_soak_jobs.txt
+(echo "$HDR"; echo "# command: ./experiments/mad_banks/probe   (streams of 64 multiply-adds per trip with explicit register numbers; best of 5 launches)"; cat gpurun_out/${TAG}_mad_banks.txt) > profiles/${TAG}_mad_banks.txt
+(echo "$HDR"; echo "# command: ./experiments/sync_latency/probe   (launch -> the host knows, for a kernel that spins 5 / 300 us; median of 300)"; cat gpurun_out/${TAG}_sync_latency.txt) > profiles/${TAG}_sync_latency.txt
+(echo "$HDR"; echo "# command: python bench.py --workload msm --log2n <17|18|20> --msm-async <jobs in flight> --opt msm_lanes=<lanes> --no-cpu-baseline --no-extras   (default since round 6: three lanes)"; cat gpurun_out/${TAG}_msm_lanes.txt) > profiles/${TAG}_msm_lanes.txt
 python3 tools/design_numbers.py $TAG

@@ -61,4 +61,9 @@ bash tools/peak_clock.sh > gpurun_out/${TAG}_peak_clock.log 2>&1; cp gpurun_out/
 for o in "msm_front1=1" "msm_front1=0" "msm_front1=1" "msm_front1=0" "msm_acc_lds=1" "msm_acc_lds=0" "msm_acc_lds=1" "msm_acc_lds=0"; do python bench.py --opt $o --workload msm --log2n 17 --steps 10 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$o  msm 2^17: %.4f ms per call, verified %s' % (d['config']['ms_per_pass'], d['verified']))"; done > gpurun_out/${TAG}_msm17_ab.txt 2>&1
 for lg in 18 19; do for w in 16 17 16 17; do python bench.py --opt msm_windows=$w --workload msm --log2n $lg --steps 10 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('msm_windows=$w  msm 2^$lg: %.4f ms per call, verified %s' % (d['config']['ms_per_pass'], d['verified']))"; done; done > gpurun_out/${TAG}_msm_windows_ab.txt 2>&1
 timeout 400 python tests/soak_jobs.py 180 9000 > gpurun_out/${TAG}_soak_jobs.txt 2>&1 || echo "JOBS SOAK FAILED" >> gpurun_out/${TAG}_soak_jobs.txt
+[ -x experiments/mad_banks/probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o experiments/mad_banks/probe experiments/mad_banks/probe.hip 2>/dev/null
+[ -x experiments/sync_latency/probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o experiments/sync_latency/probe experiments/sync_latency/probe.hip 2>/dev/null
+./experiments/mad_banks/probe > gpurun_out/${TAG}_mad_banks.txt 2>&1          # multiply-add issue rate against VGPR banks, operand kinds and waves per SIMD
+./experiments/sync_latency/probe > gpurun_out/${TAG}_sync_latency.txt 2>&1    # what the host's wait for a kernel costs: event, stream, flag in host memory
+for N in 17 18 20; do for L in 2 3 4; do for A in 2 4 6; do python bench.py --workload msm --log2n $N --msm-async $A --opt msm_lanes=$L --no-cpu-baseline --no-extras 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('2^$N lanes $L async $A: %.4f ms per MSM, frac %.3f, verified %s' % (d['config']['ms_per_pass'], d['roofline']['frac'], d['verified']))"; done; done; done > gpurun_out/${TAG}_msm_lanes.txt 2>&1
 tail -1 gpurun_out/${TAG}_profile.log
