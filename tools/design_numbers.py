@@ -74,6 +74,28 @@ def markdown():
     return "\n".join(out)
 
 
+def baseline_table():
+    """one row per BASELINE config with frac (measured peak) and frac_nominal (39.32 T) side by side"""
+    out = ["| Config | GPU (1 x MI355X) | `frac` (measured multiply-add peak) | `frac_nominal` (1024 SIMDs x 16 lanes x 2.4 GHz) | CPU port of the reference algorithm |", "|---|---|---|---|---|"]
+    d, fb, m20, m17, m17a, dec = line("bench_default"), line("fixedbase_bench"), line("bench_msm20"), line("bench_msm17"), line("bench_msm17_async4"), line("decompress_bench")
+    d1, m20a = line("bench_dec1"), line("bench_msm20_async4")
+    cb = d["cpu_baseline"]
+    rn = lambda x: x["roofline"].get("frac_nominal") or 0
+    out.append("| 2. var-base 2^20 (constant-time ladder) | **%.1f M scalar-muls/s** (%.2f ms per pass) | **%.3f** | %.3f | %.1f k/s one thread, %.0f k/s on %d threads |" % (
+        d["value"] / 1e6, d["config"]["ms_per_pass"], d["roofline"]["frac"], rn(d), cb["single_thread"]["value"] / 1e3, cb["all_cores"]["value"] / 1e3, cb["all_cores"]["threads"]))
+    out.append("| 3. fixed-base 2^24 (signed comb, shuffle select) | **%.0f M scalar-muls/s** (%.2f ms) | %.3f | %.3f | |" % (fb["value"] / 1e6, fb["config"]["ms_per_pass"], fb["roofline"]["frac"], rn(fb)))
+    out.append("| 4. MSM 2^20 terms on one GPU | %.0f M terms/s per call (%.3f ms); four jobs in flight %.0f M terms/s (%.3f ms) | %.3f per call, %.3f in flight | %.3f, %.3f | |" % (
+        m20["value"] / 1e6, m20["config"]["ms_per_pass"], m20a["value"] / 1e6, m20a["config"]["ms_per_pass"], m20["roofline"]["frac"], m20a["roofline"]["frac"], rn(m20), rn(m20a)))
+    out.append("| 4. one rank's share at 8 GPUs: MSM 2^17 terms | %.4f ms per call (%s ms without the profiling events); four jobs in flight %.4f ms per MSM | %.3f per call, %.3f in flight | %.3f, %.3f | |" % (
+        m17["config"]["ms_per_pass"], ("%.4f" % m17["config"]["ms_per_call_without_events"]["median"]) if "ms_per_call_without_events" in m17["config"] else "?", m17a["config"]["ms_per_pass"],
+        m17["roofline"]["frac"], m17a["roofline"]["frac"], rn(m17), rn(m17a)))
+    out.append("| 5. decompress 2^23 per GPU (= 2^26 over 8) | decode only %.0f M points/s; + small-order check + `mul_by_cofactor` %.0f M/s | %.3f | %.3f | |" % (d1["value"] / 1e6, dec["value"] / 1e6, d1["roofline"]["frac"], rn(d1)))
+    return "\n".join(out)
+
+
+if "--baseline" in sys.argv:
+    print(baseline_table())
+    sys.exit(0)
 if MARKDOWN:
     md = markdown()
     if WRITE:
