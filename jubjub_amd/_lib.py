@@ -3,8 +3,8 @@ there is no CPU fallback in the product path."""
 import ctypes as C
 import os
 
-# HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  A context with jobs in flight uses five streams (launch, two
-# copy streams, two MSM lanes): with four queues two of them share one and the pipelines run 1.7-2x slower (profiles/r4_pcie_inclusive.txt).  The C
+# HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  A context with jobs in flight uses up to six streams (launch, two
+# copy streams, three MSM lanes since round 6): with four queues two of them share one and the pipelines run 1.7-2x slower (profiles/r4_pcie_inclusive.txt).  The C
 # library never touches the environment (it warns once on stderr when it creates its fifth stream with fewer than 8 queues configured); this
 # PYTHON package sets the variable, if the application has not, before the HIP runtime is loaded -- a HIP runtime variable, not a switch of ours.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
