@@ -8,7 +8,7 @@ import os
 import re
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r5"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r6"
 prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
 for wl in ("default", "fixedbase", "msm20", "msm22", "msm17"):
     rows = []
