@@ -3,6 +3,7 @@ Multi-rank path of bench.py on real hardware (one GPU is enough): the ranks benc
 exchange of the MSM's 64-byte partial points (gloo with two ranks stacked on one GPU; RCCL with one rank), strong and weak
 scaling shards built from the global unit indices, and the folded point against the oracle.
 """
+import functools
 import json
 import os
 import subprocess
@@ -39,6 +40,7 @@ def run_bench(args, env_extra, timeout=400):
     return json.loads(lines[0])
 
 
+@functools.lru_cache(maxsize=None)      # five tests ask for the same 2^16-term point: ~28 s of Python big-integer input synthesis each time
 def oracle_msm(total):
     import bench
 
